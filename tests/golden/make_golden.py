@@ -1,0 +1,457 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by importing the *reference* (FeiiYin/SPI at
+/root/reference) on CPU.  Runs only in the build container (the GPU box has no reference);
+the committed ``*.npz`` / ``*.json`` files are data: inputs + the reference's outputs.
+
+    python tests/golden/make_golden.py [ops renderer synthesis geometry schedule trajectory manifest]
+
+Every section also prints max |reference - oracle| so the oracle is pinned at generation time.
+"""
+import json
+import math
+import os
+import sys
+
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests'), REF, REF + '/eg3d', REF + '/spi']
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from synth_weights import synth_tensor, synth_state_dict  # noqa: E402
+from oracle import stylegan_ref as osg, renderer_ref as orr, losses_ref as olo  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t)
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print(f'  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)')
+
+
+def diff(tag, a, b):
+    a, b = torch.as_tensor(npy(a)).double(), torch.as_tensor(npy(b)).double()
+    d = (a - b).abs().max().item()
+    rel = d / max(a.abs().max().item(), 1e-30)
+    print(f'    pin {tag:34s} max|ref-oracle| = {d:.3e}  (rel {rel:.2e})')
+    return d
+
+
+RK = dict(superresolution_module='training.superresolution.SuperresolutionHybrid8XDC', sr_antialias=True,
+          superresolution_noise_mode='none', c_gen_conditioning_zero=False, c_scale=1.0, clamp_mode='softplus',
+          disparity_space_sampling=False, decoder_lr_mul=1.0, box_warp=1, ray_start=2.25, ray_end=3.3,
+          depth_resolution=12, depth_resolution_importance=12, white_back=False)
+
+
+def build_ref_generator(narrow=True, rk=None):
+    from training.triplane import TriPlaneGenerator
+    rk = dict(RK if rk is None else rk)
+    cb, cm = (2048, 32) if narrow else (32768, 512)
+    G = TriPlaneGenerator(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3,
+                          mapping_kwargs=dict(num_layers=2), channel_base=cb, channel_max=cm,
+                          fused_modconv_default='inference_only', num_fp16_res=0, conv_clamp=None, sr_num_fp16_res=4,
+                          sr_kwargs=dict(channel_base=cb, channel_max=cm, fused_modconv_default='inference_only'),
+                          rendering_kwargs=rk).eval()
+    sd = G.state_dict()
+    G.load_state_dict({k: synth_tensor(k, v.shape) for k, v in sd.items()})
+    return G
+
+
+class Recorder:
+    """Record torch.rand / rand_like / randn_like draws made by the reference."""
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        self._o = (torch.rand, torch.rand_like, torch.randn_like)
+        rec = self
+
+        def wrap(fn):
+            def inner(*a, **k):
+                out = fn(*a, **k)
+                rec.draws.append(out.detach().clone())
+                return out
+            return inner
+        torch.rand, torch.rand_like, torch.randn_like = [wrap(f) for f in self._o]
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.rand_like, torch.randn_like = self._o
+
+
+# ------------------------------------------------------------------------------------------------
+def sec_manifest():
+    for kind, narrow in (('narrow', True), ('full', False)):
+        G = build_ref_generator(narrow)
+        man = {k: list(v.shape) for k, v in G.state_dict().items()}
+        with open(os.path.join(HERE, f'manifest_{kind}.json'), 'w') as f:
+            json.dump(man, f, indent=0)
+        nparam = sum(p.numel() for p in G.parameters())
+        print(f'  manifest_{kind}.json: {len(man)} entries, {nparam} params')
+
+
+def sec_ops():
+    from torch_utils.ops import bias_act, upfirdn2d, filtered_lrelu, conv2d_resample
+    from training.networks_stylegan2 import modulated_conv2d
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    # bias_act: forward + grad wrt x and b
+    x = torch.randn(2, 6, 5, 7, generator=g) * 3
+    b = torch.randn(6, generator=g)
+    dy = torch.randn(2, 6, 5, 7, generator=g)
+    out['ba_x'], out['ba_b'], out['ba_dy'] = x, b, dy
+    cases = [('lrelu', None, None, None), ('lrelu', 0.2, math.sqrt(2), 2.0), ('linear', None, None, 1.5),
+             ('linear', None, None, None), ('relu', None, None, None), ('sigmoid', None, None, None),
+             ('tanh', None, None, None), ('softplus', None, None, None), ('swish', None, None, None),
+             ('elu', None, None, None), ('selu', None, None, None)]
+    for i, (act, alpha, gain, clamp) in enumerate(cases):
+        xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = bias_act.bias_act(xr, br, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        gx, gb = torch.autograd.grad(y, [xr, br], dy)
+        out[f'ba_y{i}'], out[f'ba_gx{i}'], out[f'ba_gb{i}'] = y, gx, gb
+        diff(f'bias_act[{act},clamp={clamp}]', y, osg.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp))
+    out['ba_cases'] = np.array([json.dumps(cases)])
+    # upfirdn2d
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    out['fir'] = f
+    diff('setup_filter', f, osg.fir_filter())
+    x = torch.randn(2, 3, 9, 9, generator=g)
+    out['uf_x'] = x
+    ucases = [dict(up=1, down=1, padding=[1, 1, 1, 1], gain=4.0, flip_filter=False),
+              dict(up=2, down=1, padding=[2, 1, 2, 1], gain=4.0, flip_filter=False),
+              dict(up=1, down=2, padding=[1, 1, 1, 1], gain=1.0, flip_filter=True),
+              dict(up=1, down=2, padding=[2, 2, 2, 2], gain=4.0, flip_filter=True),
+              dict(up=1, down=1, padding=[2, 1, 2, 1], gain=1.0, flip_filter=True),
+              dict(up=2, down=2, padding=[3, 2, 1, 0], gain=2.0, flip_filter=False)]
+    for i, kw in enumerate(ucases):
+        xr = x.clone().requires_grad_(True)
+        y = upfirdn2d.upfirdn2d(xr, f, **kw)
+        dyu = torch.randn(y.shape, generator=g)
+        gx, = torch.autograd.grad(y, xr, dyu)
+        out[f'uf_y{i}'], out[f'uf_dy{i}'], out[f'uf_gx{i}'] = y, dyu, gx
+        diff(f'upfirdn2d[{i}]', y, osg.upfirdn2d(x, f, **kw))
+    out['uf_cases'] = np.array([json.dumps(ucases)])
+    diff('upsample2d', upfirdn2d.upsample2d(x, f), osg.upsample2d(x, f))
+    # filtered_lrelu (ref path)
+    fu = upfirdn2d.setup_filter([1, 3, 3, 1])
+    fd = upfirdn2d.setup_filter([1, 2, 1])
+    xb = torch.randn(2, 3, 8, 8, generator=g)
+    bb = torch.randn(3, generator=g)
+    flc = [dict(up=2, down=2, padding=[3, 2, 3, 2], gain=math.sqrt(2), slope=0.2, clamp=None, flip_filter=False),
+           dict(up=2, down=1, padding=[2, 1, 2, 1], gain=1.3, slope=0.1, clamp=0.8, flip_filter=False),
+           dict(up=1, down=2, padding=[1, 1, 1, 1], gain=1.0, slope=0.2, clamp=None, flip_filter=True)]
+    out['fl_x'], out['fl_b'], out['fl_fu'], out['fl_fd'] = xb, bb, fu, fd
+    for i, kw in enumerate(flc):
+        xr = xb.clone().requires_grad_(True)
+        y = filtered_lrelu.filtered_lrelu(xr, fu=fu, fd=fd, b=bb, impl='ref', **kw)
+        dyf = torch.randn(y.shape, generator=g)
+        gx, = torch.autograd.grad(y, xr, dyf)
+        out[f'fl_y{i}'], out[f'fl_dy{i}'], out[f'fl_gx{i}'] = y, dyf, gx
+        diff(f'filtered_lrelu[{i}]', y, osg.filtered_lrelu(xb, fu, fd, bb, **kw))
+    out['fl_cases'] = np.array([json.dumps(flc)])
+    # modulated conv: up=1 3x3, up=2 3x3, 1x1 no-demod; batch 2; grads wrt x, weight, styles
+    for tag, (ic, oc, k, up, demod, hw) in dict(c1=(8, 12, 3, 1, True, 6), c0=(8, 12, 3, 2, True, 5),
+                                                 rgb=(8, 5, 1, 1, False, 6)).items():
+        x = torch.randn(2, ic, hw, hw, generator=g).requires_grad_(True)
+        w = torch.randn(oc, ic, k, k, generator=g).requires_grad_(True)
+        s = (1 + 0.3 * torch.randn(2, ic, generator=g)).requires_grad_(True)
+        res = hw * up
+        noise = torch.randn(res, res, generator=g) * 0.1 if demod else None
+        y = modulated_conv2d(x=x, weight=w, styles=s, noise=noise, up=up, padding=k // 2, resample_filter=f,
+                             demodulate=demod, flip_weight=(up == 1), fused_modconv=True)
+        dym = torch.randn(y.shape, generator=g)
+        gx, gw, gs = torch.autograd.grad(y, [x, w, s], dym)
+        for nm, v in dict(x=x, w=w, s=s, y=y, dy=dym, gx=gx, gw=gw, gs=gs).items():
+            out[f'mc_{tag}_{nm}'] = v
+        if noise is not None:
+            out[f'mc_{tag}_noise'] = noise
+        diff(f'modulated_conv2d[{tag}]', y, osg.modulated_conv2d(x, w, s, noise=noise, up=up, padding=k // 2, f=f,
+                                                                 demodulate=demod, flip_weight=(up == 1)))
+    save('ops', **out)
+
+
+def sec_renderer():
+    from training.volumetric_rendering.renderer import ImportanceRenderer, sample_from_planes
+    from training.volumetric_rendering.ray_marcher import MipRayMarcher2
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    from training.triplane import OSGDecoder
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import camera_utils as cu
+    g = torch.Generator().manual_seed(5)
+    out = {}
+    # rays
+    c = torch.cat([cu.cal_canonical_c(0.4, -0.1), cu.cal_canonical_c(-0.3, 0.2)], 0)
+    c[1, 17] = 0.03     # exercise the skew term
+    ro, rd = RaySampler()(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 8)
+    out['cam'], out['ray_o'], out['ray_d'] = c, ro, rd
+    oo, od = orr.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 8)
+    diff('ray origins', ro, oo)
+    diff('ray dirs', rd, od)
+    # decoder + planes
+    dec = OSGDecoder(32, {'decoder_lr_mul': 1, 'decoder_output_dim': 32})
+    dsd = {k: synth_tensor('decoder.' + k, v.shape) for k, v in dec.state_dict().items()}
+    dsd['net.0.bias'] = dsd['net.0.bias'] * 3
+    dsd['net.2.bias'] = dsd['net.2.bias'] * 3
+    dec.load_state_dict(dsd)
+    P = {'decoder.' + k: v for k, v in dsd.items()}
+    for k, v in P.items():
+        out['P_' + k] = v
+    planes = torch.randn(2, 3, 32, 16, 16, generator=g)
+    out['planes'] = planes
+    # gather + decode on arbitrary coords (some outside the box)
+    coords = (torch.rand(2, 300, 3, generator=g) - 0.5) * 1.3
+    out['coords'] = coords
+    pr, dr = planes.clone().requires_grad_(True), [p.requires_grad_(True) for p in dec.parameters()]
+    feats = sample_from_planes(ImportanceRenderer().plane_axes, pr, coords, padding_mode='zeros', box_warp=1)
+    o = dec(feats, None)
+    out['gd_feats'], out['gd_rgb'], out['gd_sigma'] = feats, o['rgb'], o['sigma']
+    d_rgb = torch.randn(o['rgb'].shape, generator=g)
+    d_sig = torch.randn(o['sigma'].shape, generator=g)
+    grads = torch.autograd.grad([o['rgb'], o['sigma']], [pr] + list(dec.parameters()), [d_rgb, d_sig])
+    out['gd_drgb'], out['gd_dsigma'], out['gd_gplanes'] = d_rgb, d_sig, grads[0]
+    for (k, _), gv in zip(dec.named_parameters(), grads[1:]):
+        out['gd_g_' + k] = gv
+    f2 = orr.sample_planes(planes, coords)
+    diff('sample_planes', feats, f2)
+    r2, s2 = orr.osg_decoder(P, f2)
+    diff('decoder rgb', o['rgb'], r2)
+    diff('decoder sigma', o['sigma'], s2)
+    # ray marcher (S = 24 sorted depths), with grads
+    n, m, s = 2, 40, 24
+    col = torch.rand(n, m, s, 32, generator=g).requires_grad_(True)
+    den = (torch.randn(n, m, s, 1, generator=g) * 3 + 1).requires_grad_(True)
+    dep = (torch.sort(torch.rand(n, m, s, 1, generator=g) * 1.05 + 2.25, dim=2)[0]).requires_grad_(True)
+    den.data[0, 0] = -50.0      # an empty ray: weight_total == 0 -> nan -> inf -> clamp to max depth
+    for wb in (False, True):
+        rgb, depth, w = MipRayMarcher2()(col, den, dep, {'clamp_mode': 'softplus', 'white_back': wb})
+        d1, d2, d3 = (torch.randn(rgb.shape, generator=g), torch.randn(depth.shape, generator=g),
+                      torch.randn(w.shape, generator=g))
+        gc, gs_, gd_ = torch.autograd.grad([rgb, depth, w], [col, den, dep], [d1, d2, d3])
+        t = f'rm{int(wb)}_'
+        for nm, v in dict(rgb=rgb, depth=depth, w=w, drgb=d1, ddepth=d2, dw=d3, gcol=gc, gden=gs_, gdep=gd_).items():
+            out[t + nm] = v
+        a, b_, c_ = orr.ray_march(col, den, dep, white_back=wb)
+        diff(f'ray_march rgb wb={wb}', rgb, a)
+        diff(f'ray_march depth wb={wb}', depth, b_)
+        diff(f'ray_march weights wb={wb}', w, c_)
+    out['rm_col'], out['rm_den'], out['rm_dep'] = col, den, dep
+    # importance sampling with recorded u
+    R = ImportanceRenderer()
+    wts = torch.rand(n, m, s - 1, 1, generator=g) ** 4
+    wts[0, 1] = 0.0
+    with Recorder() as rec:
+        torch.manual_seed(3)
+        fine = R.sample_importance(dep.detach(), wts, 20)
+    out['is_w'], out['is_u'], out['is_fine'] = wts, rec.draws[0], fine
+    diff('importance depths', fine, orr.importance_depths(dep.detach(), wts, 20, u=rec.draws[0]))
+    # full renderer forward + grads (planes & decoder), recorded draws
+    opts = dict(RK)
+    n, res = 2, 8
+    ro, rd = RaySampler()(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), res)
+    pr = planes.clone().requires_grad_(True)
+    for p in dec.parameters():
+        p.grad = None
+    with Recorder() as rec:
+        torch.manual_seed(7)
+        rgb, depth, wsum = R(pr, dec, ro, rd, opts)
+    xi, u = rec.draws
+    d1, d2 = torch.randn(rgb.shape, generator=g), torch.randn(depth.shape, generator=g)
+    grads = torch.autograd.grad([rgb, depth], [pr] + list(dec.parameters()), [d1, d2])
+    out['fr_xi'], out['fr_u'], out['fr_rgb'], out['fr_depth'], out['fr_wsum'] = xi, u, rgb, depth, wsum
+    out['fr_drgb'], out['fr_ddepth'], out['fr_gplanes'] = d1, d2, grads[0]
+    for (k, _), gv in zip(dec.named_parameters(), grads[1:]):
+        out['fr_g_' + k] = gv
+    a, b_, c_ = orr.render(P, planes, ro, rd, opts, xi=xi, u=u)
+    diff('render rgb', rgb, a)
+    diff('render depth', depth, b_)
+    diff('render weight sum', wsum, c_)
+    save('renderer', **out)
+
+
+def sec_synthesis():
+    """Narrow generator (2.84 M params, rendering res 32, 12+12 samples): outputs + grad wrt ws."""
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import camera_utils as cu
+    G = build_ref_generator(True)
+    G.neural_rendering_resolution = 32
+    g = torch.Generator().manual_seed(9)
+    ws = (torch.randn(2, 14, 512, generator=g)).requires_grad_(True)
+    c = torch.cat([cu.cal_canonical_c(0.4, 0.0), cu.cal_mirror_c(cu.cal_canonical_c(0.4, 0.0))], 0)
+    with Recorder() as rec:
+        torch.manual_seed(0)
+        o = G.synthesis(ws, c, noise_mode='const')
+    xi, u = rec.draws
+    planes = G.backbone.synthesis(ws, noise_mode='const')
+    d_img = torch.randn(o['image'].shape, generator=g)
+    d_dep = torch.randn(o['image_depth'].shape, generator=g)
+    loss = (o['image'] * d_img).sum() / 1000 + (o['image_depth'] * d_dep).sum()
+    gws, = torch.autograd.grad(loss, ws)
+    P = {k: v for k, v in G.state_dict().items()}
+    opts = dict(RK)
+    wso = ws.detach().clone().requires_grad_(True)
+    oo = orr.synthesis(P, wso, c, opts, neural_rendering_resolution=32, xi=xi, u=u)
+    lo = (oo['image'] * d_img).sum() / 1000 + (oo['image_depth'] * d_dep).sum()
+    gwo, = torch.autograd.grad(lo, wso)
+    diff('synthesis planes', planes, oo['planes'].reshape(planes.shape))
+    diff('synthesis image', o['image'], oo['image'])
+    diff('synthesis image_raw', o['image_raw'], oo['image_raw'])
+    diff('synthesis image_depth', o['image_depth'], oo['image_depth'])
+    diff('synthesis grad ws', gws, gwo)
+    z = torch.randn(4, 512, generator=g)
+    wmap = G.mapping(z, c[:1].repeat(4, 1))
+    diff('mapping', wmap, osg.mapping(P, z, c[:1].repeat(4, 1) * 1.0))
+    save('synthesis_narrow', ws=ws, c=c, xi=xi, u=u, planes_sub=planes[:, ::7, ::5, ::5], image_sub=o['image'][:, :, ::8, ::8],
+         image_raw=o['image_raw'], image_depth=o['image_depth'], d_img_seed=np.array([9]), d_img=d_img[:, :, ::8, ::8],
+         d_dep=d_dep, gws=gws, image_mean=o['image'].mean(), image_absmean=o['image'].abs().mean(),
+         map_z=z, map_w=wmap[:, 0])
+
+
+def sec_geometry():
+    import spi.utils.camera_utils as rcu
+    rcu.GAUSS_CONST = torch.sqrt(torch.tensor(2 * torch.pi))
+    from spi.utils.rotate import rotate as rrotate
+    from spi.utils.mask_utils import calculate_face_mask
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import camera_utils as cu
+    torch.Tensor.cuda = lambda self, *a, **k: self       # rotate.py hard-codes .cuda()
+    g = torch.Generator().manual_seed(21)
+    out = {}
+    cams = []
+    for i, (yw, pt) in enumerate(((0.0, 0.0), (0.4, 0.0), (-0.55, 0.2), (0.1, -0.3))):
+        cr = rcu.cal_canonical_c(yw, pt)
+        cams.append(cr)
+        diff(f'cal_canonical_c[{i}]', cr, cu.cal_canonical_c(yw, pt))
+    cams = torch.cat(cams, 0)
+    out['canon'] = cams
+    out['mirror'] = rcu.cal_mirror_c(cams)
+    diff('cal_mirror_c', out['mirror'], cu.cal_mirror_c(cams))
+    out['weight'] = rcu.cal_camera_weight(cams)
+    diff('cal_camera_weight', out['weight'], cu.cal_camera_weight(cams))
+    out['weight_m'] = rcu.cal_camera_weight(out['mirror'])
+    out['gauss_weight'] = torch.stack(rcu.cal_camera_gauss_weight(cams))
+    diff('cal_camera_gauss_weight', out['gauss_weight'], torch.stack(cu.cal_camera_gauss_weight(cams)))
+    with Recorder() as rec:
+        torch.manual_seed(4)
+        sur = rcu.sample_surrounding_camera(cams[1:2].clone(), batch_size=4, yaw_range=0.2, pitch_range=0.1)
+    out['sur'], out['sur_r0'], out['sur_r1'] = sur, rec.draws[0], rec.draws[1]
+    diff('sample_surrounding_camera', sur, cu.sample_surrounding_camera(cams[1:2], 4, 0.2, 0.1, rand=rec.draws))
+    with Recorder() as rec:
+        torch.manual_seed(5)
+        sc = rcu.sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4)
+    out['sc'], out['sc_r0'], out['sc_r1'] = sc, rec.draws[0], rec.draws[1]
+    diff('sample_camera', sc, cu.sample_camera(4, 0.7, 0.4, rand=rec.draws))
+    # face mask
+    parsing = torch.randint(0, 19, (1, 1, 32, 32), generator=g)
+    out['parsing'], out['face_mask'] = parsing, calculate_face_mask(parsing)
+    # rotate: smooth synthetic depth maps at 128^2, images at 64^2 (resolution = src_image.shape[-1])
+    n, res = 2, 64
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 128), torch.linspace(-1, 1, 128), indexing='ij')
+    bump = torch.exp(-(xx ** 2 + yy ** 2) * 2)
+    tdepth = (2.7 - 0.25 * bump)[None, None].repeat(n, 1, 1, 1) + 0.002 * torch.randn(n, 1, 128, 128, generator=g)
+    sdepth = (2.7 - 0.25 * bump)[None, None].repeat(n, 1, 1, 1) + 0.002 * torch.randn(n, 1, 128, 128, generator=g)
+    img = torch.rand(n, 3, res, res, generator=g) * 2 - 1
+    msk = (torch.rand(n, 1, res, res, generator=g) > 0.3).float()
+    src_cam = cams[1:2].repeat(n, 1)
+    rgb, m = rrotate(target_camera=sur[:n], target_depth=tdepth, src_image=img, src_camera=src_cam, src_depth=sdepth,
+                     src_mask=msk, EPS=5e-2)
+    out.update(rot_tdepth=tdepth, rot_sdepth=sdepth, rot_img=img, rot_msk=msk, rot_rgb=rgb, rot_mask=m)
+    r2, m2 = olo.rotate(sur[:n], tdepth, img, src_cam, sdepth, msk, EPS=5e-2)
+    diff('rotate rgb', rgb, r2)
+    diff('rotate mask', m, m2)
+    print(f'    rotate mask coverage = {m.mean().item():.3f}')
+    save('geometry', **out)
+
+
+def sec_schedule():
+    """Stage-1 lr / w-noise schedules (mirror_projector.py:84-91) restated as the host math the reference runs."""
+    out = {}
+    for num_steps in (10, 500):
+        lrs, ns = [], []
+        for step in range(num_steps):
+            t = step / num_steps
+            ns.append(0.05 * max(0.0, 1.0 - t / 0.75) ** 2)
+            r = min(1.0, (1.0 - t) / 0.25)
+            r = 0.5 - 0.5 * np.cos(r * np.pi)
+            r = r * min(1.0, t / 0.05)
+            lrs.append(0.01 * r)
+        out[f'lr_{num_steps}'] = np.array(lrs)
+        out[f'noise_{num_steps}'] = np.array(ns)
+    save('schedule', **out)
+
+
+def sec_trajectory():
+    """3 steps of the reference's mirror_projector.project and w_plus_projector.project on the narrow
+    generator, with a seeded-weight LPIPS (oracle's) injected as lpips_func."""
+    import spi.utils.camera_utils as rcu
+    rcu.GAUSS_CONST = torch.sqrt(torch.tensor(2 * torch.pi))
+    from spi.configs import global_config, paths_config
+    global_config.device = 'cpu'
+    import spi.training.projectors.mirror_projector as mp
+    import spi.training.projectors.w_plus_projector as wp
+    mp.log_image = lambda *a, **k: None
+    wp.log_image = lambda *a, **k: None
+    mp.tqdm = lambda x: x
+    wp.tqdm = lambda x: x
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import camera_utils as cu
+    G = build_ref_generator(True)
+    G.neural_rendering_resolution = 128   # mirror_projector.py:74 hard-codes a 128^2 bg mask
+    W = olo.make_vgg16_weights(seed=0)
+    lp = lambda a, b: olo.lpips(W, a, b)
+    g = torch.Generator().manual_seed(31)
+    target = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    c = cu.cal_canonical_c(0.4, 0.0)
+    fg = torch.zeros(1, 1, 512, 512)
+    fg[:, :, 100:400, 120:380] = 1
+    steps_log = []
+    orig_step = torch.optim.Adam.step
+
+    def logging_step(self, *a, **k):
+        r = orig_step(self, *a, **k)
+        steps_log.append(self.param_groups[0]['params'][0].detach().clone())
+        return r
+    torch.optim.Adam.step = logging_step
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        w = mp.project(G, target, c, lp, fg, num_steps=3, w_avg_samples=64, device=torch.device('cpu'), w_name='t')
+        w_mir = torch.stack(steps_log)
+        steps_log.clear()
+        torch.manual_seed(0)
+        np.random.seed(0)
+        w2 = wp.project(G, target, c, lp, num_steps=3, w_avg_samples=64, device=torch.device('cpu'), w_name='t')
+        w_plus = torch.stack(steps_log)
+    finally:
+        torch.optim.Adam.step = orig_step
+    # pin the oracle loops against the reference trajectories
+    from oracle import loops_ref as olp
+    P = {k: v for k, v in G.state_dict().items()}
+    opts = dict(RK)
+    for mirror, ref_w in ((True, w_mir), (False, w_plus)):
+        torch.manual_seed(0)
+        np.random.seed(0)
+        log = []
+        olp.project_w_plus(P, target, c, lp, opts, mirror=mirror, num_steps=3, w_avg_samples=64, nrr=128, log=log)
+        diff(f'stage-1 trajectory mirror={mirror}', ref_w, torch.stack([l['w'] for l in log]))
+    save('trajectory', target_seed=np.array([31]), c=c, w_mir=w_mir[:, 0], w_mir_final=w[0], w_plus=w_plus[:, 0],
+         w_plus_final=w2[0])
+
+
+SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, synthesis=sec_synthesis,
+                geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory)
+
+if __name__ == '__main__':
+    todo = sys.argv[1:] or list(SECTIONS)
+    for s in todo:
+        print(f'[{s}]')
+        SECTIONS[s]()
