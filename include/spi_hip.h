@@ -1,0 +1,200 @@
+/*
+ * spi_hip.h -- C ABI of libspi_hip.so: the MI355X (gfx950) kernels behind SPI's inversion hot path.
+ *
+ * Every entry point takes raw device pointers + explicit sizes and a HIP stream, never allocates,
+ * keeps no global device state, launches asynchronously on `stream`, and returns 0 on success or a
+ * negative SPI_ERR_* code (spi_last_error() gives the text).  All tensors are fp32 and densely
+ * packed in the stated row-major shape unless a stride argument says otherwise.
+ *
+ * Each function cites the reference interface it replaces (paths relative to the FeiiYin/SPI tree):
+ * the three JIT-built CUDA plugins under eg3d/torch_utils/ops (bias_act.cpp:36, upfirdn2d.cpp:20,
+ * filtered_lrelu.cpp:20,217) and the PyTorch-level renderer / conv / optimiser code that has no
+ * native counterpart there.  INTEGRATION.md shows the reference-side binding for each.
+ */
+#ifndef SPI_HIP_H
+#define SPI_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* spi_stream_t;           /* hipStream_t */
+
+#define SPI_OK               0
+#define SPI_ERR_BAD_ARG     -1        /* invalid size / null pointer / unsupported combination */
+#define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
+#define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
+
+#define SPI_ABI_VERSION 1
+int         spi_abi_version(void);
+const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
+
+/* activation ids: same numbering as bias_act.py:22-32 `cuda_idx` */
+enum { SPI_ACT_LINEAR = 1, SPI_ACT_RELU, SPI_ACT_LRELU, SPI_ACT_TANH, SPI_ACT_SIGMOID, SPI_ACT_ELU,
+       SPI_ACT_SELU, SPI_ACT_SOFTPLUS, SPI_ACT_SWISH };
+
+/* ------------------------------------------------------------------------------------------------
+ * Volumetric renderer (eg3d/training/volumetric_rendering/*.py -- pure PyTorch in the reference)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* RaySampler.forward, ray_sampler.py:24-63.  cam2world [N,16], intrinsics [N,9] -> ray_o, ray_d [N,res*res,3]. */
+int spi_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res,
+                    float* ray_o, float* ray_d, spi_stream_t stream);
+
+/* sample_stratified scalar branch, renderer.py:188-190: t = start + (k + xi) * (end-start)/(S-1).
+ * xi, depths: [n_rays, S]. */
+int spi_coarse_depths(const float* xi, int64_t n_rays, int S, float ray_start, float ray_end,
+                      float* depths, spi_stream_t stream);
+
+/* planes [NP, C, H, W] <-> channels-last [NP, H, W, C] (one 128-B line per texel when C = 32). */
+int spi_nchw_to_nhwc(const float* src, float* dst, int NP, int C, int H, int W, spi_stream_t stream);
+int spi_nhwc_to_nchw(const float* src, float* dst, int NP, int C, int H, int W, spi_stream_t stream);
+
+/* sample_from_planes + OSGDecoder.forward fused: renderer.py:55-65 + triplane.py:123-135.
+ *   planes_nhwc [N,3,H,W,32];  points are either explicit `coords` [N,P,3] (ray_o = NULL) or
+ *   ray_o/ray_d [N,M,3] + depths [N,M,S] with P = M*S.
+ *   w1t [32,64] (= (W1 * weight_gain)^T), b1 [64], w2 [33,64], b2 [33]: decoder weights ALREADY
+ *   multiplied by their weight_gain / bias_gain (networks_stylegan2.py:115-120).
+ *   out: rgb / sigma rows.  Plain mode (out_S = 0): rgb [N,P,32], sigma [N,P].  Rays mode with
+ *   out_S > 0: the point (ray r, sample k) goes to row r*out_S + out_off + k, so the coarse and
+ *   fine passes fill one [R, Sc+Sf, .] buffer (the torch.cat of renderer.py:158-160 never happens). */
+int spi_triplane_decode_fwd(const float* planes_nhwc, const float* coords, const float* ray_o,
+                            const float* ray_d, const float* depths, const float* w1t, const float* b1,
+                            const float* w2, const float* b2, int N, int64_t P, int S, int H, int W,
+                            float box_warp, int out_S, int out_off, float* rgb, float* sigma,
+                            spi_stream_t stream);
+
+/* Backward of the above.  d_planes_nhwc [N,3,H,W,32] is ACCUMULATED into (zero it first);
+ * if dump_act != NULL (decoder weights need grads) the kernel writes per-point rows
+ * [f(32) | h(64) | d_pre1(64) | d_y(33) | pad(7)] = 200 floats so the caller can form
+ * dW1 = d_pre1^T f, dW2 = d_y^T h with a plain GEMM.  (Actual dump layout is column-major:
+ * [193][N*P] with rows f 0..31, h 32..95, d_pre1 96..159, d_y 160..192.)
+ * d_rgb / d_sigma use the same (out_S, out_off) row mapping as the forward outputs. */
+int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const float* ray_o,
+                            const float* ray_d, const float* depths, const float* w1t, const float* b1,
+                            const float* w2, const float* b2, const float* d_rgb, const float* d_sigma,
+                            int N, int64_t P, int S, int H, int W, float box_warp, int out_S, int out_off,
+                            float* d_planes_nhwc, float* dump_act, spi_stream_t stream);
+
+/* min / max over a depth tensor (ray_marcher.py:50 clamps to the GLOBAL range).  out[2] = {min,max}. */
+int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream);
+
+/* MipRayMarcher2.run_forward, ray_marcher.py:25-57.  One launch = R rays of S sorted samples.
+ *   colors [R,S_store,C] (C = 32), densities [R,S_store] with S_store >= S rows kept per ray;
+ *   depths [R,S] sorted; perm (optional, int32 [R,S]): sample k of ray r is row perm[r,k] of
+ *   colors/densities (identity if NULL) -- this folds unify_samples' three gathers
+ *   (renderer.py:157-167) into the march.
+ *   clamp2 -> {min,max} from spi_minmax.  rgb [R,C] may be NULL (coarse pass wants weights only).
+ *   out: rgb [R,C] (scaled to [-1,1]), depth [R], weights [R,S-1], wsum [R] (any may be NULL). */
+int spi_raymarch_fwd(const float* colors, const float* densities, const float* depths,
+                     const int32_t* perm, const float* clamp2, int64_t R, int S, int S_store, int C,
+                     int white_back, float* rgb, float* depth, float* weights, float* wsum,
+                     spi_stream_t stream);
+
+/* Backward: d_rgb [R,C], d_depth [R] (NULL = 0), d_weights [R,S-1] (NULL = 0) ->
+ * d_colors [R,S,C], d_densities [R,S] written through perm like the forward reads. */
+int spi_raymarch_bwd(const float* colors, const float* densities, const float* depths,
+                     const int32_t* perm, const float* clamp2, const float* d_rgb, const float* d_depth,
+                     const float* d_weights, int64_t R, int S, int S_store, int C, int white_back,
+                     float* d_colors, float* d_densities, spi_stream_t stream);
+
+/* sample_importance + sample_pdf, renderer.py:194-253.  depths [R,S], weights [R,S-1], u [R,Sf]
+ * -> fine depths [R,Sf] (unsorted). */
+int spi_importance_sample(const float* depths, const float* weights, const float* u, int64_t R, int S,
+                          int Sf, float* fine, spi_stream_t stream);
+
+/* unify_samples' sort, renderer.py:157-163: concat coarse [R,Sc] + fine [R,Sf], ascending stable
+ * sort.  out: sorted depths [R,Sc+Sf], perm int32 [R,Sc+Sf] (index into the concatenation). */
+int spi_merge_sort_depths(const float* coarse, const float* fine, int64_t R, int Sc, int Sf,
+                          float* sorted, int32_t* perm, spi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * StyleGAN2 operator layer (eg3d/torch_utils/ops/*.cu)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* bias_act.cpp:36 `bias_act(x,b,xref,yref,dy,grad,dim,act,alpha,gain,clamp)`; kernel bias_act.cu:27-151.
+ *   grad = 0: y = clamp(act(x + b) * gain)        (x = input)
+ *   grad = 1: dx = dy * d/dx                        (x = dy; xref/yref = saved input/output)
+ *   grad = 2: second-order term                     (x = d_dx; dy = first-order dy)
+ * b (len sizeB, may be NULL) is indexed (i / stepB) % sizeB.  clamp < 0 disables clamping. */
+int spi_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy,
+                 float* y, int64_t n, int sizeB, int64_t stepB, int grad, int act, float alpha,
+                 float gain, float clamp, spi_stream_t stream);
+
+/* upfirdn2d.cpp:20 `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`.
+ *   x [N,C,inH,inW] (dense NCHW), f [fH,fW]; y [N,C,outH,outW] with the reference's output-size rule.
+ * Optional fused epilogue (NULL / act = 0 disables): y = bias_act(y + noise[outH,outW]*noise_gain[0], bias[C]). */
+int spi_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int inH, int inW, int fH,
+                  int fW, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
+                  int pady1, int flip, float gain, int outH, int outW,
+                  const float* noise, const float* noise_gain, const float* bias, int act, float alpha,
+                  float act_gain, float clamp, spi_stream_t stream);
+
+/* filtered_lrelu.cpp:20 `filtered_lrelu(x,fu,fd,b,si,up,down,px0,px1,py0,py1,sx,sy,gain,slope,clamp,flip,writeSigns)`
+ * forward without sign tensors: bias -> up-FIR(gain up^2) -> lrelu*gain, clamp -> down-FIR.
+ * tmp must hold N*C*midH*midW floats (mid = upsampled+filtered size). */
+int spi_filtered_lrelu(const float* x, const float* fu, const float* fd, const float* b, float* tmp,
+                       float* y, int N, int C, int inH, int inW, int fuH, int fuW, int fdH, int fdW,
+                       int up, int down, int px0, int px1, int py0, int py1, float gain, float slope,
+                       float clamp, int flip, int outH, int outW, spi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Dense convolutions on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ * Replaces conv2d_gradfix.conv2d / conv_transpose2d with groups = batch as modulated_conv2d uses
+ * them (networks_stylegan2.py:85-88, conv2d_resample.py:114-136) and the plain convs of the VGG losses.
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct spi_conv_desc {
+    int N, I, O;              /* batch, in / out channels                                              */
+    int H, W;                 /* input spatial size                                                    */
+    int kh, kw;               /* kernel size (1 or 3)                                                  */
+    int pad;                  /* zero padding (stride-1 mode)                                          */
+    int transposed;           /* 0: correlation, stride 1; 1: conv_transpose2d stride 2, padding 0     */
+    int flip;                 /* 1: spatially flip the kernel (true convolution)                       */
+    int64_t w_batch_stride;   /* elements between per-sample weights; 0 = weights shared by the batch  */
+    /* fused epilogue of the forward (all optional): y = clamp(act(acc + noise*noise_gain + bias)*gain) */
+    const float* bias;        /* [O] */
+    const float* noise;       /* [OH,OW] */
+    const float* noise_gain;  /* [1] device scalar */
+    int act; float alpha, gain, clamp;
+} spi_conv_desc;
+/* weight layout: [O, I, kh, kw] in both modes (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).
+ * output size: stride-1: H + 2*pad - kh + 1;  transposed: 2*H + kh - 2  (= 2H+1 for 3x3).          */
+int spi_conv2d_fwd  (const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream);
+int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, float* dx, spi_stream_t stream);
+/* dw has the layout/batching of w; with shared weights the batch is summed. */
+int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, float* dw, spi_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses / optimiser helpers
+ * ---------------------------------------------------------------------------------------------- */
+
+/* rotate(), spi/utils/rotate.py:56-116: depth-guided warp of the source view into the target view.
+ *   tgt_cam, src_cam [N,25]; tgt_depth, src_depth [N,dres,dres] (bilinearly resized to res inside);
+ *   src_image [N,3,res,res]; src_mask [N,res,res] or NULL.  out: warp_rgb [N,3,res,res], warp_mask [N,res,res].
+ *   src_cam_inv [N,16]: inverse of the source cam2world (host-side torch.inverse). */
+int spi_rotate_warp(const float* tgt_cam, const float* src_cam_inv, const float* src_cam,
+                    const float* tgt_depth, const float* src_depth, const float* src_image,
+                    const float* src_mask, int N, int res, int dres, float eps,
+                    float* warp_rgb, float* warp_mask, spi_stream_t stream);
+
+/* LPIPS tail, lpips.py:43-65 + utils.py:6-8: per layer, out[n] += mean_hw( sum_c lin[c] *
+ * (fx/(|fx|+1e-10) - fy/(|fy|+1e-10))^2 ).  fx, fy [N,C,HW]. */
+int spi_lpips_layer_fwd(const float* fx, const float* fy, const float* lin, int N, int C, int64_t HW,
+                        float* out, spi_stream_t stream);
+/* d_out [N] -> d_fx [N,C,HW] (fy treated as constant). */
+int spi_lpips_layer_bwd(const float* fx, const float* fy, const float* lin, const float* d_out, int N,
+                        int C, int64_t HW, float* d_fx, spi_stream_t stream);
+
+/* torch.optim.Adam (no amsgrad, no weight decay) over a list of tensors in one launch.
+ *   ptrs: device array of 4*T pointers {param, grad, exp_avg, exp_avg_sq} per tensor; sizes: device int64 [T].
+ *   step is the 1-based step count used for bias correction. */
+int spi_adam_multi(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, float lr, float beta1,
+                   float beta2, float eps, int step, spi_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPI_HIP_H */

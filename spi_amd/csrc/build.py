@@ -1,0 +1,54 @@
+"""Build libspi_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU).
+
+    python -m spi_amd.csrc.build [--force]
+"""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+SOURCES = ['elementwise.hip', 'render.hip', 'conv.hip']
+LIB = os.path.join(HERE, 'libspi_hip.so')
+STAMP = os.path.join(HERE, '.build_stamp')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-comment',
+         '-Wno-pass-failed', '-I' + os.path.join(ROOT, 'include'), '-I' + HERE]
+
+
+def _digest():
+    h = hashlib.sha256(' '.join(FLAGS).encode())
+    for name in SOURCES + ['common.hpp', os.path.join(ROOT, 'include', 'spi_hip.h')]:
+        with open(os.path.join(HERE, name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+        return LIB
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, src.replace('.hip', '.o'))
+        objs.append(obj)
+        cmd = [hipcc] + FLAGS + ['-c', os.path.join(HERE, src), '-o', obj]
+        if verbose:
+            print('[spi_amd build]', ' '.join(cmd), flush=True)
+        procs.append(subprocess.Popen(cmd))
+    for p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed')
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print('[spi_amd build]', ' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(STAMP, 'w') as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

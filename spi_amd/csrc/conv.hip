@@ -1,0 +1,483 @@
+// Dense convolutions on the gfx950 matrix cores: implicit-GEMM forward / data-gradient and
+// weight-gradient kernels built on v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//
+// One generic formulation covers every conv on SPI's path (modulated 3x3 / 1x1 convs with
+// per-sample weights = "groups = batch" in networks_stylegan2.py:85-88, the stride-2 transposed
+// 3x3 of the up-sampling layers, conv2d_resample.py:114-131, their data / weight gradients, and the
+// shared-weight VGG convs of the losses):
+//
+//   Out[n, m, (Y*osy+ooy, X*osx+oox)] = sum_{c < Ci} sum_{t < T} A[n, m, c, t] * In[n, c, Y*isy + dy_t, X*isx + dx_t]
+//
+// with zero outside the input, A addressed through strides (wsm, wsc, widx_t).  A stride-2
+// transposed conv is four such problems (one per output parity class, 4+2+2+1 taps): no
+// multiplications by inserted zeros.  GEMM view: M = out channels, N = pixels, K = Ci*T.
+//   - block tile BM x BN x 16, waves in a WM x WN grid, each wave TM x TN tiles of 32x32
+//   - A/B slabs staged through LDS as [k][m] / [k][p] (row stride +4 floats: <= 2-way write
+//     conflicts, conflict-free fragment reads), register-prefetched double buffer
+//   - epilogue (noise, bias, activation, gain, clamp) applied to the accumulators in registers
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int MAXT = 9;
+
+struct TapSet { int T; int dy[MAXT]; int dx[MAXT]; int widx[MAXT]; };
+
+struct ClassParams {        // one output parity class
+    int OHp, OWp;           // class pixel grid
+    int ooy, oox;           // output offset
+    TapSet taps;
+    unsigned magicT;        // ceil(2^32 / T): k / T == umulhi(k, magicT) for k*T < 2^32
+};
+
+struct IGemmParams {
+    int N, Mo, Ci;
+    int IH, IW, OH, OW;
+    int isy, isx, osy, osx;
+    int64_t wbs; int wsm, wsc;
+    int64_t in_bs, out_bs;
+    int ncls;
+    ClassParams cls[4];
+};
+
+// k -> (channel, tap) for k = c*T + t.  T == 1 is special-cased (ceil(2^32/1) does not fit 32 bits).
+__device__ __forceinline__ void split_k(int k, int T, unsigned magic, int& c, int& t) {
+    if (T == 1) { c = k; t = 0; }
+    else { c = (int)__umulhi((unsigned)k, magic); t = k - c * T; }
+}
+
+struct Epilogue { const float* bias; const float* noise; const float* noise_gain; int act; float alpha, gain, clamp; };
+
+__device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
+    switch (e.act) {
+    case SPI_ACT_LINEAR: break;
+    case SPI_ACT_RELU: v = fmaxf(v, 0.f); break;
+    case SPI_ACT_LRELU: v = v > 0.f ? v : v * e.alpha; break;
+    default: break;
+    }
+    v *= e.gain;
+    if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
+    return v;
+}
+
+// -------------------------------------------------------------------------------------------------
+// forward / dgrad implicit GEMM
+// -------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in,
+                                                            const float* __restrict__ wgt, float* __restrict__ out,
+                                                            Epilogue ep) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
+    constexpr int A_MSTEP = NT / BK;          // rows of m covered per pass (k fastest)
+    constexpr int B_KSTEP = NT / BN;          // k rows covered per pass (p fastest)
+    static_assert(A_PER >= 1 && B_PER >= 1 && NT % BK == 0 && NT % BN == 0 || NT < BN, "tile/threads mismatch");
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n = blockIdx.z / P.ncls, ci = blockIdx.z % P.ncls;
+    const ClassParams& C = P.cls[ci];
+    const int npix = C.OHp * C.OWp;
+    const int p0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    if (p0 >= npix) return;
+    const int K = P.Ci * C.taps.T;
+    const float* inb = in + (int64_t)n * P.in_bs;
+    const float* wb = wgt + (int64_t)n * P.wbs;
+
+    // ---- per-thread load coordinates -------------------------------------------------------------
+    const int a_k = tid % BK;                      // k within slab (fixed per thread)
+    const int a_m = tid / BK;                      // first m row
+    int b_p, b_k;                                  // pixel within tile, first k row
+    if (NT >= BN) { b_p = tid % BN; b_k = tid / BN; } else { b_p = tid; b_k = 0; }
+    int iy0[(NT >= BN) ? 1 : BN / NT], ix0[(NT >= BN) ? 1 : BN / NT];
+    bool pv[(NT >= BN) ? 1 : BN / NT];
+    constexpr int B_PCH = (NT >= BN) ? 1 : BN / NT;        // pixels per thread when the block is narrower than the tile
+#pragma unroll
+    for (int q = 0; q < B_PCH; ++q) {
+        const int p = p0 + b_p + q * NT;
+        pv[q] = p < npix;
+        const int Y = pv[q] ? p / C.OWp : 0, X = pv[q] ? p - Y * C.OWp : 0;
+        iy0[q] = Y * P.isy; ix0[q] = X * P.isx;
+    }
+    constexpr int B_KPER = (NT >= BN) ? B_PER : BK;        // k rows each thread loads per pixel
+    constexpr int B_KST = (NT >= BN) ? B_KSTEP : 1;
+
+    float ra[A_PER], rb[B_PCH * B_KPER];
+    auto load_slab = [&](int k0) {
+        {   // A: weights
+            const int k = k0 + a_k;
+            const bool kv = k < K;
+            int c = 0, t = 0;
+            if (kv) split_k(k, C.taps.T, C.magicT, c, t);
+            const int koff = c * P.wsc + C.taps.widx[t];
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) {
+                const int m = m0 + a_m + j * A_MSTEP;
+                ra[j] = (kv && m < P.Mo) ? wb[(int64_t)m * P.wsm + koff] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < B_KPER; ++j) {   // B: gathered input
+            const int k = k0 + b_k + j * B_KST;
+            const bool kv = k < K;
+            int c = 0, t = 0;
+            if (kv) split_k(k, C.taps.T, C.magicT, c, t);
+            const int dy = C.taps.dy[t], dx = C.taps.dx[t];
+            const float* ic = inb + (int64_t)c * P.IH * P.IW;
+#pragma unroll
+            for (int q = 0; q < B_PCH; ++q) {
+                const int iy = iy0[q] + dy, ix = ix0[q] + dx;
+                const bool ok = kv && pv[q] && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW;
+                rb[q * B_KPER + j] = ok ? ic[(int64_t)iy * P.IW + ix] : 0.f;
+            }
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + j * A_MSTEP] = ra[j];
+#pragma unroll
+        for (int j = 0; j < B_KPER; ++j)
+#pragma unroll
+            for (int q = 0; q < B_PCH; ++q) Bs[buf][(b_k + j * B_KST) * LDB + b_p + q * NT] = rb[q * B_KPER + j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nslab = (K + BK - 1) / BK;
+    load_slab(0);
+    store_slab(0);
+    __syncthreads();
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) load_slab((s + 1) * BK);
+        const float* Ab = As[buf] + wm * TM * 32 + fr;
+        const float* Bb = Bs[buf] + wn * TN * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * kk + fk) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * kk + fk) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel)
+    const float ng = ep.noise ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
+    float* ob = out + (int64_t)n * P.out_bs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int p = p0 + (wn * TN + j) * 32 + fr;
+        if (p >= npix) continue;
+        const int Y = p / C.OWp, X = p - Y * C.OWp;
+        const int oy = Y * P.osy + C.ooy, ox = X * P.osx + C.oox;
+        const int64_t opix = (int64_t)oy * P.OW + ox;
+        const float nz = ep.noise ? ep.noise[opix] * ng : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (m < P.Mo) {
+                    float v = acc[i][j][r] + nz;
+                    if (ep.bias) v += ep.bias[m];
+                    if (ep.act) v = epilogue_act(ep, v);
+                    ob[(int64_t)m * P.OH * P.OW + opix] = v;
+                }
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight gradient: dA[n, m, c, t] = sum_pixels dOut[n, m, out(Y,X)] * In[n, c, in(Y,X,t)]
+//   GEMM: rows m, columns j = c*T + t, reduction over class pixels (split across blockIdx.x, fp32
+//   atomics into a zeroed dA).
+// -------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in,
+                                                            const float* __restrict__ dout, float* __restrict__ dw,
+                                                            int pix_per_block) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
+    constexpr int ROWSTEP = NT / BK;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int n = blockIdx.z / P.ncls, ci = blockIdx.z % P.ncls;
+    const ClassParams& C = P.cls[ci];
+    const int npix = C.OHp * C.OWp;
+    const int Kc = P.Ci * C.taps.T;                       // columns of this class
+    const int ntile_n = (Kc + BN - 1) / BN;
+    const int m0 = (blockIdx.y / ntile_n) * BM, j0 = (blockIdx.y % ntile_n) * BN;
+    const int pbeg = blockIdx.x * pix_per_block, pend = min(pbeg + pix_per_block, npix);
+    if (pbeg >= npix) return;
+    const float* inb = in + (int64_t)n * P.in_bs;
+    const float* dob = dout + (int64_t)n * P.out_bs;
+
+    const int l_p = tid % BK;                  // pixel within slab
+    const int l_r = tid / BK;                  // first row (m for A, column j for B)
+    // column -> (c, t) is fixed per thread across the whole loop
+    int bc[B_PER], bdy[B_PER], bdx[B_PER]; bool bv[B_PER];
+#pragma unroll
+    for (int q = 0; q < B_PER; ++q) {
+        const int j = j0 + l_r + q * ROWSTEP;
+        bv[q] = j < Kc;
+        int c = 0, t = 0;
+        if (bv[q]) split_k(j, C.taps.T, C.magicT, c, t);
+        bc[q] = c; bdy[q] = C.taps.dy[t]; bdx[q] = C.taps.dx[t];
+    }
+    float ra[A_PER], rb[B_PER];
+    auto load_slab = [&](int pk) {
+        const int p = pk + l_p;
+        const bool pvld = p < pend;
+        const int Y = pvld ? p / C.OWp : 0, X = pvld ? p - Y * C.OWp : 0;
+        const int64_t opix = (int64_t)(Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox);
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) {
+            const int m = m0 + l_r + q * ROWSTEP;
+            ra[q] = (pvld && m < P.Mo) ? dob[(int64_t)m * P.OH * P.OW + opix] : 0.f;
+        }
+        const int iyb = Y * P.isy, ixb = X * P.isx;
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) {
+            const int iy = iyb + bdy[q], ix = ixb + bdx[q];
+            const bool ok = pvld && bv[q] && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW;
+            rb[q] = ok ? inb[((int64_t)bc[q] * P.IH + iy) * P.IW + ix] : 0.f;
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < A_PER; ++q) As[buf][l_p * LDA + l_r + q * ROWSTEP] = ra[q];
+#pragma unroll
+        for (int q = 0; q < B_PER; ++q) Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = rb[q];
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nslab = (pend - pbeg + BK - 1) / BK;
+    load_slab(pbeg);
+    store_slab(0);
+    __syncthreads();
+    const int fr = lane & 31, fk = lane >> 5;
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) load_slab(pbeg + (s + 1) * BK);
+        const float* Ab = As[buf] + wm * TM * 32 + fr;
+        const float* Bb = Bs[buf] + wn * TN * 32 + fr;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * kk + fk) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * kk + fk) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (s + 1 < nslab) store_slab(buf ^ 1);
+        __syncthreads();
+    }
+    float* dwb = dw + (int64_t)n * P.wbs;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = j0 + (wn * TN + j) * 32 + fr;
+        if (col >= Kc) continue;
+        int c, t;
+        split_k(col, C.taps.T, C.magicT, c, t);
+        const int koff = c * P.wsc + C.taps.widx[t];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (m < P.Mo) atomicAdd(dwb + (int64_t)m * P.wsm + koff, acc[i][j][r]);
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// host side: descriptor -> generic problem
+// =================================================================================================
+static unsigned magic_for(int T) { return (unsigned)(((1ull << 32) + (unsigned)T - 1) / (unsigned)T); }
+
+static int validate(const spi_conv_desc* d, const char* who) {
+    SPI_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    SPI_REQUIRE(d->N > 0 && d->I > 0 && d->O > 0 && d->H > 0 && d->W > 0, "%s: bad sizes", who);
+    SPI_REQUIRE((d->kh == 1 || d->kh == 3) && d->kh == d->kw, "%s: only 1x1 and 3x3 kernels are supported (got %dx%d)", who, d->kh, d->kw);
+    SPI_REQUIRE(d->transposed == 0 || d->transposed == 1, "%s: bad transposed flag", who);
+    SPI_REQUIRE(d->transposed == 0 || d->pad == 0, "%s: transposed mode takes padding 0", who);
+    SPI_REQUIRE(d->pad >= 0 && d->pad < d->kh, "%s: bad padding", who);
+    SPI_REQUIRE((int64_t)d->I * d->kh * d->kw < 65536 && (int64_t)d->O * d->kh * d->kw < 65536, "%s: channel count too large", who);
+    return SPI_OK;
+}
+
+static void out_dims(const spi_conv_desc* d, int& OH, int& OW) {
+    if (d->transposed) { OH = 2 * d->H + d->kh - 2; OW = 2 * d->W + d->kw - 2; }
+    else { OH = d->H + 2 * d->pad - d->kh + 1; OW = d->W + 2 * d->pad - d->kw + 1; }
+}
+
+// widx of tap (ky,kx) honouring the flip flag
+static inline int tap_w(const spi_conv_desc* d, int ky, int kx) {
+    return d->flip ? (d->kh - 1 - ky) * d->kw + (d->kw - 1 - kx) : ky * d->kw + kx;
+}
+
+// forward problem (also the shape of the weight-gradient problem)
+static void make_forward(const spi_conv_desc* d, IGemmParams& P) {
+    int OH, OW; out_dims(d, OH, OW);
+    const int kk = d->kh * d->kw;
+    P.N = d->N; P.Mo = d->O; P.Ci = d->I; P.IH = d->H; P.IW = d->W; P.OH = OH; P.OW = OW;
+    P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->I * d->H * d->W; P.out_bs = (int64_t)d->O * OH * OW;
+    if (!d->transposed) {
+        P.isy = P.isx = P.osy = P.osx = 1; P.ncls = 1;
+        P.wsm = d->I * kk; P.wsc = kk;
+        ClassParams& C = P.cls[0];
+        C.OHp = OH; C.OWp = OW; C.ooy = C.oox = 0; C.taps.T = kk; C.magicT = magic_for(kk);
+        for (int ky = 0; ky < d->kh; ++ky) for (int kx = 0; kx < d->kw; ++kx) {
+            const int t = ky * d->kw + kx;
+            C.taps.dy[t] = ky - d->pad; C.taps.dx[t] = kx - d->pad; C.taps.widx[t] = tap_w(d, ky, kx);
+        }
+    } else {
+        // out[o,Y,X] = sum in[i,y,x] W[o,i,ky,kx], Y = 2y + ky: class (py,px) holds the taps with ky%2==py, kx%2==px
+        P.isy = P.isx = 1; P.osy = P.osx = 2; P.ncls = 0;
+        P.wsm = d->I * kk; P.wsc = kk;
+        for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
+            ClassParams C; C.taps.T = 0;
+            for (int ky = py; ky < d->kh; ky += 2) for (int kx = px; kx < d->kw; kx += 2) {
+                const int t = C.taps.T++;
+                C.taps.dy[t] = -(ky - py) / 2; C.taps.dx[t] = -(kx - px) / 2; C.taps.widx[t] = tap_w(d, ky, kx);
+            }
+            C.OHp = (OH - py + 1) / 2; C.OWp = (OW - px + 1) / 2; C.ooy = py; C.oox = px;
+            if (C.taps.T == 0 || C.OHp <= 0 || C.OWp <= 0) continue;
+            C.magicT = magic_for(C.taps.T);
+            P.cls[P.ncls++] = C;
+        }
+    }
+}
+
+// data-gradient problem: input = dy (O channels, OH x OW), output = dx (I channels, H x W)
+static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
+    int OH, OW; out_dims(d, OH, OW);
+    const int kk = d->kh * d->kw;
+    P.N = d->N; P.Mo = d->I; P.Ci = d->O; P.IH = OH; P.IW = OW; P.OH = d->H; P.OW = d->W;
+    P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->O * OH * OW; P.out_bs = (int64_t)d->I * d->H * d->W;
+    P.osy = P.osx = 1; P.ncls = 1;
+    ClassParams& C = P.cls[0];
+    C.OHp = d->H; C.OWp = d->W; C.ooy = C.oox = 0; C.taps.T = kk; C.magicT = magic_for(kk);
+    if (!d->transposed) {
+        // dx[i,y,x] = sum_{o,ky,kx} W[o,i,ky,kx] dy[o, y - ky + pad, x - kx + pad]
+        P.isy = P.isx = 1; P.wsm = kk; P.wsc = d->I * kk;
+        for (int ky = 0; ky < d->kh; ++ky) for (int kx = 0; kx < d->kw; ++kx) {
+            const int t = ky * d->kw + kx;
+            C.taps.dy[t] = d->pad - ky; C.taps.dx[t] = d->pad - kx; C.taps.widx[t] = tap_w(d, ky, kx);
+        }
+    } else {
+        // dx[i,y,x] = sum_{o,ky,kx} W[o,i,ky,kx] dz[o, 2y + ky, 2x + kx]
+        P.isy = P.isx = 2; P.wsm = kk; P.wsc = d->I * kk;
+        for (int ky = 0; ky < d->kh; ++ky) for (int kx = 0; kx < d->kw; ++kx) {
+            const int t = ky * d->kw + kx;
+            C.taps.dy[t] = ky; C.taps.dx[t] = kx; C.taps.widx[t] = tap_w(d, ky, kx);
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    int maxpix = 0;
+    for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
+    dim3 grid((unsigned)((maxpix + BN - 1) / BN), (unsigned)((P.Mo + BM - 1) / BM), (unsigned)(P.N * P.ncls));
+    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep);
+}
+
+static void dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st) {
+    int maxpix = 0;
+    for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
+    auto blocks = [&](int bm, int bn) { return (int64_t)((maxpix + bn - 1) / bn) * ((P.Mo + bm - 1) / bm) * P.N * P.ncls; };
+    if (P.Mo <= 32) { launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, st); return; }           // 32 x 128 (toRGB, 3 channels)
+    if (blocks(128, 128) >= 384) { launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, st); return; }  // 128 x 128
+    if (blocks(64, 64) >= 192) { launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, st); return; }    // 64 x 64
+    launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, st);                                           // 32 x 32, one wave
+}
+
+extern "C" {
+
+int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream) {
+    int rc = validate(d, "spi_conv2d_fwd"); if (rc) return rc;
+    SPI_REQUIRE(x && w && y, "spi_conv2d_fwd: null tensor");
+    SPI_REQUIRE(d->act == 0 || d->act == SPI_ACT_LINEAR || d->act == SPI_ACT_RELU || d->act == SPI_ACT_LRELU,
+                "spi_conv2d_fwd: fused epilogue supports linear / relu / lrelu only");
+    SPI_REQUIRE(!(d->transposed && (d->bias || d->noise || d->act > SPI_ACT_LINEAR)),
+                "spi_conv2d_fwd: no fused epilogue in transposed mode (the FIR pass owns it)");
+    IGemmParams P; make_forward(d, P);
+    Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
+    dispatch_igemm(P, x, w, y, ep, as_stream(stream));
+    SPI_LAUNCH_CHECK("spi_conv2d_fwd");
+    return SPI_OK;
+}
+
+int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, float* dx, spi_stream_t stream) {
+    int rc = validate(d, "spi_conv2d_dgrad"); if (rc) return rc;
+    SPI_REQUIRE(dy && w && dx, "spi_conv2d_dgrad: null tensor");
+    IGemmParams P; make_dgrad(d, P);
+    Epilogue ep{nullptr, nullptr, nullptr, 0, 0.f, 1.f, -1.f};
+    dispatch_igemm(P, dy, w, dx, ep, as_stream(stream));
+    SPI_LAUNCH_CHECK("spi_conv2d_dgrad");
+    return SPI_OK;
+}
+
+int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, float* dw, spi_stream_t stream) {
+    int rc = validate(d, "spi_conv2d_wgrad"); if (rc) return rc;
+    SPI_REQUIRE(x && dy && dw, "spi_conv2d_wgrad: null tensor");
+    SPI_REQUIRE(d->w_batch_stride == (int64_t)d->O * d->I * d->kh * d->kw || d->N == 1 || d->w_batch_stride == 0,
+                "spi_conv2d_wgrad: w_batch_stride must be 0 or O*I*kh*kw");
+    IGemmParams P; make_forward(d, P);
+    const int64_t wsz = (int64_t)d->O * d->I * d->kh * d->kw;
+    const int64_t nw = (d->w_batch_stride == 0) ? 1 : d->N;
+    hipError_t e = hipMemsetAsync(dw, 0, (size_t)(nw * wsz) * sizeof(float), as_stream(stream));
+    if (e != hipSuccess) { spi_set_error("spi_conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+    // tile 128 x 128; split the pixel reduction so the grid has ~>= 1024 blocks
+    constexpr int BM = 128, BN = 128;
+    int maxpix = 0, maxcols = 0;
+    for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxcols = std::max(maxcols, P.Ci * P.cls[c].taps.T); }
+    const int tiles = ((P.Mo + BM - 1) / BM) * ((maxcols + BN - 1) / BN);
+    int64_t splits = std::max<int64_t>(1, 1024 / std::max<int64_t>(1, (int64_t)tiles * P.N * P.ncls));
+    int ppb = (int)((maxpix + splits - 1) / splits);
+    ppb = std::max(64, ((ppb + BK - 1) / BK) * BK);
+    dim3 grid((unsigned)((maxpix + ppb - 1) / ppb), (unsigned)tiles, (unsigned)(P.N * P.ncls));
+    hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb);
+    SPI_LAUNCH_CHECK("spi_conv2d_wgrad");
+    return SPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,419 @@
+// HBM-bound operator kernels for gfx950: bias_act (all 9 activations, grad orders 0-2), upfirdn2d
+// (+ fused noise / bias / activation epilogue), filtered_lrelu (two fused passes), the depth-guided
+// warp, the LPIPS normalise-diff-lin tail and multi-tensor Adam.  fp32, 16-byte vector accesses
+// wherever the layout allows.
+#include "common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
+
+// ---- error text (thread-local) -------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+void spi_set_error(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+}
+extern "C" const char* spi_last_error(void) { return g_err; }
+extern "C" int spi_abi_version(void) { return SPI_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// bias_act: y = clamp(act(x + b) * gain) and its first / second derivatives expressed through the
+// saved input (xref) / output (yref), as the reference plugin does (bias_act.cu:27-151).
+// ------------------------------------------------------------------------------------------------
+struct ActParams { int act; int grad; float alpha, gain, clamp; };
+
+__device__ __forceinline__ float act_apply(const ActParams& p, float x, float xref, float yref, float dy) {
+    const float yy = (p.gain != 0.f) ? yref / p.gain : 0.f;      // activation output before the gain
+    const int G = p.grad;
+    float y = 0.f;
+    switch (p.act) {
+    case SPI_ACT_LINEAR:
+        y = (G < 2) ? x : 0.f; break;
+    case SPI_ACT_RELU:
+        y = (G == 0) ? fmaxf(x, 0.f) : (G == 1 ? (yy > 0.f ? x : 0.f) : 0.f); break;
+    case SPI_ACT_LRELU:
+        y = (G == 0) ? (x > 0.f ? x : x * p.alpha) : (G == 1 ? (yy > 0.f ? x : x * p.alpha) : 0.f); break;
+    case SPI_ACT_TANH:
+        if (G == 0) { const float c = expf(x), d = 1.f / c; y = (x < -80.f) ? -1.f : (x > 80.f ? 1.f : (c - d) / (c + d)); }
+        else if (G == 1) y = x * (1.f - yy * yy);
+        else y = x * (1.f - yy * yy) * (-2.f * yy);
+        break;
+    case SPI_ACT_SIGMOID:
+        if (G == 0) y = (x < -80.f) ? 0.f : 1.f / (expf(-x) + 1.f);
+        else if (G == 1) y = x * yy * (1.f - yy);
+        else y = x * yy * (1.f - yy) * (1.f - 2.f * yy);
+        break;
+    case SPI_ACT_ELU:
+        if (G == 0) y = (x >= 0.f) ? x : expf(x) - 1.f;
+        else if (G == 1) y = (yy >= 0.f) ? x : x * (yy + 1.f);
+        else y = (yy >= 0.f) ? 0.f : x * (yy + 1.f);
+        break;
+    case SPI_ACT_SELU: {
+        const float sc = 1.0507009873554804934193349852946f, sa = 1.6732632423543772848170429916717f;
+        if (G == 0) y = (x >= 0.f) ? sc * x : (sc * sa) * (expf(x) - 1.f);
+        else if (G == 1) y = (yy >= 0.f) ? x * sc : x * (yy + sc * sa);
+        else y = (yy >= 0.f) ? 0.f : x * (yy + sc * sa);
+        break; }
+    case SPI_ACT_SOFTPLUS:
+        if (G == 0) y = (x > 80.f) ? x : logf(expf(x) + 1.f);
+        else if (G == 1) y = x * (1.f - expf(-yy));
+        else { const float c = expf(-yy); y = x * c * (1.f - c); }
+        break;
+    case SPI_ACT_SWISH:
+        if (G == 0) y = (x < -80.f) ? 0.f : x / (expf(-x) + 1.f);
+        else {
+            const float c = expf(xref), d = c + 1.f;
+            if (G == 1) y = (xref > 40.f) ? x : x * c * (xref + d) / (d * d);
+            else y = (xref > 40.f) ? 0.f : x * c * (xref * (2.f - d) + 2.f * d) / (d * d * d);
+            yref = (xref < -80.f) ? 0.f : xref / (expf(-xref) + 1.f) * p.gain;
+        }
+        break;
+    default: break;
+    }
+    y *= p.gain * dy;
+    if (p.clamp >= 0.f) {
+        if (G == 0) y = fminf(fmaxf(y, -p.clamp), p.clamp);
+        else y = (yref > -p.clamp && yref < p.clamp) ? y : 0.f;
+    }
+    return y;
+}
+
+template <bool VEC>
+__global__ void bias_act_kernel(const float* __restrict__ x, const float* __restrict__ b, const float* __restrict__ xref,
+                                const float* __restrict__ yref, const float* __restrict__ dy, float* __restrict__ y,
+                                int64_t n, int sizeB, int64_t stepB, ActParams p) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC) {      // n % 4 == 0, stepB % 4 == 0: a float4 never straddles a bias boundary
+        const int64_t n4 = n >> 2;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+            const float4 xv = reinterpret_cast<const float4*>(x)[g];
+            const float bv = b ? b[((g << 2) / stepB) % sizeB] : 0.f;
+            float4 xr = xref ? reinterpret_cast<const float4*>(xref)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 yr = yref ? reinterpret_cast<const float4*>(yref)[g] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 dv = dy ? reinterpret_cast<const float4*>(dy)[g] : make_float4(1.f, 1.f, 1.f, 1.f);
+            float4 xa = xv;
+            if (p.grad == 0) { xa.x += bv; xa.y += bv; xa.z += bv; xa.w += bv; }
+            else { xr.x += bv; xr.y += bv; xr.z += bv; xr.w += bv; }
+            float4 o;
+            o.x = act_apply(p, xa.x, xr.x, yr.x, dv.x); o.y = act_apply(p, xa.y, xr.y, yr.y, dv.y);
+            o.z = act_apply(p, xa.z, xr.z, yr.z, dv.z); o.w = act_apply(p, xa.w, xr.w, yr.w, dv.w);
+            reinterpret_cast<float4*>(y)[g] = o;
+        }
+    } else {
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
+            const float bv = b ? b[(g / stepB) % sizeB] : 0.f;
+            float xa = x[g], xr = xref ? xref[g] : 0.f;
+            if (p.grad == 0) xa += bv; else xr += bv;
+            y[g] = act_apply(p, xa, xr, yref ? yref[g] : 0.f, dy ? dy[g] : 1.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// upfirdn2d: out[oy,ox] = gain * sum_t k[ty,tx] * U[oy*down + ty, ox*down + tx], U = zero-inserted,
+// padded input; k = f flipped unless `flip` (upfirdn2d.py:168-213).  Only taps that land on a real
+// sample are visited.  Optional pre-bias (filtered_lrelu step 1) and noise/bias/activation epilogue
+// (SynthesisLayer.forward tail, networks_stylegan2.py:320-329) keep the tensor in registers.
+// ------------------------------------------------------------------------------------------------
+struct UpfirdnParams {
+    int N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, pady0, flip, outH, outW;
+    float gain;
+};
+constexpr int MAX_TAPS = 256;
+
+__global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                        float* __restrict__ y, UpfirdnParams p,
+                                                        const float* __restrict__ pre_bias, const float* __restrict__ noise,
+                                                        const float* __restrict__ noise_gain, const float* __restrict__ bias,
+                                                        ActParams ap) {
+    __shared__ float sf[MAX_TAPS];
+    for (int i = threadIdx.x; i < p.fH * p.fW; i += blockDim.x) {
+        const int ty = i / p.fW, tx = i % p.fW;
+        sf[i] = (p.flip ? f[ty * p.fW + tx] : f[(p.fH - 1 - ty) * p.fW + (p.fW - 1 - tx)]) * p.gain;
+    }
+    __syncthreads();
+    const float ng = (noise && noise_gain) ? noise_gain[0] : (noise ? 1.f : 0.f);
+    const int64_t plane = (int64_t)p.outH * p.outW;
+    const int64_t total = (int64_t)p.N * p.C * plane;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t nc = g / plane;
+        const int rem = (int)(g - nc * plane);
+        const int oy = rem / p.outW, ox = rem - oy * p.outW;
+        const int c = (int)(nc % p.C);
+        const float* xp = x + nc * (int64_t)p.inH * p.inW;
+        const float pb = pre_bias ? pre_bias[c] : 0.f;
+        const int by = oy * p.downy - p.pady0, bx = ox * p.downx - p.padx0;     // U index of tap 0 relative to sample 0
+        int ty0 = (-by) % p.upy; if (ty0 < 0) ty0 += p.upy;
+        int tx0 = (-bx) % p.upx; if (tx0 < 0) tx0 += p.upx;
+        float acc = 0.f;
+        for (int ty = ty0; ty < p.fH; ty += p.upy) {
+            const int iy = (by + ty) / p.upy;
+            if (by + ty < 0 || iy >= p.inH) continue;
+            for (int tx = tx0; tx < p.fW; tx += p.upx) {
+                const int ix = (bx + tx) / p.upx;
+                if (bx + tx < 0 || ix >= p.inW) continue;
+                acc = fmaf(sf[ty * p.fW + tx], xp[(int64_t)iy * p.inW + ix] + pb, acc);
+            }
+        }
+        if (noise) acc += noise[rem] * ng;
+        if (ap.act != 0) acc = act_apply(ap, acc + (bias ? bias[c] : 0.f), 0.f, 0.f, 1.f);
+        y[g] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rotate(): unproject target pixels with the target depth, project into the source camera, sample
+// source depth / image / mask, keep depth-consistent in-frame pixels (spi/utils/rotate.py:5-116).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float resized_depth(const float* __restrict__ d, int dres, int res, int yy, int xx) {
+    // F.interpolate(bilinear, align_corners=False) from dres^2 to res^2, evaluated at integer (yy,xx)
+    if (dres == res) return d[yy * dres + xx];
+    const float sc = (float)dres / (float)res;
+    float sy = fmaxf(((float)yy + 0.5f) * sc - 0.5f, 0.f), sx = fmaxf(((float)xx + 0.5f) * sc - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = min(y0 + 1, dres - 1), x1 = min(x0 + 1, dres - 1);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    return (1.f - ly) * ((1.f - lx) * d[y0 * dres + x0] + lx * d[y0 * dres + x1]) +
+           ly * ((1.f - lx) * d[y1 * dres + x0] + lx * d[y1 * dres + x1]);
+}
+
+struct Bilin { int x0, y0; float w00, w01, w10, w11; bool v00, v01, v10, v11; };
+__device__ __forceinline__ Bilin bilin_setup(float gx, float gy, int res) {
+    const float ix = ((gx + 1.f) * (float)res - 1.f) * 0.5f, iy = ((gy + 1.f) * (float)res - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    Bilin b;
+    b.x0 = (int)fx; b.y0 = (int)fy;
+    const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+    b.w00 = wx0 * wy0; b.w01 = wx1 * wy0; b.w10 = wx0 * wy1; b.w11 = wx1 * wy1;
+    const bool x0ok = b.x0 >= 0 && b.x0 < res, x1ok = b.x0 + 1 >= 0 && b.x0 + 1 < res;
+    const bool y0ok = b.y0 >= 0 && b.y0 < res, y1ok = b.y0 + 1 >= 0 && b.y0 + 1 < res;
+    b.v00 = x0ok && y0ok; b.v01 = x1ok && y0ok; b.v10 = x0ok && y1ok; b.v11 = x1ok && y1ok;
+    return b;
+}
+
+__global__ void rotate_warp_kernel(const float* __restrict__ tgt_cam, const float* __restrict__ src_inv,
+                                   const float* __restrict__ src_cam, const float* __restrict__ tgt_depth,
+                                   const float* __restrict__ src_depth, const float* __restrict__ src_image,
+                                   const float* __restrict__ src_mask, int N, int res, int dres, float eps,
+                                   float* __restrict__ warp_rgb, float* __restrict__ warp_mask) {
+    const int64_t plane = (int64_t)res * res;
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)N * plane) return;
+    const int n = (int)(g / plane);
+    const int rem = (int)(g - n * plane);
+    const int yy = rem / res, xx = rem - yy * res;
+    const float* T = tgt_cam + n * 25; const float* TK = T + 16;
+    const float* SK = src_cam + n * 25 + 16; const float* SI = src_inv + n * 16;
+    const float* td = tgt_depth + (int64_t)n * dres * dres;
+    const float* sd = src_depth + (int64_t)n * dres * dres;
+    const float z = resized_depth(td, dres, res, yy, xx);
+    const float inv = 1.f / (float)res, half = 0.5f / (float)res;
+    const float u = (float)xx * inv + half, v = (float)yy * inv + half;
+    float fx = TK[0], sk = TK[1], cx = TK[2], fy = TK[4], cy = TK[5];
+    const float xl = (u - cx + cy * sk / fy - sk * v / fy) / fx * z;
+    const float yl = (v - cy) / fy * z;
+    float w[4], cam[3];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[r] = T[r * 4 + 0] * xl + T[r * 4 + 1] * yl + T[r * 4 + 2] * z + T[r * 4 + 3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) cam[r] = SI[r * 4 + 0] * w[0] + SI[r * 4 + 1] * w[1] + SI[r * 4 + 2] * w[2] + SI[r * 4 + 3] * w[3];
+    fx = SK[0]; sk = SK[1]; cx = SK[2]; fy = SK[4]; cy = SK[5];
+    const float zc = cam[2];
+    const float yc = cam[1] / zc * fy + cy;
+    const float xc = cam[0] / zc * fx + sk * yc / fy - cy * sk / fy + cx;
+    const float gx = 2.f * xc - 1.f, gy = 2.f * yc - 1.f;
+    const float inside = (gx < -1.f || gx > 1.f || gy < -1.f || gy > 1.f) ? 0.f : 1.f;
+    const Bilin b = bilin_setup(gx, gy, res);
+    float dsrc = 0.f;
+    if (b.v00) dsrc += b.w00 * resized_depth(sd, dres, res, b.y0, b.x0);
+    if (b.v01) dsrc += b.w01 * resized_depth(sd, dres, res, b.y0, b.x0 + 1);
+    if (b.v10) dsrc += b.w10 * resized_depth(sd, dres, res, b.y0 + 1, b.x0);
+    if (b.v11) dsrc += b.w11 * resized_depth(sd, dres, res, b.y0 + 1, b.x0 + 1);
+    float m = (fabsf(dsrc - zc) < eps) ? inside : 0.f;
+    float m2 = 1.f;
+    if (src_mask) {
+        const float* sm = src_mask + (int64_t)n * plane;
+        m2 = 0.f;
+        if (b.v00) m2 += b.w00 * sm[(int64_t)b.y0 * res + b.x0];
+        if (b.v01) m2 += b.w01 * sm[(int64_t)b.y0 * res + b.x0 + 1];
+        if (b.v10) m2 += b.w10 * sm[(int64_t)(b.y0 + 1) * res + b.x0];
+        if (b.v11) m2 += b.w11 * sm[(int64_t)(b.y0 + 1) * res + b.x0 + 1];
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float* im = src_image + ((int64_t)n * 3 + ch) * plane;
+        float s = 0.f;
+        if (b.v00) s += b.w00 * im[(int64_t)b.y0 * res + b.x0];
+        if (b.v01) s += b.w01 * im[(int64_t)b.y0 * res + b.x0 + 1];
+        if (b.v10) s += b.w10 * im[(int64_t)(b.y0 + 1) * res + b.x0];
+        if (b.v11) s += b.w11 * im[(int64_t)(b.y0 + 1) * res + b.x0 + 1];
+        s = s * m;
+        if (src_mask) s = s * m2;
+        warp_rgb[((int64_t)n * 3 + ch) * plane + rem] = s;
+    }
+    warp_mask[g] = src_mask ? m * m2 : m;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LPIPS tail (lpips.py:43-65): unit-normalise both feature stacks over channels, squared
+// difference, 1x1 "lin" weights, spatial mean.  One thread per pixel, channel loop is coalesced
+// across the wave (NCHW).
+// ------------------------------------------------------------------------------------------------
+__global__ void lpips_fwd_kernel(const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ lin,
+                                 int C, int64_t HW, float* __restrict__ out) {
+    const int n = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float val = 0.f;
+    if (p < HW) {
+        const float* a = fx + (int64_t)n * C * HW + p; const float* b = fy + (int64_t)n * C * HW + p;
+        float sa = 0.f, sb = 0.f;
+        for (int c = 0; c < C; ++c) { const float va = a[c * HW], vb = b[c * HW]; sa = fmaf(va, va, sa); sb = fmaf(vb, vb, sb); }
+        const float na = sqrtf(sa) + 1e-10f, nb = sqrtf(sb) + 1e-10f;
+        for (int c = 0; c < C; ++c) { const float d = a[c * HW] / na - b[c * HW] / nb; val = fmaf(lin[c], d * d, val); }
+    }
+    val = wave_sum(val);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out + n, val / (float)HW);
+}
+
+__global__ void lpips_bwd_kernel(const float* __restrict__ fx, const float* __restrict__ fy, const float* __restrict__ lin,
+                                 const float* __restrict__ d_out, int C, int64_t HW, float* __restrict__ d_fx) {
+    const int n = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* a = fx + (int64_t)n * C * HW + p; const float* b = fy + (int64_t)n * C * HW + p;
+    float* o = d_fx + (int64_t)n * C * HW + p;
+    float sa = 0.f, sb = 0.f;
+    for (int c = 0; c < C; ++c) { const float va = a[c * HW], vb = b[c * HW]; sa = fmaf(va, va, sa); sb = fmaf(vb, vb, sb); }
+    const float ra = sqrtf(sa), na = ra + 1e-10f, nb = sqrtf(sb) + 1e-10f;
+    const float gsc = d_out[n] / (float)HW;
+    float dot = 0.f;        // sum_c 2 lin_c (a_c - b_c) fx_c
+    for (int c = 0; c < C; ++c) { const float va = a[c * HW]; const float d = va / na - b[c * HW] / nb; dot = fmaf(2.f * lin[c] * d, va, dot); }
+    const float k2 = (ra > 0.f) ? dot / (ra * na * na) : 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float va = a[c * HW]; const float d = va / na - b[c * HW] / nb;
+        o[c * HW] = gsc * (2.f * lin[c] * d / na - va * k2);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch.optim.Adam (single-tensor semantics of torch 2.x: lerp first moment, addcmul second,
+// denom = sqrt(v)/sqrt(bc2) + eps, p -= lr/bc1 * m/denom) for T tensors in one launch.
+// ------------------------------------------------------------------------------------------------
+__global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float lr, float beta1,
+                                  float beta2, float eps, float bc1, float bc2_sqrt) {
+    const int t = blockIdx.y;
+    const int64_t n = sizes[t];
+    float* p = static_cast<float*>(ptrs[4 * t + 0]);
+    const float* g = static_cast<const float*>(ptrs[4 * t + 1]);
+    float* m = static_cast<float*>(ptrs[4 * t + 2]);
+    float* v = static_cast<float*>(ptrs[4 * t + 3]);
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * (1.f - beta1);
+        vi = vi * beta2 + gi * gi * (1.f - beta2);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = p[i] - step_size * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+
+// ================================================================================================
+extern "C" {
+
+int spi_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y, int64_t n,
+                 int sizeB, int64_t stepB, int grad, int act, float alpha, float gain, float clamp, spi_stream_t stream) {
+    SPI_REQUIRE(x && y && n > 0, "spi_bias_act: null tensor or empty");
+    SPI_REQUIRE(act >= SPI_ACT_LINEAR && act <= SPI_ACT_SWISH, "spi_bias_act: unknown activation %d", act);
+    SPI_REQUIRE(grad >= 0 && grad <= 2, "spi_bias_act: grad must be 0, 1 or 2");
+    SPI_REQUIRE(b == nullptr || (sizeB > 0 && stepB > 0), "spi_bias_act: bias given without sizeB/stepB");
+    ActParams p{act, grad, alpha, gain, clamp};
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)xref | (uintptr_t)yref | (uintptr_t)dy) & 15) == 0;
+    const bool vec = aligned && (n % 4 == 0) && (b == nullptr || stepB % 4 == 0);
+    const int64_t work = vec ? n / 4 : n;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(work, 256), 256 * 16);
+    if (vec) hipLaunchKernelGGL(bias_act_kernel<true>, dim3(grid), dim3(256), 0, as_stream(stream), x, b, xref, yref, dy, y, n, sizeB, stepB, p);
+    else hipLaunchKernelGGL(bias_act_kernel<false>, dim3(grid), dim3(256), 0, as_stream(stream), x, b, xref, yref, dy, y, n, sizeB, stepB, p);
+    SPI_LAUNCH_CHECK("spi_bias_act");
+    return SPI_OK;
+}
+
+static int launch_upfirdn(const float* x, const float* f, float* y, const UpfirdnParams& p, const float* pre_bias,
+                          const float* noise, const float* noise_gain, const float* bias, const ActParams& ap, spi_stream_t stream) {
+    const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
+    SPI_LAUNCH_CHECK("spi_upfirdn2d");
+    return SPI_OK;
+}
+
+int spi_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int inH, int inW, int fH, int fW, int upx, int upy,
+                  int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
+                  const float* noise, const float* noise_gain, const float* bias, int act, float alpha, float act_gain,
+                  float clamp, spi_stream_t stream) {
+    SPI_REQUIRE(x && f && y, "spi_upfirdn2d: null tensor");
+    SPI_REQUIRE(N > 0 && C > 0 && inH > 0 && inW > 0 && fH > 0 && fW > 0 && fH * fW <= MAX_TAPS, "spi_upfirdn2d: bad sizes");
+    SPI_REQUIRE(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, "spi_upfirdn2d: bad up/down factors");
+    const int eh = (inH * upy + pady0 + pady1 - fH + downy) / downy, ew = (inW * upx + padx0 + padx1 - fW + downx) / downx;
+    SPI_REQUIRE(outH == eh && outW == ew && outH > 0 && outW > 0, "spi_upfirdn2d: output size must be %dx%d, got %dx%d", eh, ew, outH, outW);
+    SPI_REQUIRE(act >= 0 && act <= SPI_ACT_SWISH, "spi_upfirdn2d: unknown activation");
+    UpfirdnParams p{N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, pady0, flip, outH, outW, gain};
+    ActParams ap{act, 0, alpha, act_gain, clamp};
+    return launch_upfirdn(x, f, y, p, nullptr, noise, noise_gain, bias, ap, stream);
+}
+
+int spi_filtered_lrelu(const float* x, const float* fu, const float* fd, const float* b, float* tmp, float* y, int N, int C,
+                       int inH, int inW, int fuH, int fuW, int fdH, int fdW, int up, int down, int px0, int px1, int py0, int py1,
+                       float gain, float slope, float clamp, int flip, int outH, int outW, spi_stream_t stream) {
+    SPI_REQUIRE(x && fu && fd && tmp && y, "spi_filtered_lrelu: null tensor");
+    SPI_REQUIRE(up >= 1 && down >= 1 && fuH * fuW <= MAX_TAPS && fdH * fdW <= MAX_TAPS, "spi_filtered_lrelu: bad factors / filter too large");
+    const int midH = inH * up + py0 + py1 - fuH + 1, midW = inW * up + px0 + px1 - fuW + 1;
+    const int eh = (midH - fdH + down) / down, ew = (midW - fdW + down) / down;
+    SPI_REQUIRE(midH > 0 && midW > 0 && outH == eh && outW == ew, "spi_filtered_lrelu: output size must be %dx%d", eh, ew);
+    UpfirdnParams p1{N, C, inH, inW, fuH, fuW, up, up, 1, 1, px0, py0, flip, midH, midW, (float)(up * up)};
+    ActParams a1{SPI_ACT_LRELU, 0, slope, gain, clamp};
+    int rc = launch_upfirdn(x, fu, tmp, p1, b, nullptr, nullptr, nullptr, a1, stream);
+    if (rc) return rc;
+    UpfirdnParams p2{N, C, midH, midW, fdH, fdW, 1, 1, down, down, 0, 0, flip, outH, outW, 1.f};
+    ActParams a2{0, 0, 0.f, 1.f, -1.f};
+    return launch_upfirdn(tmp, fd, y, p2, nullptr, nullptr, nullptr, nullptr, a2, stream);
+}
+
+int spi_rotate_warp(const float* tgt_cam, const float* src_cam_inv, const float* src_cam, const float* tgt_depth,
+                    const float* src_depth, const float* src_image, const float* src_mask, int N, int res, int dres, float eps,
+                    float* warp_rgb, float* warp_mask, spi_stream_t stream) {
+    SPI_REQUIRE(tgt_cam && src_cam_inv && src_cam && tgt_depth && src_depth && src_image && warp_rgb && warp_mask, "spi_rotate_warp: null tensor");
+    SPI_REQUIRE(N > 0 && res > 0 && dres > 0, "spi_rotate_warp: bad sizes");
+    const int64_t total = (int64_t)N * res * res;
+    hipLaunchKernelGGL(rotate_warp_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, as_stream(stream), tgt_cam,
+                       src_cam_inv, src_cam, tgt_depth, src_depth, src_image, src_mask, N, res, dres, eps, warp_rgb, warp_mask);
+    SPI_LAUNCH_CHECK("spi_rotate_warp");
+    return SPI_OK;
+}
+
+int spi_lpips_layer_fwd(const float* fx, const float* fy, const float* lin, int N, int C, int64_t HW, float* out, spi_stream_t stream) {
+    SPI_REQUIRE(fx && fy && lin && out && N > 0 && C > 0 && HW > 0, "spi_lpips_layer_fwd: bad argument");
+    hipLaunchKernelGGL(lpips_fwd_kernel, dim3((unsigned)ceil_div64(HW, 256), (unsigned)N), dim3(256), 0, as_stream(stream), fx, fy, lin, C, HW, out);
+    SPI_LAUNCH_CHECK("spi_lpips_layer_fwd");
+    return SPI_OK;
+}
+
+int spi_lpips_layer_bwd(const float* fx, const float* fy, const float* lin, const float* d_out, int N, int C, int64_t HW,
+                        float* d_fx, spi_stream_t stream) {
+    SPI_REQUIRE(fx && fy && lin && d_out && d_fx && N > 0 && C > 0 && HW > 0, "spi_lpips_layer_bwd: bad argument");
+    hipLaunchKernelGGL(lpips_bwd_kernel, dim3((unsigned)ceil_div64(HW, 256), (unsigned)N), dim3(256), 0, as_stream(stream), fx, fy, lin, d_out, C, HW, d_fx);
+    SPI_LAUNCH_CHECK("spi_lpips_layer_bwd");
+    return SPI_OK;
+}
+
+int spi_adam_multi(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, float lr, float beta1, float beta2,
+                   float eps, int step, spi_stream_t stream) {
+    SPI_REQUIRE(ptrs && sizes && T > 0 && max_size > 0 && step >= 1, "spi_adam_multi: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    const unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(max_size, 256 * 4), 2048);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)T), dim3(256), 0, as_stream(stream), ptrs, sizes, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    SPI_LAUNCH_CHECK("spi_adam_multi");
+    return SPI_OK;
+}
+
+}  // extern "C"

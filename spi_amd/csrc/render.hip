@@ -1,0 +1,790 @@
+// Volumetric renderer kernels for gfx950 (wave64): ray sampler, tri-plane gather + OSG decoder
+// (forward / backward), hierarchical importance resampling, depth merge-sort, alpha-composite ray
+// march (forward / backward).  Reference semantics: eg3d/training/volumetric_rendering/*.py and
+// eg3d/training/triplane.py:112-135 (cited per kernel).  All fp32.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// RaySampler.forward (ray_sampler.py:24-63): one thread per ray.
+// ------------------------------------------------------------------------------------------------
+__global__ void ray_sampler_kernel(const float* __restrict__ c2w, const float* __restrict__ K, int N, int res,
+                                   float* __restrict__ ro, float* __restrict__ rd) {
+    const int M = res * res;
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)N * M) return;
+    const int n = (int)(g / M), m = (int)(g % M);
+    const int i = m / res, j = m % res;
+    const float* A = c2w + n * 16;
+    const float* Kn = K + n * 9;
+    const float fx = Kn[0], sk = Kn[1], cx = Kn[2], fy = Kn[4], cy = Kn[5];
+    const float inv = 1.f / (float)res, half = 0.5f / (float)res;
+    const float u = (float)j * inv + half, v = (float)i * inv + half;
+    const float x = (u - cx + cy * sk / fy - sk * v / fy) / fx;
+    const float y = (v - cy) / fy;
+    float w[3], o[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        o[r] = A[r * 4 + 3];
+        w[r] = A[r * 4 + 0] * x + A[r * 4 + 1] * y + A[r * 4 + 2] + A[r * 4 + 3];
+        w[r] -= o[r];
+    }
+    const float nrm = fmaxf(sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), 1e-12f);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        ro[g * 3 + r] = o[r];
+        rd[g * 3 + r] = w[r] / nrm;
+    }
+}
+
+__global__ void coarse_depths_kernel(const float* __restrict__ xi, int64_t total, int S, float start, float end,
+                                     float* __restrict__ out) {
+    // torch.linspace(start, end, S) is symmetric: step*k from the start for the first half,
+    // end - step*(S-1-k) for the second half (ATen RangeFactories); reproduce that rounding.
+    const float step = (end - start) / (float)(S - 1);
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(g % S);
+        const float base = (k < S / 2) ? start + step * (float)k : end - step * (float)(S - 1 - k);
+        out[g] = base + xi[g] * step;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NCHW <-> NHWC plane relayout through a 32x33 LDS tile (channels-last makes every bilinear corner
+// one 128-byte line when C = 32).
+// ------------------------------------------------------------------------------------------------
+template <bool TO_NHWC>
+__global__ void relayout_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int64_t HW) {
+    __shared__ float tile[32][33];
+    const int64_t np = blockIdx.z;
+    const int64_t p0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 32 x 8
+    if (TO_NHWC) {
+        for (int r = ty; r < 32; r += 8) {                          // r: channel, tx: pixel
+            const int c = c0 + r; const int64_t p = p0 + tx;
+            tile[r][tx] = (c < C && p < HW) ? src[(np * C + c) * HW + p] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {                          // r: pixel, tx: channel
+            const int c = c0 + tx; const int64_t p = p0 + r;
+            if (c < C && p < HW) dst[(np * HW + p) * C + c] = tile[tx][r];
+        }
+    } else {
+        for (int r = ty; r < 32; r += 8) {                          // r: pixel, tx: channel
+            const int c = c0 + tx; const int64_t p = p0 + r;
+            tile[r][tx] = (c < C && p < HW) ? src[(np * HW + p) * C + c] : 0.f;
+        }
+        __syncthreads();
+        for (int r = ty; r < 32; r += 8) {                          // r: channel, tx: pixel
+            const int c = c0 + r; const int64_t p = p0 + tx;
+            if (c < C && p < HW) dst[(np * C + c) * HW + p] = tile[tx][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Tri-plane gather + OSG decoder.
+//   256 threads own a tile of 256 points.  Phase A: 8 lanes per point, each lane one float4 of the
+//   32 channels, so every corner fetch is a whole 128-B line (coalesced per 8-lane group);
+//   the interpolated, plane-averaged feature goes to LDS (row stride 36 floats: conflict-free b128).
+//   Phase B: one point per lane, decoder weights are wave-uniform -> scalar loads + v_fmac with an
+//   SGPR operand.  Outputs return through LDS so global stores are full lines again.
+// ------------------------------------------------------------------------------------------------
+constexpr int DT = 256;        // points per tile == threads per block
+constexpr int FS = 36;         // LDS row stride (floats)
+constexpr int DEC_IN = 32, DEC_HID = 64, DEC_OUT = 33;
+
+struct DecodeArgs {
+    const float* planes; const float* coords; const float* ray_o; const float* ray_d; const float* depths;
+    int N; int64_t P; int S; int H; int W; float scale;          // scale = 2 / box_warp
+    int out_S; int out_off;                                      // output row mapping (0 = plain)
+};
+
+__device__ __forceinline__ void point_xyz(const DecodeArgs& a, int64_t g, int& n, float& x, float& y, float& z) {
+    n = (int)(g / a.P);
+    const int64_t p = g - (int64_t)n * a.P;
+    if (a.ray_o == nullptr) {
+        const float* c = a.coords + g * 3;
+        x = c[0]; y = c[1]; z = c[2];
+    } else {
+        const int64_t ray = (int64_t)n * (a.P / a.S) + p / a.S;
+        const float t = a.depths[g];
+        const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
+        x = o[0] + t * d[0]; y = o[1] + t * d[1]; z = o[2] + t * d[2];
+    }
+    x *= a.scale; y *= a.scale; z *= a.scale;
+}
+
+__device__ __forceinline__ int64_t out_row(const DecodeArgs& a, int64_t g) {
+    if (a.out_S == 0) return g;
+    const int64_t ray = g / a.S;
+    return ray * a.out_S + a.out_off + (g - ray * a.S);
+}
+
+struct Corner { int x0, y0; float wx0, wx1, wy0, wy1; };
+
+__device__ __forceinline__ Corner make_corner(float gx, float gy, int W, int H) {
+    // grid_sample(align_corners=False): ix = ((gx + 1) * W - 1) / 2  (ATen grid_sampler_unnormalize)
+    const float ix = ((gx + 1.f) * (float)W - 1.f) * 0.5f;
+    const float iy = ((gy + 1.f) * (float)H - 1.f) * 0.5f;
+    const float fx = floorf(ix), fy = floorf(iy);
+    Corner c;
+    c.x0 = (int)fx; c.y0 = (int)fy;
+    c.wx1 = ix - fx; c.wx0 = (fx + 1.f) - ix;
+    c.wy1 = iy - fy; c.wy0 = (fy + 1.f) - iy;
+    return c;
+}
+
+__device__ __forceinline__ void plane_uv(int pl, float x, float y, float z, float& gx, float& gy) {
+    // renderer.py:23-53 with the inverse plane axes: planes are sampled at (x,y), (x,z), (z,x)
+    gx = (pl == 2) ? z : x;
+    gy = (pl == 0) ? y : ((pl == 1) ? z : x);
+}
+
+// Phase A shared by forward and backward: feat[s][0..31] = mean over planes of the bilinear samples.
+__device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, int64_t total, float* feat) {
+    const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+#pragma unroll 2
+    for (int pass = 0; pass < DT / 32; ++pass) {
+        const int s = pass * 32 + grp;
+        const int64_t g = base + s;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g < total) {
+            int n; float x, y, z;
+            point_xyz(a, g, n, x, y, z);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                float gx, gy;
+                plane_uv(pl, x, y, z, gx, gy);
+                const Corner c = make_corner(gx, gy, a.W, a.H);
+                const float* pb = a.planes + ((int64_t)(n * 3 + pl) * a.H * a.W) * DEC_IN + sub * 4;
+                const bool x0ok = (c.x0 >= 0) & (c.x0 < a.W), x1ok = (c.x0 + 1 >= 0) & (c.x0 + 1 < a.W);
+                const bool y0ok = (c.y0 >= 0) & (c.y0 < a.H), y1ok = (c.y0 + 1 >= 0) & (c.y0 + 1 < a.H);
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v00 = (x0ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0) * DEC_IN) : z4;
+                const float4 v01 = (x1ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0 + 1) * DEC_IN) : z4;
+                const float4 v10 = (x0ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0) * DEC_IN) : z4;
+                const float4 v11 = (x1ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0 + 1) * DEC_IN) : z4;
+                const float w00 = c.wx0 * c.wy0, w01 = c.wx1 * c.wy0, w10 = c.wx0 * c.wy1, w11 = c.wx1 * c.wy1;
+                acc.x += v00.x * w00 + v01.x * w01 + v10.x * w10 + v11.x * w11;
+                acc.y += v00.y * w00 + v01.y * w01 + v10.y * w10 + v11.y * w11;
+                acc.z += v00.z * w00 + v01.z * w01 + v10.z * w10 + v11.z * w11;
+                acc.w += v00.w * w00 + v01.w * w01 + v10.w * w10 + v11.w * w11;
+            }
+            acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+        }
+        *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
+    }
+}
+
+// Decoder MLP.  Both layers walk ROWS of 64 contiguous weights (w1t = W1^T [32][64], w2 [33][64]) in a
+// runtime loop: the row is wave-uniform -> 4 x s_load_dwordx16 + 64 v_fmac with an SGPR operand;
+// the per-point vector that is indexed by the loop variable lives in LDS, the 64 accumulators in
+// registers.  (A fully unrolled version makes the compiler hoist all 4160 weights into SGPRs and
+// spill them through v_writelane/v_readlane.)
+__device__ __forceinline__ void layer1_forward(const float* __restrict__ w1t, const float* __restrict__ b1,
+                                               const float* frow, float (&h)[DEC_HID]) {
+#pragma unroll
+    for (int j = 0; j < DEC_HID; ++j) h[j] = b1[j];
+#pragma unroll 2
+    for (int i = 0; i < DEC_IN; ++i) {
+        const float fi = frow[i];
+        const float* wr = w1t + i * DEC_HID;
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) h[j] = fmaf(wr[j], fi, h[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < DEC_HID; ++j) h[j] = softplus_fast(h[j]);
+}
+
+__global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ rgb, float* __restrict__ sigma) {
+    __shared__ __attribute__((aligned(16))) float feat[DT * FS];
+    const int64_t total = (int64_t)a.N * a.P;
+    const int64_t base = (int64_t)blockIdx.x * DT;
+    gather_tile(a, base, total, feat);
+    __syncthreads();
+    const int t = threadIdx.x;
+    float* frow = feat + t * FS;
+    float h[DEC_HID];
+    layer1_forward(w1t, b1, frow, h);
+    // layer 2, one output per iteration; the rgb row overwrites this thread's own feature row
+#pragma unroll 2
+    for (int o = 0; o < DEC_OUT; ++o) {
+        const float* wr = w2 + o * DEC_HID;
+        float acc = b2[o];
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], h[j], acc);
+        if (o == 0) { if (base + t < total) sigma[out_row(a, base + t)] = acc; }
+        else frow[o - 1] = sigmoid_fast(acc) * 1.002f - 0.001f;
+    }
+    __syncthreads();
+    // the tile's rgb block is contiguous in global memory: 256 points x 32 floats
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * DT + t;                 // float4 index within the tile
+        const int s = e >> 3, q = e & 7;
+        if (base + s < total)
+            *reinterpret_cast<float4*>(rgb + out_row(a, base + s) * DEC_IN + q * 4) = *reinterpret_cast<const float4*>(feat + s * FS + q * 4);
+    }
+}
+
+__global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        const float* __restrict__ d_rgb, const float* __restrict__ d_sigma,
+                                                        float* __restrict__ d_planes, float* __restrict__ dump) {
+    __shared__ __attribute__((aligned(16))) float feat[DT * FS];
+    __shared__ __attribute__((aligned(16))) float gbuf[DT * FS];
+    const int64_t total = (int64_t)a.N * a.P;
+    const int64_t base = (int64_t)blockIdx.x * DT;
+    const int t = threadIdx.x;
+    // stage the tile's d_rgb rows (contiguous 32 KB) while the gathers are in flight
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = it * DT + t;
+        const int s = e >> 3, q = e & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + s < total) v = *reinterpret_cast<const float4*>(d_rgb + out_row(a, base + s) * DEC_IN + q * 4);
+        *reinterpret_cast<float4*>(gbuf + s * FS + q * 4) = v;
+    }
+    gather_tile(a, base, total, feat);
+    __syncthreads();
+    const bool valid = base + t < total;
+    const bool dumping = (dump != nullptr) && valid;
+    float* frow = feat + t * FS;
+    float* grow = gbuf + t * FS;
+    float h[DEC_HID];
+    layer1_forward(w1t, b1, frow, h);
+    // dump layout: [193][total] (rows: f 0..31, h 32..95, d_pre1 96..159, d_y 160..192), coalesced per row
+    if (dumping) {
+        for (int i = 0; i < DEC_IN; ++i) dump[(int64_t)i * total + base + t] = frow[i];
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) dump[(int64_t)(32 + j) * total + base + t] = h[j];
+    }
+    // layer 2 forward + backward in one sweep over its rows: y_o -> d_y_o -> dp[j] += W2[o][j] d_y_o
+    float dp[DEC_HID];
+#pragma unroll
+    for (int j = 0; j < DEC_HID; ++j) dp[j] = 0.f;
+    const float dsig = valid ? d_sigma[out_row(a, base + t)] : 0.f;
+#pragma unroll 2
+    for (int o = 0; o < DEC_OUT; ++o) {
+        const float* wr = w2 + o * DEC_HID;
+        float acc = b2[o];
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], h[j], acc);
+        float dyo;
+        if (o == 0) dyo = dsig;                                  // sigma = y[0]
+        else { const float sg = sigmoid_fast(acc); dyo = grow[o - 1] * 1.002f * sg * (1.f - sg); }   // rgb = sigmoid*1.002-0.001
+        if (dumping) dump[(int64_t)(160 + o) * total + base + t] = dyo;
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) dp[j] = fmaf(wr[j], dyo, dp[j]);
+    }
+    // through the softplus: softplus'(pre) = sigmoid(pre) = 1 - exp(-h)
+#pragma unroll
+    for (int j = 0; j < DEC_HID; ++j) dp[j] *= (h[j] > 20.f) ? 1.f : (1.f - exp_fast(-h[j]));
+    if (dumping) {
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) dump[(int64_t)(96 + j) * total + base + t] = dp[j];
+    }
+    // d_f[i] = sum_j W1[j][i] d_pre1[j]; the plane mean contributes the 1/3
+#pragma unroll 2
+    for (int i = 0; i < DEC_IN; ++i) {
+        const float* wr = w1t + i * DEC_HID;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], dp[j], acc);
+        grow[i] = acc / 3.f;
+    }
+    __syncthreads();
+    // scatter-add into the channels-last plane gradient: 8 lanes per point, one float4 of channels each
+    const int sub = t & 7, grp = t >> 3;
+    for (int pass = 0; pass < DT / 32; ++pass) {
+        const int s = pass * 32 + grp;
+        const int64_t g = base + s;
+        if (g >= total) continue;
+        const float4 d4 = *reinterpret_cast<const float4*>(gbuf + s * FS + sub * 4);
+        int n; float x, y3, z;
+        point_xyz(a, g, n, x, y3, z);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            float gx, gy;
+            plane_uv(pl, x, y3, z, gx, gy);
+            const Corner c = make_corner(gx, gy, a.W, a.H);
+            float* pb = d_planes + ((int64_t)(n * 3 + pl) * a.H * a.W) * DEC_IN + sub * 4;
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    const int xx = c.x0 + cx, yy = c.y0 + cy;
+                    if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
+                    const float w = (cx ? c.wx1 : c.wx0) * (cy ? c.wy1 : c.wy0);
+                    float* p = pb + ((int64_t)yy * a.W + xx) * DEC_IN;
+                    atomicAdd(p + 0, d4.x * w); atomicAdd(p + 1, d4.y * w);
+                    atomicAdd(p + 2, d4.z * w); atomicAdd(p + 3, d4.w * w);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// min / max reduction (ray_marcher.py:50 clamps composite depth to the range of ALL depths)
+// ------------------------------------------------------------------------------------------------
+__global__ void minmax_init_kernel(float* out2) { out2[0] = INFINITY; out2[1] = -INFINITY; }
+
+__device__ __forceinline__ void atomic_min_f(float* addr, float v) {     // valid for any sign
+    if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f(float* addr, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void minmax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out2) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += (int64_t)gridDim.x * blockDim.x) {
+        const float v = x[g];
+        lo = fminf(lo, v); hi = fmaxf(hi, v);
+    }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if ((threadIdx.x & 63) == 0) { atomic_min_f(out2, lo); atomic_max_f(out2 + 1, hi); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MipRayMarcher2 (ray_marcher.py:25-57).  One wave64 per ray, 4 rays per block.
+//   scalars per interval live one-per-lane (S <= 256 -> up to 4 chunks); transmittance is an
+//   exclusive product scan done with wave shuffles; colour rows are read 8 rows (1 KB) per
+//   wave-instruction, 8 lanes x float4 per 128-B row, and reduced across the row groups by xor-shuffles.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXS = 256;
+constexpr int RM_WAVES = 4;
+
+struct MarchLds { float sig[MAXS]; float dep[MAXS]; float w[MAXS]; float q[MAXS]; };
+
+__device__ __forceinline__ int64_t row_of(const int32_t* perm, int64_t r, int S, int S_store, int k) {
+    return r * S_store + (perm ? perm[r * S + k] : k);
+}
+
+// Computes alpha / transmittance / weight for every interval of the ray into per-lane registers.
+// chunk c, lane l <-> interval k = c*64 + l.
+template <int NCH>
+__device__ __forceinline__ void march_scalars(MarchLds& L, const float* __restrict__ densities, const float* __restrict__ depths,
+                                              const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane,
+                                              float (&alpha)[NCH], float (&trans)[NCH], float (&delta)[NCH],
+                                              float (&smid)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 64 + lane;
+        if (k < S) { L.sig[k] = densities[row_of(perm, r, S, S_store, k)]; L.dep[k] = depths[r * S + k]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float carry = 1.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 64 + lane;
+        float a = 0.f, om = 1.f, dl = 0.f, sm = 0.f;
+        if (k < S - 1) {
+            dl = L.dep[k + 1] - L.dep[k];
+            sm = (L.sig[k] + L.sig[k + 1]) / 2.f;
+            a = 1.f - expf(-softplus_f(sm - 1.f) * dl);
+            om = 1.f - a + 1e-10f;
+        }
+        const float incl = wave_scan_mul(om, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.f;
+        alpha[c] = a; delta[c] = dl; smid[c] = sm;
+        trans[c] = carry * excl;
+        carry *= __shfl(incl, 63, 64);
+    }
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
+        const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
+        const int32_t* __restrict__ perm, const float* __restrict__ clamp2, int64_t R, int S, int S_store, int white_back,
+        float* __restrict__ rgb, float* __restrict__ depth_out, float* __restrict__ weights, float* __restrict__ wsum_out) {
+    __shared__ MarchLds lds[RM_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
+    if (r >= R) return;
+    MarchLds& L = lds[wave];
+    float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
+    march_scalars<NCH>(L, densities, depths, perm, r, S, S_store, lane, alpha, trans, delta, smid);
+    float wsum = 0.f, dnum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 64 + lane;
+        const float w = alpha[c] * trans[c];
+        if (k < S - 1) {
+            wsum += w;
+            dnum += w * ((L.dep[k] + L.dep[k + 1]) / 2.f);
+            if (weights) weights[r * (S - 1) + k] = w;
+        }
+        if (k < S) L.w[k] = (k < S - 1) ? w : 0.f;
+    }
+    wsum = wave_sum(wsum); dnum = wave_sum(dnum);
+    if (lane == 0) {
+        if (depth_out) {
+            float d = dnum / wsum;
+            if (d != d) d = INFINITY;                               // nan_to_num(nan -> inf)
+            d = fminf(fmaxf(d, clamp2[0]), clamp2[1]);
+            depth_out[r] = d;
+        }
+        if (wsum_out) wsum_out[r] = wsum;
+    }
+    if (rgb == nullptr) return;
+    __builtin_amdgcn_wave_barrier();
+    // sum_k w_k (c_k + c_{k+1})/2  ==  sum_k c_k * (w_{k-1} + w_k)/2
+    const int sub = lane & 7, rg = lane >> 3;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+    for (int k0 = 0; k0 < S; k0 += 8) {
+        const int k = k0 + rg;
+        if (k < S) {
+            const float v = 0.5f * ((k > 0 ? L.w[k - 1] : 0.f) + L.w[k]);
+            const float4 c = *reinterpret_cast<const float4*>(colors + row_of(perm, r, S, S_store, k) * 32 + sub * 4);
+            acc.x = fmaf(v, c.x, acc.x); acc.y = fmaf(v, c.y, acc.y);
+            acc.z = fmaf(v, c.z, acc.z); acc.w = fmaf(v, c.w, acc.w);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+        acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+        acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+    }
+    if (rg == 0) {
+        const float wb = white_back ? 1.f - wsum : 0.f;
+        float4 o4 = make_float4((acc.x + wb) * 2.f - 1.f, (acc.y + wb) * 2.f - 1.f, (acc.z + wb) * 2.f - 1.f,
+                                (acc.w + wb) * 2.f - 1.f);
+        *reinterpret_cast<float4*>(rgb + r * 32 + sub * 4) = o4;
+    }
+}
+
+template <int NCH>
+__global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
+        const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
+        const int32_t* __restrict__ perm, const float* __restrict__ clamp2, const float* __restrict__ d_rgb,
+        const float* __restrict__ d_depth, const float* __restrict__ d_weights, int64_t R, int S, int S_store, int white_back,
+        float* __restrict__ d_colors, float* __restrict__ d_densities) {
+    __shared__ MarchLds lds[RM_WAVES];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
+    if (r >= R) return;
+    MarchLds& L = lds[wave];
+    float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
+    march_scalars<NCH>(L, densities, depths, perm, r, S, S_store, lane, alpha, trans, delta, smid);
+    float wsum = 0.f, dnum = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 64 + lane;
+        const float w = alpha[c] * trans[c];
+        if (k < S - 1) { wsum += w; dnum += w * ((L.dep[k] + L.dep[k + 1]) / 2.f); }
+        if (k < S) L.w[k] = (k < S - 1) ? w : 0.f;
+    }
+    wsum = wave_sum(wsum); dnum = wave_sum(dnum);
+    __builtin_amdgcn_wave_barrier();
+    // pass 1 over the colour rows: q_k = <d_rgb, c_k>; write d_colors rows = d_rgb * (w_{k-1} + w_k)
+    const int sub = lane & 7, rg = lane >> 3;
+    const float4 g4 = *reinterpret_cast<const float4*>(d_rgb + r * 32 + sub * 4);
+#pragma unroll 4
+    for (int k0 = 0; k0 < S; k0 += 8) {
+        const int k = k0 + rg;
+        float part = 0.f;
+        if (k < S) {
+            const int64_t row = row_of(perm, r, S, S_store, k);
+            const float4 c = *reinterpret_cast<const float4*>(colors + row * 32 + sub * 4);
+            part = g4.x * c.x + g4.y * c.y + g4.z * c.z + g4.w * c.w;
+            const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
+            *reinterpret_cast<float4*>(d_colors + row * 32 + sub * 4) = make_float4(g4.x * v, g4.y * v, g4.z * v, g4.w * v);
+        }
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+        if (k < S && sub == 0) L.q[k] = part;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // dL/dw_k
+    float depth_scale = 0.f, D = 0.f;
+    if (d_depth) {
+        D = dnum / wsum;
+        const bool ok = (D == D) && (D >= clamp2[0]) && (D <= clamp2[1]) && (fabsf(D) != INFINITY);
+        depth_scale = ok ? d_depth[r] / wsum : 0.f;      // empty rays: the reference yields NaN here; we give 0
+        if (!ok) D = 0.f;
+    }
+    float gsum = 0.f;
+    if (white_back) gsum = -2.f * wave_sum(rg == 0 ? (g4.x + g4.y + g4.z + g4.w) : 0.f);
+    float gw[NCH];                    // g_k * w_k
+    float g[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 64 + lane;
+        float gk = 0.f;
+        if (k < S - 1) {
+            gk = L.q[k] + L.q[k + 1] + depth_scale * ((L.dep[k] + L.dep[k + 1]) / 2.f - D) + gsum;
+            if (d_weights) gk += d_weights[r * (S - 1) + k];
+        }
+        g[c] = gk;
+        gw[c] = gk * alpha[c] * trans[c];
+    }
+    // suffix (exclusive) sums of g_m w_m over m > k
+    float total = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) total += gw[c];
+    total = wave_sum(total);
+    float before = 0.f;               // sum over earlier chunks
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 64 + lane;
+        const float incl = wave_scan_add(gw[c], lane) + before;     // sum_{m <= k}
+        const float suffix = total - incl;                          // sum_{m > k}
+        before += __shfl(incl - before, 63, 64);
+        float ds = 0.f;
+        if (k < S - 1) {
+            const float om = 1.f - alpha[c] + 1e-10f;
+            const float da = g[c] * trans[c] - suffix / om;
+            const float dsh = da * delta[c] * (1.f - alpha[c]);             // d alpha / d sigma_hat = delta * exp(-sigma_hat delta)
+            ds = dsh * sigmoid_f(smid[c] - 1.f) * 0.5f;                     // softplus'(x-1) and the midpoint's 1/2
+        }
+        if (k < S) L.q[k] = ds;                                             // reuse q: contribution of interval k
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = c * 64 + lane;
+        if (k < S) {
+            const float v = (k < S - 1 ? L.q[k] : 0.f) + (k > 0 ? L.q[k - 1] : 0.f);
+            d_densities[row_of(perm, r, S, S_store, k)] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample_importance / sample_pdf (renderer.py:194-253): one wave per ray.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) importance_kernel(const float* __restrict__ depths, const float* __restrict__ weights,
+                                                         const float* __restrict__ u, int64_t R, int S, int Sf,
+                                                         float* __restrict__ fine) {
+    __shared__ float s_w[4][MAXS + 2];
+    __shared__ float s_cdf[4][MAXS];
+    __shared__ float s_bin[4][MAXS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const int L = S - 1;                       // number of coarse weights
+    float* w = s_w[wave]; float* cdf = s_cdf[wave]; float* bin = s_bin[wave];
+    for (int k = lane; k < L; k += 64) w[k + 1] = weights[r * L + k];
+    if (lane == 0) { w[0] = -INFINITY; w[L + 1] = -INFINITY; }
+    for (int k = lane; k < L; k += 64) bin[k] = 0.5f * (depths[r * S + k] + depths[r * S + k + 1]);
+    __builtin_amdgcn_wave_barrier();
+    // smoothed a_i = (max(w_{i-1},w_i) + max(w_i,w_{i+1}))/2 + 0.01 for i in [0,L); pdf uses a_1..a_{L-2}
+    const int NP = L - 2;                      // pdf entries
+    float tot = 0.f;
+    float pv[(MAXS + 63) / 64];
+#pragma unroll
+    for (int c = 0; c < (MAXS + 63) / 64; ++c) {
+        const int j = c * 64 + lane;           // pdf index -> a_{j+1}
+        float v = 0.f;
+        if (j < NP) {
+            const int i = j + 1;
+            const float m0 = fmaxf(w[i], w[i + 1]);       // w[] is shifted by one: w[i] = weight_{i-1}
+            const float m1 = fmaxf(w[i + 1], w[i + 2]);
+            v = 0.5f * (m0 + m1) + 0.01f + 1e-5f;
+        }
+        pv[c] = v; tot += v;
+    }
+    tot = wave_sum(tot);
+    float carry = 0.f;
+#pragma unroll
+    for (int c = 0; c < (MAXS + 63) / 64; ++c) {
+        const int j = c * 64 + lane;
+        const float incl = wave_scan_add(pv[c] / tot, lane) + carry;
+        if (j < NP) cdf[j + 1] = incl;
+        carry = __shfl(incl, 63, 64);
+    }
+    if (lane == 0) cdf[0] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    const int NC = NP + 1;                     // cdf entries
+    for (int j = lane; j < Sf; j += 64) {
+        const float uu = u[r * Sf + j];
+        int lo = 0, hi = NC;                   // searchsorted(right=True): first index with cdf > u
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cdf[mid] <= uu) lo = mid + 1; else hi = mid; }
+        const int below = max(lo - 1, 0), above = min(lo, NP);
+        float den = cdf[above] - cdf[below];
+        if (den < 1e-5f) den = 1.f;
+        fine[r * Sf + j] = bin[below] + (uu - cdf[below]) / den * (bin[above] - bin[below]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// unify_samples' sort (renderer.py:157-163) as a stable rank sort: one wave per ray.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) merge_sort_kernel(const float* __restrict__ coarse, const float* __restrict__ fine,
+                                                         int64_t R, int Sc, int Sf, float* __restrict__ sorted,
+                                                         int32_t* __restrict__ perm) {
+    __shared__ float s_d[4][MAXS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= R) return;
+    const int S = Sc + Sf;
+    float* d = s_d[wave];
+    for (int k = lane; k < S; k += 64) d[k] = (k < Sc) ? coarse[r * Sc + k] : fine[r * Sf + (k - Sc)];
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < S; k += 64) {
+        const float v = d[k];
+        int rank = 0;
+        for (int m = 0; m < S; ++m) {
+            const float o = d[m];
+            rank += (o < v) || (o == v && m < k);
+        }
+        sorted[r * S + rank] = v;
+        perm[r * S + rank] = k;
+    }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int spi_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* ray_o, float* ray_d,
+                    spi_stream_t stream) {
+    SPI_REQUIRE(cam2world && intrinsics && ray_o && ray_d && N > 0 && res > 0, "spi_ray_sampler: bad argument");
+    const int64_t total = (int64_t)N * res * res;
+    hipLaunchKernelGGL(ray_sampler_kernel, dim3((unsigned)ceil_div64(total, 256)), dim3(256), 0, as_stream(stream),
+                       cam2world, intrinsics, N, res, ray_o, ray_d);
+    SPI_LAUNCH_CHECK("spi_ray_sampler");
+    return SPI_OK;
+}
+
+int spi_coarse_depths(const float* xi, int64_t n_rays, int S, float ray_start, float ray_end, float* depths,
+                      spi_stream_t stream) {
+    SPI_REQUIRE(xi && depths && n_rays > 0 && S > 1, "spi_coarse_depths: bad argument");
+    const int64_t total = n_rays * S;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(total, 256), 4096);
+    hipLaunchKernelGGL(coarse_depths_kernel, dim3(grid), dim3(256), 0, as_stream(stream), xi, total, S, ray_start, ray_end, depths);
+    SPI_LAUNCH_CHECK("spi_coarse_depths");
+    return SPI_OK;
+}
+
+static int relayout(const float* src, float* dst, int NP, int C, int H, int W, bool to_nhwc, spi_stream_t stream) {
+    SPI_REQUIRE(src && dst && NP > 0 && C > 0 && H > 0 && W > 0, "spi relayout: bad argument");
+    const int64_t HW = (int64_t)H * W;
+    dim3 grid((unsigned)ceil_div64(HW, 32), (unsigned)((C + 31) / 32), (unsigned)NP);
+    if (to_nhwc) hipLaunchKernelGGL(relayout_kernel<true>, grid, dim3(256), 0, as_stream(stream), src, dst, C, HW);
+    else hipLaunchKernelGGL(relayout_kernel<false>, grid, dim3(256), 0, as_stream(stream), src, dst, C, HW);
+    SPI_LAUNCH_CHECK("spi relayout");
+    return SPI_OK;
+}
+int spi_nchw_to_nhwc(const float* src, float* dst, int NP, int C, int H, int W, spi_stream_t s) { return relayout(src, dst, NP, C, H, W, true, s); }
+int spi_nhwc_to_nchw(const float* src, float* dst, int NP, int C, int H, int W, spi_stream_t s) { return relayout(src, dst, NP, C, H, W, false, s); }
+
+static int fill_decode_args(DecodeArgs& a, const float* planes, const float* coords, const float* ray_o, const float* ray_d,
+                            const float* depths, const float* w1, const float* b1, const float* w2, const float* b2,
+                            int N, int64_t P, int S, int H, int W, float box_warp, int out_S, int out_off) {
+    SPI_REQUIRE(planes && w1 && b1 && w2 && b2, "spi_triplane_decode: null tensor");
+    SPI_REQUIRE(out_S == 0 || (ray_o != nullptr && out_off >= 0 && out_off + S <= out_S), "spi_triplane_decode: bad out_S/out_off");
+    SPI_REQUIRE(N > 0 && P > 0 && H > 0 && W > 0 && box_warp > 0.f, "spi_triplane_decode: bad size");
+    if (ray_o == nullptr) SPI_REQUIRE(coords != nullptr, "spi_triplane_decode: need coords or rays");
+    else SPI_REQUIRE(ray_d && depths && S > 0 && P % S == 0, "spi_triplane_decode: rays mode needs ray_d, depths, P %% S == 0");
+    a.planes = planes; a.coords = coords; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths;
+    a.N = N; a.P = P; a.S = S > 0 ? S : 1; a.H = H; a.W = W; a.out_S = out_S; a.out_off = out_off;
+    a.scale = 2.f / box_warp;
+    return SPI_OK;
+}
+
+int spi_triplane_decode_fwd(const float* planes_nhwc, const float* coords, const float* ray_o, const float* ray_d,
+                            const float* depths, const float* w1, const float* b1, const float* w2, const float* b2,
+                            int N, int64_t P, int S, int H, int W, float box_warp, int out_S, int out_off, float* rgb,
+                            float* sigma, spi_stream_t stream) {
+    DecodeArgs a;
+    int rc = fill_decode_args(a, planes_nhwc, coords, ray_o, ray_d, depths, w1, b1, w2, b2, N, P, S, H, W, box_warp, out_S, out_off);
+    if (rc) return rc;
+    SPI_REQUIRE(rgb && sigma, "spi_triplane_decode_fwd: null output");
+    const int64_t total = (int64_t)N * P;
+    hipLaunchKernelGGL(decode_fwd_kernel, dim3((unsigned)ceil_div64(total, DT)), dim3(DT), 0, as_stream(stream), a, w1, b1, w2, b2, rgb, sigma);
+    SPI_LAUNCH_CHECK("spi_triplane_decode_fwd");
+    return SPI_OK;
+}
+
+int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const float* ray_o, const float* ray_d,
+                            const float* depths, const float* w1, const float* b1, const float* w2, const float* b2,
+                            const float* d_rgb, const float* d_sigma, int N, int64_t P, int S, int H, int W, float box_warp,
+                            int out_S, int out_off, float* d_planes_nhwc, float* dump_act, spi_stream_t stream) {
+    DecodeArgs a;
+    int rc = fill_decode_args(a, planes_nhwc, coords, ray_o, ray_d, depths, w1, b1, w2, b2, N, P, S, H, W, box_warp, out_S, out_off);
+    if (rc) return rc;
+    SPI_REQUIRE(d_rgb && d_sigma && d_planes_nhwc, "spi_triplane_decode_bwd: null tensor");
+    const int64_t total = (int64_t)N * P;
+    hipLaunchKernelGGL(decode_bwd_kernel, dim3((unsigned)ceil_div64(total, DT)), dim3(DT), 0, as_stream(stream), a, w1, b1, w2,
+                       b2, d_rgb, d_sigma, d_planes_nhwc, dump_act);
+    SPI_LAUNCH_CHECK("spi_triplane_decode_bwd");
+    return SPI_OK;
+}
+
+int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream) {
+    SPI_REQUIRE(x && out2 && n > 0, "spi_minmax: bad argument");
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, as_stream(stream), out2);
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n, 256 * 8), 1024);
+    hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, n, out2);
+    SPI_LAUNCH_CHECK("spi_minmax");
+    return SPI_OK;
+}
+
+int spi_raymarch_fwd(const float* colors, const float* densities, const float* depths, const int32_t* perm,
+                     const float* clamp2, int64_t R, int S, int S_store, int C, int white_back, float* rgb, float* depth,
+                     float* weights, float* wsum, spi_stream_t stream) {
+    SPI_REQUIRE(S_store >= S, "spi_raymarch_fwd: S_store must be >= S");
+    SPI_REQUIRE(densities && depths && R > 0, "spi_raymarch_fwd: null tensor");
+    SPI_REQUIRE(S >= 2 && S <= MAXS, "spi_raymarch_fwd: need 2 <= S <= %d, got %d", MAXS, S);
+    SPI_REQUIRE(C == 32, "spi_raymarch_fwd: only C = 32 feature channels are supported, got %d", C);
+    SPI_REQUIRE(rgb == nullptr || colors != nullptr, "spi_raymarch_fwd: rgb requested without colors");
+    SPI_REQUIRE(depth == nullptr || clamp2 != nullptr, "spi_raymarch_fwd: depth requested without clamp range");
+    dim3 grid((unsigned)ceil_div64(R, RM_WAVES)), block(64 * RM_WAVES);
+    const int nch = (S + 63) / 64;
+#define LAUNCH_FWD(NCH) hipLaunchKernelGGL(raymarch_fwd_kernel<NCH>, grid, block, 0, as_stream(stream), colors, densities, \
+                                          depths, perm, clamp2, R, S, S_store, white_back, rgb, depth, weights, wsum)
+    switch (nch) { case 1: LAUNCH_FWD(1); break; case 2: LAUNCH_FWD(2); break; case 3: LAUNCH_FWD(3); break; default: LAUNCH_FWD(4); }
+#undef LAUNCH_FWD
+    SPI_LAUNCH_CHECK("spi_raymarch_fwd");
+    return SPI_OK;
+}
+
+int spi_raymarch_bwd(const float* colors, const float* densities, const float* depths, const int32_t* perm,
+                     const float* clamp2, const float* d_rgb, const float* d_depth, const float* d_weights, int64_t R,
+                     int S, int S_store, int C, int white_back, float* d_colors, float* d_densities, spi_stream_t stream) {
+    SPI_REQUIRE(S_store >= S, "spi_raymarch_bwd: S_store must be >= S");
+    SPI_REQUIRE(colors && densities && depths && d_rgb && d_colors && d_densities && R > 0, "spi_raymarch_bwd: null tensor");
+    SPI_REQUIRE(S >= 2 && S <= MAXS, "spi_raymarch_bwd: need 2 <= S <= %d, got %d", MAXS, S);
+    SPI_REQUIRE(C == 32, "spi_raymarch_bwd: only C = 32 feature channels are supported, got %d", C);
+    SPI_REQUIRE(d_depth == nullptr || clamp2 != nullptr, "spi_raymarch_bwd: d_depth given without clamp range");
+    dim3 grid((unsigned)ceil_div64(R, RM_WAVES)), block(64 * RM_WAVES);
+    const int nch = (S + 63) / 64;
+#define LAUNCH_BWD(NCH) hipLaunchKernelGGL(raymarch_bwd_kernel<NCH>, grid, block, 0, as_stream(stream), colors, densities, \
+                                          depths, perm, clamp2, d_rgb, d_depth, d_weights, R, S, S_store, white_back, d_colors, d_densities)
+    switch (nch) { case 1: LAUNCH_BWD(1); break; case 2: LAUNCH_BWD(2); break; case 3: LAUNCH_BWD(3); break; default: LAUNCH_BWD(4); }
+#undef LAUNCH_BWD
+    SPI_LAUNCH_CHECK("spi_raymarch_bwd");
+    return SPI_OK;
+}
+
+int spi_importance_sample(const float* depths, const float* weights, const float* u, int64_t R, int S, int Sf, float* fine,
+                          spi_stream_t stream) {
+    SPI_REQUIRE(depths && weights && u && fine && R > 0 && Sf > 0, "spi_importance_sample: bad argument");
+    SPI_REQUIRE(S >= 4 && S <= MAXS, "spi_importance_sample: need 4 <= S <= %d, got %d", MAXS, S);
+    hipLaunchKernelGGL(importance_kernel, dim3((unsigned)ceil_div64(R, 4)), dim3(256), 0, as_stream(stream), depths, weights, u,
+                       R, S, Sf, fine);
+    SPI_LAUNCH_CHECK("spi_importance_sample");
+    return SPI_OK;
+}
+
+int spi_merge_sort_depths(const float* coarse, const float* fine, int64_t R, int Sc, int Sf, float* sorted, int32_t* perm,
+                          spi_stream_t stream) {
+    SPI_REQUIRE(coarse && fine && sorted && perm && R > 0 && Sc > 0 && Sf > 0, "spi_merge_sort_depths: bad argument");
+    SPI_REQUIRE(Sc + Sf <= MAXS, "spi_merge_sort_depths: Sc + Sf must be <= %d", MAXS);
+    hipLaunchKernelGGL(merge_sort_kernel, dim3((unsigned)ceil_div64(R, 4)), dim3(256), 0, as_stream(stream), coarse, fine, R, Sc,
+                       Sf, sorted, perm);
+    SPI_LAUNCH_CHECK("spi_merge_sort_depths");
+    return SPI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+"""ctypes binding of libspi_hip.so (the C ABI in include/spi_hip.h).
+
+Thin by design: tensors go down as raw device pointers + sizes + the current HIP stream; outputs
+are allocated by the caller with ``torch.empty``.  There is NO fallback: if the library cannot be
+loaded, or a tensor is not a contiguous fp32 GPU tensor, the call raises.
+"""
+import ctypes
+import os
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
+_lib = None
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_p = ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [('N', c_i), ('I', c_i), ('O', c_i), ('H', c_i), ('W', c_i), ('kh', c_i), ('kw', c_i), ('pad', c_i),
+                ('transposed', c_i), ('flip', c_i), ('w_batch_stride', c_l), ('bias', c_p), ('noise', c_p),
+                ('noise_gain', c_p), ('act', c_i), ('alpha', c_f), ('gain', c_f), ('clamp', c_f)]
+
+
+_SIGS = {
+    'spi_abi_version': ([], c_i),
+    'spi_ray_sampler': ([c_p, c_p, c_i, c_i, c_p, c_p, c_p], c_i),
+    'spi_coarse_depths': ([c_p, c_l, c_i, c_f, c_f, c_p, c_p], c_i),
+    'spi_nchw_to_nhwc': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
+    'spi_nhwc_to_nchw': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
+    'spi_triplane_decode_fwd': ([c_p] * 9 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
+    'spi_triplane_decode_bwd': ([c_p] * 11 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
+    'spi_minmax': ([c_p, c_l, c_p, c_p], c_i),
+    'spi_raymarch_fwd': ([c_p] * 5 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 5, c_i),
+    'spi_raymarch_bwd': ([c_p] * 8 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 3, c_i),
+    'spi_importance_sample': ([c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_p], c_i),
+    'spi_merge_sort_depths': ([c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p], c_i),
+    'spi_bias_act': ([c_p] * 6 + [c_l, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p], c_i),
+    'spi_upfirdn2d': ([c_p] * 3 + [c_i] * 15 + [c_f, c_i, c_i] + [c_p] * 3 + [c_i, c_f, c_f, c_f, c_p], c_i),
+    'spi_filtered_lrelu': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f, c_i, c_i, c_i, c_p], c_i),
+    'spi_conv2d_fwd': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
+    'spi_conv2d_dgrad': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
+    'spi_conv2d_wgrad': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
+    'spi_rotate_warp': ([c_p] * 7 + [c_i, c_i, c_i, c_f, c_p, c_p, c_p], c_i),
+    'spi_lpips_layer_fwd': ([c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
+    'spi_lpips_layer_bwd': ([c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
+    'spi_adam_multi': ([c_p, c_p, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p], c_i),
+}
+EXPORTS = sorted(list(_SIGS) + ['spi_last_error'])
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the shared library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f'{LIB_PATH} not found: build it with `python -m spi_amd.csrc.build` '
+                               '(spi_amd has no CPU / PyTorch fallback for its kernels)')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (args, res) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = res
+        L.spi_last_error.restype = ctypes.c_char_p
+        if L.spi_abi_version() != 1:
+            raise RuntimeError('libspi_hip.so ABI version mismatch')
+        _lib = L
+    return _lib
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32 / int32 GPU tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('spi_amd kernels need GPU tensors (no CPU fallback); got a %s tensor' % t.device.type)
+    if not t.is_contiguous():
+        raise RuntimeError('spi_amd kernels need contiguous tensors')
+    if t.dtype not in (torch.float32, torch.int32, torch.int64):
+        raise RuntimeError(f'unsupported dtype {t.dtype}')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f'{name} failed ({rc}): {lib().spi_last_error().decode()}')
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,75 @@
+"""bias_act on HIP: ``y = clamp(act(x + b) * gain)`` in one pass, with its first-order backward.
+
+Same surface as the reference's ``bias_act`` (eg3d/torch_utils/ops/bias_act.py:54-88); ``impl`` is
+accepted for signature compatibility but there is only the HIP implementation -- CPU tensors raise.
+The backward uses the saved input/output exactly as the reference's plugin does (bias_act.py:159-205,
+bias_act.cu: grad = 1).  Second-order gradients are not on the inversion path and are not provided.
+"""
+import math
+import torch
+from ... import hip
+
+_SQRT2 = math.sqrt(2.0)
+# name -> (act id, default alpha, default gain, which of x / y the gradient needs)
+activation_funcs = {
+    'linear': (1, 0.0, 1.0, ''), 'relu': (2, 0.0, _SQRT2, 'y'), 'lrelu': (3, 0.2, _SQRT2, 'y'),
+    'tanh': (4, 0.0, 1.0, 'y'), 'sigmoid': (5, 0.0, 1.0, 'y'), 'elu': (6, 0.0, 1.0, 'y'),
+    'selu': (7, 0.0, 1.0, 'y'), 'softplus': (8, 0.0, 1.0, 'y'), 'swish': (9, 0.0, _SQRT2, 'x'),
+}
+
+
+def def_gain(act):
+    return activation_funcs[act][2]
+
+
+def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
+    y = torch.empty_like(x)
+    size_b = b.numel() if b is not None else 0
+    step_b = 1
+    if b is not None:
+        for d in x.shape[dim + 1:]:
+            step_b *= d
+    hip.call('spi_bias_act', hip.ptr(x), hip.ptr(b), hip.ptr(xref), hip.ptr(yref), hip.ptr(dy), hip.ptr(y), x.numel(), size_b,
+             step_b, grad, act_id, alpha, gain, clamp, hip.stream())
+    return y
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, dim, act_id, alpha, gain, clamp, ref):
+        x = x.contiguous().float()
+        bb = b.contiguous().float() if b is not None else None
+        y = _launch(x, bb, None, None, None, 0, dim, act_id, alpha, gain, clamp)
+        # the clamp mask needs the output for every activation (the reference's plugin drops it for
+        # 'linear' and so ignores the clamp in that backward; its CPU path -- our oracle -- does not)
+        ctx.save_for_backward(x if 'x' in ref else None, bb if 'x' in ref else None, y if ('y' in ref or clamp >= 0) else None)
+        ctx.cfg = (dim, act_id, alpha, gain, clamp, b is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, b, y = ctx.saved_tensors
+        dim, act_id, alpha, gain, clamp, has_b = ctx.cfg
+        dy = dy.contiguous().float()
+        dx = dy
+        if act_id != 1 or gain != 1 or clamp >= 0:
+            dx = _launch(dy, b, x, y, None, 1, dim, act_id, alpha, gain, clamp)
+        db = None
+        if has_b and ctx.needs_input_grad[1]:
+            db = dx.sum([i for i in range(dx.ndim) if i != dim])
+        return dx, db, None, None, None, None, None, None
+
+
+def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, impl='hip'):
+    if act not in activation_funcs:
+        raise KeyError(act)
+    act_id, d_alpha, d_gain, ref = activation_funcs[act]
+    alpha = float(d_alpha if alpha is None else alpha)
+    gain = float(d_gain if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    if b is not None:
+        assert b.ndim == 1 and 0 <= dim < x.ndim and b.shape[0] == x.shape[dim]
+    if act_id == 1 and gain == 1 and clamp < 0 and b is None:
+        return x
+    return _BiasAct.apply(x, b, dim, act_id, alpha, gain, clamp, ref)

@@ -1,0 +1,94 @@
+"""Dense 2-D convolutions on the MI355X matrix cores (fp32 MFMA), with autograd.
+
+Replaces what the reference gets from cuDNN through ``conv2d_gradfix.conv2d`` / ``conv_transpose2d``
+(eg3d/torch_utils/ops/conv2d_gradfix.py:37-45) in the two shapes the generator uses
+(eg3d/torch_utils/ops/conv2d_resample.py:114-136):
+
+  * ``groups = batch`` convs with per-sample weights ``w [N, O, I, k, k]`` -- the fused modulated
+    convolution of ``modulated_conv2d`` (networks_stylegan2.py:85-88).  No [1, N*I, H, W] reshapes:
+    the kernel indexes the sample's weights directly.
+  * shared-weight convs ``w [O, I, k, k]`` (VGG feature extractors of the losses).
+
+``transposed=True`` is ``conv_transpose2d(stride=2, padding=0)``: out[o, 2y+ky, 2x+kx] += x[i,y,x] w[o,i,ky,kx]
+(note the [O, I] weight order also in this mode).  ``flip=True`` flips the kernel spatially.
+An optional fused epilogue applies ``+ noise * strength``, ``+ bias``, activation, gain, clamp to the
+accumulators (SynthesisLayer.forward tail, networks_stylegan2.py:320-329) for stride-1 convs.
+"""
+import ctypes
+import torch
+from ... import hip
+from . import bias_act as _ba
+
+
+def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0):
+    return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
+                        act, alpha, gain, clamp)
+
+
+def out_size(h, k, pad, transposed):
+    return 2 * h + k - 2 if transposed else h + 2 * pad - k + 1
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp):
+        x = x.contiguous().float()
+        w = w.contiguous().float()
+        n, i, h, wd = x.shape
+        per_sample = (w.ndim == 5)
+        o, k = w.shape[-4], w.shape[-1]
+        assert w.shape[-3] == i and (not per_sample or w.shape[0] == n)
+        wbs = o * i * k * k if per_sample else 0
+        oh, ow = out_size(h, k, pad, transposed), out_size(wd, k, pad, transposed)
+        y = torch.empty(n, o, oh, ow, device=x.device, dtype=torch.float32)
+        bb = bias.contiguous().float() if bias is not None else None
+        nz = noise.contiguous().float() if noise is not None else None
+        ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp)
+        hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
+        has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
+        ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)
+        ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, w, y, nz, ng = ctx.saved_tensors
+        pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs = ctx.cfg
+        n, i, h, wd = x.shape
+        o, k = w.shape[-4], w.shape[-1]
+        dz = dy.contiguous().float()
+        if has_epi:
+            dz = _ba._launch(dz, None, None, y, None, 1, 1, act_id, alpha, gain, clamp)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs)
+        dx = dw = d_bias = d_noise = d_strength = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w), hip.ptr(dx), hip.stream())
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(dz), hip.ptr(dw), hip.stream())
+        if ctx.needs_input_grad[2]:
+            d_bias = dz.sum([0, 2, 3])
+        if nz is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
+            dsum = dz.sum([0, 1])
+            if ctx.needs_input_grad[3]:
+                d_noise = dsum * (ng if ng is not None else 1.0)
+            if ctx.needs_input_grad[4]:
+                d_strength = (dsum * nz).sum().reshape(())
+        return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None
+
+
+def conv2d(x, w, bias=None, noise=None, noise_strength=None, padding=0, transposed=False, flip=False, act=None, alpha=None,
+           gain=None, clamp=None):
+    """x [N,I,H,W]; w [O,I,k,k] (shared) or [N,O,I,k,k] (per sample).  act=None -> no activation/gain/clamp."""
+    if act is None:
+        act_id, a, g, c = (1 if (bias is not None or noise is not None) else 0), 0.0, 1.0, -1.0
+    else:
+        act_id, d_alpha, d_gain, _ = _ba.activation_funcs[act]
+        assert act_id in (1, 2, 3), 'fused epilogue supports linear / relu / lrelu'
+        a = float(d_alpha if alpha is None else alpha)
+        g = float(d_gain if gain is None else gain)
+        c = float(-1 if clamp is None else clamp)
+    return _Conv2d.apply(x, w, bias, noise, noise_strength, int(padding), bool(transposed), bool(flip), act_id, a, g, c)

@@ -1,0 +1,258 @@
+"""StyleGAN2 generator half on MI355X kernels (drop-in surface of eg3d/training/networks_stylegan2.py:27-552).
+
+Class names, constructor arguments, attribute names and ``state_dict`` keys follow the reference so
+an EG3D checkpoint's ``G_ema`` state loads unchanged and the SPI projectors can find
+``backbone.synthesis.named_buffers()`` / ``noise_const`` / ``mapping.num_ws``.
+
+What differs (MI355X-first):
+  * every dense conv runs on the fp32 matrix cores through ``ops.conv2d_mfma`` with the sample's own
+    modulated weights (``groups = batch`` in the reference, networks_stylegan2.py:85-88) -- no
+    [1, N*C, H, W] reshapes, no cuDNN;
+  * the layer tail (+ noise, + bias, lrelu, gain, clamp) is fused into the conv epilogue (stride-1
+    layers) or into the 4x4 FIR pass that follows the stride-2 transposed conv (up layers);
+  * precision is explicit: fp32 everywhere (the reference's rule "fp16 iff use_fp16 and the tensor is
+    on 'cuda'", :421-423, would silently pick fp16 on ROCm where tensors also report 'cuda').
+Only the fused-modconv path exists (what SPI runs: G.eval() + 'inference_only', :427-428); the
+discriminator half of the reference file is out of scope.
+"""
+import numpy as np
+import torch
+
+from ..torch_utils.ops import bias_act, upfirdn2d, conv2d_mfma
+
+
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True, noise_strength=None, bias=None, act=None, gain=None, clamp=None):
+    """Modulate -> (demodulate) -> conv [-> FIR] [-> + noise -> + bias -> act], reference :34-91 (fused path).
+
+    ``noise`` may be the final noise tensor (reference style) or, with ``noise_strength`` given, the
+    raw ``noise_const`` buffer so that both receive gradients from the fused epilogue.
+    ``bias``/``act``/``gain``/``clamp`` optionally fuse the bias_act that follows in SynthesisLayer / ToRGBLayer.
+    """
+    if not fused_modconv:
+        raise NotImplementedError('only the fused modulated convolution is implemented (SPI runs the generator in eval mode)')
+    assert down == 1 and up in (1, 2)
+    n = x.shape[0]
+    oc, ic, kh, kw = weight.shape
+    assert styles.shape == (n, ic)
+    w = weight.unsqueeze(0) * styles.reshape(n, 1, ic, 1, 1)                       # [N,O,I,k,k]
+    if demodulate:
+        w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(n, oc, 1, 1, 1)
+    if up == 1:
+        return conv2d_mfma.conv2d(x, w, bias=bias, noise=noise, noise_strength=noise_strength, padding=padding,
+                                  flip=not flip_weight, act=act, gain=gain, clamp=clamp)
+    # up = 2: stride-2 transposed conv, then the 4x4 low-pass (gain up^2) with the layer tail fused in
+    assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
+    z = conv2d_mfma.conv2d(x, w, transposed=True, flip=flip_weight)
+    return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
+                                        padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], np.float32(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / np.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None and self.bias_gain != 1:
+            b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())          # plain library GEMM
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+    def extra_repr(self):
+        return f'in_features={self.in_features:d}, out_features={self.out_features:d}, activation={self.activation:s}'
+
+
+class MappingNetwork(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.998):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws = z_dim, c_dim, w_dim, num_ws
+        self.num_layers, self.w_avg_beta = num_layers, w_avg_beta
+        if embed_features is None:
+            embed_features = w_dim
+        if c_dim == 0:
+            embed_features = 0
+        if layer_features is None:
+            layer_features = w_dim
+        feats = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx in range(num_layers):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(feats[idx], feats[idx + 1], activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        x = None
+        if self.z_dim > 0:
+            x = normalize_2nd_moment(z.to(torch.float32))
+        if self.c_dim > 0:
+            y = normalize_2nd_moment(self.embed(c.to(torch.float32)))
+            x = torch.cat([x, y], dim=1) if x is not None else y
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if update_emas and self.w_avg_beta is not None:
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class SynthesisLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True, activation='lrelu',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.resolution = in_channels, out_channels, w_dim, resolution
+        self.up, self.use_noise, self.activation, self.conv_clamp = up, use_noise, activation, conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.def_gain(activation)
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        if use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+        assert noise_mode in ['random', 'const', 'none']
+        styles = self.affine(w)
+        noise = strength = None
+        if self.use_noise and noise_mode == 'random':
+            noise = torch.randn([self.resolution, self.resolution], device=x.device)
+            if x.shape[0] != 1:
+                raise NotImplementedError("noise_mode='random' with batch > 1 is not on the SPI path")
+            strength = self.noise_strength
+        if self.use_noise and noise_mode == 'const':
+            noise, strength = self.noise_const, self.noise_strength
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, noise_strength=strength, up=self.up,
+                                padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1),
+                                fused_modconv=fused_modconv, bias=self.bias, act=self.activation, gain=self.act_gain * gain,
+                                clamp=clamp)
+
+    def extra_repr(self):
+        return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, resolution={self.resolution:d}, up={self.up}'
+
+
+class ToRGBLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.w_dim, self.conv_clamp = in_channels, out_channels, w_dim, conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+    def forward(self, x, w, fused_modconv=True):
+        styles = self.affine(w) * self.weight_gain
+        return modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
+                                bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp)
+
+
+class SynthesisBlock(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture='skip',
+                 resample_filter=[1, 3, 3, 1], conv_clamp=256, use_fp16=False, fp16_channels_last=False,
+                 fused_modconv_default=True, **layer_kwargs):
+        assert architecture == 'skip', "only the 'skip' architecture is on the SPI path"
+        super().__init__()
+        self.in_channels, self.w_dim, self.resolution, self.img_channels = in_channels, w_dim, resolution, img_channels
+        self.is_last, self.architecture, self.use_fp16 = is_last, architecture, use_fp16
+        self.fused_modconv_default = fused_modconv_default
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(resample_filter))
+        self.num_conv = 0
+        self.num_torgb = 0
+        if in_channels == 0:
+            self.const = torch.nn.Parameter(torch.randn([out_channels, resolution, resolution]))
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
+                                        resample_filter=resample_filter, conv_clamp=conv_clamp, **layer_kwargs)
+            self.num_conv += 1
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, **layer_kwargs)
+        self.num_conv += 1
+        self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
+        self.num_torgb += 1
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+        assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim
+        if fused_modconv is None:
+            fused_modconv = self.fused_modconv_default
+        if fused_modconv == 'inference_only':
+            fused_modconv = not self.training
+        wi = 0
+        if self.in_channels == 0:
+            x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+        else:
+            x = self.conv0(x.float(), ws[:, wi], fused_modconv=fused_modconv, **layer_kwargs)
+            wi += 1
+        x = self.conv1(x, ws[:, wi], fused_modconv=fused_modconv, **layer_kwargs)
+        wi += 1
+        if img is not None:
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        y = self.torgb(x, ws[:, wi], fused_modconv=fused_modconv)
+        img = img + y if img is not None else y
+        return x, img
+
+
+class SynthesisNetwork(torch.nn.Module):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=4, **block_kwargs):
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim, self.img_resolution, self.img_channels, self.num_fp16_res = w_dim, img_resolution, img_channels, num_fp16_res
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            block = SynthesisBlock(channels[res // 2] if res > 4 else 0, channels[res], w_dim=w_dim, resolution=res,
+                                   img_channels=img_channels, is_last=(res == self.img_resolution),
+                                   use_fp16=(res >= fp16_resolution), **block_kwargs)
+            self.num_ws += block.num_conv
+            if res == self.img_resolution:
+                self.num_ws += block.num_torgb
+            setattr(self, f'b{res}', block)
+
+    def forward(self, ws, **block_kwargs):
+        assert ws.shape[1] == self.num_ws and ws.shape[2] == self.w_dim
+        ws = ws.to(torch.float32)
+        x = img = None
+        w_idx = 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
+            w_idx += block.num_conv
+        return img
+
+
+class Generator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs={}, **synthesis_kwargs):
+        super().__init__()
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, **synthesis_kwargs)
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **mapping_kwargs)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)

@@ -1,0 +1,60 @@
+import os
+import sys
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no GPU in this container')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
+class Golden:
+    def __init__(self, name):
+        self.z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+
+    def __getitem__(self, k):
+        return torch.from_numpy(np.asarray(self.z[k]))
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+    def keys(self):
+        return self.z.files
+
+
+@pytest.fixture(scope='session')
+def golden():
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = Golden(name)
+        return cache[name]
+    return get
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def assert_close(a, b, rel=1e-5, what=''):
+    e = rel_err(a, b)
+    assert e <= rel, f'{what}: max-normalised error {e:.3e} > {rel:.1e}'

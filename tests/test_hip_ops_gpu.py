@@ -1,0 +1,99 @@
+"""GPU parity of the StyleGAN2 operator kernels (bias_act, upfirdn2d, filtered_lrelu) through the C ABI."""
+import json
+import math
+import pytest
+import torch
+
+from conftest import assert_close
+from oracle import stylegan_ref as osg
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_bias_act_golden(golden):
+    from spi_amd.torch_utils.ops import bias_act
+    g = golden('ops')
+    cases = json.loads(str(g.z['ba_cases'][0]))
+    for i, (act, alpha, gain, clamp) in enumerate(cases):
+        x = g['ba_x'].to(DEV).requires_grad_(True)
+        b = g['ba_b'].to(DEV).requires_grad_(True)
+        y = bias_act.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        assert_close(y, g[f'ba_y{i}'], 2e-6, f'bias_act {act} fwd')
+        gx, gb = torch.autograd.grad(y, [x, b], g['ba_dy'].to(DEV))
+        assert_close(gx, g[f'ba_gx{i}'], 5e-6, f'bias_act {act} dx')
+        assert_close(gb, g[f'ba_gb{i}'], 5e-6, f'bias_act {act} db')
+
+
+@pytest.mark.parametrize('shape,dim', [((3, 5), 1), ((2, 7, 3), 1), ((1, 128, 64, 64), 1), ((2, 3, 5, 7), 3), ((5,), 0)])
+def test_bias_act_shapes_vs_oracle(shape, dim):
+    from spi_amd.torch_utils.ops import bias_act
+    gen = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=gen) * 2
+    b = torch.randn(shape[dim], generator=gen)
+    for act, clamp in (('lrelu', None), ('lrelu', 0.7), ('linear', 0.5)):
+        y = bias_act.bias_act(x.to(DEV), b.to(DEV), dim=dim, act=act, clamp=clamp)
+        assert_close(y, osg.bias_act(x, b, dim=dim, act=act, clamp=clamp), 1e-6, f'{shape} {act}')
+
+
+def test_bias_act_refuses_cpu():
+    from spi_amd.torch_utils.ops import bias_act
+    with pytest.raises(RuntimeError):
+        bias_act.bias_act(torch.randn(4, 4), torch.randn(4), act='lrelu')
+
+
+def test_upfirdn2d_golden(golden):
+    from spi_amd.torch_utils.ops import upfirdn2d
+    g = golden('ops')
+    f = g['fir'].to(DEV)
+    cases = json.loads(str(g.z['uf_cases'][0]))
+    for i, kw in enumerate(cases):
+        x = g['uf_x'].to(DEV).requires_grad_(True)
+        y = upfirdn2d.upfirdn2d(x, f, **kw)
+        assert_close(y, g[f'uf_y{i}'], 2e-6, f'upfirdn2d[{i}] fwd')
+        gx, = torch.autograd.grad(y, x, g[f'uf_dy{i}'].to(DEV))
+        assert_close(gx, g[f'uf_gx{i}'], 2e-6, f'upfirdn2d[{i}] dx')
+
+
+def test_upfirdn2d_layer_shapes_vs_oracle():
+    """The two hot instances: FIR after the transposed conv (up=1, pad 1, gain 4) and skip-image upsample (up=2)."""
+    from spi_amd.torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(2)
+    f = osg.fir_filter()
+    x = torch.randn(2, 16, 65, 65, generator=gen)
+    assert_close(upfirdn2d.upfirdn2d(x.to(DEV), f.to(DEV), padding=[1, 1, 1, 1], gain=4), osg.upfirdn2d(x, f, padding=(1, 1, 1, 1), gain=4), 1e-6, 'fir')
+    x = torch.randn(1, 96, 32, 32, generator=gen)
+    assert_close(upfirdn2d.upsample2d(x.to(DEV), f.to(DEV)), osg.upsample2d(x, f), 1e-6, 'upsample2d')
+    # separable 1-D filter and identity filter
+    f1 = torch.tensor([1., 2., 4., 8., 8., 4., 2., 1.]) / 30
+    x = torch.randn(1, 3, 20, 20, generator=gen)
+    assert_close(upfirdn2d.upfirdn2d(x.to(DEV), f1.to(DEV), up=2, padding=[4, 3, 4, 3], gain=4), osg.upfirdn2d(x, f1, up=2, padding=(4, 3, 4, 3), gain=4), 2e-6, 'separable')
+    assert_close(upfirdn2d.upfirdn2d(x.to(DEV), None, down=2), osg.upfirdn2d(x, None, down=2), 1e-7, 'identity filter')
+
+
+def test_upfirdn2d_bias_act_fused_vs_oracle():
+    from spi_amd.torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(4)
+    f = osg.fir_filter()
+    x = torch.randn(2, 6, 17, 17, generator=gen, requires_grad=True)
+    noise = torch.randn(16, 16, generator=gen, requires_grad=True)
+    strength = torch.tensor(0.3, requires_grad=True)
+    bias = torch.randn(6, generator=gen, requires_grad=True)
+    dy = torch.randn(2, 6, 16, 16, generator=gen)
+    ref = osg.bias_act(osg.upfirdn2d(x, f, padding=(1, 1, 1, 1), gain=4) + noise * strength, bias, act='lrelu', clamp=1.5)
+    gref = torch.autograd.grad(ref, [x, noise, strength, bias], dy)
+    xs = [t.detach().to(DEV).requires_grad_(True) for t in (x, noise, strength, bias)]
+    y = upfirdn2d.upfirdn2d_bias_act(xs[0], f.to(DEV), noise=xs[1], noise_strength=xs[2], bias=xs[3], padding=[1, 1, 1, 1], gain=4,
+                                     act='lrelu', clamp=1.5)
+    assert_close(y, ref, 2e-6, 'fused fwd')
+    for a, b, nm in zip(torch.autograd.grad(y, xs, dy.to(DEV)), gref, ('dx', 'dnoise', 'dstrength', 'dbias')):
+        assert_close(a, b, 1e-5, 'fused ' + nm)
+
+
+def test_filtered_lrelu_golden(golden):
+    from spi_amd.torch_utils.ops import filtered_lrelu
+    g = golden('ops')
+    cases = json.loads(str(g.z['fl_cases'][0]))
+    for i, kw in enumerate(cases):
+        y = filtered_lrelu.filtered_lrelu(g['fl_x'].to(DEV), fu=g['fl_fu'].to(DEV), fd=g['fl_fd'].to(DEV), b=g['fl_b'].to(DEV), **kw)
+        assert_close(y, g[f'fl_y{i}'], 2e-6, f'filtered_lrelu[{i}]')

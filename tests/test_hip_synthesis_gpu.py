@@ -1,0 +1,78 @@
+"""GPU parity of TriPlaneGenerator.synthesis (HIP path) against the golden vectors and the oracle."""
+import pytest
+import torch
+
+from conftest import assert_close, rel_err
+from synth_weights import load_manifest, synth_state_dict
+from oracle import renderer_ref as orr, stylegan_ref as osg
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _narrow_G():
+    from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+    G = TriPlaneGenerator(**ffhq512_kwargs(narrow=True, depth_resolution=12, depth_resolution_importance=12)).eval()
+    G.load_state_dict(synth_state_dict(load_manifest('narrow')))
+    return G.to(DEV)
+
+
+def test_synthesis_narrow_golden(golden):
+    g = golden('synthesis_narrow')
+    G = _narrow_G()
+    G.neural_rendering_resolution = 32
+    ws = g['ws'].to(DEV).requires_grad_(True)
+    out = G.synthesis(ws, g['c'].to(DEV), noise_mode='const', render_noise=(g['xi'], g['u']))
+    planes = G.backbone.synthesis(ws, noise_mode='const')
+    assert_close(planes[:, ::7, ::5, ::5], g['planes_sub'], 2e-5, 'planes')
+    # north_star: <= 1e-3 relative on rendered RGB / depth
+    assert_close(out['image_raw'], g['image_raw'], 1e-3, 'image_raw')
+    assert_close(out['image_depth'], g['image_depth'], 1e-3, 'image_depth')
+    assert_close(out['image'][:, :, ::8, ::8], g['image_sub'], 1e-3, 'image')
+    assert abs(out['image'].mean().item() - g['image_mean'].item()) < 1e-4
+    # what the kernels actually reach
+    assert rel_err(out['image_raw'], g['image_raw']) < 1e-4 and rel_err(out['image_depth'], g['image_depth']) < 1e-5
+    # gradient wrt W+ through SR, renderer (both outputs) and backbone
+    d_img = torch.zeros_like(out['image'])
+    d_img[:, :, ::8, ::8] = g['d_img'].to(DEV)      # the fixture stores d_img on the ::8 lattice only
+    loss = (out['image'][:, :, ::8, ::8] * g['d_img'].to(DEV)).sum() / 1000 + (out['image_depth'] * g['d_dep'].to(DEV)).sum()
+    gws, = torch.autograd.grad(loss, ws)
+    assert gws.shape == g['gws'].shape and torch.isfinite(gws).all()
+
+
+def test_synthesis_narrow_grad_vs_oracle(golden):
+    """Same loss on both sides (oracle on CPU, HIP on GPU): gradient wrt W+ and wrt a few generator weights."""
+    g = golden('synthesis_narrow')
+    G = _narrow_G()
+    G.neural_rendering_resolution = 32
+    P = {k: v.clone() for k, v in synth_state_dict(load_manifest('narrow')).items()}
+    names = ['decoder.net.0.weight', 'backbone.synthesis.b32.conv0.weight', 'backbone.synthesis.b16.conv1.affine.bias',
+             'superresolution.block1.conv1.weight', 'backbone.synthesis.b8.torgb.bias', 'backbone.synthesis.b64.conv1.noise_strength',
+             'superresolution.block0.conv0.bias']
+    for k in names:
+        P[k].requires_grad_(True)
+    gen = torch.Generator().manual_seed(77)
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12)
+    ws = g['ws'][:1].clone().requires_grad_(True)
+    c = g['c'][:1]
+    xi, u = g['xi'][:1], g['u'][:1024]
+    o = orr.synthesis(P, ws, c, opts, neural_rendering_resolution=32, xi=xi, u=u)
+    d_img = torch.randn(o['image'].shape, generator=gen)
+    d_dep = torch.randn(o['image_depth'].shape, generator=gen)
+    loss = (o['image'] * d_img).mean() + (o['image_depth'] * d_dep).mean()
+    gref = torch.autograd.grad(loss, [ws] + [P[k] for k in names])
+    wsg = ws.detach().to(DEV).requires_grad_(True)
+    params = dict(G.named_parameters())
+    out = G.synthesis(wsg, c.to(DEV), noise_mode='const', render_noise=(xi, u))
+    lossg = (out['image'] * d_img.to(DEV)).mean() + (out['image_depth'] * d_dep.to(DEV)).mean()
+    assert abs(lossg.item() - loss.item()) <= 1e-2 * abs(loss.item()) + 1e-6       # north_star: 1e-2 rel on loss values
+    ggpu = torch.autograd.grad(lossg, [wsg] + [params[k] for k in names])
+    for a, b, nm in zip(ggpu, gref, ['ws'] + names):
+        assert_close(a, b, 2e-3, 'grad ' + nm)
+
+
+def test_mapping_golden(golden):
+    g = golden('synthesis_narrow')
+    G = _narrow_G()
+    w = G.mapping(g['map_z'].to(DEV), g['c'][:1].repeat(4, 1).to(DEV))
+    assert_close(w[:, 0], g['map_w'], 1e-5, 'mapping')

@@ -1,0 +1,181 @@
+"""CPU suite: the oracle against the golden vectors captured from the reference, host-side logic of
+the product against the same vectors, and the C-ABI surface (no compute calls without a GPU)."""
+import json
+import math
+import os
+import re
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, ROOT
+from synth_weights import load_manifest, synth_state_dict
+from oracle import stylegan_ref as osg, renderer_ref as orr, losses_ref as olo, loops_ref as olp
+
+
+# ---- operator layer ---------------------------------------------------------------------------------
+def test_oracle_bias_act(golden):
+    g = golden('ops')
+    for i, (act, alpha, gain, clamp) in enumerate(json.loads(str(g.z['ba_cases'][0]))):
+        x, b = g['ba_x'].requires_grad_(True), g['ba_b'].requires_grad_(True)
+        y = osg.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        assert_close(y, g[f'ba_y{i}'], 1e-7, act)
+        gx, gb = torch.autograd.grad(y, [x, b], g['ba_dy'])
+        assert_close(gx, g[f'ba_gx{i}'], 1e-6, act + ' dx')
+        assert_close(gb, g[f'ba_gb{i}'], 1e-6, act + ' db')
+
+
+def test_oracle_upfirdn2d_and_filtered_lrelu(golden):
+    g = golden('ops')
+    assert torch.equal(osg.fir_filter(), g['fir'])
+    for i, kw in enumerate(json.loads(str(g.z['uf_cases'][0]))):
+        x = g['uf_x'].requires_grad_(True)
+        y = osg.upfirdn2d(x, g['fir'], **kw)
+        assert_close(y, g[f'uf_y{i}'], 1e-7, f'upfirdn2d[{i}]')
+        assert_close(torch.autograd.grad(y, x, g[f'uf_dy{i}'])[0], g[f'uf_gx{i}'], 1e-6, f'upfirdn2d[{i}] dx')
+    for i, kw in enumerate(json.loads(str(g.z['fl_cases'][0]))):
+        assert_close(osg.filtered_lrelu(g['fl_x'], g['fl_fu'], g['fl_fd'], g['fl_b'], **kw), g[f'fl_y{i}'], 1e-7, f'flrelu[{i}]')
+
+
+def test_oracle_modulated_conv(golden):
+    g = golden('ops')
+    for tag, (k, up, demod) in dict(c1=(3, 1, True), c0=(3, 2, True), rgb=(1, 1, False)).items():
+        x, w, s = (g[f'mc_{tag}_{n}'].requires_grad_(True) for n in 'xws')
+        noise = g[f'mc_{tag}_noise'] if f'mc_{tag}_noise' in g else None
+        y = osg.modulated_conv2d(x, w, s, noise=noise, up=up, padding=k // 2, f=g['fir'], demodulate=demod, flip_weight=(up == 1))
+        assert_close(y, g[f'mc_{tag}_y'], 1e-6, tag)
+        for a, nm in zip(torch.autograd.grad(y, [x, w, s], g[f'mc_{tag}_dy']), ('gx', 'gw', 'gs')):
+            assert_close(a, g[f'mc_{tag}_{nm}'], 1e-5, f'{tag} {nm}')
+
+
+# ---- renderer -----------------------------------------------------------------------------------------
+def _P(g):
+    return {k[2:]: g[k] for k in g.keys() if k.startswith('P_decoder.')}
+
+
+def test_oracle_renderer_pieces(golden):
+    g = golden('renderer')
+    c = g['cam']
+    ro, rd = orr.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 8)
+    assert_close(ro, g['ray_o'], 1e-7, 'ray_o'); assert_close(rd, g['ray_d'], 1e-7, 'ray_d')
+    feats = orr.sample_planes(g['planes'], g['coords'])
+    assert_close(feats, g['gd_feats'], 1e-7, 'gather')
+    rgb, sigma = orr.osg_decoder(_P(g), feats)
+    assert_close(rgb, g['gd_rgb'], 1e-6, 'decoder rgb'); assert_close(sigma, g['gd_sigma'], 1e-6, 'decoder sigma')
+    for wb in (0, 1):
+        a, b, w = orr.ray_march(g['rm_col'], g['rm_den'], g['rm_dep'], white_back=bool(wb))
+        assert_close(a, g[f'rm{wb}_rgb'], 1e-6, 'march rgb'); assert_close(b, g[f'rm{wb}_depth'], 1e-6, 'march depth')
+        assert_close(w, g[f'rm{wb}_w'], 1e-6, 'march w')
+    assert_close(orr.importance_depths(g['rm_dep'], g['is_w'], 20, u=g['is_u']), g['is_fine'], 1e-6, 'importance')
+
+
+def test_oracle_full_render(golden):
+    g = golden('renderer')
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12)
+    c = g['cam']
+    ro, rd = orr.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 8)
+    planes = g['planes'].requires_grad_(True)
+    rgb, depth, wsum = orr.render(_P(g), planes, ro, rd, opts, xi=g['fr_xi'], u=g['fr_u'])
+    assert_close(rgb, g['fr_rgb'], 1e-6, 'rgb'); assert_close(depth, g['fr_depth'], 1e-6, 'depth'); assert_close(wsum, g['fr_wsum'], 1e-6, 'wsum')
+    gp, = torch.autograd.grad([rgb, depth], [planes], [g['fr_drgb'], g['fr_ddepth']])
+    assert_close(gp, g['fr_gplanes'], 1e-5, 'grad planes')
+
+
+def test_oracle_synthesis_narrow(golden):
+    g = golden('synthesis_narrow')
+    P = synth_state_dict(load_manifest('narrow'))
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12)
+    with torch.no_grad():
+        o = orr.synthesis(P, g['ws'], g['c'], opts, neural_rendering_resolution=32, xi=g['xi'], u=g['u'])
+    assert_close(o['image_raw'], g['image_raw'], 1e-5, 'image_raw')
+    assert_close(o['image_depth'], g['image_depth'], 1e-6, 'image_depth')
+    assert_close(o['image'][:, :, ::8, ::8], g['image_sub'], 1e-5, 'image')
+    assert_close(osg.mapping(P, g['map_z'], g['c'][:1].repeat(4, 1))[:, 0], g['map_w'], 1e-6, 'mapping')
+
+
+# ---- geometry / host logic ------------------------------------------------------------------------------
+def test_camera_utils_golden(golden):
+    from spi_amd.utils import camera_utils as cu
+    g = golden('geometry')
+    cams = torch.cat([cu.cal_canonical_c(y, p) for y, p in ((0.0, 0.0), (0.4, 0.0), (-0.55, 0.2), (0.1, -0.3))], 0)
+    assert_close(cams, g['canon'], 1e-7, 'cal_canonical_c')
+    assert_close(cu.cal_mirror_c(cams), g['mirror'], 1e-7, 'cal_mirror_c')
+    assert_close(cu.cal_camera_weight(cams), g['weight'], 1e-6, 'cal_camera_weight')
+    assert_close(cu.cal_camera_weight(cu.cal_mirror_c(cams)), g['weight_m'], 1e-6, 'mirror weight')
+    assert cu.cal_camera_weight(cams)[0] == 0 and abs(cu.cal_camera_weight(cams)[1].item() - 0.414) < 2e-3
+    assert_close(torch.stack(cu.cal_camera_gauss_weight(cams)), g['gauss_weight'], 1e-6, 'gauss weight')
+    assert_close(cu.sample_surrounding_camera(cams[1:2], 4, 0.2, 0.1, rand=(g['sur_r0'], g['sur_r1'])), g['sur'], 1e-6, 'surrounding')
+    assert_close(cu.sample_camera(4, 0.7, 0.4, rand=(g['sc_r0'], g['sc_r1'])), g['sc'], 1e-6, 'sample_camera')
+    from spi_amd.utils.mask_utils import calculate_face_mask
+    assert torch.equal(calculate_face_mask(g['parsing']), g['face_mask'])
+
+
+def test_oracle_rotate_golden(golden):
+    g = golden('geometry')
+    rgb, m = olo.rotate(g['sur'][:2], g['rot_tdepth'], g['rot_img'], g['canon'][1:2].repeat(2, 1), g['rot_sdepth'], g['rot_msk'], EPS=5e-2)
+    assert_close(rgb, g['rot_rgb'], 1e-6, 'rotate rgb'); assert_close(m, g['rot_mask'], 1e-6, 'rotate mask')
+
+
+def test_stage1_schedule_golden(golden):
+    from spi_amd.training.projectors.schedule import stage1_schedule
+    g = golden('schedule')
+    for n in (10, 500):
+        for fn in (olp.stage1_schedule, stage1_schedule):
+            lr = np.array([fn(s, n, 1.0)[0] for s in range(n)])
+            ns = np.array([fn(s, n, 1.0)[1] for s in range(n)])
+            assert np.abs(lr - g.z[f'lr_{n}']).max() < 1e-12 and np.abs(ns - g.z[f'noise_{n}']).max() < 1e-12
+
+
+@pytest.mark.timeout(900)
+def test_oracle_stage1_trajectory(golden):
+    """Two steps of the oracle's mirror projector reproduce the reference's W+ trajectory (narrow generator)."""
+    g = golden('trajectory')
+    P = synth_state_dict(load_manifest('narrow'))
+    W = olo.make_vgg16_weights(seed=0)
+    gen = torch.Generator().manual_seed(31)
+    target = torch.rand(1, 3, 512, 512, generator=gen) * 2 - 1
+    fg = torch.zeros(1, 1, 512, 512)
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12)
+    torch.manual_seed(0); np.random.seed(0)
+    log = []
+    olp.project_w_plus(P, target, g['c'], lambda a, b: olo.lpips(W, a, b), opts, mirror=True, num_steps=3, w_avg_samples=64,
+                       nrr=128, log=log)
+    got = torch.stack([l['w'] for l in log])[:, 0]
+    assert_close(got, g['w_mir'], 1e-5, 'stage-1 W+ trajectory')
+
+
+# ---- boundary ----------------------------------------------------------------------------------------
+def test_state_dict_manifest_matches_reference():
+    from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+    for kind, narrow in (('narrow', True), ('full', False)):
+        sd = TriPlaneGenerator(**ffhq512_kwargs(narrow=narrow)).state_dict()
+        man = load_manifest(kind)
+        assert list(sd.keys()) == list(man.keys())
+        assert all(tuple(sd[k].shape) == man[k] for k in man)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import ctypes
+    from spi_amd import hip
+    hdr = open(os.path.join(ROOT, 'include', 'spi_hip.h')).read()
+    declared = sorted(set(re.findall(r'\b(spi_[a-z0-9_]+)\s*\(', hdr)))
+    assert len(declared) >= 20
+    L = ctypes.CDLL(hip.LIB_PATH)
+    missing = [n for n in declared if not hasattr(L, n)]
+    assert not missing, missing
+    assert sorted(hip.EXPORTS) == declared
+    assert hip.lib().spi_abi_version() == 1
+
+
+def test_product_has_no_cpu_fallback():
+    from spi_amd.torch_utils.ops import bias_act, upfirdn2d
+    with pytest.raises(RuntimeError):
+        bias_act.bias_act(torch.randn(2, 3), torch.randn(3), act='lrelu')
+    with pytest.raises(RuntimeError):
+        upfirdn2d.upfirdn2d(torch.randn(1, 1, 8, 8), upfirdn2d.setup_filter([1, 3, 3, 1]))
+    # nothing under spi_amd/ may import the oracle
+    for dp, _, fs in os.walk(os.path.join(ROOT, 'spi_amd')):
+        for f in fs:
+            if f.endswith('.py'):
+                src = open(os.path.join(dp, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
