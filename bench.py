@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Benchmark of the SPI inversion hot path on MI355X (contract: see the task description / DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched through torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): 1 image per GPU, first_inv_type=mir (500 steps) + G_1_type=RotBbox (1000 steps),
+EG3D ffhqrebalanced512-128 architecture at 512^2 with 96 coarse + 96 fine samples per ray, fp32, synthetic inputs
+and seeded random-init weights (no checkpoint / dataset exists offline).  A "step" is one iteration of the hot path;
+the K timed steps keep the configuration's 1:2 mix of stage-1 ('mir') and stage-2 ('RotBbox') iterations, with the
+stage-2 part a whole number of 4-iteration super-cycles so the every-4th-step branches are amortised exactly.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RAYMARCH_BYTES_PER_RAY = lambda S, C=32: S * (C + 2) * 4 + (C + 1 + (S - 1)) * 4
+HBM_PEAK_GBS = 8000.0                                                                    # MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=24)
+    ap.add_argument('--warmup', type=int, default=6)
+    ap.add_argument('--depth', type=int, default=96, help='coarse = fine samples per ray')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--narrow', action='store_true', help='debug: reduced-width generator (NOT the benchmark configuration)')
+    return ap.parse_args()
+
+
+def split_steps(k):
+    """K steps -> (stage-1 steps, stage-2 steps) in the 500:1000 proportion, stage-2 a multiple of 4."""
+    k2 = max(4, int(round(k * 2 / 3 / 4)) * 4) if k >= 6 else max(0, k - k // 3)
+    k2 = min(k2, k)
+    return k - k2, k2
+
+
+def cpu_baseline(depth, narrow):
+    """Oracle (CPU restatement of the reference, oracle/loops_ref.py) timed on this box's host cores:
+    ONE stage-2 main-branch iteration (G.synthesis fwd+bwd, L2 + LPIPS, Adam over all G parameters)."""
+    from oracle import loops_ref as olp, losses_ref as olo, renderer_ref as orr
+    from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+    from spi_amd.data.images_dataset import SyntheticDataset
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    G = TriPlaneGenerator(**ffhq512_kwargs(narrow=narrow))
+    P = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    pnames = [k for k, _ in G.named_parameters()]
+    del G
+    st = olp.Stage2State(P, pnames)
+    W = olo.make_vgg16_weights(seed=0)
+    d = SyntheticDataset(1)[0]
+    data = dict(img=d['img'][None], c=torch.as_tensor(d['c']).reshape(1, 25))
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=depth, depth_resolution_importance=depth)
+    w = torch.randn(1, 14, 512) * 0.5
+    t0 = time.perf_counter()
+    olp.stage2_iteration(st, 1, data, w, opts, lambda a, b: olo.lpips(W, a, b), None, pti_only=True)
+    dt = time.perf_counter() - t0
+    return dict(value=1.0 / dt, unit='iters/s', cores=cores, kind='port',
+                sample=f'1 stage-2 main-branch iteration (1 synthesis fwd+bwd at 512^2 / {depth}+{depth} samples, L2+LPIPS, Adam over '
+                       f'all G parameters; the every-4th-step rot / mirror-rot / depth branches are NOT in the sample), {dt:.1f} s, '
+                       f'torch {torch.__version__} CPU fp32, {cores} threads')
+
+
+def main():
+    args = parse()
+    from spi_amd import dist as sdist
+    rank, world, local = sdist.init_from_env()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local)
+    dev = torch.device(f'cuda:{local}')
+    from spi_amd import hip
+    hip.lib()                                                    # fail loudly if libspi_hip.so is missing
+    from spi_amd.configs import hyperparameters, paths_config, global_config
+    from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.training.projectors.common import Projection
+    from spi_amd.training.projectors.mirror_projector import mirror_setup
+    from spi_amd.training.volumetric_rendering import renderer as rmod
+    from spi_amd.data.images_dataset import SyntheticDataset
+    import tempfile
+
+    global_config.device = str(dev)
+    tmp = tempfile.mkdtemp(prefix='spi_bench_')
+    for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
+        setattr(paths_config, k, f'{tmp}/{k}/')
+    hyperparameters.first_inv_type, hyperparameters.first_inv_steps = 'mir', 500
+    hyperparameters.G_1_type, hyperparameters.G_1_step = 'RotBbox', 1000
+    hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda, hyperparameters.pt_tv_lambda = 0.1, 0.05, 1.0, 0.0
+    hyperparameters.LPIPS_value_threshold = -1.0                 # random weights: never early-stop inside the timed region
+
+    torch.manual_seed(0)
+    G = TriPlaneGenerator(**ffhq512_kwargs(narrow=args.narrow, depth_resolution=args.depth, depth_resolution_importance=args.depth))
+    G = G.eval().requires_grad_(False).to(dev)
+    G.neural_rendering_resolution = 128
+    coach = RotBboxCoach(None, False, G=G)
+    d = SyntheticDataset(world)[rank]                            # one independent image per rank
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in d.items()}
+    ctx = coach.prepare_image(data)
+    cameras, dist_fn = mirror_setup(ctx['image'], ctx['camera'], coach.lpips_loss, dev)
+    proj = Projection(coach.G, cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=500, w_avg_samples=600, device=dev)
+    w_pivot = proj.w_opt.detach().clone()
+
+    def run(n1, n2, s1_base, s2_base):
+        for i in range(n1):
+            proj.step(s1_base + i)
+        for i in range(n2):
+            coach.train_step(s2_base + i, ctx, w_pivot)
+
+    w1, w2 = split_steps(args.warmup)
+    k1, k2 = split_steps(args.steps)
+    run(w1, w2, 25, 0)                                           # untimed warm-up (past the 5 % lr ramp-up)
+    rmod.MARCH_EVENTS = []                                       # HIP events around every final-march launch in the timed region
+    sdist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
+    torch.cuda.synchronize(); sdist.barrier()
+    dt = time.perf_counter() - t0
+    events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
+    dt = sdist.reduce_stats([dt], device=dev, op='max')[0]
+    march_ms = [a.elapsed_time(b) for a, b, _ in events]
+    march_rays = [r for _, _, r in events]
+
+    if rank == 0:
+        S = 2 * args.depth
+        per_ray = RAYMARCH_BYTES_PER_RAY(S)
+        tot_bytes = sum(march_rays) * per_ray
+        tot_s = sum(march_ms) / 1e3
+        achieved = tot_bytes / tot_s / 1e9 if tot_s > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'raymarch_pmc.json')
+        if os.path.exists(pmc):
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_16384_rays')
+        out = {
+            'metric': 'SPI inversion iters/sec (512^2, 96+96 ray samples)', 'value': world * args.steps / dt, 'unit': 'iters/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
+            'random-init weights of the ffhqrebalanced512-128 architecture)',
+            'config': {'workload': 'configs[1]: 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
+                                   f'{args.depth}+{args.depth} samples', 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
+                       'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow)},
+            'roofline': {'kernel': 'raymarch_fwd_kernel<3> (final composite, S=%d, C=32)' % S, 'bound': 'hbm', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'launches': len(march_ms), 'avg_launch_us': (sum(march_ms) / max(len(march_ms), 1)) * 1e3,
+                         'bytes_per_ray': per_ray, 'rays_per_launch': (sum(march_rays) / max(len(march_rays), 1))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == '__main__':
+    main()

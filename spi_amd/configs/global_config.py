@@ -1,0 +1,12 @@
+"""Run-wide settings (mirror of spi/configs/global_config.py).  ``device`` follows LOCAL_RANK instead of
+being pinned to 'cuda:0' so that one process per GPU works under torchrun."""
+import os
+
+cuda_visible_devices = os.environ.get('HIP_VISIBLE_DEVICES', os.environ.get('CUDA_VISIBLE_DEVICES', '0'))
+device = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', 0))
+
+training_step = 1
+log_snapshot = 500
+pivotal_training_steps = 0
+model_snapshot_interval = 400
+run_name = ''

@@ -1,0 +1,106 @@
+"""Box contextual loss on eye / mouth crops (drop-in surface of spi/criteria/bbox_cx_loss.py:141-182).
+
+``BoxCXLoss()(x, y, lm)``: reduce to 256^2, ImageNet-normalise, RoI-align three landmark boxes to
+80x80, VGG19 ``features[:6]`` (MFMA conv kernel), contextual loss between the [n,128,40,40] maps.
+``roi_align`` is torchvision's op in the reference (not installed here): it is restated from its
+published definition (aligned=False, spatial_scale=1, sampling_ratio=-1) as batched gathers, one box
+per batch element as ``get_bbox`` builds them (:41-61).  The 1600x1600 cosine matrices are plain
+batched GEMMs (``torch.bmm``).
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+from .lpips.networks import VGG19Head
+
+
+def get_landmark_bbox(lm, scale=1):
+    """[mouth, l_eye, r_eye, nose] boxes (x1, y1, x2, y2) per batch element.  The pad is 8 for the mouth and 15
+    from the first eye on (the ``p = 15`` assignment persists in the reference, :32-33)."""
+    boxes, p = [], 8
+    for i, (a, b) in enumerate(((48, 68), (36, 42), (42, 48), (27, 36))):
+        pts = lm[:, a:b]
+        ly, ry = pts[:, :, 0].min(1)[0], pts[:, :, 0].max(1)[0]
+        lx, rx = pts[:, :, 1].min(1)[0], pts[:, :, 1].max(1)[0]
+        lx, rx, ly, ry = (lx * scale).long(), (rx * scale).long(), (ly * scale).long(), (ry * scale).long()
+        if i in (1, 2):
+            p = 15
+        boxes.append(torch.stack([ly - p, lx - p, ry + p, rx + p], dim=1))
+    return boxes
+
+
+def roi_align(x, boxes, output_size=80):
+    """x [N,C,H,W]; boxes [N,4] float (x1,y1,x2,y2), box i applies to image i.  Differentiable wrt x."""
+    n, c, h, w = x.shape
+    out = output_size
+    bx = boxes.detach().float().cpu()            # box geometry is host data (landmarks), like the reference's .long() math
+    res = []
+    for i in range(n):
+        x1, y1, x2, y2 = [float(v) for v in bx[i]]
+        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
+        gw, gh = int(math.ceil(rw / out)), int(math.ceil(rh / out))
+        bw, bh = rw / out, rh / out
+        ar = torch.arange(out, dtype=torch.float32).view(-1, 1)
+        xs = (ar * bw + (torch.arange(gw, dtype=torch.float32).view(1, -1) + 0.5) * bw / gw + x1).reshape(-1).to(x.device)
+        ys = (ar * bh + (torch.arange(gh, dtype=torch.float32).view(1, -1) + 0.5) * bh / gh + y1).reshape(-1).to(x.device)
+
+        def axis(t, size):
+            valid = ((t >= -1.0) & (t <= size)).float()
+            t = t.clamp(min=0)
+            lo = t.floor().long()
+            edge = lo >= size - 1
+            lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
+            hi = torch.where(edge, lo, lo + 1)
+            t = torch.where(edge, lo.float(), t)
+            return lo, hi, t - lo.float(), valid
+        xl, xh, xf, xv = axis(xs, w)
+        yl, yh, yf, yv = axis(ys, h)
+        img = x[i]
+        top, bot = img[:, yl, :], img[:, yh, :]
+        val = ((top[:, :, xl] * (1 - xf) + top[:, :, xh] * xf) * (1 - yf).view(1, -1, 1)
+               + (bot[:, :, xl] * (1 - xf) + bot[:, :, xh] * xf) * yf.view(1, -1, 1))
+        val = val * yv.view(1, -1, 1) * xv.view(1, 1, -1)
+        res.append(val.reshape(c, out, gh, out, gw).mean(dim=(2, 4)))
+    return torch.stack(res)
+
+
+def compute_cosine_distance(x, y):
+    y_mu = y.mean(dim=(0, 2, 3), keepdim=True)
+    xn = F.normalize(x - y_mu, p=2, dim=1).flatten(2)
+    yn = F.normalize(y - y_mu, p=2, dim=1).flatten(2)
+    return 1 - torch.bmm(xn.transpose(1, 2), yn)
+
+
+def compute_relative_distance(dist_raw):
+    dist_min, _ = torch.min(dist_raw, dim=2, keepdim=True)
+    return torch.clamp(dist_raw / (dist_min + 1e-5), max=10., min=-10)
+
+
+def compute_cx(dist_tilde, band_width):
+    w = torch.exp((1 - dist_tilde) / band_width)
+    return w / torch.sum(w, dim=2, keepdim=True)
+
+
+class BoxCXLoss(torch.nn.Module):
+    def __init__(self, band_width=0.5, weights=None, seed=1):
+        super().__init__()
+        self.band_width = band_width
+        self.vgg_model = VGG19Head(weights=weights, seed=seed)
+        self.register_buffer('vgg_mean', torch.tensor([[[0.485]], [[0.456]], [[0.406]]]))
+        self.register_buffer('vgg_std', torch.tensor([[[0.229]], [[0.224]], [[0.225]]]))
+
+    def forward(self, x, y, lm):
+        if x.shape[-1] > 256:
+            x = F.interpolate(x, (256, 256), mode='bilinear', align_corners=False)
+        if y.shape[-1] > 256:
+            y = F.interpolate(y, (256, 256), mode='bilinear', align_corners=False)
+        x = (x - self.vgg_mean) / self.vgg_std
+        y = (y - self.vgg_mean) / self.vgg_std
+        loss = 0
+        for box in get_landmark_bbox(lm)[:3]:
+            fx = self.vgg_model(roi_align(x, box.float()))
+            fy = self.vgg_model(roi_align(y, box.float()))
+            cx = compute_cx(compute_relative_distance(compute_cosine_distance(fx, fy)), self.band_width)
+            cx = torch.mean(torch.max(cx, dim=1)[0], dim=1)
+            loss = loss + torch.mean(-torch.log(cx + 1e-5))
+        return loss * 0.1

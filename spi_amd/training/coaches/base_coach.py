@@ -1,0 +1,149 @@
+"""Shared state of the stage-2 coaches (mirror of spi/training/coaches/base_coach.py:36-270).
+
+Same responsibilities and names -- ``restart_training``, ``get_inversion`` / ``calc_inversions`` (stage-1 dispatch on
+``first_inv_type``), ``save`` / ``load`` / ``post_process``, ``build_name`` -- with these MI355X-first changes, all
+result-identical to the reference:
+  * the generator is read from disk ONCE; ``restart_training`` restores G from the frozen ``original_G`` that
+    already sits in HBM instead of unpickling both copies again per image (base_coach.py:53-60);
+  * one fused Adam launch per step (training/optim.py);
+  * ``use_wandb`` only gates disk logging (it never touched wandb in the reference either).
+"""
+import abc
+import os
+import numpy as np
+import torch
+
+from ...configs import global_config, paths_config, hyperparameters
+from ...criteria.lpips.lpips import LPIPS
+from ...utils import load_utils
+from ...utils.camera_utils import cal_mirror_c
+from ..optim import Adam
+from ..projectors import w_plus_projector, mirror_projector, w_projector
+
+
+def toogle_grad(model, flag=True):
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def fix_seed():
+    torch.manual_seed(0)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(0)
+    np.random.seed(0)
+
+
+class BaseCoach:
+    def __init__(self, data_loader, use_wandb, G=None, lpips_loss=None, vgg16=None, rng=None):
+        self.use_wandb = use_wandb
+        self.data_loader = data_loader
+        self.w_pivots = {}
+        self.image_counter = 0
+        self.metric_dic = {}
+        self.coach_name = 'Base_coach'
+        self.device = torch.device(global_config.device)
+        self.rng = rng
+        self.lpips_loss = (lpips_loss if lpips_loss is not None else LPIPS(net_type='vgg')).to(self.device).eval()
+        self.vgg16 = vgg16
+        self.original_G = (G if G is not None else load_utils.load_eg3d(device=self.device)).to(self.device)
+        self.original_G.eval().requires_grad_(False)
+        self.G = None
+        self.optimizer = None
+        self.restart_training()
+
+    def restart_training(self):
+        if self.G is None:
+            self.G = load_utils.build_generator(self.original_G.init_args, self.original_G.init_kwargs, None, self.device)
+            self.G.rendering_kwargs = self.original_G.rendering_kwargs
+            self.G.neural_rendering_resolution = self.original_G.neural_rendering_resolution
+            self.G.eval()
+            toogle_grad(self.G, True)
+            with torch.no_grad():
+                self.G.load_state_dict(self.original_G.state_dict())
+            self.optimizer = self.configure_optimizers()
+        else:
+            with torch.no_grad():
+                self.G.load_state_dict(self.original_G.state_dict())     # copy_ into the flat parameter buffer
+            self.optimizer.reset_state()
+        fix_seed()
+
+    def configure_optimizers(self):
+        return Adam(self.G.parameters(), lr=hyperparameters.pti_learning_rate)
+
+    def get_inversion(self, image_name, image, camera, fg_mask=None):
+        embedding_dir = f'{paths_config.embedding_base_dir}/{self.coach_name}/'
+        os.makedirs(embedding_dir, exist_ok=True)
+        w_pivot = None
+        if hyperparameters.load_embedding_coach_name is not None:
+            w_pivot = self.load_inversions(f'{paths_config.embedding_base_dir}/{hyperparameters.load_embedding_coach_name}/', image_name)
+        if w_pivot is None:
+            w_pivot = self.calc_inversions(image_name, image, camera, fg_mask)
+        torch.save(w_pivot.detach().cpu(), f'{embedding_dir}/{image_name}.pt')
+        return w_pivot.to(self.device)
+
+    def load_inversions(self, embedding_dir, image_name):
+        if image_name in self.w_pivots:
+            return self.w_pivots[image_name]
+        path = f'{embedding_dir}/{image_name}.pt'
+        if not os.path.isfile(path):
+            print('[ERROR]: No existing w codes.')
+            return None
+        w = torch.load(path, map_location='cpu').to(self.device)
+        self.w_pivots[image_name] = w
+        return w
+
+    def calc_inversions(self, image_name, image, camera, fg_mask=None):
+        kind = hyperparameters.first_inv_type
+        assert kind in ['sg', 'sgw+', 'mir']
+        common = dict(device=self.device, w_avg_samples=600, num_steps=hyperparameters.first_inv_steps, verbose=self.use_wandb,
+                      w_name=image_name, initial_w=None, rng=self.rng)
+        if kind == 'sg':
+            if self.vgg16 is None:
+                raise RuntimeError("first_inv_type='sg' needs the NVIDIA vgg16 feature extractor (paths_config.VGG_PATH); none was given")
+            return w_projector.project(self.G, image, camera, vgg16=self.vgg16, **common)
+        if kind == 'sgw+':
+            return w_plus_projector.project(self.G, image, camera, lpips_func=self.lpips_loss, **common)
+        return mirror_projector.project(self.G, image, camera, lpips_func=self.lpips_loss, fg_mask=fg_mask, **common)
+
+    @abc.abstractmethod
+    def train(self):
+        pass
+
+    def save(self, w, c, G, path):
+        torch.save({'w': w.detach().cpu(), 'c': c.detach().cpu(), 'G': {k: v.detach().cpu() for k, v in G.state_dict().items()}}, path)
+
+    def load(self, path):
+        ckpt = torch.load(path, map_location='cpu')
+        self.G.load_state_dict(ckpt['G'])
+        return ckpt['w'].to(self.device), ckpt['c'].to(self.device), self.G
+
+    def log_image(self, w, c, G, path):
+        from PIL import Image
+        if len(w.size()) <= 2:
+            w = w.unsqueeze(0)
+        with torch.no_grad():
+            img = G.synthesis(w, c, noise_mode='const')['image'][0].permute(1, 2, 0)
+            img = (img * 127.5 + 128).clamp(0, 255).to(torch.uint8).cpu().numpy()
+        Image.fromarray(img).save(path)
+
+    def post_process(self, w, c, G, name):
+        self.save(w, c, G, path=os.path.join(paths_config.checkpoints_dir, self.coach_name, f'{name}.pt'))
+        self.log_image(w, c, G, path=os.path.join(paths_config.images_output_dir, self.coach_name, name + '.jpg'))
+        self.log_image(w, cal_mirror_c(c), G, path=os.path.join(paths_config.mirror_images_output_dir, self.coach_name, name + '.jpg'))
+
+    def build_name(self):
+        hp = hyperparameters
+        self.coach_name += f'_{hp.first_inv_type}_{hp.first_inv_steps}_{hp.G_1_type}_{hp.G_1_step}'
+        if hp.use_encoder:
+            self.coach_name += '_wenc'
+        if hp.use_G_avg:
+            self.coach_name += '_wgavg'
+        self.coach_name += f'_rot_{hp.pt_rot_lambda}_mirrorrot_{hp.pt_mirror_rot_lambda}_depth_{hp.pt_depth_lambda}_tv_{hp.pt_tv_lambda}'
+        if hp.use_adapt_yaw_range:
+            self.coach_name += '_wadyaw'
+        if hp.description is not None:
+            self.coach_name += '_' + hp.description
+        print('[COACH]:', self.coach_name)
+        for d in (paths_config.checkpoints_dir, paths_config.embedding_base_dir, paths_config.experiments_output_dir,
+                  paths_config.images_output_dir, paths_config.mirror_images_output_dir):
+            os.makedirs(os.path.join(d, self.coach_name), exist_ok=True)

@@ -1,0 +1,135 @@
+"""SPI stage 2: generator tuning with rotated / mirrored pseudo-views (mirror of
+spi/training/coaches/rot_bbox_cx_coach.py:17-171).
+
+Per iteration (``train_step``), exactly as the reference's loop body :68-157:
+  main view     G.synthesis(w, c) -> L2 + LPIPS -> backward                                (:69-85)
+  every 4th     rot:        4 surrounding cameras -> warp the input into them (HIP ``rotate``) -> LPIPS * 0.1 * 4   (:87-105)
+                mirror-rot: same around the mirror camera with the flipped input -> BoxCX * 0.05 * 4              (:107-131)
+                depth:      4 random cameras, depth of G vs depth of the frozen original G -> L2 * 1               (:133-141)
+  early stop if LPIPS <= 0.05, else ONE optimiser step over the accumulated gradients               (:148-151)
+Result-identical savings: target LPIPS features are cached; the depth branch skips the
+super-resolution network (only ``image_depth`` is consumed, :136-138); w_pivot is detached.
+"""
+import os
+import torch
+
+from ...configs import paths_config, hyperparameters, global_config
+from ...criteria.l2_loss import l2_loss
+from ...criteria.bbox_cx_loss import BoxCXLoss
+from ...utils.rotate import rotate
+from ...utils.mask_utils import calculate_face_mask
+from ...utils.camera_utils import cal_mirror_c, cal_camera_weight, sample_surrounding_camera, sample_camera, cal_camera_gauss_weight
+from ...utils.rng import DeviceRNG
+from .base_coach import BaseCoach
+
+
+class RotBboxCoach(BaseCoach):
+    def __init__(self, data_loader, use_wandb, box_cx_loss=None, **kw):
+        super().__init__(data_loader, use_wandb, **kw)
+        self.coach_name = 'RotBboxCoach'
+        self.build_name()
+        self.box_cx_loss = (box_cx_loss if box_cx_loss is not None else BoxCXLoss()).to(self.device).eval()
+        self.rot_bs = 4
+
+    def prepare_image(self, data):
+        """Per-image constants of the loop (:34-43,58-66)."""
+        dev = self.device
+        image = data['img'].to(dev).float()
+        camera = torch.as_tensor(data['c']).to(dev).float().reshape(-1, 25)
+        mask = data['mask'].to(dev)[:, 0] if data['mask'].ndim == 5 else data['mask'].to(dev)
+        mask = mask.reshape(1, 1, *mask.shape[-2:])
+        ctx = dict(image=image, camera=camera, image_m=torch.flip(image, dims=[3]), camera_m=cal_mirror_c(camera=camera),
+                   fg_mask=1 - (mask == 0).float(), face_mask=calculate_face_mask(mask).float(), lm=data['lm'].to(dev).float().reshape(1, 68, 2))
+        ctx['face_mask_m'] = torch.flip(ctx['face_mask'], dims=[3])
+        ctx['weight_m'] = float(cal_camera_weight(camera)[0])
+        ctx['yaw_range'] = float(cal_camera_gauss_weight(camera)[0]) if hyperparameters.use_adapt_yaw_range else 0.2
+        ctx['target_feats'] = self.lpips_loss.features(image)
+        return ctx
+
+    def _synth(self, G, ws, cams, rng, **kw):
+        n, m = cams.shape[0], G.neural_rendering_resolution ** 2
+        rk = G.rendering_kwargs
+        noise = (rng.rand(n, m, int(rk['depth_resolution']), 1), rng.rand(n * m, max(int(rk['depth_resolution_importance']), 1)))
+        return G.synthesis(ws, cams, noise_mode='const', render_noise=noise, **kw)
+
+    def train_step(self, i, ctx, w_pivot, rng=None):
+        """One iteration of the stage-2 loop.  Returns (stop, losses dict of 0-dim device tensors)."""
+        hp = hyperparameters
+        rng = rng or self.rng or DeviceRNG(self.device)
+        G, rot_bs = self.G, self.rot_bs
+        ws = w_pivot.detach()
+        self.optimizer.zero_grad()
+        gen = self._synth(G, ws, ctx['camera'], rng)
+        losses = {}
+        loss = 0.0
+        if hp.pt_l2_lambda > 0:
+            losses['l2'] = l2_loss(gen['image'], ctx['image'])
+            loss = loss + losses['l2'] * hp.pt_l2_lambda
+        if hp.pt_lpips_lambda > 0:
+            losses['lpips'] = torch.squeeze(self.lpips_loss(gen['image'], y_feats=ctx['target_feats']))
+            loss = loss + losses['lpips'] * hp.pt_lpips_lambda
+        loss.backward()
+        if i % rot_bs == 0:
+            depth_main = gen['image_depth'].detach()
+            if hp.pt_rot_lambda > 0:
+                cams = sample_surrounding_camera(ctx['camera'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
+                                                 rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
+                gs = self._synth(G, ws.repeat(rot_bs, 1, 1), cams, rng)
+                warp_img, warp_mask = rotate(target_camera=cams, target_depth=gs['image_depth'], src_image=ctx['image'].repeat(rot_bs, 1, 1, 1),
+                                             src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
+                                             src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
+                losses['rot'] = self.lpips_loss(gs['image'] * warp_mask, warp_img) * hp.pt_rot_lambda * rot_bs
+                losses['rot'].backward()
+            if hp.pt_mirror_rot_lambda > 0 and ctx['weight_m'] > 0:
+                cams_m = sample_surrounding_camera(ctx['camera_m'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
+                                                   rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
+                gm = self._synth(G, ws.repeat(rot_bs, 1, 1), cams_m, rng)
+                warp_m, mask_m = rotate(target_camera=cams_m, target_depth=gm['image_depth'], src_image=ctx['image_m'].repeat(rot_bs, 1, 1, 1),
+                                        src_camera=ctx['camera_m'].repeat(rot_bs, 1), src_depth=torch.flip(depth_main, dims=[3]).repeat(rot_bs, 1, 1, 1),
+                                        src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
+                flip_warp, flip_mask = torch.flip(warp_m, dims=[3]), torch.flip(mask_m, dims=[3])
+                losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
+                                                        ctx['lm'].repeat(rot_bs, 1, 1)) * hp.pt_mirror_rot_lambda * rot_bs
+                losses['mirror_rot'].backward()
+            if hp.pt_depth_lambda > 0:
+                cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
+                ws4 = ws.repeat(4, 1, 1)
+                sample_depth = self._synth(G, ws4, cams_d, rng, skip_superresolution=True)['image_depth']
+                with torch.no_grad():
+                    stable_depth = self._synth(self.original_G, ws4, cams_d, rng, skip_superresolution=True)['image_depth']
+                losses['depth'] = l2_loss(stable_depth, sample_depth) * hp.pt_depth_lambda
+                losses['depth'].backward()
+            if hp.pt_tv_lambda > 0:
+                from ...criteria.tv_loss import cal_tv_loss
+                losses['tv'] = cal_tv_loss(ws, G) * hp.pt_tv_lambda
+                losses['tv'].backward()
+        if 'lpips' in losses and bool(losses['lpips'] <= hp.LPIPS_value_threshold):       # the loop's one host sync (:148)
+            return True, losses
+        self.optimizer.step()
+        return False, losses
+
+    def train(self):
+        paths_config.experiments_output_dir += f'{self.coach_name}'
+        output_dir = paths_config.experiments_output_dir
+        stats = []
+        for idx, data in enumerate(self.data_loader):
+            if self.image_counter >= hyperparameters.max_images_to_invert:
+                break
+            image_name = data['name'][0] if isinstance(data['name'], (list, tuple)) else data['name']
+            ctx = self.prepare_image(data)
+            paths_config.experiments_output_dir = os.path.join(output_dir, image_name)
+            os.makedirs(paths_config.experiments_output_dir, exist_ok=True)
+            self.restart_training()
+            w_pivot = self.get_inversion(image_name, ctx['image'], ctx['camera'], fg_mask=ctx['fg_mask'])
+            iters = 0
+            for i in range(hyperparameters.G_1_step):
+                stop, losses = self.train_step(i, ctx, w_pivot)
+                iters += 1
+                if stop:
+                    break
+                global_config.training_step += 1
+            self.image_counter += 1
+            stats.append(dict(name=image_name, iters=iters, **{k: float(v) for k, v in losses.items()}) if iters else dict(name=image_name, iters=0))
+            self.post_process(w_pivot, ctx['camera'], self.G, image_name)
+        paths_config.experiments_output_dir = output_dir
+        return stats

@@ -1,0 +1,66 @@
+"""Adam for the inversion loops: one HIP launch per step over flat parameter / gradient / moment buffers.
+
+Semantics of ``torch.optim.Adam(params, lr, betas=(0.9, 0.999), eps=1e-8)`` as both SPI loops use it
+(spi/training/projectors/mirror_projector.py:58, spi/training/coaches/base_coach.py:133-135).
+MI355X-first: at construction every parameter's storage is moved into ONE contiguous fp32 buffer
+(``p.data`` becomes a view) and so is its gradient; ``zero_grad`` is one memset, ``step`` is one
+kernel (``spi_adam_multi``) streaming 4 flat arrays -- 28 B/parameter, HBM-bound -- instead of
+O(#tensors) launches.  A parameter that receives no gradient sees g = 0, for which the update is
+exactly 0 (m = v = 0): the same end state as torch skipping it.
+"""
+import torch
+from .. import hip
+
+
+class Adam:
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        assert len(self.params) > 0
+        dev = self.params[0].device
+        self.param_groups = [dict(params=self.params, lr=lr, betas=betas, eps=eps)]
+        total = sum(p.numel() for p in self.params)
+        self.flat_p = torch.empty(total, device=dev, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            self.flat_p[off:off + n].copy_(p.data.reshape(-1))
+            p.data = self.flat_p[off:off + n].view(p.shape)
+            p.grad = self.flat_g[off:off + n].view(p.shape)
+            off += n
+        self.step_count = 0
+        self._table = torch.tensor([self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr()],
+                                   dtype=torch.int64, device=dev)
+        self._sizes = torch.tensor([total], dtype=torch.int64, device=dev)
+        self._total = total
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_g.zero_()
+        off = 0
+        for p in self.params:               # re-attach in case autograd replaced a .grad tensor
+            n = p.numel()
+            g = p.grad
+            if g is None or g.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+            off += n
+
+    def reset_state(self):
+        self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.flat_g.zero_()
+        self.step_count = 0
+
+    @torch.no_grad()
+    def step(self):
+        off = 0
+        for p in self.params:               # gradients that autograd placed elsewhere are folded back in
+            n = p.numel()
+            g = p.grad
+            if g is not None and g.data_ptr() != self.flat_g.data_ptr() + 4 * off:
+                self.flat_g[off:off + n].add_(g.reshape(-1))
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+            off += n
+        self.step_count += 1
+        grp = self.param_groups[0]
+        hip.call('spi_adam_multi', hip.ptr(self._table), hip.ptr(self._sizes), 1, self._total, float(grp['lr']), float(grp['betas'][0]),
+                 float(grp['betas'][1]), float(grp['eps']), self.step_count, hip.stream())

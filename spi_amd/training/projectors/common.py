@@ -1,0 +1,102 @@
+"""Shared machinery of the three stage-1 projectors (W, W+, mirrored W+).
+
+Restates the common body of spi/training/projectors/{w,w_plus,mirror}_projector.py:
+  w statistics            mirror_projector.py:36-44   (600 z from RandomState(123) through the mapping net)
+  optimiser set           :47-64                      (w_opt + the 13 ``noise_const`` maps, re-initialised to N(0,1))
+  lr / noise schedule     :84-95
+  noise regulariser       :107-115                    (roll-correlation pyramid down to 8x8, weight 1e5)
+  noise renormalisation   :128-131
+MI355X-first changes, all result-identical: one fused Adam launch per step; the (fixed) target's
+LPIPS features are computed once instead of every step; the unused ``bg_loss`` / dilated-mask
+computations (:68-74,117-118) are not performed; no per-step host sync.
+"""
+import copy
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ...configs import hyperparameters
+from ...utils.rng import DeviceRNG
+from ..optim import Adam
+from .schedule import stage1_schedule
+
+
+def w_statistics(G, c, w_avg_samples, device):
+    z = np.random.RandomState(123).randn(w_avg_samples, G.z_dim)
+    with torch.no_grad():
+        w = G.mapping(torch.from_numpy(z).to(device), c.repeat(w_avg_samples, 1))
+    w = w[:, :1, :].cpu().numpy().astype(np.float32)
+    w_avg = np.mean(w, axis=0, keepdims=True)
+    w_std = (np.sum((w - w_avg) ** 2) / w_avg_samples) ** 0.5
+    return w_avg, float(w_std)
+
+
+def noise_regulariser(noise_bufs):
+    reg = 0.0
+    for v in noise_bufs:
+        noise = v[None, None, :, :]
+        while True:
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=3)).mean() ** 2
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=2)).mean() ** 2
+            if noise.shape[2] <= 8:
+                break
+            noise = F.avg_pool2d(noise, kernel_size=2)
+    return reg
+
+
+class Projection:
+    """State of one stage-1 optimisation; ``step(i)`` is the loop body of mirror_projector.py:81-131."""
+    def __init__(self, G, cameras, dist_fn, *, w_mode, initial_w, num_steps, w_avg_samples, device, rng=None,
+                 regularize_noise_weight=1e5, schedule_kwargs=None):
+        self.rng = rng or DeviceRNG(device)
+        self.G = G = copy.deepcopy(G).eval().requires_grad_(False).to(device).float()
+        self.num_ws = G.backbone.mapping.num_ws
+        self.cameras, self.dist_fn, self.w_mode, self.num_steps = cameras, dist_fn, w_mode, num_steps
+        self.reg_weight, self.sched = regularize_noise_weight, (schedule_kwargs or {})
+        w_avg, self.w_std = w_statistics(G, cameras[:1], w_avg_samples, device)
+        self.noise_bufs = {name: buf for (name, buf) in G.backbone.synthesis.named_buffers() if 'noise_const' in name}
+        start_w = initial_w if initial_w is not None else w_avg
+        if w_mode == 'w+' and initial_w is None:
+            start_w = np.repeat(start_w, self.num_ws, axis=1)
+        self.w_opt = torch.tensor(start_w, dtype=torch.float32, device=device, requires_grad=True)
+        for buf in self.noise_bufs.values():
+            buf[:] = self.rng.randn(*buf.shape)
+            buf.requires_grad = True
+        self.optimizer = Adam([self.w_opt] + list(self.noise_bufs.values()), betas=(0.9, 0.999), lr=hyperparameters.first_inv_lr)
+
+    def step(self, step):
+        G, rng, w_opt = self.G, self.rng, self.w_opt
+        lr, w_noise_scale = stage1_schedule(step, self.num_steps, self.w_std, **self.sched)
+        self.optimizer.param_groups[0]['lr'] = lr
+        ws = w_opt + rng.randn(*w_opt.shape) * w_noise_scale
+        if self.w_mode == 'w':
+            ws = ws.repeat([1, self.num_ws, 1])
+        batch = self.cameras.shape[0]
+        ws = ws.repeat(batch, 1, 1)
+        m = G.neural_rendering_resolution ** 2
+        rk = G.rendering_kwargs
+        noise = (rng.rand(batch, m, int(rk['depth_resolution']), 1), rng.rand(batch * m, max(int(rk['depth_resolution_importance']), 1)))
+        images = G.synthesis(ws, self.cameras, noise_mode='const', render_noise=noise)['image']
+        dist = self.dist_fn(images)
+        reg_loss = noise_regulariser(self.noise_bufs.values())
+        loss = dist + reg_loss * self.reg_weight
+        self.optimizer.zero_grad()
+        loss.backward()
+        self.optimizer.step()
+        with torch.no_grad():
+            for buf in self.noise_bufs.values():
+                buf -= buf.mean()
+                buf *= buf.square().mean().rsqrt()
+        return dict(dist=dist.detach(), reg=reg_loss.detach(), loss=loss.detach())
+
+
+def run_projection(G, cameras, dist_fn, *, w_mode, initial_w, num_steps, w_avg_samples, device, rng=None, log=None,
+                   regularize_noise_weight=1e5, schedule_kwargs=None):
+    """Generic stage-1 loop.  ``cameras`` [B,25]; ``dist_fn(images [B,3,R,R]) -> scalar``; w_mode 'w' | 'w+'."""
+    proj = Projection(G, cameras, dist_fn, w_mode=w_mode, initial_w=initial_w, num_steps=num_steps, w_avg_samples=w_avg_samples,
+                      device=device, rng=rng, regularize_noise_weight=regularize_noise_weight, schedule_kwargs=schedule_kwargs)
+    for step in range(num_steps):
+        out = proj.step(step)
+        if log is not None:
+            log.append(dict(out, w=proj.w_opt.detach().clone()))
+    return proj.w_opt

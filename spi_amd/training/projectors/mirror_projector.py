@@ -1,0 +1,40 @@
+"""SPI stage 1: W+ projection with the mirrored pseudo-view ("mir").
+
+Same surface as spi/training/projectors/mirror_projector.py:12-140 ``project(G, target, c, lpips_func, fg_mask, *,
+initial_w, num_steps, w_avg_samples, ..., device, w_name) -> w_opt [1,14,512]``: each step renders the
+view and its mirror camera as one batch of 2 and minimises
+``LPIPS(view, target) + LPIPS(mirror view, flip(target)) * weight_m + 1e5 * noise_reg``.
+"""
+import torch
+
+from ...utils.camera_utils import cal_mirror_c, cal_camera_weight
+from .common import run_projection, Projection
+
+
+def mirror_setup(target, c, lpips_func, device):
+    """-> (cameras [2,25], dist_fn) of the view + mirrored-view objective (:66-72,99-104)."""
+    target = target.to(device).float()
+    target_m = torch.flip(target, dims=[3])
+    camera_m = cal_mirror_c(camera=c)
+    cameras = torch.cat([c, camera_m], dim=0).to(device)
+    weight_m = cal_camera_weight(camera_m)[0]
+    feats, feats_m = (lpips_func.features(target), lpips_func.features(target_m)) if hasattr(lpips_func, 'features') else (None, None)
+
+    def dist_fn(images):
+        if feats is not None:
+            return lpips_func(images[:1], y_feats=feats) + lpips_func(images[1:], y_feats=feats_m) * weight_m
+        return lpips_func(images[:1], target) + lpips_func(images[1:], target_m) * weight_m
+    return cameras, dist_fn
+
+
+def project(G, target, c, lpips_func, fg_mask=None, *, initial_w=None, num_steps=1000, w_avg_samples=10000,
+            initial_learning_rate=0.01, initial_noise_factor=0.05, lr_rampdown_length=0.25, lr_rampup_length=0.05,
+            noise_ramp_length=0.75, regularize_noise_weight=1e5, verbose=False, device, image_log_step=500, w_name='', rng=None,
+            log=None):
+    assert target.shape[1:] == (G.img_channels, G.img_resolution, G.img_resolution)
+    cameras, dist_fn = mirror_setup(target, c, lpips_func, device)
+
+    sched = dict(initial_learning_rate=initial_learning_rate, initial_noise_factor=initial_noise_factor,
+                 lr_rampdown_length=lr_rampdown_length, lr_rampup_length=lr_rampup_length, noise_ramp_length=noise_ramp_length)
+    return run_projection(G, cameras, dist_fn, w_mode='w+', initial_w=initial_w, num_steps=num_steps, w_avg_samples=w_avg_samples,
+                          device=device, rng=rng, log=log, regularize_noise_weight=regularize_noise_weight, schedule_kwargs=sched)

@@ -25,6 +25,7 @@ from ... import hip
 from .ray_marcher import MipRayMarcher2, depth_range
 
 DEC_DUMP_ROWS = 193
+MARCH_EVENTS = None      # bench.py: list collecting (start, end, rays) HIP events around every final-march launch
 
 
 def decoder_tensors(decoder):
@@ -136,8 +137,15 @@ class _Render(torch.autograd.Function):
         rgb = torch.empty(n, m, 32, device=dev, dtype=torch.float32)
         depth = torch.empty(n, m, 1, device=dev, dtype=torch.float32)
         wsum = torch.empty(n, m, 1, device=dev, dtype=torch.float32)
+        if MARCH_EVENTS is not None:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         hip.call('spi_raymarch_fwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), r, s, s, 32,
                  white_back, hip.ptr(rgb), hip.ptr(depth), None, hip.ptr(wsum), hip.stream())
+        if MARCH_EVENTS is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            MARCH_EVENTS.append((e0, e1, r))
         ctx.save_for_backward(planes_nhwc, *dec, ray_o, ray_d, d_c, d_f, rgb_all, sig_all, d_all, perm, clamp2)
         ctx.meta = (n, m, sc, sf, box_warp, white_back, gains)
         ctx.aux = dict(depths_coarse=d_c, depths_fine=d_f, depths_sorted=d_all, perm=perm)

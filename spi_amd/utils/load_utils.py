@@ -1,0 +1,128 @@
+"""Generator loading for the inversion (mirror of spi/utils/load_utils.py:15-33).
+
+``load_eg3d()`` returns a ``TriPlaneGenerator`` in eval mode with ``neural_rendering_resolution = 128``,
+rebuilt from the checkpoint's ``init_args/init_kwargs`` and filled with its parameters and buffers --
+what the reference does through ``legacy.load_network_pkl`` + ``misc.copy_params_and_buffers``.
+
+Checkpoint ingestion never executes the module source embedded in EG3D pickles
+(eg3d/torch_utils/persistence.py:120-128,181-204): a restricted unpickler maps
+``_reconstruct_persistent_obj`` to a plain stub and only the tensors / constructor arguments are read.
+With no checkpoint on disk (this environment), ``synthetic=True`` builds the ffhqrebalanced512-128
+architecture with seeded random weights.
+"""
+import io
+import os
+import pickle
+import torch
+
+from ..configs import paths_config, hyperparameters
+from ..training.triplane import TriPlaneGenerator, ffhq512_kwargs
+
+
+class EasyDict(dict):
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        self[name] = value
+
+
+class PersistentStub:
+    """What a persistent_class instance unpickles to here: its class name and raw state, nothing executed."""
+    def __init__(self, meta):
+        self.class_name = meta['class_name']
+        self.state = meta['state']
+
+
+def _reconstruct_stub(meta):
+    assert meta.get('type') == 'class'
+    return PersistentStub(meta)
+
+
+_SAFE_PREFIXES = ('torch', 'numpy', 'collections', '_codecs')
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        if module == 'torch_utils.persistence' and name == '_reconstruct_persistent_obj':
+            return _reconstruct_stub
+        if module in ('dnnlib.util', 'dnnlib') and name == 'EasyDict':
+            return EasyDict
+        if module == 'builtins' and name in ('dict', 'list', 'tuple', 'set', 'frozenset', 'int', 'float', 'bool', 'str', 'bytes',
+                                             'slice', 'complex', 'getattr'):
+            return super().find_class(module, name)
+        if module.split('.')[0] in _SAFE_PREFIXES:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f'refusing to import {module}.{name} from a network pickle')
+
+
+def _flatten(node, prefix, out):
+    d = node.state if isinstance(node, PersistentStub) else node.__dict__
+    skip = d.get('_non_persistent_buffers_set', set())
+    for name, p in (d.get('_parameters') or {}).items():
+        if p is not None:
+            out[prefix + name] = p.detach()
+    for name, b in (d.get('_buffers') or {}).items():
+        if b is not None and name not in skip:
+            out[prefix + name] = b.detach()
+    for name, child in (d.get('_modules') or {}).items():
+        if child is not None:
+            _flatten(child, prefix + name + '.', out)
+
+
+def read_network_pkl(f, key='G_ema'):
+    """-> (init_args, init_kwargs, state_dict, extra attributes) of data[key] in an EG3D network pickle."""
+    data = _RestrictedUnpickler(f).load()
+    net = data[key]
+    if not isinstance(net, PersistentStub):
+        raise pickle.UnpicklingError(f'{key} is not a persistent_class object')
+    sd = {}
+    _flatten(net, '', sd)
+    st = net.state
+    extra = {k: st[k] for k in ('rendering_kwargs', 'neural_rendering_resolution') if k in st}
+    return tuple(st.get('_init_args', ())), dict(st.get('_init_kwargs', {})), sd, extra
+
+
+def _plain(o):
+    if isinstance(o, dict):
+        return {k: _plain(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return type(o)(_plain(v) for v in o)
+    return o
+
+
+def build_generator(init_args=(), init_kwargs=None, state_dict=None, device='cpu'):
+    G = TriPlaneGenerator(*init_args, **_plain(init_kwargs)).eval().requires_grad_(False)
+    if state_dict is not None:
+        G.load_state_dict(state_dict, strict=True)
+    return G.to(device)
+
+
+def load_eg3d(reload_modules=True, device='cuda', network_pkl=None, synthetic=False, seed=0):
+    if network_pkl is None:
+        network_pkl = paths_config.EG3D_PATH
+    if os.path.isfile(network_pkl):
+        if network_pkl.endswith('.pt'):                       # this implementation's own {init_kwargs, state_dict} format
+            blob = torch.load(network_pkl, map_location='cpu')
+            G = build_generator((), blob['init_kwargs'], blob['state_dict'], device)
+        else:
+            with open(network_pkl, 'rb') as f:
+                args, kwargs, sd, extra = read_network_pkl(f)
+            G = build_generator(args, kwargs, sd, device)
+            if 'rendering_kwargs' in extra:
+                G.rendering_kwargs = _plain(extra['rendering_kwargs'])
+    elif synthetic:
+        torch.manual_seed(seed)
+        G = build_generator((), ffhq512_kwargs(), None, device)
+    else:
+        raise FileNotFoundError(f'{network_pkl} not found (pass synthetic=True / --synthetic for a seeded random-init generator)')
+    if hyperparameters.depth_resolution is not None:
+        G.rendering_kwargs = dict(G.rendering_kwargs, depth_resolution=int(hyperparameters.depth_resolution))
+    if hyperparameters.depth_resolution_importance is not None:
+        G.rendering_kwargs = dict(G.rendering_kwargs, depth_resolution_importance=int(hyperparameters.depth_resolution_importance))
+    G.neural_rendering_resolution = 128
+    G.eval()
+    return G

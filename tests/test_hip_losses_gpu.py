@@ -1,0 +1,191 @@
+"""GPU parity of the loss-side kernels (LPIPS tail, VGG convs, BoxCX, rotate warp, fused Adam) and of the two loops."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, rel_err
+from synth_weights import load_manifest, synth_state_dict
+from oracle import losses_ref as olo, loops_ref as olp, renderer_ref as orr
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def test_rotate_golden(golden):
+    from spi_amd.utils.rotate import rotate
+    g = golden('geometry')
+    rgb, m = rotate(g['sur'][:2].to(DEV), g['rot_tdepth'].to(DEV), g['rot_img'].to(DEV), g['canon'][1:2].repeat(2, 1).to(DEV),
+                    g['rot_sdepth'].to(DEV), g['rot_msk'].to(DEV), EPS=5e-2)
+    # the visibility mask is a threshold test: allow a handful of pixels to flip at the 5e-2 boundary
+    flips = ((m.cpu() > 0) != (g['rot_mask'] > 0)).float().mean().item()
+    assert flips < 1e-3, flips
+    same = ((m.cpu() > 0) == (g['rot_mask'] > 0)).expand_as(rgb.cpu())
+    assert (rgb.cpu() - g['rot_rgb'])[same].abs().max() < 2e-5
+
+
+def test_rotate_512_vs_oracle():
+    from spi_amd.utils.rotate import rotate
+    from spi_amd.utils import camera_utils as cu
+    gen = torch.Generator().manual_seed(5)
+    n = 2
+    cam = cu.cal_canonical_c(0.4, 0.0)
+    tgt = cu.sample_surrounding_camera(cam, n, 0.2, 0.1, rand=(torch.rand(n, 1, generator=gen), torch.rand(n, 1, generator=gen)))
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, 128), torch.linspace(-1, 1, 128), indexing='ij')
+    d = (2.7 - 0.25 * torch.exp(-(xx ** 2 + yy ** 2) * 2))[None, None].repeat(n, 1, 1, 1)
+    img = torch.rand(n, 3, 512, 512, generator=gen) * 2 - 1
+    msk = (torch.rand(n, 1, 512, 512, generator=gen) > 0.3).float()
+    a, am = olo.rotate(tgt, d, img, cam.repeat(n, 1), d, msk)
+    b, bm = rotate(tgt.to(DEV), d.to(DEV), img.to(DEV), cam.repeat(n, 1).to(DEV), d.to(DEV), msk.to(DEV))
+    flips = ((bm.cpu() > 0) != (am > 0)).float().mean().item()
+    assert flips < 1e-3 and am.mean() > 0.3
+    same = ((bm.cpu() > 0) == (am > 0)).expand_as(a)
+    assert (b.cpu() - a)[same].abs().max() < 5e-5
+
+
+def test_lpips_vs_oracle():
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    W = olo.make_vgg16_weights(seed=0)
+    gen = torch.Generator().manual_seed(2)
+    x = (torch.rand(2, 3, 256, 256, generator=gen) * 2 - 1).requires_grad_(True)
+    y = torch.rand(2, 3, 256, 256, generator=gen) * 2 - 1
+    ref = olo.lpips(W, x, y)
+    gref, = torch.autograd.grad(ref, x)
+    net = LPIPS(weights=W).to(DEV)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    out = net(xg, y.to(DEV))
+    assert abs(out.item() - ref.item()) <= 1e-3 * abs(ref.item())          # loss values: north_star asks 1e-2
+    gg, = torch.autograd.grad(out, xg)
+    assert_close(gg, gref, 2e-3, 'lpips grad')
+    out2 = net(xg, y_feats=net.features(y.to(DEV)))                          # cached-target path is the same number
+    assert abs(out2.item() - out.item()) < 1e-7 * max(1.0, abs(out.item()))
+    big = torch.rand(1, 3, 512, 512, generator=gen) * 2 - 1                  # the 512 -> 256 bilinear reduction path
+    assert abs(net(big.to(DEV), big.flip(3).to(DEV)).item() - olo.lpips(W, big, big.flip(3)).item()) < 1e-3 * olo.lpips(W, big, big.flip(3)).item()
+
+
+def test_box_cx_vs_oracle():
+    from spi_amd.criteria.bbox_cx_loss import BoxCXLoss
+    from spi_amd.data.images_dataset import synthetic_landmarks
+    W19 = olo.make_vgg19_head_weights(seed=1)
+    gen = torch.Generator().manual_seed(3)
+    x = torch.rand(2, 3, 512, 512, generator=gen).requires_grad_(True)
+    y = (x.detach() + 0.2 * torch.randn(2, 3, 512, 512, generator=gen)).clamp(0, 1)
+    lm = synthetic_landmarks()[None].repeat(2, 1, 1)
+    ref = olo.box_cx_loss(W19, x, y, lm)
+    gref, = torch.autograd.grad(ref, x)
+    net = BoxCXLoss(weights=W19).to(DEV)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    out = net(xg, y.to(DEV), lm.to(DEV))
+    assert abs(out.item() - ref.item()) <= 1e-3 * abs(ref.item())
+    gg, = torch.autograd.grad(out, xg)
+    assert_close(gg, gref, 5e-3, 'boxcx grad')
+
+
+def test_fused_adam_vs_torch():
+    from spi_amd.training.optim import Adam
+    gen = torch.Generator().manual_seed(4)
+    shapes = [(3, 5), (7,), (2, 3, 4, 5), ()]
+    ref_p = [torch.randn(*s, generator=gen).requires_grad_(True) for s in shapes]
+    gpu_p = [p.detach().clone().to(DEV).requires_grad_(True) for p in ref_p]
+    ropt = torch.optim.Adam(ref_p, lr=3e-3)
+    gopt = Adam(gpu_p, lr=3e-3)
+    for step in range(5):
+        grads = [torch.randn(*s, generator=gen) for s in shapes]
+        ropt.zero_grad(); gopt.zero_grad()
+        for p, q, g in zip(ref_p, gpu_p, grads):
+            if step == 2 and p.ndim == 1:
+                continue                       # a tensor that gets no gradient this step
+            (p * g).sum().backward(); (q * g.to(DEV)).sum().backward()
+        ropt.step(); gopt.step()
+    for p, q in zip(ref_p, gpu_p):
+        if p.ndim == 1:
+            continue                           # torch skips the tensor on a None-grad step, the flat kernel decays its moments
+        assert_close(q, p, 2e-6, 'adam param')
+
+
+def _narrow(depth=12):
+    from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+    G = TriPlaneGenerator(**ffhq512_kwargs(narrow=True, depth_resolution=depth, depth_resolution_importance=depth)).eval()
+    G.load_state_dict(synth_state_dict(load_manifest('narrow')))
+    G.neural_rendering_resolution = 64
+    return G.to(DEV).requires_grad_(False)
+
+
+@pytest.mark.timeout(1500)
+def test_stage1_mirror_trajectory_vs_oracle():
+    """BASELINE config 1/2 plumbing at reduced width: 2 steps of the mirror projector, oracle draws replayed on the GPU."""
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.training.projectors import mirror_projector
+    from spi_amd.utils.rng import ReplayRNG
+    from spi_amd.utils import camera_utils as cu
+    P = synth_state_dict(load_manifest('narrow'))
+    W = olo.make_vgg16_weights(seed=0)
+    gen = torch.Generator().manual_seed(31)
+    target = torch.rand(1, 3, 512, 512, generator=gen) * 2 - 1
+    c = cu.cal_canonical_c(0.4, 0.0)
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12)
+    torch.manual_seed(0); np.random.seed(0)
+    draws, log = olp.Draws(), []
+    olp.project_w_plus(P, target, c, lambda a, b: olo.lpips(W, a, b), opts, mirror=True, num_steps=2, w_avg_samples=64, nrr=64,
+                       draws=draws, log=log)
+    glog = []
+    w = mirror_projector.project(_narrow(), target.to(DEV), c.to(DEV), LPIPS(weights=W).to(DEV), None, num_steps=2, w_avg_samples=64,
+                                 device=torch.device(DEV), rng=ReplayRNG(draws.log, DEV), log=glog)
+    for a, b in zip(glog, log):
+        assert abs(a['dist'].item() - b['dist']) <= 1e-2 * abs(b['dist'])          # north_star: 1e-2 rel on loss values
+        assert abs(a['loss'].item() - b['loss']) <= 1e-2 * abs(b['loss'])
+    # Adam's first steps move every coordinate by ~lr regardless of gradient scale: compare the displacement
+    w0 = log[0]['w'] * 0 + torch.from_numpy(olp.w_stats(P, c, 64)[0]).repeat(1, 14, 1)
+    assert rel_err(glog[-1]['w'].cpu() - w0, log[-1]['w'] - w0) < 5e-2
+    assert w.shape == (1, 14, 512)
+
+
+@pytest.mark.timeout(2400)
+def test_stage2_rotbbox_iteration_vs_oracle():
+    """One full stage-2 iteration (i = 0: main + rot + mirror-rot + depth branches) and one plain iteration."""
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.criteria.bbox_cx_loss import BoxCXLoss
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.data.images_dataset import SyntheticDataset
+    from spi_amd.utils.rng import ReplayRNG
+    from spi_amd.configs import hyperparameters, paths_config
+    import tempfile
+    P = synth_state_dict(load_manifest('narrow'))
+    W, W19 = olo.make_vgg16_weights(seed=0), olo.make_vgg19_head_weights(seed=1)
+    data = SyntheticDataset(1)[0]
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in data.items()}
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12)
+    gen = torch.Generator().manual_seed(6)
+    w_pivot = torch.randn(1, 14, 512, generator=gen)
+    # oracle
+    man = load_manifest('narrow')
+    pnames = [k for k in man if not (k.endswith('noise_const') or k.endswith('resample_filter') or k.endswith('w_avg'))]
+    st = olp.Stage2State(P, pnames)
+    mask = data['mask'].reshape(1, 1, 512, 512)
+    od = dict(img=data['img'], c=torch.as_tensor(data['c']).reshape(1, 25), lm=data['lm'].reshape(1, 68, 2),
+              face_mask=olp.face_mask_from_parsing(mask).float())
+    draws = olp.Draws()
+    torch.manual_seed(0)
+    ref = [olp.stage2_iteration(st, i, od, w_pivot, opts, lambda a, b: olo.lpips(W, a, b), lambda a, b, l: olo.box_cx_loss(W19, a, b, l),
+                                nrr=64, draws=draws) for i in range(2)]
+    # GPU
+    tmp = tempfile.mkdtemp()
+    for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
+        setattr(paths_config, k, f'{tmp}/{k}/')
+    hyperparameters.first_inv_type, hyperparameters.G_1_type = 'mir', 'RotBbox'
+    hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda = 0.1, 0.05, 1.0
+    coach = RotBboxCoach(None, False, G=_narrow(), lpips_loss=LPIPS(weights=W), box_cx_loss=BoxCXLoss(weights=W19))
+    ctx = coach.prepare_image(data)
+    rng = ReplayRNG(draws.log, DEV)
+    got = [coach.train_step(i, ctx, w_pivot.to(DEV), rng=rng)[1] for i in range(2)]
+    assert rng.pos == len(draws.log)                                    # same number / order / shape of random draws
+    for g, r in zip(got, ref):
+        for k in ('l2', 'lpips', 'rot', 'mirror_rot', 'depth'):
+            if k in r:
+                assert abs(g[k].item() - r[k]) <= 1e-2 * abs(r[k]) + 1e-7, (k, g[k].item(), r[k])     # north_star tolerance on losses
+    # parameters after two optimiser steps
+    sd = coach.G.state_dict()
+    for k in ('backbone.synthesis.b64.conv1.weight', 'superresolution.block1.conv1.weight', 'decoder.net.2.weight', 'backbone.synthesis.b8.torgb.bias'):
+        d_ref = st.P[k].detach() - st.P0[k]
+        d_gpu = sd[k].cpu() - st.P0[k]
+        agree = (torch.sign(d_ref) == torch.sign(d_gpu)).float().mean().item()
+        assert agree > 0.97, (k, agree)
