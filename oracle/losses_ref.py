@@ -194,8 +194,9 @@ def rotate(target_camera, target_depth, src_image, src_camera, src_depth, src_ma
     gex, gin = src_camera[:, :16].reshape(n, 4, 4), src_camera[:, 16:].reshape(n, 3, 3)
 
     def up(d):
-        d = d.reshape(n, 1, 128, 128)
-        if res != 128:
+        dr = d.shape[-1]                       # 128 in the reference (rotate.py:102,108 hard-code it)
+        d = d.reshape(n, 1, dr, dr)
+        if res != dr:
             d = F.interpolate(d, (res, res), mode='bilinear', align_corners=False)
         return d.reshape(n, res, res)
     td, gd = up(target_depth), up(src_depth)
