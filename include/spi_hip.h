@@ -78,6 +78,20 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
                             int N, int64_t P, int S, int H, int W, float box_warp, int out_S, int out_off,
                             float* d_planes_nhwc, float* dump_act, spi_stream_t stream);
 
+/* Same backward for the render path, tiled for scatter locality: points are visited as 8x8 patches of
+ * neighbouring rays (ray m = row * ray_w + col) x 4 consecutive SORTED sample positions; plane-gradient
+ * contributions are pre-summed in an LDS window before touching HBM.  Sample (r, k) has depth
+ * depths_sorted[r, k] and colour/density/gradient row r*S + perm[r, k] (perm may be NULL = identity).
+ * dump_act (optional) must hold 193 * spi_triplane_decode_bwd_sorted_cols(...) floats (column-major as
+ * above; padding columns are zero).  d_planes_nhwc is accumulated into. */
+int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d,
+                                   const float* depths_sorted, const int32_t* perm, const float* w1t,
+                                   const float* b1, const float* w2, const float* b2, const float* d_rgb,
+                                   const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
+                                   float box_warp, float* d_planes_nhwc, float* dump_act, int64_t* dump_cols,
+                                   spi_stream_t stream);
+int64_t spi_triplane_decode_bwd_sorted_cols(int N, int M, int S, int ray_w);
+
 /* min / max over a depth tensor (ray_marcher.py:50 clamps to the GLOBAL range).  out[2] = {min,max}. */
 int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream);
 

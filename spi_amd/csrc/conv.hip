@@ -63,77 +63,80 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 
 // -------------------------------------------------------------------------------------------------
 // forward / dgrad implicit GEMM
+//   K is walked tap-major: slab s covers tap t = s / nchunk and 16 input channels c0 = (s % nchunk)*16,
+//   so the gather offset (dy,dx) and the bounds test are per-slab constants for a thread's pixel and the
+//   8 B-loads of a thread differ only by a channel stride (no per-element index arithmetic).
+//   SPLITK: blockIdx.z also enumerates K ranges; partial tiles are atomically added into a zeroed
+//   output and the epilogue runs as a separate tiny kernel (used when the tile grid alone cannot
+//   fill 256 CUs: the 4^2..32^2 layers whose 4608-deep K loop would otherwise run on a few blocks).
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool SPLITK>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ wgt, float* __restrict__ out,
-                                                            Epilogue ep) {
+                                                            Epilogue ep, int nsplit) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
     constexpr int A_MSTEP = NT / BK;          // rows of m covered per pass (k fastest)
     constexpr int B_KSTEP = NT / BN;          // k rows covered per pass (p fastest)
-    static_assert(A_PER >= 1 && B_PER >= 1 && NT % BK == 0 && NT % BN == 0 || NT < BN, "tile/threads mismatch");
+    static_assert(NT >= BN && NT % BK == 0 && NT % BN == 0 && A_PER >= 1 && B_PER >= 1, "tile/threads mismatch");
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int n = blockIdx.z / P.ncls, ci = blockIdx.z % P.ncls;
+    int zi = blockIdx.z;
+    const int split = SPLITK ? zi % nsplit : 0;
+    if (SPLITK) zi /= nsplit;
+    const int n = zi / P.ncls, ci = zi % P.ncls;
     const ClassParams& C = P.cls[ci];
     const int npix = C.OHp * C.OWp;
     const int p0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     if (p0 >= npix) return;
-    const int K = P.Ci * C.taps.T;
+    const int T = C.taps.T;
+    const int nchunk = (P.Ci + BK - 1) / BK;
+    const int nslab_all = T * nchunk;
+    int s_beg = 0, s_end = nslab_all;
+    if (SPLITK) {
+        const int per = (nslab_all + nsplit - 1) / nsplit;
+        s_beg = split * per; s_end = min(s_beg + per, nslab_all);
+        if (s_beg >= s_end) return;
+    }
     const float* inb = in + (int64_t)n * P.in_bs;
     const float* wb = wgt + (int64_t)n * P.wbs;
+    const int64_t chs = (int64_t)P.IH * P.IW;
 
-    // ---- per-thread load coordinates -------------------------------------------------------------
-    const int a_k = tid % BK;                      // k within slab (fixed per thread)
-    const int a_m = tid / BK;                      // first m row
-    int b_p, b_k;                                  // pixel within tile, first k row
-    if (NT >= BN) { b_p = tid % BN; b_k = tid / BN; } else { b_p = tid; b_k = 0; }
-    int iy0[(NT >= BN) ? 1 : BN / NT], ix0[(NT >= BN) ? 1 : BN / NT];
-    bool pv[(NT >= BN) ? 1 : BN / NT];
-    constexpr int B_PCH = (NT >= BN) ? 1 : BN / NT;        // pixels per thread when the block is narrower than the tile
-#pragma unroll
-    for (int q = 0; q < B_PCH; ++q) {
-        const int p = p0 + b_p + q * NT;
-        pv[q] = p < npix;
-        const int Y = pv[q] ? p / C.OWp : 0, X = pv[q] ? p - Y * C.OWp : 0;
-        iy0[q] = Y * P.isy; ix0[q] = X * P.isx;
-    }
-    constexpr int B_KPER = (NT >= BN) ? B_PER : BK;        // k rows each thread loads per pixel
-    constexpr int B_KST = (NT >= BN) ? B_KSTEP : 1;
+    // ---- per-thread load coordinates
+    const int a_k = tid % BK, a_m = tid / BK;
+    const int b_p = tid % BN, b_k = tid / BN;
+    const int p = p0 + b_p;
+    const bool pv = p < npix;
+    const int Y = pv ? p / C.OWp : 0, X = pv ? p - Y * C.OWp : 0;
+    const int iy0 = Y * P.isy, ix0 = X * P.isx;
 
-    float ra[A_PER], rb[B_PCH * B_KPER];
-    auto load_slab = [&](int k0) {
-        {   // A: weights
-            const int k = k0 + a_k;
-            const bool kv = k < K;
-            int c = 0, t = 0;
-            if (kv) split_k(k, C.taps.T, C.magicT, c, t);
+    float ra[A_PER], rb[B_PER];
+    auto load_slab = [&](int s) {
+        const int t = s / nchunk;
+        const int c0 = (s - t * nchunk) * BK;
+        {   // A: weights  A[m][c0 + a_k][t]
+            const int c = c0 + a_k;
+            const bool cv = c < P.Ci;
             const int koff = c * P.wsc + C.taps.widx[t];
 #pragma unroll
             for (int j = 0; j < A_PER; ++j) {
                 const int m = m0 + a_m + j * A_MSTEP;
-                ra[j] = (kv && m < P.Mo) ? wb[(int64_t)m * P.wsm + koff] : 0.f;
+                ra[j] = (cv && m < P.Mo) ? wb[(int64_t)m * P.wsm + koff] : 0.f;
             }
         }
+        {   // B: input pixel shifted by the tap, channels c0 + b_k + j*B_KSTEP
+            const int iy = iy0 + C.taps.dy[t], ix = ix0 + C.taps.dx[t];
+            const bool ok = pv && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW;
+            const float* ip = inb + (int64_t)(c0 + b_k) * chs + (int64_t)iy * P.IW + ix;
 #pragma unroll
-        for (int j = 0; j < B_KPER; ++j) {   // B: gathered input
-            const int k = k0 + b_k + j * B_KST;
-            const bool kv = k < K;
-            int c = 0, t = 0;
-            if (kv) split_k(k, C.taps.T, C.magicT, c, t);
-            const int dy = C.taps.dy[t], dx = C.taps.dx[t];
-            const float* ic = inb + (int64_t)c * P.IH * P.IW;
-#pragma unroll
-            for (int q = 0; q < B_PCH; ++q) {
-                const int iy = iy0[q] + dy, ix = ix0[q] + dx;
-                const bool ok = kv && pv[q] && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW;
-                rb[q * B_KPER + j] = ok ? ic[(int64_t)iy * P.IW + ix] : 0.f;
+            for (int j = 0; j < B_PER; ++j) {
+                const int c = c0 + b_k + j * B_KSTEP;
+                rb[j] = (ok && c < P.Ci) ? ip[(int64_t)j * B_KSTEP * chs] : 0.f;
             }
         }
     };
@@ -141,9 +144,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + j * A_MSTEP] = ra[j];
 #pragma unroll
-        for (int j = 0; j < B_KPER; ++j)
-#pragma unroll
-            for (int q = 0; q < B_PCH; ++q) Bs[buf][(b_k + j * B_KST) * LDB + b_p + q * NT] = rb[q * B_KPER + j];
+        for (int j = 0; j < B_PER; ++j) Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = rb[j];
     };
 
     f32x16 acc[TM][TN];
@@ -154,14 +155,13 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nslab = (K + BK - 1) / BK;
-    load_slab(0);
+    load_slab(s_beg);
     store_slab(0);
     __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nslab) load_slab((s + 1) * BK);
+    for (int s = s_beg; s < s_end; ++s) {
+        const int buf = (s - s_beg) & 1;
+        if (s + 1 < s_end) load_slab(s + 1);
         const float* Ab = As[buf] + wm * TM * 32 + fr;
         const float* Bb = Bs[buf] + wn * TN * 32 + fr;
 #pragma unroll
@@ -177,34 +177,51 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (s + 1 < nslab) store_slab(buf ^ 1);
+        if (s + 1 < s_end) store_slab(buf ^ 1);
         __syncthreads();
     }
 
     // ---- epilogue: C/D layout col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel)
-    const float ng = ep.noise ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
+    const float ng = (!SPLITK && ep.noise) ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
     float* ob = out + (int64_t)n * P.out_bs;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int p = p0 + (wn * TN + j) * 32 + fr;
-        if (p >= npix) continue;
-        const int Y = p / C.OWp, X = p - Y * C.OWp;
-        const int oy = Y * P.osy + C.ooy, ox = X * P.osx + C.oox;
-        const int64_t opix = (int64_t)oy * P.OW + ox;
-        const float nz = ep.noise ? ep.noise[opix] * ng : 0.f;
+        const int pp = p0 + (wn * TN + j) * 32 + fr;
+        if (pp >= npix) continue;
+        const int Yo = pp / C.OWp, Xo = pp - Yo * C.OWp;
+        const int64_t opix = (int64_t)(Yo * P.osy + C.ooy) * P.OW + (Xo * P.osx + C.oox);
+        const float nz = (!SPLITK && ep.noise) ? ep.noise[opix] * ng : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (m < P.Mo) {
-                    float v = acc[i][j][r] + nz;
-                    if (ep.bias) v += ep.bias[m];
-                    if (ep.act) v = epilogue_act(ep, v);
-                    ob[(int64_t)m * P.OH * P.OW + opix] = v;
+                    float* dst = ob + (int64_t)m * P.OH * P.OW + opix;
+                    if (SPLITK) atomicAdd(dst, acc[i][j][r]);
+                    else {
+                        float v = acc[i][j][r] + nz;
+                        if (ep.bias) v += ep.bias[m];
+                        if (ep.act) v = epilogue_act(ep, v);
+                        *dst = v;
+                    }
                 }
             }
         }
+    }
+}
+
+// epilogue for the split-K path: y = act(y + noise*gain + bias) over [N, O, HW]
+__global__ void conv_epilogue_kernel(float* __restrict__ y, int64_t total, int O, int64_t HW, Epilogue ep) {
+    const float ng = ep.noise ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = g % HW;
+        const int m = (int)((g / HW) % O);
+        float v = y[g];
+        if (ep.noise) v += ep.noise[pix] * ng;
+        if (ep.bias) v += ep.bias[m];
+        if (ep.act) v = epilogue_act(ep, v);
+        y[g] = v;
     }
 }
 
@@ -412,22 +429,45 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st) {
+static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, int nsplit, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     int maxpix = 0;
     for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
-    dim3 grid((unsigned)((maxpix + BN - 1) / BN), (unsigned)((P.Mo + BM - 1) / BM), (unsigned)(P.N * P.ncls));
-    hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep);
+    dim3 grid((unsigned)((maxpix + BN - 1) / BN), (unsigned)((P.Mo + BM - 1) / BM), (unsigned)(P.N * P.ncls * nsplit));
+    if (nsplit > 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
+    else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
 }
 
-static void dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st) {
-    int maxpix = 0;
-    for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
+static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st) {
+    int maxpix = 0, maxT = 0;
+    for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxT = std::max(maxT, P.cls[c].taps.T); }
     auto blocks = [&](int bm, int bn) { return (int64_t)((maxpix + bn - 1) / bn) * ((P.Mo + bm - 1) / bm) * P.N * P.ncls; };
-    if (P.Mo <= 32) { launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, st); return; }           // 32 x 128 (toRGB, 3 channels)
-    if (blocks(128, 128) >= 384) { launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, st); return; }  // 128 x 128
-    if (blocks(64, 64) >= 192) { launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, st); return; }    // 64 x 64
-    launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, st);                                           // 32 x 32, one wave
+    const int nslab = maxT * ((P.Ci + BK - 1) / BK);
+    int cfg;                    // 0: 32x128, 1: 128x128, 2: 64x64, 3: 32x32
+    if (P.Mo <= 32) cfg = 0;
+    else if (blocks(128, 128) >= 384) cfg = 1;
+    else if (P.Mo >= 64 && maxpix >= 64) cfg = 2;
+    else cfg = 3;
+    static const int bm_of[4] = {32, 128, 64, 32}, bn_of[4] = {128, 128, 64, 32};
+    const int64_t nb = blocks(bm_of[cfg], bn_of[cfg]);
+    int nsplit = 1;
+    if (nb < 512 && nslab >= 8) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);
+    if (nsplit > 1) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)P.N * P.out_bs * sizeof(float), st);
+        if (e != hipSuccess) { spi_set_error("conv: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+    }
+    switch (cfg) {
+    case 0: launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, nsplit, st); break;
+    case 1: launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, nsplit, st); break;
+    case 2: launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, nsplit, st); break;
+    default: launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, nsplit, st); break;
+    }
+    if (nsplit > 1 && (ep.bias || ep.noise || ep.act)) {
+        const int64_t total = (int64_t)P.N * P.out_bs;
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(conv_epilogue_kernel, dim3(grid), dim3(256), 0, st, out, total, P.Mo, (int64_t)P.OH * P.OW, ep);
+    }
+    return SPI_OK;
 }
 
 extern "C" {
@@ -441,7 +481,7 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
                 "spi_conv2d_fwd: no fused epilogue in transposed mode (the FIR pass owns it)");
     IGemmParams P; make_forward(d, P);
     Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
-    dispatch_igemm(P, x, w, y, ep, as_stream(stream));
+    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream)); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_fwd");
     return SPI_OK;
 }
@@ -451,7 +491,7 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     SPI_REQUIRE(dy && w && dx, "spi_conv2d_dgrad: null tensor");
     IGemmParams P; make_dgrad(d, P);
     Epilogue ep{nullptr, nullptr, nullptr, 0, 0.f, 1.f, -1.f};
-    dispatch_igemm(P, dy, w, dx, ep, as_stream(stream));
+    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream)); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_dgrad");
     return SPI_OK;
 }

@@ -329,6 +329,204 @@ __global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of gather + decoder for the render path, tiled for scatter locality.
+//   A tile is an 8x8 patch of neighbouring rays x 4 consecutive SORTED sample positions: those 256
+//   points land on a few dozen texels per plane, so their plane-gradient contributions are first
+//   summed in a 16x16-texel LDS window (ds_add_f32) and only the window's non-zero texels go to HBM
+//   with global atomics -- instead of 384 global atomics per point.  Corners outside the window
+//   fall back to direct global atomics, so the result never depends on the window placement.
+//   Sample (ray, k) is read through the sort permutation: its colour/density row is perm[ray,k] and
+//   its depth is depths_sorted[ray,k]; the coarse / fine depth arrays are not needed.
+// ------------------------------------------------------------------------------------------------
+constexpr int WIN = 16;                       // window edge in texels; WIN*WIN*32 floats == DT*32 <= DT*FS
+
+struct TiledArgs {
+    const float* planes; const float* ray_o; const float* ray_d; const float* depths; const int32_t* perm;
+    int N; int M; int S; int H; int W; float scale;
+    int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
+    int patches; int kchunks;
+};
+
+__global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                              const float* __restrict__ w2, const float* __restrict__ b2,
+                                                              const float* __restrict__ d_rgb, const float* __restrict__ d_sigma,
+                                                              float* __restrict__ d_planes, float* __restrict__ dump) {
+    __shared__ __attribute__((aligned(16))) float feat[DT * FS];
+    __shared__ __attribute__((aligned(16))) float gbuf[DT * FS];
+    __shared__ float s_x[DT], s_y[DT], s_z[DT];
+    __shared__ int64_t s_row[DT];
+    __shared__ int s_acc[8];
+    const int t = threadIdx.x;
+    const int tile = blockIdx.x;
+    const int n = tile / (a.patches * a.kchunks);
+    const int rem = tile - n * (a.patches * a.kchunks);
+    const int patch = rem / a.kchunks, kc = rem - patch * a.kchunks;
+    // ---- point owned by this thread
+    const int rl = t & 63, kk = t >> 6;
+    int m;
+    if (a.patch2d) {
+        const int pw = a.ray_w >> 3;
+        const int py = patch / pw, px = patch - py * pw;
+        m = ((py << 3) + (rl >> 3)) * a.ray_w + (px << 3) + (rl & 7);
+    } else {
+        m = patch * 64 + rl;
+    }
+    const int k = kc * 4 + kk;
+    const bool valid = (m < a.M) && (k < a.S);
+    int64_t row = -1;
+    float x = 0.f, y = 0.f, z = 0.f;
+    if (valid) {
+        const int64_t ray = (int64_t)n * a.M + m;
+        const int64_t si = ray * a.S + k;
+        row = ray * a.S + (a.perm ? a.perm[si] : k);
+        const float dpt = a.depths[si];
+        const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
+        x = (o[0] + dpt * d[0]) * a.scale; y = (o[1] + dpt * d[1]) * a.scale; z = (o[2] + dpt * d[2]) * a.scale;
+    }
+    s_x[t] = x; s_y[t] = y; s_z[t] = z; s_row[t] = row;
+    __syncthreads();
+    // ---- phase A: gather features and stage d_rgb rows, 8 lanes per point
+    const int sub = t & 7, grp = t >> 3;
+    const int64_t plane_sz = (int64_t)a.H * a.W * DEC_IN;
+#pragma unroll 2
+    for (int pass = 0; pass < DT / 32; ++pass) {
+        const int s = pass * 32 + grp;
+        const int64_t prow = s_row[s];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), g4 = acc;
+        if (prow >= 0) {
+            const float qx = s_x[s], qy = s_y[s], qz = s_z[s];
+            g4 = *reinterpret_cast<const float4*>(d_rgb + prow * DEC_IN + sub * 4);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                float gx, gy;
+                plane_uv(pl, qx, qy, qz, gx, gy);
+                const Corner c = make_corner(gx, gy, a.W, a.H);
+                const float* pb = a.planes + (int64_t)(n * 3 + pl) * plane_sz + sub * 4;
+                const bool x0ok = (c.x0 >= 0) & (c.x0 < a.W), x1ok = (c.x0 + 1 >= 0) & (c.x0 + 1 < a.W);
+                const bool y0ok = (c.y0 >= 0) & (c.y0 < a.H), y1ok = (c.y0 + 1 >= 0) & (c.y0 + 1 < a.H);
+                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v00 = (x0ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0) * DEC_IN) : z4;
+                const float4 v01 = (x1ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0 + 1) * DEC_IN) : z4;
+                const float4 v10 = (x0ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0) * DEC_IN) : z4;
+                const float4 v11 = (x1ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0 + 1) * DEC_IN) : z4;
+                const float w00 = c.wx0 * c.wy0, w01 = c.wx1 * c.wy0, w10 = c.wx0 * c.wy1, w11 = c.wx1 * c.wy1;
+                acc.x += v00.x * w00 + v01.x * w01 + v10.x * w10 + v11.x * w11;
+                acc.y += v00.y * w00 + v01.y * w01 + v10.y * w10 + v11.y * w11;
+                acc.z += v00.z * w00 + v01.z * w01 + v10.z * w10 + v11.z * w11;
+                acc.w += v00.w * w00 + v01.w * w01 + v10.w * w10 + v11.w * w11;
+            }
+            acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+        }
+        *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
+        *reinterpret_cast<float4*>(gbuf + s * FS + sub * 4) = g4;
+    }
+    __syncthreads();
+    // ---- phase B: decoder forward + backward for this thread's point
+    const int64_t total = (int64_t)gridDim.x * DT;            // dump columns: tile-linear index
+    const int64_t dcol = (int64_t)tile * DT + t;
+    const bool dumping = (dump != nullptr);
+    float* frow = feat + t * FS;
+    float* grow = gbuf + t * FS;
+    float h[DEC_HID];
+    layer1_forward(w1t, b1, frow, h);
+    if (dumping) {
+        for (int i = 0; i < DEC_IN; ++i) dump[(int64_t)i * total + dcol] = valid ? frow[i] : 0.f;
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) dump[(int64_t)(32 + j) * total + dcol] = valid ? h[j] : 0.f;
+    }
+    float dp[DEC_HID];
+#pragma unroll
+    for (int j = 0; j < DEC_HID; ++j) dp[j] = 0.f;
+    const float dsig = valid ? d_sigma[row] : 0.f;
+#pragma unroll 2
+    for (int o = 0; o < DEC_OUT; ++o) {
+        const float* wr = w2 + o * DEC_HID;
+        float acc = b2[o];
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], h[j], acc);
+        float dyo;
+        if (o == 0) dyo = dsig;
+        else { const float sg = sigmoid_fast(acc); dyo = grow[o - 1] * 1.002f * sg * (1.f - sg); }
+        if (!valid) dyo = 0.f;
+        if (dumping) dump[(int64_t)(160 + o) * total + dcol] = dyo;
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) dp[j] = fmaf(wr[j], dyo, dp[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < DEC_HID; ++j) dp[j] *= (h[j] > 20.f) ? 1.f : (1.f - exp_fast(-h[j]));
+    if (dumping) {
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) dump[(int64_t)(96 + j) * total + dcol] = dp[j];
+    }
+#pragma unroll 2
+    for (int i = 0; i < DEC_IN; ++i) {
+        const float* wr = w1t + i * DEC_HID;
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], dp[j], acc);
+        grow[i] = acc / 3.f;
+    }
+    // ---- phase C: per plane, accumulate in an LDS window (reusing `feat`), then flush it
+    for (int pl = 0; pl < 3; ++pl) {
+        __syncthreads();                                   // feat free (phase B done / previous flush done); gbuf complete
+        if (t < 4) s_acc[t] = 0;
+        for (int i = t; i < WIN * WIN * DEC_IN; i += DT) feat[i] = 0.f;
+        __syncthreads();
+        {   // window centre = mean corner position of the tile's valid points
+            float gx, gy;
+            plane_uv(pl, x, y, z, gx, gy);
+            const Corner c = make_corner(gx, gy, a.W, a.H);
+            if (valid) {
+                atomicAdd(&s_acc[0], min(max(c.x0, -1), a.W)); atomicAdd(&s_acc[1], min(max(c.y0, -1), a.H)); atomicAdd(&s_acc[2], 1);
+            }
+        }
+        __syncthreads();
+        const int cnt = max(s_acc[2], 1);
+        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;
+        float* gplane = d_planes + (int64_t)(n * 3 + pl) * plane_sz;
+        for (int pass = 0; pass < DT / 32; ++pass) {
+            const int s = pass * 32 + grp;
+            if (s_row[s] < 0) continue;
+            const float4 d4 = *reinterpret_cast<const float4*>(gbuf + s * FS + sub * 4);
+            float gx, gy;
+            plane_uv(pl, s_x[s], s_y[s], s_z[s], gx, gy);
+            const Corner c = make_corner(gx, gy, a.W, a.H);
+#pragma unroll
+            for (int cy = 0; cy < 2; ++cy) {
+#pragma unroll
+                for (int cx = 0; cx < 2; ++cx) {
+                    const int xx = c.x0 + cx, yy = c.y0 + cy;
+                    if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
+                    const float w = (cx ? c.wx1 : c.wx0) * (cy ? c.wy1 : c.wy0);
+                    const int lx = xx - wx0, ly = yy - wy0;
+                    if (lx >= 0 && lx < WIN && ly >= 0 && ly < WIN) {             // LDS atomics (ds_add_f32)
+                        const int wi = (ly * WIN + lx) * DEC_IN + sub * 4;
+                        atomicAdd(&feat[wi + 0], d4.x * w); atomicAdd(&feat[wi + 1], d4.y * w);
+                        atomicAdd(&feat[wi + 2], d4.z * w); atomicAdd(&feat[wi + 3], d4.w * w);
+                    } else {                                                       // rare: straight to HBM
+                        float* p = gplane + ((int64_t)yy * a.W + xx) * DEC_IN + sub * 4;
+                        atomicAdd(p + 0, d4.x * w); atomicAdd(p + 1, d4.y * w);
+                        atomicAdd(p + 2, d4.z * w); atomicAdd(p + 3, d4.w * w);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        for (int pass = 0; pass < (WIN * WIN) / 32; ++pass) {          // flush: 8 lanes per texel
+            const int tex = pass * 32 + grp;
+            const int xx = wx0 + (tex % WIN), yy = wy0 + (tex / WIN);
+            if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
+            const float4 v = *reinterpret_cast<const float4*>(feat + tex * DEC_IN + sub * 4);
+            float* p = gplane + ((int64_t)yy * a.W + xx) * DEC_IN + sub * 4;
+            if (v.x != 0.f) atomicAdd(p + 0, v.x);
+            if (v.y != 0.f) atomicAdd(p + 1, v.y);
+            if (v.z != 0.f) atomicAdd(p + 2, v.z);
+            if (v.w != 0.f) atomicAdd(p + 3, v.w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // min / max reduction (ray_marcher.py:50 clamps composite depth to the range of ALL depths)
 // ------------------------------------------------------------------------------------------------
 __global__ void minmax_init_kernel(float* out2) { out2[0] = INFINITY; out2[1] = -INFINITY; }
@@ -719,6 +917,34 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
                        b2, d_rgb, d_sigma, d_planes_nhwc, dump_act);
     SPI_LAUNCH_CHECK("spi_triplane_decode_bwd");
     return SPI_OK;
+}
+
+int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d, const float* depths_sorted,
+                                   const int32_t* perm, const float* w1t, const float* b1, const float* w2, const float* b2,
+                                   const float* d_rgb, const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
+                                   float box_warp, float* d_planes_nhwc, float* dump_act, int64_t* dump_cols, spi_stream_t stream) {
+    SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_rgb && d_sigma && d_planes_nhwc,
+                "spi_triplane_decode_bwd_sorted: null tensor");
+    SPI_REQUIRE(N > 0 && M > 0 && S > 0 && H > 0 && W > 0 && box_warp > 0.f && ray_w > 0, "spi_triplane_decode_bwd_sorted: bad size");
+    TiledArgs a;
+    a.planes = planes_nhwc; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths_sorted; a.perm = perm;
+    a.N = N; a.M = M; a.S = S; a.H = H; a.W = W; a.scale = 2.f / box_warp; a.ray_w = ray_w;
+    a.patch2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
+    a.patches = a.patch2d ? M / 64 : (M + 63) / 64;
+    a.kchunks = (S + 3) / 4;
+    const int64_t tiles = (int64_t)N * a.patches * a.kchunks;
+    if (dump_cols) *dump_cols = tiles * DT;
+    if (d_rgb == nullptr) return SPI_OK;
+    hipLaunchKernelGGL(decode_bwd_tiled_kernel, dim3((unsigned)tiles), dim3(DT), 0, as_stream(stream), a, w1t, b1, w2, b2, d_rgb, d_sigma,
+                       d_planes_nhwc, dump_act);
+    SPI_LAUNCH_CHECK("spi_triplane_decode_bwd_sorted");
+    return SPI_OK;
+}
+
+int64_t spi_triplane_decode_bwd_sorted_cols(int N, int M, int S, int ray_w) {
+    const bool p2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
+    const int64_t patches = p2d ? M / 64 : (M + 63) / 64;
+    return (int64_t)N * patches * ((S + 3) / 4) * DT;
 }
 
 int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream) {

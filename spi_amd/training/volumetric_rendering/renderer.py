@@ -169,13 +169,21 @@ class _Render(torch.autograd.Function):
                  hip.ptr(dd), None, r, s, s, 32, white_back, hip.ptr(d_col), hip.ptr(d_sig), hip.stream())
         want_w = any(ctx.needs_input_grad[1:5])
         d_planes = torch.zeros_like(planes_nhwc)
-        gw = _decode_bwd(planes_nhwc, dec, d_col, d_sig, d_planes, rays=(ray_o, ray_d), depths=d_c, box_warp=box_warp, out_S=s,
-                         out_off=0, want_wgrad=want_w)
-        if sf > 0:
-            gf = _decode_bwd(planes_nhwc, dec, d_col, d_sig, d_planes, rays=(ray_o, ray_d), depths=d_f, box_warp=box_warp, out_S=s,
-                             out_off=sc, want_wgrad=want_w)
-            if want_w:
-                gw = tuple(a + b for a, b in zip(gw, gf))
+        # one pass over all Sc+Sf samples in sorted order, 8x8 ray patches (LDS-aggregated scatter)
+        _, _, hh, ww, _ = planes_nhwc.shape
+        res = int(round(math.sqrt(m)))
+        ray_w = res if res * res == m else m
+        dump = None
+        if want_w:
+            cols = hip.lib().spi_triplane_decode_bwd_sorted_cols(n, m, s, ray_w)
+            dump = torch.empty(DEC_DUMP_ROWS, cols, device=dev, dtype=torch.float32)
+        hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes_nhwc), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(d_all), hip.ptr(perm),
+                 hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_col), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
+                 hip.ptr(d_planes), hip.ptr(dump), None, hip.stream())
+        gw = None
+        if want_w:
+            f, hid, dpre, dy = dump[0:32], dump[32:96], dump[96:160], dump[160:193]
+            gw = (dpre @ f.t(), dpre.sum(1), dy @ hid.t(), dy.sum(1))
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
         if want_w:
