@@ -92,6 +92,11 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
                                    spi_stream_t stream);
 int64_t spi_triplane_decode_bwd_sorted_cols(int N, int M, int S, int ray_w);
 
+/* Decoder weight gradients from a dump written by the backward kernels (rows f | h | d_pre1 | d_y, each
+ * `cols` long): dw1 [64,32], db1 [64], dw2 [33,64], db2 [33] wrt the gained weights (overwritten). */
+int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, float* dw2, float* db2,
+                      spi_stream_t stream);
+
 /* min / max over a depth tensor (ray_marcher.py:50 clamps to the GLOBAL range).  out[2] = {min,max}. */
 int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream);
 

@@ -338,13 +338,14 @@ __global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const floa
 //   Sample (ray, k) is read through the sort permutation: its colour/density row is perm[ray,k] and
 //   its depth is depths_sorted[ray,k]; the coarse / fine depth arrays are not needed.
 // ------------------------------------------------------------------------------------------------
-constexpr int WIN = 16;                       // window edge in texels; WIN*WIN*32 floats == DT*32 <= DT*FS
+constexpr int WIN = 12;                       // window edge in texels; WIN*WIN*32 int64 accumulators == DT*FS floats of LDS
 
 struct TiledArgs {
     const float* planes; const float* ray_o; const float* ray_d; const float* depths; const int32_t* perm;
     int N; int M; int S; int H; int W; float scale;
     int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
     int patches; int kchunks;
+    int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 2 = no LDS window, 4 = skip MLP
 };
 
 __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
@@ -354,7 +355,9 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
     __shared__ __attribute__((aligned(16))) float feat[DT * FS];
     __shared__ __attribute__((aligned(16))) float gbuf[DT * FS];
     __shared__ float s_x[DT], s_y[DT], s_z[DT];
-    __shared__ int64_t s_row[DT];
+    __shared__ int s_row[DT];                 // row index into the [R*S] sample arrays (-1 = padding point)
+    __shared__ int s_cxy[DT];                 // per plane: window-relative corner (x0 - wx0) | (y0 - wy0) << 16, biased by +0x4000
+    __shared__ float s_wx[DT], s_wy[DT];      // per plane: bilinear fractions
     __shared__ int s_acc[8];
     const int t = threadIdx.x;
     const int tile = blockIdx.x;
@@ -373,12 +376,12 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
     }
     const int k = kc * 4 + kk;
     const bool valid = (m < a.M) && (k < a.S);
-    int64_t row = -1;
+    int row = -1;
     float x = 0.f, y = 0.f, z = 0.f;
     if (valid) {
         const int64_t ray = (int64_t)n * a.M + m;
         const int64_t si = ray * a.S + k;
-        row = ray * a.S + (a.perm ? a.perm[si] : k);
+        row = (int)(ray * a.S + (a.perm ? a.perm[si] : k));
         const float dpt = a.depths[si];
         const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
         x = (o[0] + dpt * d[0]) * a.scale; y = (o[1] + dpt * d[1]) * a.scale; z = (o[2] + dpt * d[2]) * a.scale;
@@ -466,63 +469,183 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
         for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], dp[j], acc);
         grow[i] = acc / 3.f;
     }
-    // ---- phase C: per plane, accumulate in an LDS window (reusing `feat`), then flush it
+    // ---- phase C: per plane, accumulate in an LDS window (reusing `feat`), then flush it.
+    // LDS float atomics are ~30x slower than integer ones on gfx950 (ds_add_f32: ~190 cycles per
+    // wave-instruction, ds_add_u64: ~10; tools/ubench/lds_atomic.hip), so the window holds 64-bit
+    // fixed-point sums scaled by a per-tile power of two: every fp32 product is represented exactly
+    // (down to 2^-40 of the tile's largest |gradient|), the sum is order-independent, and it is
+    // converted back to fp32 once at the flush.
+    if (a.dbg & 1) return;
+    static_assert(WIN * WIN * DEC_IN * 8 <= DT * FS * 4, "window must fit the feature buffer");
+    long long* win = reinterpret_cast<long long*>(feat);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < DEC_IN; ++i) amax = fmaxf(amax, fabsf(grow[i]));
+    amax = wave_max(amax);
+    __syncthreads();                                       // feat free (phase B done); gbuf complete
+    if (t < 8) s_acc[t] = 0;
+    __syncthreads();
+    if ((t & 63) == 0) atomicMax(&s_acc[4], __float_as_int(amax));        // amax >= 0: int order == float order
+    __syncthreads();
+    const float tile_max = __int_as_float(s_acc[4]);
+    if (!(tile_max > 0.f)) return;                          // all gradients zero (block-uniform)
+    const int e2 = ilogbf(tile_max);
+    const float to_fix = ldexpf(1.f, 40 - e2), from_fix = ldexpf(1.f, e2 - 40);
+    const int lane = t & 63, wave = t >> 6, half = lane >> 5, ch = lane & 31;
     for (int pl = 0; pl < 3; ++pl) {
-        __syncthreads();                                   // feat free (phase B done / previous flush done); gbuf complete
+        __syncthreads();                                   // previous flush done
         if (t < 4) s_acc[t] = 0;
-        for (int i = t; i < WIN * WIN * DEC_IN; i += DT) feat[i] = 0.f;
+        for (int i = t; i < WIN * WIN * DEC_IN; i += DT) win[i] = 0;
+        float gx, gy;
+        plane_uv(pl, x, y, z, gx, gy);
+        const Corner c = make_corner(gx, gy, a.W, a.H);
+        const int cx0 = min(max(c.x0, -2), a.W), cy0 = min(max(c.y0, -2), a.H);     // clamped: far-outside points stay outside
         __syncthreads();
-        {   // window centre = mean corner position of the tile's valid points
-            float gx, gy;
-            plane_uv(pl, x, y, z, gx, gy);
-            const Corner c = make_corner(gx, gy, a.W, a.H);
-            if (valid) {
-                atomicAdd(&s_acc[0], min(max(c.x0, -1), a.W)); atomicAdd(&s_acc[1], min(max(c.y0, -1), a.H)); atomicAdd(&s_acc[2], 1);
-            }
-        }
+        if (valid) { atomicAdd(&s_acc[0], cx0); atomicAdd(&s_acc[1], cy0); atomicAdd(&s_acc[2], 1); }
         __syncthreads();
         const int cnt = max(s_acc[2], 1);
-        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;
+        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;    // window centred on the mean corner
+        s_cxy[t] = ((cx0 - wx0 + 0x4000) & 0xffff) | ((cy0 - wy0 + 0x4000) << 16);
+        s_wx[t] = c.wx1; s_wy[t] = c.wy1;
+        __syncthreads();
         float* gplane = d_planes + (int64_t)(n * 3 + pl) * plane_sz;
-        for (int pass = 0; pass < DT / 32; ++pass) {
-            const int s = pass * 32 + grp;
-            if (s_row[s] < 0) continue;
-            const float4 d4 = *reinterpret_cast<const float4*>(gbuf + s * FS + sub * 4);
-            float gx, gy;
-            plane_uv(pl, s_x[s], s_y[s], s_z[s], gx, gy);
-            const Corner c = make_corner(gx, gy, a.W, a.H);
+        // a half-wave (32 lanes = the 32 channels of one 128-B texel row) per point
+#pragma unroll 2
+        for (int i = 0; i < 64; i += 2) {
+            const int sp = wave * 64 + i + half;
+            if (s_row[sp] < 0) continue;
+            const float dv = gbuf[sp * FS + ch];
+            const int pk = s_cxy[sp];
+            const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
+            const float fx1 = s_wx[sp], fy1 = s_wy[sp];
+            const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
 #pragma unroll
-            for (int cy = 0; cy < 2; ++cy) {
-#pragma unroll
-                for (int cx = 0; cx < 2; ++cx) {
-                    const int xx = c.x0 + cx, yy = c.y0 + cy;
-                    if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-                    const float w = (cx ? c.wx1 : c.wx0) * (cy ? c.wy1 : c.wy0);
-                    const int lx = xx - wx0, ly = yy - wy0;
-                    if (lx >= 0 && lx < WIN && ly >= 0 && ly < WIN) {             // LDS atomics (ds_add_f32)
-                        const int wi = (ly * WIN + lx) * DEC_IN + sub * 4;
-                        atomicAdd(&feat[wi + 0], d4.x * w); atomicAdd(&feat[wi + 1], d4.y * w);
-                        atomicAdd(&feat[wi + 2], d4.z * w); atomicAdd(&feat[wi + 3], d4.w * w);
-                    } else {                                                       // rare: straight to HBM
-                        float* p = gplane + ((int64_t)yy * a.W + xx) * DEC_IN + sub * 4;
-                        atomicAdd(p + 0, d4.x * w); atomicAdd(p + 1, d4.y * w);
-                        atomicAdd(p + 2, d4.z * w); atomicAdd(p + 3, d4.w * w);
-                    }
+            for (int q = 0; q < 4; ++q) {
+                const int cx = q & 1, cy = q >> 1;
+                const int xl = lx + cx, yl = ly + cy;
+                const int xx = xl + wx0, yy = yl + wy0;
+                if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
+                const float v = dv * ((cx ? fx1 : fx0) * (cy ? fy1 : fy0));
+                if (!(a.dbg & 2) && xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
+                    if (!(a.dbg & 32))
+                        atomicAdd(reinterpret_cast<unsigned long long*>(&win[(yl * WIN + xl) * DEC_IN + ch]),
+                                  (unsigned long long)__float2ll_rn(v * to_fix));                        // ds_add_u64
+                } else if (!(a.dbg & 16)) {
+                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, v);                        // rare: straight to HBM
                 }
             }
         }
         __syncthreads();
-        for (int pass = 0; pass < (WIN * WIN) / 32; ++pass) {          // flush: 8 lanes per texel
-            const int tex = pass * 32 + grp;
+        if (a.dbg & 8) continue;
+        for (int j = 0; j < (WIN * WIN) / 8; ++j) {                    // flush: one half-wave per texel row (128 B)
+            const int tex = j * 8 + wave * 2 + half;
             const int xx = wx0 + (tex % WIN), yy = wy0 + (tex / WIN);
             if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-            const float4 v = *reinterpret_cast<const float4*>(feat + tex * DEC_IN + sub * 4);
-            float* p = gplane + ((int64_t)yy * a.W + xx) * DEC_IN + sub * 4;
-            if (v.x != 0.f) atomicAdd(p + 0, v.x);
-            if (v.y != 0.f) atomicAdd(p + 1, v.y);
-            if (v.z != 0.f) atomicAdd(p + 2, v.z);
-            if (v.w != 0.f) atomicAdd(p + 3, v.w);
+            const long long q = win[tex * DEC_IN + ch];
+            if (q != 0) atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, __ll2float_rn(q) * from_fix);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder weight gradients from the activation dump of the backward kernels
+//   dump rows (each `cols` long, contiguous): f 0..31 | h 32..95 | d_pre1 96..159 | d_y 160..192 (160 = sigma)
+//   dW1[j][i] = sum_p d_pre1[j][p] f[i][p]      (64 x 32)      db1[j] = sum_p d_pre1[j][p]
+//   dW2[o][j] = sum_p d_y[o][p]   h[j][p]       (33 x 64)      db2[o] = sum_p d_y[o][p]
+//   A streaming reduction over points: HBM-bound (772 B/point).  Four 32x32 MFMA tiles, one per wave
+//   (dW1 rows 0-31 / 32-63, dW2 rgb rows x h cols 0-31 / 32-63); the sigma row of dW2 and the two bias
+//   sums ride along on the VALU while the tiles are staged.  Blocks own point chunks and add their
+//   partial results to the (pre-zeroed) outputs with global atomics.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+constexpr int WG_BK = 16;                  // points per slab
+constexpr int WG_LD = 192 + 4;             // LDS row: [dpre 64 | dy_rgb 32 | f 32 | h 64] + pad
+
+__global__ void __launch_bounds__(256) decoder_wgrad_kernel(const float* __restrict__ dump, int64_t cols, int64_t chunk,
+                                                            float* __restrict__ dw1, float* __restrict__ db1,
+                                                            float* __restrict__ dw2, float* __restrict__ db2) {
+    __shared__ __attribute__((aligned(16))) float sm[2][WG_BK * WG_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t pbeg = (int64_t)blockIdx.x * chunk, pend = min(pbeg + chunk, cols);
+    if (pbeg >= pend) return;
+    // staging map: thread -> (row r = tid / 4 [+64, +128], 4 consecutive points p4 = tid % 4)
+    const int r0 = tid >> 2, p4 = (tid & 3) * 4;
+    // LDS column of the three rows this thread stages, and their dump rows
+    //   LDS cols: 0..63 dpre (dump 96..159), 64..95 dy_rgb (161..192), 96..127 f (0..31), 128..191 h (32..95)
+    int lcol[3], drow[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int lc = r0 + 64 * q;
+        lcol[q] = lc;
+        drow[q] = lc < 64 ? 96 + lc : (lc < 96 ? 161 + (lc - 64) : (lc < 128 ? lc - 96 : 32 + (lc - 128)));
+    }
+    float4 rv[3]; float4 sg4;                       // sg4: d_y sigma for the thread's 4 points
+    float bsum[3] = {0.f, 0.f, 0.f};                // row sums of dpre / dy_rgb rows handled by this thread (q = 0,1)
+    float sigacc = 0.f;                             // sum_p dsig[p] * h[j][p] for the h row of q = 2 ... and q = 1/0? (only h rows)
+    float sigsum = 0.f;
+    auto load = [&](int64_t p) {
+        const int64_t pp = p + p4;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const float* src = dump + (int64_t)drow[q] * cols + pp;
+            if (pp + 3 < pend) rv[q] = *reinterpret_cast<const float4*>(src);
+            else { rv[q].x = pp < pend ? src[0] : 0.f; rv[q].y = pp + 1 < pend ? src[1] : 0.f; rv[q].z = pp + 2 < pend ? src[2] : 0.f; rv[q].w = 0.f; }
+        }
+        const float* ss = dump + (int64_t)160 * cols + pp;
+        if (pp + 3 < pend) sg4 = *reinterpret_cast<const float4*>(ss);
+        else { sg4.x = pp < pend ? ss[0] : 0.f; sg4.y = pp + 1 < pend ? ss[1] : 0.f; sg4.z = pp + 2 < pend ? ss[2] : 0.f; sg4.w = 0.f; }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float* d = sm[buf] + p4 * WG_LD + lcol[q];
+            d[0] = rv[q].x; d[WG_LD] = rv[q].y; d[2 * WG_LD] = rv[q].z; d[3 * WG_LD] = rv[q].w;
+            bsum[q] += (rv[q].x + rv[q].y) + (rv[q].z + rv[q].w);
+        }
+        // rows with LDS col >= 128 are h rows: q = 2 always (r0 + 128 >= 128)
+        sigacc += rv[2].x * sg4.x + rv[2].y * sg4.y + rv[2].z * sg4.z + rv[2].w * sg4.w;
+        if (r0 == 0) sigsum += (sg4.x + sg4.y) + (sg4.z + sg4.w);
+    };
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // wave -> tile: 0: dW1 rows 0-31, 1: dW1 rows 32-63 (A = dpre cols, B = f);  2: dW2 rgb x h 0-31, 3: dW2 rgb x h 32-63
+    const int a_off = wave == 0 ? 0 : (wave == 1 ? 32 : 64);
+    const int b_off = wave < 2 ? 96 : (wave == 2 ? 128 : 160);
+    const int fr = lane & 31, fk = lane >> 5;
+    const int nslab = (int)((pend - pbeg + WG_BK - 1) / WG_BK);
+    load(pbeg); store(0);
+    __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) load(pbeg + (int64_t)(s + 1) * WG_BK);
+        const float* base = sm[buf];
+#pragma unroll
+        for (int kk = 0; kk < WG_BK / 2; ++kk) {
+            const float af = base[(2 * kk + fk) * WG_LD + a_off + fr];
+            const float bf = base[(2 * kk + fk) * WG_LD + b_off + fr];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+        }
+        if (s + 1 < nslab) store(buf ^ 1);
+        __syncthreads();
+    }
+    // ---- write-out.  acc[r]: row (r&3) + 8*(r>>2) + 4*fk of the tile's A rows, column fr of its B rows
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * fk;
+        if (wave < 2) atomicAdd(dw1 + (wave * 32 + row) * 32 + fr, acc[r]);                        // dW1[j][i]
+        else atomicAdd(dw2 + (1 + row) * 64 + (wave - 2) * 32 + fr, acc[r]);                       // dW2[1 + rgb][j]
+    }
+    // row sums: the 4 threads sharing a row (tid & 3) combine, then one atomic per row
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { bsum[q] += __shfl_xor(bsum[q], 1, 64); bsum[q] += __shfl_xor(bsum[q], 2, 64); }
+    sigacc += __shfl_xor(sigacc, 1, 64); sigacc += __shfl_xor(sigacc, 2, 64);
+    sigsum += __shfl_xor(sigsum, 1, 64); sigsum += __shfl_xor(sigsum, 2, 64);
+    if ((tid & 3) == 0) {
+        atomicAdd(db1 + r0, bsum[0]);                                  // q = 0: dpre row r0
+        if (r0 < 32) atomicAdd(db2 + 1 + r0, bsum[1]);                 // q = 1: lcol 64..95 are dy_rgb rows (r0 < 32); 96..127 are f rows (no sum needed)
+        atomicAdd(dw2 + r0, sigacc);                                   // q = 2: h row r0 -> dW2[sigma][r0]
+        if (r0 == 0) atomicAdd(db2, sigsum);
     }
 }
 
@@ -842,7 +965,10 @@ __global__ void __launch_bounds__(256) merge_sort_kernel(const float* __restrict
 // ================================================================================================
 // C ABI
 // ================================================================================================
+static int g_spi_debug = 0;
 extern "C" {
+
+void spi_debug_set(int flags) { g_spi_debug = flags; }      /* profiling experiments only; 0 in normal operation */
 
 int spi_ray_sampler(const float* cam2world, const float* intrinsics, int N, int res, float* ray_o, float* ray_d,
                     spi_stream_t stream) {
@@ -932,6 +1058,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     a.patch2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
     a.patches = a.patch2d ? M / 64 : (M + 63) / 64;
     a.kchunks = (S + 3) / 4;
+    a.dbg = g_spi_debug;
     const int64_t tiles = (int64_t)N * a.patches * a.kchunks;
     if (dump_cols) *dump_cols = tiles * DT;
     if (d_rgb == nullptr) return SPI_OK;
@@ -945,6 +1072,20 @@ int64_t spi_triplane_decode_bwd_sorted_cols(int N, int M, int S, int ray_w) {
     const bool p2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
     const int64_t patches = p2d ? M / 64 : (M + 63) / 64;
     return (int64_t)N * patches * ((S + 3) / 4) * DT;
+}
+
+int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, float* dw2, float* db2, spi_stream_t stream) {
+    SPI_REQUIRE(dump && dw1 && db1 && dw2 && db2 && cols > 0, "spi_decoder_wgrad: bad argument");
+    SPI_REQUIRE(cols % 4 == 0 && ((uintptr_t)dump & 15) == 0, "spi_decoder_wgrad: dump must be 16-byte aligned with cols %% 4 == 0");
+    hipStream_t st = as_stream(stream);
+    hipMemsetAsync(dw1, 0, 64 * 32 * sizeof(float), st); hipMemsetAsync(db1, 0, 64 * sizeof(float), st);
+    hipMemsetAsync(dw2, 0, 33 * 64 * sizeof(float), st); hipMemsetAsync(db2, 0, 33 * sizeof(float), st);
+    int64_t chunk = (cols + 1023) / 1024;                    // ~1024 blocks
+    chunk = std::max<int64_t>(256, ((chunk + WG_BK - 1) / WG_BK) * WG_BK);
+    const unsigned grid = (unsigned)ceil_div64(cols, chunk);
+    hipLaunchKernelGGL(decoder_wgrad_kernel, dim3(grid), dim3(256), 0, st, dump, cols, chunk, dw1, db1, dw2, db2);
+    SPI_LAUNCH_CHECK("spi_decoder_wgrad");
+    return SPI_OK;
 }
 
 int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream) {

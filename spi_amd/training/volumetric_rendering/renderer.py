@@ -90,10 +90,21 @@ def _decode_bwd(planes_nhwc, dec, d_rgb, d_sigma, d_planes, *, coords=None, rays
     hip.call('spi_triplane_decode_bwd', hip.ptr(planes_nhwc), hip.ptr(coords) if coords is not None else None, ro, rd, dp,
              hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), hip.ptr(d_sigma), n, p, s, h, w, float(box_warp),
              out_S, out_off, hip.ptr(d_planes), hip.ptr(dump), hip.stream())
-    if not want_wgrad:
-        return None
-    f, hid, dpre, dy = dump[0:32], dump[32:96], dump[96:160], dump[160:193]
-    return dpre @ f.t(), dpre.sum(1), dy @ hid.t(), dy.sum(1)        # plain GEMMs over the point dimension
+    return _decoder_wgrad(dump) if want_wgrad else None
+
+
+def _decoder_wgrad(dump):
+    """(dW1 [64,32], db1 [64], dW2 [33,64], db2 [33]) from an activation dump [193, cols]: one streaming MFMA kernel."""
+    dev = dump.device
+    cols = dump.shape[1]
+    if cols % 4 != 0:                      # explicit-coordinate path with an odd point count: pad the columns
+        pad = 4 - cols % 4
+        dump = torch.cat([dump, dump.new_zeros(dump.shape[0], pad)], dim=1).contiguous()
+        cols += pad
+    gw1 = torch.empty(64, 32, device=dev); gb1 = torch.empty(64, device=dev)
+    gw2 = torch.empty(33, 64, device=dev); gb2 = torch.empty(33, device=dev)
+    hip.call('spi_decoder_wgrad', hip.ptr(dump), cols, hip.ptr(gw1), hip.ptr(gb1), hip.ptr(gw2), hip.ptr(gb2), hip.stream())
+    return gw1, gb1, gw2, gb2
 
 
 class _Render(torch.autograd.Function):
@@ -180,10 +191,7 @@ class _Render(torch.autograd.Function):
         hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes_nhwc), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(d_all), hip.ptr(perm),
                  hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_col), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
                  hip.ptr(d_planes), hip.ptr(dump), None, hip.stream())
-        gw = None
-        if want_w:
-            f, hid, dpre, dy = dump[0:32], dump[32:96], dump[96:160], dump[160:193]
-            gw = (dpre @ f.t(), dpre.sum(1), dy @ hid.t(), dy.sum(1))
+        gw = _decoder_wgrad(dump) if want_w else None
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
         if want_w:
