@@ -21,7 +21,10 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-RAYMARCH_BYTES_PER_RAY = lambda S, C=32: S * (C + 2) * 4 + (C + 1 + (S - 1)) * 4
+# Algorithmic bytes of the FINAL march per ray: read S*(C+1+1)*4 (colours, density, depth), write (C+1+1)*4 (rgb, depth, sum w).
+# SURVEY.md 8d's 27 008 B/ray also counts the S-1 per-sample weights; the final march does not write them (only their sum
+# is consumed, renderer.py:140), so they are left out: 26 112 + 136 = 26 248 B/ray at S = 192.
+RAYMARCH_BYTES_PER_RAY = lambda S, C=32: S * (C + 2) * 4 + (C + 2) * 4
 HBM_PEAK_GBS = 8000.0                                                                    # MI355X_MICROARCH.md
 
 

@@ -120,9 +120,10 @@ int spi_raymarch_bwd(const float* colors, const float* densities, const float* d
                      float* d_colors, float* d_densities, spi_stream_t stream);
 
 /* sample_importance + sample_pdf, renderer.py:194-253.  depths [R,S], weights [R,S-1], u [R,Sf]
- * -> fine depths [R,Sf] (unsorted). */
+ * -> fine depths [R,Sf]: in draw order like the reference (sort_out = 0) or ascending per ray (sort_out = 1;
+ * same multiset -- what the renderer uses so the later merge reads two monotone streams). */
 int spi_importance_sample(const float* depths, const float* weights, const float* u, int64_t R, int S,
-                          int Sf, float* fine, spi_stream_t stream);
+                          int Sf, float* fine, int sort_out, spi_stream_t stream);
 
 /* unify_samples' sort, renderer.py:157-163: concat coarse [R,Sc] + fine [R,Sf], ascending stable
  * sort.  out: sorted depths [R,Sc+Sf], perm int32 [R,Sc+Sf] (index into the concatenation). */

@@ -159,6 +159,100 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict_
     }
 }
 
+// Specialisations for the generator's 4x4 low-pass (the only filter on the SPI path).
+//   UP = DOWN = 1 (FIR after every stride-2 transposed conv and its adjoint): each thread produces four
+//   consecutive outputs of one row from a 4 x 7 input patch held in registers (7 loads per output
+//   instead of 16, no integer division in the tap loop).
+//   Other up/down in {1,2}: one output per thread, tap loops fully unrolled at compile time.
+template <int UP, int DOWN>
+__global__ void __launch_bounds__(256) upfirdn2d_4x4_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                            float* __restrict__ y, UpfirdnParams p,
+                                                            const float* __restrict__ pre_bias, const float* __restrict__ noise,
+                                                            const float* __restrict__ noise_gain, const float* __restrict__ bias,
+                                                            ActParams ap) {
+    __shared__ float sf[16];
+    if (threadIdx.x < 16) {
+        const int ty = threadIdx.x >> 2, tx = threadIdx.x & 3;
+        sf[threadIdx.x] = (p.flip ? f[ty * 4 + tx] : f[(3 - ty) * 4 + (3 - tx)]) * p.gain;
+    }
+    __syncthreads();
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = sf[i];
+    const float ng = (noise && noise_gain) ? noise_gain[0] : (noise ? 1.f : 0.f);
+    const int64_t plane = (int64_t)p.outH * p.outW;
+    if (UP == 1 && DOWN == 1) {
+        const int gw = (p.outW + 3) >> 2;                        // groups of 4 outputs per row
+        const int64_t total = (int64_t)p.N * p.C * p.outH * gw;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+            const int xg = (int)(g % gw);
+            const int64_t rowid = g / gw;
+            const int oy = (int)(rowid % p.outH);
+            const int64_t nc = rowid / p.outH;
+            const int c = (int)(nc % p.C);
+            const int ox = xg << 2;
+            const float* xp = x + nc * (int64_t)p.inH * p.inW;
+            const float pb = pre_bias ? pre_bias[c] : 0.f;
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const int bx = ox - p.padx0, by = oy - p.pady0;
+#pragma unroll
+            for (int ty = 0; ty < 4; ++ty) {
+                const int iy = by + ty;
+                if (iy < 0 || iy >= p.inH) continue;
+                const float* rp = xp + (int64_t)iy * p.inW;
+                float v[7];
+#pragma unroll
+                for (int i = 0; i < 7; ++i) { const int ix = bx + i; v[i] = (ix >= 0 && ix < p.inW) ? rp[ix] + pb : 0.f; }
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+#pragma unroll
+                    for (int tx = 0; tx < 4; ++tx) acc[o] = fmaf(k[ty * 4 + tx], v[o + tx], acc[o]);
+            }
+            float* yp = y + nc * plane + (int64_t)oy * p.outW + ox;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (ox + o >= p.outW) break;
+                float a = acc[o];
+                if (noise) a += noise[(int64_t)oy * p.outW + ox + o] * ng;
+                if (ap.act != 0) a = act_apply(ap, a + (bias ? bias[c] : 0.f), 0.f, 0.f, 1.f);
+                yp[o] = a;
+            }
+        }
+    } else {
+        const int64_t total = (int64_t)p.N * p.C * plane;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t nc = g / plane;
+            const int rem = (int)(g - nc * plane);
+            const int oy = rem / p.outW, ox = rem - oy * p.outW;
+            const int c = (int)(nc % p.C);
+            const float* xp = x + nc * (int64_t)p.inH * p.inW;
+            const float pb = pre_bias ? pre_bias[c] : 0.f;
+            const int by = oy * DOWN - p.pady0, bx = ox * DOWN - p.padx0;
+            const int ty0 = (UP == 1) ? 0 : (by & 1), tx0 = (UP == 1) ? 0 : (bx & 1);    // first tap that lands on a real sample
+            float acc = 0.f;
+#pragma unroll
+            for (int a = 0; a < 4 / UP; ++a) {
+                const int ty = ty0 + a * UP;
+                const int uy = by + ty;
+                const int iy = (UP == 1) ? uy : (uy >> 1);
+                if (uy < 0 || iy >= p.inH) continue;
+#pragma unroll
+                for (int b = 0; b < 4 / UP; ++b) {
+                    const int tx = tx0 + b * UP;
+                    const int ux = bx + tx;
+                    const int ix = (UP == 1) ? ux : (ux >> 1);
+                    if (ux < 0 || ix >= p.inW) continue;
+                    const float kv = (UP == 1) ? k[a * 4 + b] : sf[ty * 4 + tx];     // UP = 2: tap index depends on the output parity -> LDS lookup
+                    acc = fmaf(kv, xp[(int64_t)iy * p.inW + ix] + pb, acc);
+                }
+            }
+            if (noise) acc += noise[rem] * ng;
+            if (ap.act != 0) acc = act_apply(ap, acc + (bias ? bias[c] : 0.f), 0.f, 0.f, 1.f);
+            y[g] = acc;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // rotate(): unproject target pixels with the target depth, project into the source camera, sample
 // source depth / image / mask, keep depth-consistent in-frame pixels (spi/utils/rotate.py:5-116).
@@ -341,6 +435,15 @@ static int launch_upfirdn(const float* x, const float* f, float* y, const Upfird
                           const float* noise, const float* noise_gain, const float* bias, const ActParams& ap, spi_stream_t stream) {
     const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+    const bool k44 = p.fH == 4 && p.fW == 4 && p.upx == p.upy && p.downx == p.downy && p.upx <= 2 && p.downx <= 2 && !(p.upx == 2 && p.downx == 2);
+    if (k44 && p.upx == 1 && p.downx == 1) {
+        const unsigned g4 = (unsigned)std::min<int64_t>(ceil_div64((total + 3) / 4 + (int64_t)p.N * p.C * p.outH, 256), 256 * 32);
+        hipLaunchKernelGGL((upfirdn2d_4x4_kernel<1, 1>), dim3(g4), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
+    } else if (k44 && p.upx == 2) {
+        hipLaunchKernelGGL((upfirdn2d_4x4_kernel<2, 1>), dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
+    } else if (k44 && p.downx == 2) {
+        hipLaunchKernelGGL((upfirdn2d_4x4_kernel<1, 2>), dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
+    } else
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
     SPI_LAUNCH_CHECK("spi_upfirdn2d");
     return SPI_OK;

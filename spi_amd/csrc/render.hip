@@ -682,7 +682,7 @@ __global__ void minmax_kernel(const float* __restrict__ x, int64_t n, float* __r
 constexpr int MAXS = 256;
 constexpr int RM_WAVES = 4;
 
-struct MarchLds { float sig[MAXS]; float dep[MAXS]; float w[MAXS]; float q[MAXS]; };
+struct MarchLds { float sig[MAXS]; float dep[MAXS]; float w[MAXS]; float q[MAXS]; int row[MAXS]; };
 
 __device__ __forceinline__ int64_t row_of(const int32_t* perm, int64_t r, int S, int S_store, int k) {
     return r * S_store + (perm ? perm[r * S + k] : k);
@@ -698,7 +698,11 @@ __device__ __forceinline__ void march_scalars(MarchLds& L, const float* __restri
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int k = c * 64 + lane;
-        if (k < S) { L.sig[k] = densities[row_of(perm, r, S, S_store, k)]; L.dep[k] = depths[r * S + k]; }
+        if (k < S) {
+            const int pk = perm ? perm[r * S + k] : k;          // row of sample k inside the ray's S_store rows
+            L.row[k] = pk;
+            L.sig[k] = densities[r * S_store + pk]; L.dep[k] = depths[r * S + k];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     float carry = 1.f;
@@ -765,7 +769,7 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
         const int k = k0 + rg;
         if (k < S) {
             const float v = 0.5f * ((k > 0 ? L.w[k - 1] : 0.f) + L.w[k]);
-            const float4 c = *reinterpret_cast<const float4*>(colors + row_of(perm, r, S, S_store, k) * 32 + sub * 4);
+            const float4 c = *reinterpret_cast<const float4*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4);
             acc.x = fmaf(v, c.x, acc.x); acc.y = fmaf(v, c.y, acc.y);
             acc.z = fmaf(v, c.z, acc.z); acc.w = fmaf(v, c.w, acc.w);
         }
@@ -814,7 +818,7 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
         const int k = k0 + rg;
         float part = 0.f;
         if (k < S) {
-            const int64_t row = row_of(perm, r, S, S_store, k);
+            const int64_t row = r * S_store + L.row[k];
             const float4 c = *reinterpret_cast<const float4*>(colors + row * 32 + sub * 4);
             part = g4.x * c.x + g4.y * c.y + g4.z * c.z + g4.w * c.w;
             const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
@@ -874,7 +878,7 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
         const int k = c * 64 + lane;
         if (k < S) {
             const float v = (k < S - 1 ? L.q[k] : 0.f) + (k > 0 ? L.q[k - 1] : 0.f);
-            d_densities[row_of(perm, r, S, S_store, k)] = v;
+            d_densities[r * S_store + L.row[k]] = v;
         }
     }
 }
@@ -884,7 +888,7 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict__ depths, const float* __restrict__ weights,
                                                          const float* __restrict__ u, int64_t R, int S, int Sf,
-                                                         float* __restrict__ fine) {
+                                                         float* __restrict__ fine, int sort_out) {
     __shared__ float s_w[4][MAXS + 2];
     __shared__ float s_cdf[4][MAXS];
     __shared__ float s_bin[4][MAXS];
@@ -925,6 +929,7 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
     if (lane == 0) cdf[0] = 0.f;
     __builtin_amdgcn_wave_barrier();
     const int NC = NP + 1;                     // cdf entries
+    float* tv = w;                             // the smoothed weights are no longer needed: reuse as the sample buffer
     for (int j = lane; j < Sf; j += 64) {
         const float uu = u[r * Sf + j];
         int lo = 0, hi = NC;                   // searchsorted(right=True): first index with cdf > u
@@ -932,7 +937,19 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
         const int below = max(lo - 1, 0), above = min(lo, NP);
         float den = cdf[above] - cdf[below];
         if (den < 1e-5f) den = 1.f;
-        fine[r * Sf + j] = bin[below] + (uu - cdf[below]) / den * (bin[above] - bin[below]);
+        const float tval = bin[below] + (uu - cdf[below]) / den * (bin[above] - bin[below]);
+        if (sort_out) tv[j] = tval; else fine[r * Sf + j] = tval;
+    }
+    if (!sort_out) return;
+    // Emit the samples in ascending order (stable rank sort).  The reference keeps them in draw order and sorts
+    // coarse+fine together afterwards (renderer.py:157-163); the merged result is the same set either way, and
+    // sorted fine rows make the final march read two monotone streams through its permutation.
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < Sf; j += 64) {
+        const float v = tv[j];
+        int rank = 0;
+        for (int m2 = 0; m2 < Sf; ++m2) { const float o = tv[m2]; rank += (o < v) || (o == v && m2 < j); }
+        fine[r * Sf + rank] = v;
     }
 }
 
@@ -1135,11 +1152,11 @@ int spi_raymarch_bwd(const float* colors, const float* densities, const float* d
 }
 
 int spi_importance_sample(const float* depths, const float* weights, const float* u, int64_t R, int S, int Sf, float* fine,
-                          spi_stream_t stream) {
+                          int sort_out, spi_stream_t stream) {
     SPI_REQUIRE(depths && weights && u && fine && R > 0 && Sf > 0, "spi_importance_sample: bad argument");
-    SPI_REQUIRE(S >= 4 && S <= MAXS, "spi_importance_sample: need 4 <= S <= %d, got %d", MAXS, S);
+    SPI_REQUIRE(S >= 4 && S <= MAXS && Sf <= MAXS, "spi_importance_sample: need 4 <= S <= %d and Sf <= %d", MAXS, MAXS);
     hipLaunchKernelGGL(importance_kernel, dim3((unsigned)ceil_div64(R, 4)), dim3(256), 0, as_stream(stream), depths, weights, u,
-                       R, S, Sf, fine);
+                       R, S, Sf, fine, sort_out);
     SPI_LAUNCH_CHECK("spi_importance_sample");
     return SPI_OK;
 }

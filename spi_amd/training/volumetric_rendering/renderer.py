@@ -137,7 +137,7 @@ class _Render(torch.autograd.Function):
                      hip.ptr(w_c), None, hip.stream())
             d_f = torch.empty(n, m, sf, device=dev, dtype=torch.float32)
             u = u.reshape(n, m, sf).contiguous().float()
-            hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), r, sc, sf, hip.ptr(d_f), hip.stream())
+            hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), r, sc, sf, hip.ptr(d_f), 1, hip.stream())
             _decode_fwd(planes_nhwc, dec, rays=(ray_o, ray_d), depths=d_f, box_warp=box_warp, out=(rgb_all, sig_all), out_S=s, out_off=sc)
             d_all = torch.empty(n, m, s, device=dev, dtype=torch.float32)
             perm = torch.empty(n, m, s, device=dev, dtype=torch.int32)

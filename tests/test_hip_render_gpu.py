@@ -103,8 +103,10 @@ def test_importance_golden(golden):
     dep, w, u = g['rm_dep'].to(DEV)[..., 0].contiguous(), g['is_w'].to(DEV)[..., 0].contiguous(), g['is_u'].to(DEV).contiguous()
     n, m, s = dep.shape
     fine = torch.empty(n, m, 20, device=DEV)
-    hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(w), hip.ptr(u), n * m, s, 20, hip.ptr(fine), hip.stream())
-    assert (fine.cpu() - g['is_fine'][..., 0]).abs().max() < 2e-6
+    hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(w), hip.ptr(u), n * m, s, 20, hip.ptr(fine), 0, hip.stream())
+    assert (fine.cpu() - g['is_fine'][..., 0]).abs().max() < 2e-6                 # draw order, as the reference returns them
+    hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(w), hip.ptr(u), n * m, s, 20, hip.ptr(fine), 1, hip.stream())
+    assert (fine.cpu() - torch.sort(g['is_fine'][..., 0], dim=-1)[0]).abs().max() < 2e-6     # ascending variant: same multiset
 
 
 def test_merge_sort_matches_torch_sort():
