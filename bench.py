@@ -52,7 +52,7 @@ def cpu_baseline(depth, narrow):
     from oracle import loops_ref as olp, losses_ref as olo, renderer_ref as orr
     from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
     from spi_amd.data.images_dataset import SyntheticDataset
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)        # torch's CPU kernels stop scaling (and thrash) far below the box's 256 hardware threads
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     G = TriPlaneGenerator(**ffhq512_kwargs(narrow=narrow))
@@ -71,7 +71,7 @@ def cpu_baseline(depth, narrow):
     return dict(value=1.0 / dt, unit='iters/s', cores=cores, kind='port',
                 sample=f'1 stage-2 main-branch iteration (1 synthesis fwd+bwd at 512^2 / {depth}+{depth} samples, L2+LPIPS, Adam over '
                        f'all G parameters; the every-4th-step rot / mirror-rot / depth branches are NOT in the sample), {dt:.1f} s, '
-                       f'torch {torch.__version__} CPU fp32, {cores} threads')
+                       f'torch {torch.__version__} CPU fp32, {cores} threads of {os.cpu_count()}')
 
 
 def main():

@@ -688,13 +688,10 @@ __device__ __forceinline__ int64_t row_of(const int32_t* perm, int64_t r, int S,
     return r * S_store + (perm ? perm[r * S + k] : k);
 }
 
-// Computes alpha / transmittance / weight for every interval of the ray into per-lane registers.
-// chunk c, lane l <-> interval k = c*64 + l.
+// Stage the ray's sort permutation, densities and depths in LDS (chunk c, lane l <-> sample k = c*64 + l).
 template <int NCH>
-__device__ __forceinline__ void march_scalars(MarchLds& L, const float* __restrict__ densities, const float* __restrict__ depths,
-                                              const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane,
-                                              float (&alpha)[NCH], float (&trans)[NCH], float (&delta)[NCH],
-                                              float (&smid)[NCH]) {
+__device__ __forceinline__ void march_load(MarchLds& L, const float* __restrict__ densities, const float* __restrict__ depths,
+                                           const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int k = c * 64 + lane;
@@ -705,6 +702,12 @@ __device__ __forceinline__ void march_scalars(MarchLds& L, const float* __restri
         }
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// alpha / transmittance for every interval of the ray, one interval per lane and chunk.
+template <int NCH>
+__device__ __forceinline__ void march_scan(const MarchLds& L, int S, int lane, float (&alpha)[NCH], float (&trans)[NCH],
+                                           float (&delta)[NCH], float (&smid)[NCH]) {
     float carry = 1.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -726,6 +729,15 @@ __device__ __forceinline__ void march_scalars(MarchLds& L, const float* __restri
 }
 
 template <int NCH>
+__device__ __forceinline__ void march_scalars(MarchLds& L, const float* __restrict__ densities, const float* __restrict__ depths,
+                                              const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane,
+                                              float (&alpha)[NCH], float (&trans)[NCH], float (&delta)[NCH],
+                                              float (&smid)[NCH]) {
+    march_load<NCH>(L, densities, depths, perm, r, S, S_store, lane);
+    march_scan<NCH>(L, S, lane, alpha, trans, delta, smid);
+}
+
+template <int NCH>
 __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
         const int32_t* __restrict__ perm, const float* __restrict__ clamp2, int64_t R, int S, int S_store, int white_back,
@@ -735,8 +747,21 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
     const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
     if (r >= R) return;
     MarchLds& L = lds[wave];
+    march_load<NCH>(L, densities, depths, perm, r, S, S_store, lane);
+    // All colour rows of the ray (NCH*8 float4 per lane, 8 rows = 1 KB per wave-instruction) are requested
+    // BEFORE the scalar phase, so the ~24 KB stream is in flight while the scans and exponentials run.
+    const int sub = lane & 7, rg = lane >> 3;
+    float4 creg[NCH * 8];
+    if (rgb != nullptr) {
+#pragma unroll
+        for (int it = 0; it < NCH * 8; ++it) {
+            const int k = it * 8 + rg;
+            creg[it] = (k < S) ? *reinterpret_cast<const float4*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4)
+                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
     float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
-    march_scalars<NCH>(L, densities, depths, perm, r, S, S_store, lane, alpha, trans, delta, smid);
+    march_scan<NCH>(L, S, lane, alpha, trans, delta, smid);
     float wsum = 0.f, dnum = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -762,17 +787,13 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
     if (rgb == nullptr) return;
     __builtin_amdgcn_wave_barrier();
     // sum_k w_k (c_k + c_{k+1})/2  ==  sum_k c_k * (w_{k-1} + w_k)/2
-    const int sub = lane & 7, rg = lane >> 3;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-    for (int k0 = 0; k0 < S; k0 += 8) {
-        const int k = k0 + rg;
-        if (k < S) {
-            const float v = 0.5f * ((k > 0 ? L.w[k - 1] : 0.f) + L.w[k]);
-            const float4 c = *reinterpret_cast<const float4*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4);
-            acc.x = fmaf(v, c.x, acc.x); acc.y = fmaf(v, c.y, acc.y);
-            acc.z = fmaf(v, c.z, acc.z); acc.w = fmaf(v, c.w, acc.w);
-        }
+#pragma unroll
+    for (int it = 0; it < NCH * 8; ++it) {
+        const int k = it * 8 + rg;
+        const float v = (k < S) ? 0.5f * ((k > 0 ? L.w[k - 1] : 0.f) + L.w[k]) : 0.f;
+        acc.x = fmaf(v, creg[it].x, acc.x); acc.y = fmaf(v, creg[it].y, acc.y);
+        acc.z = fmaf(v, creg[it].z, acc.z); acc.w = fmaf(v, creg[it].w, acc.w);
     }
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {

@@ -1,0 +1,152 @@
+"""CPU tests of the host-side logic: CLI surface, naming, dataset contract, sharding + stats all-reduce over gloo
+(world_size 2), checkpoint ingestion without executing embedded code."""
+import io
+import os
+import pickle
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+
+def test_cli_flags_match_reference_readme_commands(tmp_path):
+    from spi_amd import run_inversion
+    from spi_amd.configs import hyperparameters as hp, paths_config as pc
+    from spi_amd.training.coaches.base_coach import BaseCoach
+    out = str(tmp_path) + '/'
+    run_inversion.parse_args(['--data_root', 'x', '--output_root', out, '--first_inv_type', 'mir', '--first_inv_steps', '500',
+                              '--G_1_type', 'RotBbox', '--G_1_step', '1000', '--pt_rot_lambda', '0.1', '--pt_mirror_rot_lambda', '0.05',
+                              '--pt_depth_lambda', '1', '--pt_tv_lambda', '0', '--not_use_wandb'])
+    assert (hp.first_inv_type, hp.first_inv_steps, hp.G_1_type, hp.G_1_step) == ('mir', 500, 'RotBbox', 1000)
+    assert (hp.pt_rot_lambda, hp.pt_mirror_rot_lambda, hp.pt_depth_lambda, hp.pt_tv_lambda) == (0.1, 0.05, 1.0, 0.0)
+    for d in ('checkpoints', 'embedding', 'experiments', 'image', 'image_m', 'video'):
+        assert os.path.isdir(os.path.join(out, d))
+    dummy = types.SimpleNamespace(coach_name='RotBboxCoach')
+    BaseCoach.build_name(dummy)
+    assert dummy.coach_name == 'RotBboxCoach_mir_500_RotBbox_1000_rot_0.1_mirrorrot_0.05_depth_1.0_tv_0.0'
+    run_inversion.parse_args(['--output_root', out, '--first_inv_type', 'sg', '--first_inv_steps', '500', '--G_1_type', 'pti', '--G_1_step', '1000'])
+    dummy = types.SimpleNamespace(coach_name='PTI_coach')
+    BaseCoach.build_name(dummy)
+    assert dummy.coach_name == 'PTI_coach_sg_500_pti_1000_rot_0_mirrorrot_0_depth_0_tv_0'
+    # reference defaults (run_inversion.py:18-42)
+    a = run_inversion.parse_args([])
+    assert (a.first_inv_type, a.first_inv_steps, a.G_1_step, a.G_1_type, a.G_2_step, a.data_mode) == ('pti', 500, 500, 'space', 500, 'png')
+
+
+def test_dataset_contract_and_block_sharding(tmp_path):
+    from PIL import Image
+    from spi_amd.data.images_dataset import PTIDataset, shard_block, SyntheticDataset, synthetic_landmarks
+    from spi_amd.utils.camera_utils import cal_canonical_c
+    root = tmp_path
+    names = [f'{i:03d}' for i in range(7)]
+    for nm in names:
+        for sub in ('crop', 'c', 'mask', 'lm'):
+            os.makedirs(root / sub / nm, exist_ok=True)
+        Image.fromarray((np.random.RandomState(int(nm)).rand(64, 64, 3) * 255).astype(np.uint8)).save(root / 'crop' / nm / 'target.png')
+        np.save(root / 'c' / nm / 'target.npy', cal_canonical_c(0.1)[0].numpy())
+        torch.save(torch.randint(0, 19, (1, 1, 512, 512)), root / 'mask' / nm / 'target.pt')
+        np.save(root / 'lm' / nm / 'target.npy', synthetic_landmarks().numpy())
+    kw = dict(source_root=str(root / 'crop'), c_root=str(root / 'c'), mask_root=str(root / 'mask'), lm_root=str(root / 'lm'), mode='png')
+    ds = PTIDataset(**kw)
+    d = ds[2]
+    assert len(ds) == 7 and d['name'] == '002' and d['img'].shape == (3, 512, 512) and d['img'].min() >= -1 and d['img'].max() <= 1
+    assert d['c'].dtype == np.float32 and d['c'].shape == (25,) and d['mask'].dtype == torch.int64 and d['lm'].shape == (68, 2)
+    # reference blocks: block = 7 // 3 + 1 = 3 -> [0:3], [3:6], [6:9]
+    assert [len(PTIDataset(dataset_block=f'{i}/3', **kw)) for i in (1, 2, 3)] == [3, 3, 1]
+    assert shard_block(list(range(10)), '2/4') == [3, 4, 5]
+    s = SyntheticDataset(2)[1]
+    assert s['img'].shape == (3, 512, 512) and s['mask'].shape == (1, 512, 512) and s['lm'].shape == (68, 2) and len(s['c']) == 25
+
+
+def _gloo_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from spi_amd import dist as sdist
+    r, w, _ = sdist.init_from_env(backend='gloo')
+    mine = sdist.shard_indices(7, r, w)
+    sdist.barrier()
+    tot = sdist.reduce_stats([len(mine), 10.0 * (r + 1)])
+    tmax = sdist.reduce_stats([1.0 + r], op='max')
+    q.put((r, mine, tot, tmax))
+    torch.distributed.destroy_process_group()
+
+
+def test_sharding_and_stats_allreduce_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29000 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(30) for p in procs]
+    assert [r[1] for r in res] == [[0, 1, 2, 3], [4, 5, 6]]            # reference-compatible contiguous blocks, no overlap, full cover
+    for r in res:
+        assert r[2] == [7.0, 30.0] and r[3] == [2.0]
+
+
+def test_shard_indices_cover_exactly_once():
+    from spi_amd.dist import shard_indices
+    for n in (1, 7, 8, 9, 64):
+        for w in (1, 2, 4, 8):
+            for mode in ('block', 'stride'):
+                allidx = sorted(i for r in range(w) for i in shard_indices(n, r, w, mode))
+                assert allidx == list(range(n)), (n, w, mode)
+
+
+def _reconstruct_persistent_obj(meta):            # stands in for the reference's hook while the test pickle is WRITTEN
+    raise AssertionError('must not be called')
+
+
+class _FakePersistent:
+    """Pickles like a persistence.persistent_class instance (persistence.py:120-128): reconstruct function + meta."""
+    def __init__(self, class_name, state):
+        self.class_name, self.state = class_name, state
+
+    def __reduce__(self):
+        import torch_utils.persistence as tp
+        meta = dict(type='class', version=6, module_src='raise SystemExit("embedded source must never run")', class_name=self.class_name,
+                    state=self.state)
+        return (tp._reconstruct_persistent_obj, (meta,), None, None, None)
+
+
+def test_network_pickle_reader_never_executes_embedded_source():
+    from spi_amd.utils import load_utils
+    from collections import OrderedDict
+    fake_tp = types.ModuleType('torch_utils.persistence')
+    _reconstruct_persistent_obj.__module__ = 'torch_utils.persistence'
+    _reconstruct_persistent_obj.__qualname__ = '_reconstruct_persistent_obj'
+    fake_tp._reconstruct_persistent_obj = _reconstruct_persistent_obj
+    fake_pkg = types.ModuleType('torch_utils')
+    sys.modules['torch_utils'], sys.modules['torch_utils.persistence'] = fake_pkg, fake_tp
+    try:
+        leaf = _FakePersistent('FullyConnectedLayer', dict(_parameters=OrderedDict(weight=torch.nn.Parameter(torch.ones(2, 3)), bias=None),
+                                                             _buffers=OrderedDict(), _modules=OrderedDict(), _non_persistent_buffers_set=set()))
+        seq = torch.nn.Sequential()
+        seq._modules['0'] = leaf                                         # a plain torch container holding a persistent child
+        top = _FakePersistent('TriPlaneGenerator', dict(
+            _parameters=OrderedDict(), _buffers=OrderedDict(w_avg=torch.zeros(4)), _modules=OrderedDict(decoder=seq),
+            _non_persistent_buffers_set=set(), _init_args=(), _init_kwargs=dict(z_dim=512, rendering_kwargs=dict(depth_resolution=48)),
+            rendering_kwargs=dict(depth_resolution=48), neural_rendering_resolution=64))
+        blob = pickle.dumps(dict(G=None, D=None, G_ema=top))
+    finally:
+        del sys.modules['torch_utils'], sys.modules['torch_utils.persistence']
+    args, kwargs, sd, extra = load_utils.read_network_pkl(io.BytesIO(blob))
+    assert args == () and kwargs['z_dim'] == 512 and extra['neural_rendering_resolution'] == 64
+    assert set(sd) == {'w_avg', 'decoder.0.weight'} and torch.equal(sd['decoder.0.weight'], torch.ones(2, 3))
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('echo pwned',))
+    with pytest.raises(pickle.UnpicklingError):
+        load_utils.read_network_pkl(io.BytesIO(pickle.dumps(dict(G_ema=Evil()))))
+
+
+def test_projector_w_statistics_and_schedule_host_math():
+    from spi_amd.training.projectors.schedule import stage1_schedule
+    lr0, n0 = stage1_schedule(0, 500, 2.0)
+    assert lr0 == 0.0 and abs(n0 - 0.1) < 1e-12
+    lr_mid, _ = stage1_schedule(250, 500, 2.0)
+    assert abs(lr_mid - 0.01) < 1e-12
+    assert stage1_schedule(499, 500, 2.0)[1] == 0.0

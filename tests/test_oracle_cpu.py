@@ -179,3 +179,51 @@ def test_product_has_no_cpu_fallback():
             if f.endswith('.py'):
                 src = open(os.path.join(dp, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+# ---- the C restatement (oracle/c/renderer_ref.c) against the same golden vectors -------------------------
+def _c_oracle():
+    import ctypes
+    import subprocess
+    so = os.path.join(ROOT, 'oracle', '_build', 'librenderer_ref.so')
+    if not os.path.exists(so):
+        subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle', 'c')])
+    return ctypes.CDLL(so)
+
+
+def _fp(t):
+    import ctypes
+    return t.contiguous().data_ptr()
+
+
+def test_c_oracle_against_golden(golden):
+    import ctypes
+    L = _c_oracle()
+    g = golden('renderer')
+    P = _P(g)
+    f32 = lambda t: t.detach().float().contiguous()
+    # gather + decoder
+    planes, coords = f32(g['planes']), f32(g['coords'])
+    n, p = coords.shape[:2]
+    w1, b1, w2, b2 = (f32(P['decoder.net.0.weight'] / math.sqrt(32)), f32(P['decoder.net.0.bias']), f32(P['decoder.net.2.weight'] / 8.0),
+                      f32(P['decoder.net.2.bias']))
+    rgb, sigma = torch.empty(n, p, 32), torch.empty(n, p)
+    L.ref_gather_decode(ctypes.c_void_p(_fp(planes)), ctypes.c_void_p(_fp(coords)), n, ctypes.c_int64(p), 32, 16, 16, ctypes.c_float(1.0),
+                        ctypes.c_void_p(_fp(w1)), ctypes.c_void_p(_fp(b1)), ctypes.c_void_p(_fp(w2)), ctypes.c_void_p(_fp(b2)),
+                        ctypes.c_void_p(_fp(rgb)), ctypes.c_void_p(_fp(sigma)))
+    assert_close(rgb, g['gd_rgb'], 5e-6, 'C decoder rgb'); assert_close(sigma, g['gd_sigma'][..., 0], 5e-6, 'C decoder sigma')
+    # ray march
+    col, den, dep = f32(g['rm_col']), f32(g['rm_den'][..., 0]), f32(g['rm_dep'][..., 0])
+    nn, m, s, c = col.shape
+    for wb in (0, 1):
+        o_rgb, o_d, o_w = torch.empty(nn, m, c), torch.empty(nn, m), torch.empty(nn, m, s - 1)
+        L.ref_ray_march(ctypes.c_void_p(_fp(col)), ctypes.c_void_p(_fp(den)), ctypes.c_void_p(_fp(dep)), ctypes.c_int64(nn * m), s, c, wb,
+                        ctypes.c_void_p(_fp(o_rgb)), ctypes.c_void_p(_fp(o_d)), ctypes.c_void_p(_fp(o_w)))
+        assert_close(o_rgb, g[f'rm{wb}_rgb'], 5e-6, 'C march rgb'); assert_close(o_d, g[f'rm{wb}_depth'][..., 0], 5e-6, 'C march depth')
+        assert_close(o_w, g[f'rm{wb}_w'][..., 0], 5e-6, 'C march weights')
+    # importance sampling
+    w, u = f32(g['is_w'][..., 0]), f32(g['is_u'])
+    fine = torch.empty(nn * m, 20)
+    L.ref_importance(ctypes.c_void_p(_fp(dep)), ctypes.c_void_p(_fp(w)), ctypes.c_void_p(_fp(u)), ctypes.c_int64(nn * m), s, 20,
+                     ctypes.c_void_p(_fp(fine)))
+    assert (fine.reshape(nn, m, 20) - g['is_fine'][..., 0]).abs().max() < 5e-6
