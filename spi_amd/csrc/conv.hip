@@ -37,6 +37,7 @@ struct IGemmParams {
     int isy, isx, osy, osx;
     int64_t wbs; int wsm, wsc;
     int64_t in_bs, out_bs;
+    int64_t w_elems;        // elements of one sample's weight tensor (buffer-descriptor range)
     int ncls;
     ClassParams cls[4];
 };
@@ -70,7 +71,7 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 //   output and the epilogue runs as a separate tiny kernel (used when the tile grid alone cannot
 //   fill 256 CUs: the 4^2..32^2 layers whose 4608-deep K loop would otherwise run on a few blocks).
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool SPLITK>
+template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ wgt, float* __restrict__ out,
                                                             Epilogue ep, int nsplit) {
@@ -115,37 +116,79 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     const int Y = pv ? p / C.OWp : 0, X = pv ? p - Y * C.OWp : 0;
     const int iy0 = Y * P.isy, ix0 = X * P.isx;
 
-    float ra[A_PER], rb[B_PER];
-    auto load_slab = [&](int s) {
-        const int t = s / nchunk;
-        const int c0 = (s - t * nchunk) * BK;
-        {   // A: weights  A[m][c0 + a_k][t]
-            const int c = c0 + a_k;
-            const bool cv = c < P.Ci;
-            const int koff = c * P.wsc + C.taps.widx[t];
+    // Software pipeline (two register sets, two LDS buffers).  During iteration s:
+    //   - the loads of slab s+2 are ISSUED piecewise right after the first MFMA groups, so their address
+    //     arithmetic runs in the shadow of the matrix pipe (an MFMA occupies the pipe for 64 cycles after a
+    //     4-cycle issue) and they have a whole iteration to land;
+    //   - slab s+1 (requested one iteration ago) is masked and WRITTEN to the other LDS buffer behind the
+    //     last MFMA groups.
+    // Loads are unconditional (indices clamped into range, validity kept in a bit mask that is applied at the
+    // LDS write): predicated loads turn into exec-masked branch regions that hipcc waits for immediately.
+    // BUF (Ci % 16 == 0): loads go through raw buffer descriptors -- out-of-range offsets return 0 in hardware,
+    // so rows beyond Mo and taps that fall outside the image need no clamps, masks or selects, and the per-slab
+    // part of every address is a SCALAR offset.  That matters because on gfx950 the fp32 MFMA shares the FP32
+    // lanes with the VALU: every vector instruction in the loop costs ~2.6 matrix-pipe cycles
+    // (tools/ubench/mfma_valu.hip: 157 TF with no VALU beside the MFMAs, 118 TF with 8 per MFMA).
+    struct Stage { float ra[A_PER]; float rb[B_PER]; unsigned am, bm; };
+    Stage st0, st1;
+    constexpr unsigned OOB = 0x80000000u;
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    unsigned voffA[A_PER];
+    if (BUF) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)(P.w_elems * 4), 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * 4), 0x00020000);
 #pragma unroll
-            for (int j = 0; j < A_PER; ++j) {
-                const int m = m0 + a_m + j * A_MSTEP;
-                ra[j] = (cv && m < P.Mo) ? wb[(int64_t)m * P.wsm + koff] : 0.f;
-            }
+        for (int j = 0; j < A_PER; ++j) {
+            const int m = m0 + a_m + j * A_MSTEP;
+            voffA[j] = m < P.Mo ? (unsigned)((m * P.wsm + a_k * P.wsc) * 4) : OOB;
         }
-        {   // B: input pixel shifted by the tap, channels c0 + b_k + j*B_KSTEP
-            const int iy = iy0 + C.taps.dy[t], ix = ix0 + C.taps.dx[t];
-            const bool ok = pv && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW;
-            const float* ip = inb + (int64_t)(c0 + b_k) * chs + (int64_t)iy * P.IW + ix;
-#pragma unroll
-            for (int j = 0; j < B_PER; ++j) {
-                const int c = c0 + b_k + j * B_KSTEP;
-                rb[j] = (ok && c < P.Ci) ? ip[(int64_t)j * B_KSTEP * chs] : 0.f;
-            }
+    }
+    // per-slab addressing state (scalars + one vector offset), computed once per slab by slab_setup()
+    const int chs4 = __builtin_amdgcn_readfirstlane((int)chs * 4);               // bytes between input channels (scalar)
+    const int kstr4 = __builtin_amdgcn_readfirstlane(B_KSTEP * (int)chs * 4);     // bytes between the channels one thread loads
+    struct SlabAddr { int t, c0; int soffA; unsigned voffB; int soffB; bool okB; int iy, ix; };
+    auto slab_setup = [&](int s) {
+        SlabAddr q;
+        s = min(s, s_end - 1);
+        q.t = __builtin_amdgcn_readfirstlane(s / nchunk); q.c0 = __builtin_amdgcn_readfirstlane((s - q.t * nchunk) * BK);
+        q.iy = iy0 + C.taps.dy[q.t]; q.ix = ix0 + C.taps.dx[q.t];
+        q.okB = pv && q.iy >= 0 && q.iy < P.IH && q.ix >= 0 && q.ix < P.IW;
+        q.soffA = __builtin_amdgcn_readfirstlane((q.c0 * P.wsc + C.taps.widx[q.t]) * 4);     // wave-uniform by construction: keep it in an SGPR
+        q.voffB = q.okB ? (unsigned)((q.iy * P.IW + q.ix + b_k * (int)chs) * 4) : OOB;
+        q.soffB = __builtin_amdgcn_readfirstlane(q.c0 * chs4);
+        return q;
+    };
+    auto load_a = [&](Stage& S, const SlabAddr& q, int j) {
+        if (BUF) {
+            S.ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, (int)voffA[j], q.soffA, 0));
+        } else {
+            const int c = q.c0 + a_k;
+            const int koff = min(c, P.Ci - 1) * P.wsc + C.taps.widx[q.t];
+            const int m = m0 + a_m + j * A_MSTEP;
+            S.ra[j] = wb[(int64_t)min(m, P.Mo - 1) * P.wsm + koff];
+            S.am |= (unsigned)(c < P.Ci && m < P.Mo) << j;
         }
     };
-    auto store_slab = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < A_PER; ++j) As[buf][a_k * LDA + a_m + j * A_MSTEP] = ra[j];
-#pragma unroll
-        for (int j = 0; j < B_PER; ++j) Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = rb[j];
+    auto load_b = [&](Stage& S, const SlabAddr& q, int j) {
+        if (BUF) {
+            S.rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)q.voffB, q.soffB + j * kstr4, 0));
+        } else {
+            const int64_t poff = (int64_t)min(max(q.iy, 0), P.IH - 1) * P.IW + min(max(q.ix, 0), P.IW - 1);
+            const int c = q.c0 + b_k + j * B_KSTEP;
+            S.rb[j] = inb[(int64_t)min(c, P.Ci - 1) * chs + poff];
+            S.bm |= (unsigned)(q.okB && c < P.Ci) << j;
+        }
     };
+    auto load_all = [&](Stage& S, int s) {
+        S.am = S.bm = 0;
+        const SlabAddr q = slab_setup(s);
+#pragma unroll
+        for (int j = 0; j < A_PER; ++j) load_a(S, q, j);
+#pragma unroll
+        for (int j = 0; j < B_PER; ++j) load_b(S, q, j);
+    };
+    auto store_a = [&](const Stage& S, int buf, int j) { As[buf][a_k * LDA + a_m + j * A_MSTEP] = (BUF || ((S.am >> j) & 1u)) ? S.ra[j] : 0.f; };
+    auto store_b = [&](const Stage& S, int buf, int j) { Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? S.rb[j] : 0.f; };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -155,30 +198,61 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_slab(s_beg);
-    store_slab(0);
-    __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    for (int s = s_beg; s < s_end; ++s) {
-        const int buf = (s - s_beg) & 1;
-        if (s + 1 < s_end) load_slab(s + 1);
+    // one pipeline step: MFMAs of slab s from LDS[buf]; issue loads of slab s+2 into L; write slab s+1 from W to LDS[buf^1]
+    auto step = [&](int s, int buf, Stage& L, const Stage& W) {
         const float* Ab = As[buf] + wm * TM * 32 + fr;
         const float* Bb = Bs[buf] + wn * TN * 32 + fr;
+        L.am = L.bm = 0;
+        const SlabAddr q2 = slab_setup(s + 2);
+        constexpr int NK = BK / 2;
+        // fragments are read one MFMA group ahead (two register sets), so the lgkmcnt wait in front of a
+        // group never exposes the LDS latency
+        float af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[fk * LDA + i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * kk + fk) * LDA + i * 32];
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bb[fk * LDB + j * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * kk + fk) * LDB + j * 32];
+        for (int kk = 0; kk < NK; ++kk) {
+            if (kk + 1 < NK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = Ab[(2 * (kk + 1) + fk) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(kk + 1) & 1][j] = Bb[(2 * (kk + 1) + fk) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk < NK / 2) {               // first half of the MFMA groups: request slab s+2
+#pragma unroll
+                for (int j = 0; j < A_PER; ++j) if (j * (NK / 2) / A_PER == kk) load_a(L, q2, j);
+#pragma unroll
+                for (int j = 0; j < B_PER; ++j) if (j * (NK / 2) / B_PER == kk) load_b(L, q2, j);
+            } else {                          // second half: slab s+1 goes to the other LDS buffer
+#pragma unroll
+                for (int j = 0; j < A_PER; ++j) if (j * (NK / 2) / A_PER == kk - NK / 2) store_a(W, buf ^ 1, j);
+#pragma unroll
+                for (int j = 0; j < B_PER; ++j) if (j * (NK / 2) / B_PER == kk - NK / 2) store_b(W, buf ^ 1, j);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < s_end) store_slab(buf ^ 1);
         __syncthreads();
+    };
+    // prologue: slab s_beg -> LDS[0]; slab s_beg+1 in flight in st1
+    load_all(st0, s_beg);
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) store_a(st0, 0, j);
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) store_b(st0, 0, j);
+    load_all(st1, s_beg + 1);
+    __syncthreads();
+    for (int s = s_beg; s < s_end; s += 2) {
+        step(s, 0, st0, st1);                          // loads s+2 -> st0, writes s+1 (st1) -> LDS[1]
+        if (s + 1 < s_end) step(s + 1, 1, st1, st0);   // loads s+3 -> st1, writes s+2 (st0) -> LDS[0]
     }
 
     // ---- epilogue: C/D layout col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel)
@@ -267,29 +341,34 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
         bc[q] = c; bdy[q] = C.taps.dy[t]; bdx[q] = C.taps.dx[t];
     }
     float ra[A_PER], rb[B_PER];
+    unsigned amask = 0, bmask = 0;
     auto load_slab = [&](int pk) {
+        amask = bmask = 0;
         const int p = pk + l_p;
         const bool pvld = p < pend;
-        const int Y = pvld ? p / C.OWp : 0, X = pvld ? p - Y * C.OWp : 0;
+        const int pc = min(p, npix - 1);                       // clamped: loads are unconditional, values masked afterwards
+        const int Y = pc / C.OWp, X = pc - Y * C.OWp;
         const int64_t opix = (int64_t)(Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox);
 #pragma unroll
         for (int q = 0; q < A_PER; ++q) {
             const int m = m0 + l_r + q * ROWSTEP;
-            ra[q] = (pvld && m < P.Mo) ? dob[(int64_t)m * P.OH * P.OW + opix] : 0.f;
+            ra[q] = dob[(int64_t)min(m, P.Mo - 1) * P.OH * P.OW + opix];
+            amask |= (unsigned)(pvld && m < P.Mo) << q;
         }
         const int iyb = Y * P.isy, ixb = X * P.isx;
 #pragma unroll
         for (int q = 0; q < B_PER; ++q) {
             const int iy = iyb + bdy[q], ix = ixb + bdx[q];
             const bool ok = pvld && bv[q] && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW;
-            rb[q] = ok ? inb[((int64_t)bc[q] * P.IH + iy) * P.IW + ix] : 0.f;
+            rb[q] = inb[((int64_t)bc[q] * P.IH + min(max(iy, 0), P.IH - 1)) * P.IW + min(max(ix, 0), P.IW - 1)];
+            bmask |= (unsigned)ok << q;
         }
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < A_PER; ++q) As[buf][l_p * LDA + l_r + q * ROWSTEP] = ra[q];
+        for (int q = 0; q < A_PER; ++q) As[buf][l_p * LDA + l_r + q * ROWSTEP] = ((amask >> q) & 1u) ? ra[q] : 0.f;
 #pragma unroll
-        for (int q = 0; q < B_PER; ++q) Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = rb[q];
+        for (int q = 0; q < B_PER; ++q) Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = ((bmask >> q) & 1u) ? rb[q] : 0.f;
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -375,6 +454,7 @@ static void make_forward(const spi_conv_desc* d, IGemmParams& P) {
     const int kk = d->kh * d->kw;
     P.N = d->N; P.Mo = d->O; P.Ci = d->I; P.IH = d->H; P.IW = d->W; P.OH = OH; P.OW = OW;
     P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->I * d->H * d->W; P.out_bs = (int64_t)d->O * OH * OW;
+    P.w_elems = (int64_t)d->O * d->I * kk;
     if (!d->transposed) {
         P.isy = P.isx = P.osy = P.osx = 1; P.ncls = 1;
         P.wsm = d->I * kk; P.wsc = kk;
@@ -408,6 +488,7 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
     const int kk = d->kh * d->kw;
     P.N = d->N; P.Mo = d->I; P.Ci = d->O; P.IH = OH; P.IW = OW; P.OH = d->H; P.OW = d->W;
     P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->O * OH * OW; P.out_bs = (int64_t)d->I * d->H * d->W;
+    P.w_elems = (int64_t)d->O * d->I * kk;
     P.osy = P.osx = 1; P.ncls = 1;
     ClassParams& C = P.cls[0];
     C.OHp = d->H; C.OWp = d->W; C.ooy = C.oox = 0; C.taps.T = kk; C.magicT = magic_for(kk);
@@ -434,8 +515,15 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
     int maxpix = 0;
     for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
     dim3 grid((unsigned)((maxpix + BN - 1) / BN), (unsigned)((P.Mo + BM - 1) / BM), (unsigned)(P.N * P.ncls * nsplit));
-    if (nsplit > 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
-    else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
+    // buffer-descriptor fast path: whole channel chunks, and every byte offset fits a signed 32-bit field
+    const bool buf = (P.Ci % BK == 0) && (P.in_bs * 4 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31));
+    if (nsplit > 1) {
+        if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
+        else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
+    } else {
+        if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
+        else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
+    }
 }
 
 static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st) {

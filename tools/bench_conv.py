@@ -7,6 +7,7 @@ from spi_amd import hip
 from spi_amd.torch_utils.ops import conv2d_mfma as cm
 
 SHAPES = [  # name, N, I, O, H, k, transposed, per_sample
+    ('probe 1x1 1152->128 @512 (contiguous A)', 1, 1152, 128, 512, 1, False, True),
     ('sr1.conv1 128->128 @512', 1, 128, 128, 512, 3, False, True),
     ('sr0.conv1 256->256 @256', 1, 256, 256, 256, 3, False, True),
     ('sr1.conv0 256->128 up 256->513', 1, 256, 128, 256, 3, True, True),
