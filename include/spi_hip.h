@@ -173,6 +173,8 @@ typedef struct spi_conv_desc {
     int pad;                  /* zero padding (stride-1 mode)                                          */
     int transposed;           /* 0: correlation, stride 1; 1: conv_transpose2d stride 2, padding 0     */
     int flip;                 /* 1: spatially flip the kernel (true convolution)                       */
+    int w_tap_major;          /* 0: weights [O, I, kh, kw] (PyTorch);  1: [O, kh, kw, I] (channels innermost:  */
+                              /*    contiguous slab loads and contiguous weight-gradient writes)        */
     int64_t w_batch_stride;   /* elements between per-sample weights; 0 = weights shared by the batch  */
     /* fused epilogue of the forward (all optional): y = clamp(act(acc + noise*noise_gain + bias)*gain) */
     const float* bias;        /* [O] */
@@ -180,7 +182,8 @@ typedef struct spi_conv_desc {
     const float* noise_gain;  /* [1] device scalar */
     int act; float alpha, gain, clamp;
 } spi_conv_desc;
-/* weight layout: [O, I, kh, kw] in both modes (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).
+/* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
+ * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).
  * output size: stride-1: H + 2*pad - kh + 1;  transposed: 2*H + kh - 2  (= 2H+1 for 3x3).          */
 int spi_conv2d_fwd  (const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream);
 int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, float* dx, spi_stream_t stream);

@@ -39,7 +39,7 @@ class ConvStack(torch.nn.Module):
         self.last_relu = last_relu
         self.n_conv = len(convs)
         for i, (w, b) in enumerate(convs):
-            self.register_buffer(f'w{i}', w.clone().float())
+            self.register_buffer(f'w{i}', conv2d_mfma.to_tap_major(w.clone().float()))      # [O,3,3,I]
             self.register_buffer(f'b{i}', b.clone().float())
 
     def run(self, x, taps=None):
@@ -50,7 +50,7 @@ class ConvStack(torch.nn.Module):
                 continue
             relu = self.last_relu or ci < self.n_conv - 1
             x = conv2d_mfma.conv2d(x, getattr(self, f'w{ci}'), bias=getattr(self, f'b{ci}'), padding=1, act='relu' if relu else None,
-                                   gain=1.0 if relu else None)
+                                   gain=1.0 if relu else None, tap_major=True)
             if taps is not None and ci in taps:
                 feats.append(x)
             ci += 1

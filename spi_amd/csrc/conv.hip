@@ -301,8 +301,11 @@ __global__ void conv_epilogue_kernel(float* __restrict__ y, int64_t total, int O
 
 // -------------------------------------------------------------------------------------------------
 // weight gradient: dA[n, m, c, t] = sum_pixels dOut[n, m, out(Y,X)] * In[n, c, in(Y,X,t)]
-//   GEMM: rows m, columns j = c*T + t, reduction over class pixels (split across blockIdx.x, fp32
-//   atomics into a zeroed dA).
+//   GEMM: rows m, columns j = t*Ci + c (tap-major, so a 128-column tile of a >=128-channel layer has ONE
+//   tap and its gather offset is a per-slab constant), reduction over class pixels in slabs of 16,
+//   split across blockIdx.x with fp32 atomics into a zeroed dA.  Same machinery as igemm_kernel:
+//   raw-buffer loads (hardware zero-fill out of range, no masks), two register stages, loads of slab
+//   s+2 issued and slab s+1 written to LDS behind the MFMA groups, fragments read one group ahead.
 // -------------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN>
 __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in,
@@ -313,6 +316,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     constexpr int LDA = BM + 4, LDB = BN + 4;
     constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
     constexpr int ROWSTEP = NT / BK;
+    constexpr unsigned OOB = 0x40000000u;          // two of them still add up to an out-of-range offset
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -320,56 +324,67 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     const int n = blockIdx.z / P.ncls, ci = blockIdx.z % P.ncls;
     const ClassParams& C = P.cls[ci];
     const int npix = C.OHp * C.OWp;
-    const int Kc = P.Ci * C.taps.T;                       // columns of this class
+    const int T = C.taps.T;
+    const int Kc = P.Ci * T;                               // columns of this class
     const int ntile_n = (Kc + BN - 1) / BN;
     const int m0 = (blockIdx.y / ntile_n) * BM, j0 = (blockIdx.y % ntile_n) * BN;
     const int pbeg = blockIdx.x * pix_per_block, pend = min(pbeg + pix_per_block, npix);
     if (pbeg >= npix) return;
     const float* inb = in + (int64_t)n * P.in_bs;
     const float* dob = dout + (int64_t)n * P.out_bs;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(P.out_bs * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * 4), 0x00020000);
 
     const int l_p = tid % BK;                  // pixel within slab
     const int l_r = tid / BK;                  // first row (m for A, column j for B)
-    // column -> (c, t) is fixed per thread across the whole loop
-    int bc[B_PER], bdy[B_PER], bdx[B_PER]; bool bv[B_PER];
+    // rows / columns are fixed per thread for the whole reduction
+    unsigned rowA[A_PER], chanB[B_PER];
+    int bdy[B_PER], bdx[B_PER];
+#pragma unroll
+    for (int q = 0; q < A_PER; ++q) {
+        const int m = m0 + l_r + q * ROWSTEP;
+        rowA[q] = m < P.Mo ? (unsigned)(m * P.OH * P.OW * 4) : OOB;
+    }
 #pragma unroll
     for (int q = 0; q < B_PER; ++q) {
         const int j = j0 + l_r + q * ROWSTEP;
-        bv[q] = j < Kc;
-        int c = 0, t = 0;
-        if (bv[q]) split_k(j, C.taps.T, C.magicT, c, t);
-        bc[q] = c; bdy[q] = C.taps.dy[t]; bdx[q] = C.taps.dx[t];
+        const int t = j < Kc ? j / P.Ci : 0;
+        const int c = j < Kc ? j - t * P.Ci : 0;
+        chanB[q] = j < Kc ? (unsigned)(c * P.IH * P.IW * 4) : OOB;
+        bdy[q] = C.taps.dy[t]; bdx[q] = C.taps.dx[t];
     }
-    float ra[A_PER], rb[B_PER];
-    unsigned amask = 0, bmask = 0;
-    auto load_slab = [&](int pk) {
-        amask = bmask = 0;
+    // one tap for the whole tile?  (block-uniform: channel counts that are multiples of the tile width)
+    const bool uni = (P.Ci % BN == 0);
+    struct Stage { float ra[A_PER]; float rb[B_PER]; };
+    Stage st0, st1;
+    auto load_all = [&](Stage& S, int pk) {
         const int p = pk + l_p;
         const bool pvld = p < pend;
-        const int pc = min(p, npix - 1);                       // clamped: loads are unconditional, values masked afterwards
+        const int pc = min(p, npix - 1);
         const int Y = pc / C.OWp, X = pc - Y * C.OWp;
-        const int64_t opix = (int64_t)(Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox);
+        const unsigned pixA = pvld ? (unsigned)(((Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox)) * 4) : OOB;
 #pragma unroll
-        for (int q = 0; q < A_PER; ++q) {
-            const int m = m0 + l_r + q * ROWSTEP;
-            ra[q] = dob[(int64_t)min(m, P.Mo - 1) * P.OH * P.OW + opix];
-            amask |= (unsigned)(pvld && m < P.Mo) << q;
-        }
+        for (int q = 0; q < A_PER; ++q)
+            S.ra[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, (int)(rowA[q] + pixA), 0, 0));
         const int iyb = Y * P.isy, ixb = X * P.isx;
+        if (uni) {
+            const int iy = iyb + bdy[0], ix = ixb + bdx[0];
+            const unsigned pixB = (pvld && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) ? (unsigned)((iy * P.IW + ix) * 4) : OOB;
 #pragma unroll
-        for (int q = 0; q < B_PER; ++q) {
-            const int iy = iyb + bdy[q], ix = ixb + bdx[q];
-            const bool ok = pvld && bv[q] && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW;
-            rb[q] = inb[((int64_t)bc[q] * P.IH + min(max(iy, 0), P.IH - 1)) * P.IW + min(max(ix, 0), P.IW - 1)];
-            bmask |= (unsigned)ok << q;
+            for (int q = 0; q < B_PER; ++q)
+                S.rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)(chanB[q] + pixB), 0, 0));
+        } else {
+#pragma unroll
+            for (int q = 0; q < B_PER; ++q) {
+                const int iy = iyb + bdy[q], ix = ixb + bdx[q];
+                const unsigned pixB = (pvld && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) ? (unsigned)((iy * P.IW + ix) * 4) : OOB;
+                S.rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)(chanB[q] + pixB), 0, 0));
+            }
         }
     };
-    auto store_slab = [&](int buf) {
-#pragma unroll
-        for (int q = 0; q < A_PER; ++q) As[buf][l_p * LDA + l_r + q * ROWSTEP] = ((amask >> q) & 1u) ? ra[q] : 0.f;
-#pragma unroll
-        for (int q = 0; q < B_PER; ++q) Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = ((bmask >> q) & 1u) ? rb[q] : 0.f;
-    };
+    auto store_a = [&](const Stage& S, int buf, int q) { As[buf][l_p * LDA + l_r + q * ROWSTEP] = S.ra[q]; };
+    auto store_b = [&](const Stage& S, int buf, int q) { Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = S.rb[q]; };
+
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -378,38 +393,58 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int nslab = (pend - pbeg + BK - 1) / BK;
-    load_slab(pbeg);
-    store_slab(0);
-    __syncthreads();
     const int fr = lane & 31, fk = lane >> 5;
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
-        if (s + 1 < nslab) load_slab(pbeg + (s + 1) * BK);
+    auto step = [&](int s, int buf, Stage& L, const Stage& W) {
         const float* Ab = As[buf] + wm * TM * 32 + fr;
         const float* Bb = Bs[buf] + wn * TN * 32 + fr;
+        constexpr int NK = BK / 2;
+        float af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[TM], bf[TN];
+        for (int i = 0; i < TM; ++i) af[0][i] = Ab[fk * LDA + i * 32];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ab[(2 * kk + fk) * LDA + i * 32];
+        for (int j = 0; j < TN; ++j) bf[0][j] = Bb[fk * LDB + j * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Bb[(2 * kk + fk) * LDB + j * 32];
+        for (int kk = 0; kk < NK; ++kk) {
+            if (kk + 1 < NK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = Ab[(2 * (kk + 1) + fk) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[(kk + 1) & 1][j] = Bb[(2 * (kk + 1) + fk) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (kk == 0) load_all(L, pbeg + (s + 2) * BK);      // slab s+2 (beyond pend: every element out of range -> zeros)
+            if (kk >= NK / 2) {
+#pragma unroll
+                for (int q = 0; q < A_PER; ++q) if (q * (NK / 2) / A_PER == kk - NK / 2) store_a(W, buf ^ 1, q);
+#pragma unroll
+                for (int q = 0; q < B_PER; ++q) if (q * (NK / 2) / B_PER == kk - NK / 2) store_b(W, buf ^ 1, q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (s + 1 < nslab) store_slab(buf ^ 1);
         __syncthreads();
+    };
+    load_all(st0, pbeg);
+#pragma unroll
+    for (int q = 0; q < A_PER; ++q) store_a(st0, 0, q);
+#pragma unroll
+    for (int q = 0; q < B_PER; ++q) store_b(st0, 0, q);
+    load_all(st1, pbeg + BK);
+    __syncthreads();
+    for (int s = 0; s < nslab; s += 2) {
+        step(s, 0, st0, st1);
+        if (s + 1 < nslab) step(s + 1, 1, st1, st0);
     }
     float* dwb = dw + (int64_t)n * P.wbs;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = j0 + (wn * TN + j) * 32 + fr;
         if (col >= Kc) continue;
-        int c, t;
-        split_k(col, C.taps.T, C.magicT, c, t);
+        const int t = col / P.Ci, c = col - t * P.Ci;
         const int koff = c * P.wsc + C.taps.widx[t];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -445,7 +480,8 @@ static void out_dims(const spi_conv_desc* d, int& OH, int& OW) {
 
 // widx of tap (ky,kx) honouring the flip flag
 static inline int tap_w(const spi_conv_desc* d, int ky, int kx) {
-    return d->flip ? (d->kh - 1 - ky) * d->kw + (d->kw - 1 - kx) : ky * d->kw + kx;
+    const int tap = d->flip ? (d->kh - 1 - ky) * d->kw + (d->kw - 1 - kx) : ky * d->kw + kx;
+    return d->w_tap_major ? tap * d->I : tap;           // [O, T, I] puts a whole channel row behind every tap
 }
 
 // forward problem (also the shape of the weight-gradient problem)
@@ -457,7 +493,7 @@ static void make_forward(const spi_conv_desc* d, IGemmParams& P) {
     P.w_elems = (int64_t)d->O * d->I * kk;
     if (!d->transposed) {
         P.isy = P.isx = P.osy = P.osx = 1; P.ncls = 1;
-        P.wsm = d->I * kk; P.wsc = kk;
+        P.wsm = d->I * kk; P.wsc = d->w_tap_major ? 1 : kk;
         ClassParams& C = P.cls[0];
         C.OHp = OH; C.OWp = OW; C.ooy = C.oox = 0; C.taps.T = kk; C.magicT = magic_for(kk);
         for (int ky = 0; ky < d->kh; ++ky) for (int kx = 0; kx < d->kw; ++kx) {
@@ -467,7 +503,7 @@ static void make_forward(const spi_conv_desc* d, IGemmParams& P) {
     } else {
         // out[o,Y,X] = sum in[i,y,x] W[o,i,ky,kx], Y = 2y + ky: class (py,px) holds the taps with ky%2==py, kx%2==px
         P.isy = P.isx = 1; P.osy = P.osx = 2; P.ncls = 0;
-        P.wsm = d->I * kk; P.wsc = kk;
+        P.wsm = d->I * kk; P.wsc = d->w_tap_major ? 1 : kk;
         for (int py = 0; py < 2; ++py) for (int px = 0; px < 2; ++px) {
             ClassParams C; C.taps.T = 0;
             for (int ky = py; ky < d->kh; ky += 2) for (int kx = px; kx < d->kw; kx += 2) {
@@ -494,14 +530,14 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
     C.OHp = d->H; C.OWp = d->W; C.ooy = C.oox = 0; C.taps.T = kk; C.magicT = magic_for(kk);
     if (!d->transposed) {
         // dx[i,y,x] = sum_{o,ky,kx} W[o,i,ky,kx] dy[o, y - ky + pad, x - kx + pad]
-        P.isy = P.isx = 1; P.wsm = kk; P.wsc = d->I * kk;
+        P.isy = P.isx = 1; P.wsm = d->w_tap_major ? 1 : kk; P.wsc = d->I * kk;
         for (int ky = 0; ky < d->kh; ++ky) for (int kx = 0; kx < d->kw; ++kx) {
             const int t = ky * d->kw + kx;
             C.taps.dy[t] = d->pad - ky; C.taps.dx[t] = d->pad - kx; C.taps.widx[t] = tap_w(d, ky, kx);
         }
     } else {
         // dx[i,y,x] = sum_{o,ky,kx} W[o,i,ky,kx] dz[o, 2y + ky, 2x + kx]
-        P.isy = P.isx = 2; P.wsm = kk; P.wsc = d->I * kk;
+        P.isy = P.isx = 2; P.wsm = d->w_tap_major ? 1 : kk; P.wsc = d->I * kk;
         for (int ky = 0; ky < d->kh; ++ky) for (int kx = 0; kx < d->kw; ++kx) {
             const int t = ky * d->kw + kx;
             C.taps.dy[t] = ky; C.taps.dx[t] = kx; C.taps.widx[t] = tap_w(d, ky, kx);
@@ -590,6 +626,7 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     SPI_REQUIRE(d->w_batch_stride == (int64_t)d->O * d->I * d->kh * d->kw || d->N == 1 || d->w_batch_stride == 0,
                 "spi_conv2d_wgrad: w_batch_stride must be 0 or O*I*kh*kw");
     IGemmParams P; make_forward(d, P);
+    SPI_REQUIRE(P.in_bs * 4 < (1ll << 30) && P.out_bs * 4 < (1ll << 30), "spi_conv2d_wgrad: a per-sample activation must be < 1 GiB");
     const int64_t wsz = (int64_t)d->O * d->I * d->kh * d->kw;
     const int64_t nw = (d->w_batch_stride == 0) ? 1 : d->N;
     hipError_t e = hipMemsetAsync(dw, 0, (size_t)(nw * wsz) * sizeof(float), as_stream(stream));

@@ -20,8 +20,8 @@ from ... import hip
 from . import bias_act as _ba
 
 
-def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0):
-    return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
+def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0, tap_major=0):
+    return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
                         act, alpha, gain, clamp)
 
 
@@ -32,19 +32,20 @@ def out_size(h, k, pad, transposed):
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp):
+        # w is TAP-MAJOR here: [O, k, k, I] or [N, O, k, k, I]
         x = x.contiguous().float()
         w = w.contiguous().float()
         n, i, h, wd = x.shape
         per_sample = (w.ndim == 5)
-        o, k = w.shape[-4], w.shape[-1]
-        assert w.shape[-3] == i and (not per_sample or w.shape[0] == n)
+        o, k = w.shape[-4], w.shape[-2]
+        assert w.shape[-1] == i and (not per_sample or w.shape[0] == n)
         wbs = o * i * k * k if per_sample else 0
         oh, ow = out_size(h, k, pad, transposed), out_size(wd, k, pad, transposed)
         y = torch.empty(n, o, oh, ow, device=x.device, dtype=torch.float32)
         bb = bias.contiguous().float() if bias is not None else None
         nz = noise.contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
         ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)
@@ -57,11 +58,11 @@ class _Conv2d(torch.autograd.Function):
         x, w, y, nz, ng = ctx.saved_tensors
         pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs = ctx.cfg
         n, i, h, wd = x.shape
-        o, k = w.shape[-4], w.shape[-1]
+        o, k = w.shape[-4], w.shape[-2]
         dz = dy.contiguous().float()
         if has_epi:
             dz = _ba._launch(dz, None, None, y, None, 1, 1, act_id, alpha, gain, clamp)
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1)
         dx = dw = d_bias = d_noise = d_strength = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -80,9 +81,17 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None
 
 
+def to_tap_major(w):
+    """[..., O, I, k, k] -> [..., O, k, k, I] (channels innermost), the layout the kernels consume."""
+    return w.movedim(-3, -1).contiguous()
+
+
 def conv2d(x, w, bias=None, noise=None, noise_strength=None, padding=0, transposed=False, flip=False, act=None, alpha=None,
-           gain=None, clamp=None):
-    """x [N,I,H,W]; w [O,I,k,k] (shared) or [N,O,I,k,k] (per sample).  act=None -> no activation/gain/clamp."""
+           gain=None, clamp=None, tap_major=False):
+    """x [N,I,H,W]; w [O,I,k,k] (shared) or [N,O,I,k,k] (per sample) -- or already [.., O,k,k,I] with tap_major=True.
+    act=None -> no activation/gain/clamp."""
+    if not tap_major:
+        w = to_tap_major(w)
     if act is None:
         act_id, a, g, c = (1 if (bias is not None or noise is not None) else 0), 0.0, 1.0, -1.0
     else:

@@ -39,15 +39,17 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     n = x.shape[0]
     oc, ic, kh, kw = weight.shape
     assert styles.shape == (n, ic)
-    w = weight.unsqueeze(0) * styles.reshape(n, 1, ic, 1, 1)                       # [N,O,I,k,k]
+    # modulated (and demodulated) per-sample weights, built directly in the kernels' tap-major layout [N,O,k,k,I]
+    w = weight.permute(0, 2, 3, 1).unsqueeze(0) * styles.reshape(n, 1, 1, 1, ic)
     if demodulate:
         w = w * (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(n, oc, 1, 1, 1)
+    w = w.contiguous()
     if up == 1:
         return conv2d_mfma.conv2d(x, w, bias=bias, noise=noise, noise_strength=noise_strength, padding=padding,
-                                  flip=not flip_weight, act=act, gain=gain, clamp=clamp)
+                                  flip=not flip_weight, act=act, gain=gain, clamp=clamp, tap_major=True)
     # up = 2: stride-2 transposed conv, then the 4x4 low-pass (gain up^2) with the layer tail fused in
     assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
-    z = conv2d_mfma.conv2d(x, w, transposed=True, flip=flip_weight)
+    z = conv2d_mfma.conv2d(x, w, transposed=True, flip=flip_weight, tap_major=True)
     return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
                                         padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
 

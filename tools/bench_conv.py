@@ -7,7 +7,6 @@ from spi_amd import hip
 from spi_amd.torch_utils.ops import conv2d_mfma as cm
 
 SHAPES = [  # name, N, I, O, H, k, transposed, per_sample
-    ('probe 1x1 1152->128 @512 (contiguous A)', 1, 1152, 128, 512, 1, False, True),
     ('sr1.conv1 128->128 @512', 1, 128, 128, 512, 3, False, True),
     ('sr0.conv1 256->256 @256', 1, 256, 256, 256, 3, False, True),
     ('sr1.conv0 256->128 up 256->513', 1, 256, 128, 256, 3, True, True),
@@ -50,7 +49,7 @@ def main():
         y = torch.empty(N, O, oh, oh, device=dev)
         dx = torch.empty_like(x); dw = torch.empty_like(w)
         wbs = O * I * k * k if per else 0
-        d = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs)
+        d = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1)
         s = hip.stream()
         flops = 2.0 * N * O * I * k * k * (H * H if tr else oh * oh)
         reps = 3 if flops > 2e10 else 10

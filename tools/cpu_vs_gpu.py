@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Is the loop launch-bound?  Times host enqueue (no sync) against wall (with sync) for stage-1 and stage-2 steps."""
+import os, sys, time, tempfile
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from spi_amd.configs import hyperparameters as hp, paths_config as pc, global_config as gc
+from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+from spi_amd.training.projectors.common import Projection
+from spi_amd.training.projectors.mirror_projector import mirror_setup
+from spi_amd.data.images_dataset import SyntheticDataset
+dev = torch.device('cuda:0'); gc.device = 'cuda:0'
+tmp = tempfile.mkdtemp()
+for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
+    setattr(pc, k, f'{tmp}/{k}/')
+hp.first_inv_type, hp.G_1_type = 'mir', 'RotBbox'
+hp.pt_rot_lambda, hp.pt_mirror_rot_lambda, hp.pt_depth_lambda, hp.LPIPS_value_threshold = 0.1, 0.05, 1.0, -1.0
+torch.manual_seed(0)
+G = TriPlaneGenerator(**ffhq512_kwargs(depth_resolution=96, depth_resolution_importance=96)).eval().requires_grad_(False).to(dev)
+G.neural_rendering_resolution = 128
+coach = RotBboxCoach(None, False, G=G)
+d = SyntheticDataset(1)[0]
+ctx = coach.prepare_image({k: (v[None] if torch.is_tensor(v) else v) for k, v in d.items()})
+cams, dist_fn = mirror_setup(ctx['image'], ctx['camera'], coach.lpips_loss, dev)
+proj = Projection(coach.G, cams, dist_fn, w_mode='w+', initial_w=None, num_steps=500, w_avg_samples=600, device=dev)
+w = proj.w_opt.detach().clone()
+def timed(fn, n):
+    fn(); torch.cuda.synchronize()
+    enq = tot = 0.0
+    for _ in range(n):
+        t0 = time.perf_counter(); fn(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        enq += t1 - t0; tot += t2 - t0
+    return enq / n * 1e3, tot / n * 1e3
+i = [30]
+def s1():
+    proj.step(i[0]); i[0] += 1
+print('stage-1 step: host enqueue %.1f ms, wall %.1f ms' % timed(s1, 5))
+# NB: train_step syncs once itself (early-stop test)
+print('stage-2 plain step (i%%4!=0): enqueue %.1f ms, wall %.1f ms' % timed(lambda: coach.train_step(1, ctx, w), 5))
+print('stage-2 branch step (i%%4==0): enqueue %.1f ms, wall %.1f ms' % timed(lambda: coach.train_step(0, ctx, w), 3))
