@@ -71,7 +71,9 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 //   output and the epilogue runs as a separate tiny kernel (used when the tile grid alone cannot
 //   fill 256 CUs: the 4^2..32^2 layers whose 4608-deep K loop would otherwise run on a few blocks).
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF>
+//   AMF (needs BUF): the A-tile loader runs its lanes along m instead of k -- for the dgrad of tap-major
+//   weights (m = input channel is the contiguous axis) that turns 16 scattered 4-byte reads into one line.
+template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF, bool AMF = false>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ wgt, float* __restrict__ out,
                                                             Epilogue ep, int nsplit) {
@@ -82,6 +84,8 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     constexpr int A_MSTEP = NT / BK;          // rows of m covered per pass (k fastest)
     constexpr int B_KSTEP = NT / BN;          // k rows covered per pass (p fastest)
     static_assert(NT >= BN && NT % BK == 0 && NT % BN == 0 && A_PER >= 1 && B_PER >= 1, "tile/threads mismatch");
+    static_assert(!AMF || (BUF && NT % BM == 0), "m-fast A loads need the buffer path");
+    constexpr int A_KSTEP = AMF ? NT / BM : 0; // AMF: k rows covered per pass (m fastest)
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
@@ -109,7 +113,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     const int64_t chs = (int64_t)P.IH * P.IW;
 
     // ---- per-thread load coordinates
-    const int a_k = tid % BK, a_m = tid / BK;
+    const int a_k = AMF ? tid / BM : tid % BK, a_m = AMF ? tid % BM : tid / BK;
     const int b_p = tid % BN, b_k = tid / BN;
     const int p = p0 + b_p;
     const bool pv = p < npix;
@@ -139,8 +143,9 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            const int m = m0 + a_m + j * A_MSTEP;
-            voffA[j] = m < P.Mo ? (unsigned)((m * P.wsm + a_k * P.wsc) * 4) : OOB;
+            const int m = m0 + a_m + (AMF ? 0 : j * A_MSTEP);
+            const int k = a_k + (AMF ? j * A_KSTEP : 0);
+            voffA[j] = m < P.Mo ? (unsigned)((m * P.wsm + k * P.wsc) * 4) : OOB;
         }
     }
     // per-slab addressing state (scalars + one vector offset), computed once per slab by slab_setup()
@@ -187,7 +192,10 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 #pragma unroll
         for (int j = 0; j < B_PER; ++j) load_b(S, q, j);
     };
-    auto store_a = [&](const Stage& S, int buf, int j) { As[buf][a_k * LDA + a_m + j * A_MSTEP] = (BUF || ((S.am >> j) & 1u)) ? S.ra[j] : 0.f; };
+    auto store_a = [&](const Stage& S, int buf, int j) {
+        if (AMF) As[buf][(a_k + j * A_KSTEP) * LDA + a_m] = S.ra[j];
+        else As[buf][a_k * LDA + a_m + j * A_MSTEP] = (BUF || ((S.am >> j) & 1u)) ? S.ra[j] : 0.f;
+    };
     auto store_b = [&](const Stage& S, int buf, int j) { Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? S.rb[j] : 0.f; };
 
     f32x16 acc[TM][TN];
@@ -554,10 +562,12 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
     // buffer-descriptor fast path: whole channel chunks, and every byte offset fits a signed 32-bit field
     const bool buf = (P.Ci % BK == 0) && (P.in_bs * 4 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31));
     if (nsplit > 1) {
-        if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
+        if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
+        else if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
         else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
     } else {
-        if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
+        if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
+        else if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
         else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
     }
 }
