@@ -39,6 +39,17 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-
 // MLP, where 96 activations per point would otherwise cost more issue slots than the 4160 FMAs.
 // Absolute error <= ~2e-7 on outputs that are O(1); parity tests bound the end-to-end effect.
 __device__ __forceinline__ float exp_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+// Raw buffer loads: an out-of-range byte offset returns 0 in hardware, so bounds-checked gathers need no branch.
+// (A predicated global load `ok ? p[i] : 0` becomes an exec-masked region that hipcc closes with s_waitcnt vmcnt(0):
+// a row of such loads is fully serialised -- the 4x4 FIR ran at 0.8 TB/s because of it.)
+constexpr unsigned BUF_OOB = 0x80000000u;        // beyond any num_records we create (< 2 GiB)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
+}
+
 __device__ __forceinline__ float softplus_fast(float x) {
     return x > 20.f ? x : __builtin_amdgcn_logf(1.f + exp_fast(x)) * 0.6931471805599453f;
 }

@@ -180,6 +180,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 16; ++i) k[i] = sf[i];
     const float ng = (noise && noise_gain) ? noise_gain[0] : (noise ? 1.f : 0.f);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(x, (int64_t)p.N * p.C * p.inH * p.inW * 4);          // host guarantees < 2 GiB
     const int64_t plane = (int64_t)p.outH * p.outW;
     if (UP == 1 && DOWN == 1) {
         const int gw = (p.outW + 3) >> 2;                        // groups of 4 outputs per row
@@ -191,18 +192,22 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_kernel(const float* __restr
             const int64_t nc = rowid / p.outH;
             const int c = (int)(nc % p.C);
             const int ox = xg << 2;
-            const float* xp = x + nc * (int64_t)p.inH * p.inW;
+            const unsigned xoff = (unsigned)(nc * p.inH * p.inW);
             const float pb = pre_bias ? pre_bias[c] : 0.f;
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             const int bx = ox - p.padx0, by = oy - p.pady0;
 #pragma unroll
             for (int ty = 0; ty < 4; ++ty) {
                 const int iy = by + ty;
-                if (iy < 0 || iy >= p.inH) continue;
-                const float* rp = xp + (int64_t)iy * p.inW;
+                const bool yin = iy >= 0 && iy < p.inH;
                 float v[7];
 #pragma unroll
-                for (int i = 0; i < 7; ++i) { const int ix = bx + i; v[i] = (ix >= 0 && ix < p.inW) ? rp[ix] + pb : 0.f; }
+                for (int i = 0; i < 7; ++i) {
+                    const int ix = bx + i;
+                    const bool ok = yin && ix >= 0 && ix < p.inW;
+                    v[i] = buf_load_f32(rs, ok ? (xoff + (unsigned)(iy * p.inW + ix)) * 4u : BUF_OOB);
+                    if (pre_bias) v[i] = ok ? v[i] + pb : 0.f;
+                }
 #pragma unroll
                 for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_kernel(const float* __restr
             const int rem = (int)(g - nc * plane);
             const int oy = rem / p.outW, ox = rem - oy * p.outW;
             const int c = (int)(nc % p.C);
-            const float* xp = x + nc * (int64_t)p.inH * p.inW;
+            const unsigned xoff = (unsigned)(nc * p.inH * p.inW);
             const float pb = pre_bias ? pre_bias[c] : 0.f;
             const int by = oy * DOWN - p.pady0, bx = ox * DOWN - p.padx0;
             const int ty0 = (UP == 1) ? 0 : (by & 1), tx0 = (UP == 1) ? 0 : (bx & 1);    // first tap that lands on a real sample
@@ -235,20 +240,124 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_kernel(const float* __restr
                 const int ty = ty0 + a * UP;
                 const int uy = by + ty;
                 const int iy = (UP == 1) ? uy : (uy >> 1);
-                if (uy < 0 || iy >= p.inH) continue;
+                const bool yin = uy >= 0 && iy < p.inH;
 #pragma unroll
                 for (int b = 0; b < 4 / UP; ++b) {
                     const int tx = tx0 + b * UP;
                     const int ux = bx + tx;
                     const int ix = (UP == 1) ? ux : (ux >> 1);
-                    if (ux < 0 || ix >= p.inW) continue;
+                    const bool ok = yin && ux >= 0 && ix < p.inW;
                     const float kv = (UP == 1) ? k[a * 4 + b] : sf[ty * 4 + tx];     // UP = 2: tap index depends on the output parity -> LDS lookup
-                    acc = fmaf(kv, xp[(int64_t)iy * p.inW + ix] + pb, acc);
+                    float xv = buf_load_f32(rs, ok ? (xoff + (unsigned)(iy * p.inW + ix)) * 4u : BUF_OOB);
+                    if (pre_bias) xv = ok ? xv + pb : 0.f;
+                    acc = fmaf(kv, xv, acc);
                 }
             }
             if (noise) acc += noise[rem] * ng;
             if (ap.act != 0) acc = act_apply(ap, acc + (bias ? bias[c] : 0.f), 0.f, 0.f, 1.f);
             y[g] = acc;
+        }
+    }
+}
+
+// UP = DOWN = 1 on images >= 128 px: LDS-tiled version.  A 256-thread block produces a 64 x 64 output tile from a
+// 67 x 67 input window staged in LDS: 17 row-coalesced global loads per thread, all issued before the first is
+// consumed (1.1 loads per output instead of 7); each thread then reads its 7 x 7 patch as fourteen 16-byte LDS
+// reads and writes 4 x 4 outputs.  HBM-bound: 8 B/output algorithmic.
+constexpr int FT_W = 64, FT_H = 64, FT_LD = 68, FT_ROWS = FT_H + 3, FT_PASS = (FT_ROWS + 3) / 4;
+__global__ void __launch_bounds__(256) upfirdn2d_4x4_tiled_kernel(const float* __restrict__ x, const float* __restrict__ f,
+                                                                  float* __restrict__ y, UpfirdnParams p,
+                                                                  const float* __restrict__ pre_bias, const float* __restrict__ noise,
+                                                                  const float* __restrict__ noise_gain, const float* __restrict__ bias,
+                                                                  ActParams ap) {
+    __shared__ __attribute__((aligned(16))) float tile[FT_PASS * 4 * FT_LD];
+    __shared__ float sf[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) {
+        const int ty = tid >> 2, tx = tid & 3;
+        sf[tid] = (p.flip ? f[ty * 4 + tx] : f[(3 - ty) * 4 + (3 - tx)]) * p.gain;
+    }
+    const int nc = blockIdx.z, c = nc % p.C;
+    const int ox0 = blockIdx.x * FT_W, oy0 = blockIdx.y * FT_H;
+    const float* xp = x + (int64_t)nc * p.inH * p.inW;
+    const float pb = pre_bias ? pre_bias[c] : 0.f;
+    const int bx = ox0 - p.padx0, by = oy0 - p.pady0;
+    {   // stage the window: lanes along x (64 columns), 4 rows per pass; the 3 halo columns 64..66 by the first threads.
+        // Branch-free buffer loads (out-of-image -> hardware zero), so all 18 are in flight together.
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xp, (int64_t)p.inH * p.inW * 4);
+        const int lc = tid & 63, lr = tid >> 6;
+        const int ix = bx + lc;
+        const bool xin = ix >= 0 && ix < p.inW;
+        float v[FT_PASS];
+#pragma unroll
+        for (int k = 0; k < FT_PASS; ++k) {
+            const int iy = by + lr + 4 * k;
+            const bool ok = xin && iy >= 0 && iy < p.inH;
+            v[k] = buf_load_f32(rs, ok ? (unsigned)((iy * p.inW + ix) * 4) : BUF_OOB);
+            if (pre_bias) v[k] = ok ? v[k] + pb : 0.f;
+        }
+        const int hr = min(tid / 3, FT_ROWS - 1), hc = 64 + tid % 3;
+        const int iyh = by + hr, ixh = bx + hc;
+        const bool okh = tid < FT_ROWS * 3 && iyh >= 0 && iyh < p.inH && ixh >= 0 && ixh < p.inW;
+        float h = buf_load_f32(rs, okh ? (unsigned)((iyh * p.inW + ixh) * 4) : BUF_OOB);
+        if (pre_bias) h = okh ? h + pb : 0.f;
+#pragma unroll
+        for (int k = 0; k < FT_PASS; ++k) tile[(lr + 4 * k) * FT_LD + lc] = v[k];
+        if (tid < FT_ROWS * 3) tile[hr * FT_LD + hc] = h;
+    }
+    __syncthreads();
+    float k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i] = sf[i];
+    const int tx = tid & 15, ty = tid >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[o][j] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const float4 a = *reinterpret_cast<const float4*>(&tile[(4 * ty + r) * FT_LD + 4 * tx]);
+        const float4 b = *reinterpret_cast<const float4*>(&tile[(4 * ty + r) * FT_LD + 4 * tx + 4]);
+        const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int t = r - o;                                   // filter row that input row r feeds for output row o
+            if (t < 0 || t > 3) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[o][j] = fmaf(k[t * 4 + q], v[j + q], acc[o][j]);
+        }
+    }
+    const float ng = (noise && noise_gain) ? noise_gain[0] : (noise ? 1.f : 0.f);
+    const float bv = bias ? bias[c] : 0.f;
+    const float slope = ap.act == SPI_ACT_LRELU ? ap.alpha : 1.f;
+    const int ox = ox0 + 4 * tx;
+    if (ox >= p.outW) return;
+    const bool vec = (p.outW & 3) == 0;                            // rows stay 16-byte aligned
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        const int oy = oy0 + 4 * ty + o;
+        if (oy >= p.outH) break;
+        const int64_t pix = (int64_t)oy * p.outW + ox;
+        float* yp = y + (int64_t)nc * p.outH * p.outW + pix;
+        float r4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a = acc[o][j];
+            if (noise && ox + j < p.outW) a += noise[pix + j] * ng;
+            if (ap.act != 0) {                                     // linear / lrelu only (host dispatch): no per-output switch
+                a += bv;
+                a = (a > 0.f ? a : a * slope) * ap.gain;
+                if (ap.clamp >= 0.f) a = fminf(fmaxf(a, -ap.clamp), ap.clamp);
+            }
+            r4[j] = a;
+        }
+        if (vec) *reinterpret_cast<float4*>(yp) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (ox + j < p.outW) yp[j] = r4[j];
         }
     }
 }
@@ -435,13 +544,17 @@ static int launch_upfirdn(const float* x, const float* f, float* y, const Upfird
                           const float* noise, const float* noise_gain, const float* bias, const ActParams& ap, spi_stream_t stream) {
     const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
     const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+    const bool small = (int64_t)p.N * p.C * p.inH * p.inW * 4 < (int64_t)0x7fffffff;     // one buffer descriptor spans the input
     const bool k44 = p.fH == 4 && p.fW == 4 && p.upx == p.upy && p.downx == p.downy && p.upx <= 2 && p.downx <= 2 && !(p.upx == 2 && p.downx == 2);
-    if (k44 && p.upx == 1 && p.downx == 1) {
+    if (k44 && p.upx == 1 && p.downx == 1 && p.outW >= 100 && p.outH >= 100 && (ap.act == 0 || ap.act == SPI_ACT_LINEAR || ap.act == SPI_ACT_LRELU) && (int64_t)p.N * p.C <= 65535) {
+        const dim3 g((unsigned)((p.outW + FT_W - 1) / FT_W), (unsigned)((p.outH + FT_H - 1) / FT_H), (unsigned)(p.N * p.C));
+        hipLaunchKernelGGL(upfirdn2d_4x4_tiled_kernel, g, dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
+    } else if (k44 && small && p.upx == 1 && p.downx == 1) {
         const unsigned g4 = (unsigned)std::min<int64_t>(ceil_div64((total + 3) / 4 + (int64_t)p.N * p.C * p.outH, 256), 256 * 32);
         hipLaunchKernelGGL((upfirdn2d_4x4_kernel<1, 1>), dim3(g4), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
-    } else if (k44 && p.upx == 2) {
+    } else if (k44 && small && p.upx == 2) {
         hipLaunchKernelGGL((upfirdn2d_4x4_kernel<2, 1>), dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
-    } else if (k44 && p.downx == 2) {
+    } else if (k44 && small && p.downx == 2) {
         hipLaunchKernelGGL((upfirdn2d_4x4_kernel<1, 2>), dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
     } else
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);

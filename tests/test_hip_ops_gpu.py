@@ -97,3 +97,28 @@ def test_filtered_lrelu_golden(golden):
     for i, kw in enumerate(cases):
         y = filtered_lrelu.filtered_lrelu(g['fl_x'].to(DEV), fu=g['fl_fu'].to(DEV), fd=g['fl_fd'].to(DEV), b=g['fl_b'].to(DEV), **kw)
         assert_close(y, g[f'fl_y{i}'], 2e-6, f'filtered_lrelu[{i}]')
+
+
+@pytest.mark.parametrize('inh,pad', [(201, 1), (199, 2), (130, 1), (113, 2)])
+def test_upfirdn2d_tiled_ragged_vs_oracle(inh, pad):
+    """LDS-tiled 4x4 FIR (outputs >= 100 px): ragged tile edges, unaligned rows (scalar stores) and the fused tail + gradients."""
+    from spi_amd.torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(inh)
+    f = osg.fir_filter()
+    oh = inh + 2 * pad - 3
+    x = torch.randn(2, 5, inh, inh - 7, generator=gen, requires_grad=True)
+    ow = oh - 7
+    noise = torch.randn(oh, ow, generator=gen, requires_grad=True)
+    strength = torch.tensor(0.3, requires_grad=True)
+    bias = torch.randn(5, generator=gen, requires_grad=True)
+    dy = torch.randn(2, 5, oh, ow, generator=gen)
+    ref = osg.bias_act(osg.upfirdn2d(x, f, padding=(pad,) * 4, gain=4) + noise * strength, bias, act='lrelu', clamp=1.5)
+    gref = torch.autograd.grad(ref, [x, noise, strength, bias], dy)
+    xs = [t.detach().to(DEV).requires_grad_(True) for t in (x, noise, strength, bias)]
+    y = upfirdn2d.upfirdn2d_bias_act(xs[0], f.to(DEV), noise=xs[1], noise_strength=xs[2], bias=xs[3], padding=[pad] * 4, gain=4,
+                                     act='lrelu', clamp=1.5)
+    assert_close(y, ref, 2e-6, 'tiled fused fwd')
+    for a, b, nm in zip(torch.autograd.grad(y, xs, dy.to(DEV)), gref, ('dx', 'dnoise', 'dstrength', 'dbias')):
+        assert_close(a, b, 2e-5, 'tiled fused ' + nm)
+    assert_close(upfirdn2d.upfirdn2d(x.detach().to(DEV), f.to(DEV), padding=[pad] * 4, flip_filter=True),
+                 osg.upfirdn2d(x.detach(), f, padding=(pad,) * 4, flip_filter=True), 2e-6, 'tiled plain')
