@@ -85,3 +85,29 @@ def test_modulated_conv2d_golden(golden):
         assert_close(gx, g[f'mc_{tag}_gx'], 1e-5, f'modconv {tag} dx')
         assert_close(gw, g[f'mc_{tag}_gw'], 2e-5, f'modconv {tag} dw')
         assert_close(gs, g[f'mc_{tag}_gs'], 2e-5, f'modconv {tag} dstyles')
+
+
+@pytest.mark.parametrize('n,o,i,k,demod', [(2, 24, 40, 3, True), (1, 512, 512, 3, True), (3, 3, 128, 1, False), (2, 96, 32, 1, False), (1, 7, 5, 3, True)])
+def test_modulate_weights_vs_torch(n, o, i, k, demod):
+    """spi_modulate_fwd/bwd against the reference expression (networks_stylegan2.py:62-69), output in tap-major layout."""
+    from spi_amd.training.networks_stylegan2 import modulate_weights
+    gen = torch.Generator().manual_seed(n * 1000 + o)
+    w = torch.randn(o, i, k, k, generator=gen, dtype=torch.float64, requires_grad=True)
+    s = (torch.randn(n, i, generator=gen, dtype=torch.float64) + 1).requires_grad_(True)
+    g = torch.randn(n, o, k, k, i, generator=gen, dtype=torch.float64)
+    ref = w.unsqueeze(0) * s.reshape(n, 1, i, 1, 1)
+    if demod:
+        ref = ref * (ref.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(n, o, 1, 1, 1)
+    ref = ref.permute(0, 1, 3, 4, 2)
+    gw, gs = torch.autograd.grad(ref, [w, s], g)
+    wd, sd = w.detach().float().to(DEV).requires_grad_(True), s.detach().float().to(DEV).requires_grad_(True)
+    out = modulate_weights(wd, sd, demod)
+    assert out.shape == (n, o, k, k, i) and out.is_contiguous()
+    assert_close(out, ref.float(), 2e-5, 'modulate fwd')
+    a, b = torch.autograd.grad(out, [wd, sd], g.float().to(DEV))
+    assert_close(a, gw.float(), 5e-5, 'modulate dW')
+    assert_close(b, gs.float(), 5e-5, 'modulate ds')
+    # frozen weights (stage 1): only d_styles
+    out = modulate_weights(wd.detach(), sd, demod)
+    (b2,) = torch.autograd.grad(out, [sd], g.float().to(DEV))
+    assert_close(b2, gs.float(), 5e-5, 'modulate ds (weights frozen)')
