@@ -127,7 +127,15 @@ def main():
     rmod.MARCH_EVENTS = []                                       # HIP events around every final-march launch in the timed region
     sdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
+    if os.environ.get('SPI_TORCH_PROFILE'):                      # debugging aid: per-op device time of the timed region (stderr)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=70, max_name_column_width=60), file=sys.stderr)
+    else:
+        run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
+    t_enq = time.perf_counter() - t0                             # host time to enqueue the K steps (== dt when host-bound)
     torch.cuda.synchronize(); sdist.barrier()
     dt = time.perf_counter() - t0
     events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
@@ -147,7 +155,8 @@ def main():
             traffic = json.load(open(pmc)).get('hbm_bytes_per_16384_rays')
         out = {
             'metric': 'SPI inversion iters/sec (512^2, 96+96 ray samples)', 'value': world * args.steps / dt, 'unit': 'iters/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
+            'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
             'random-init weights of the ffhqrebalanced512-128 architecture)',
             'config': {'workload': 'configs[1]: 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '

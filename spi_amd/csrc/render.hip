@@ -345,7 +345,7 @@ struct TiledArgs {
     int N; int M; int S; int H; int W; float scale;
     int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
     int patches; int kchunks;
-    int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 2 = no LDS window, 4 = skip MLP
+    int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 2 = no LDS window, 4 = skip most of the MLP, 64 = skip the plane gather
 };
 
 __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
             const float qx = s_x[s], qy = s_y[s], qz = s_z[s];
             g4 = *reinterpret_cast<const float4*>(d_rgb + prow * DEC_IN + sub * 4);
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < ((a.dbg & 64) ? 0 : 3); ++pl) {
                 float gx, gy;
                 plane_uv(pl, qx, qy, qz, gx, gy);
                 const Corner c = make_corner(gx, gy, a.W, a.H);
@@ -431,6 +431,10 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
     float* frow = feat + t * FS;
     float* grow = gbuf + t * FS;
     float h[DEC_HID];
+    if (a.dbg & 4) {
+#pragma unroll
+        for (int jj = 0; jj < DEC_HID; ++jj) h[jj] = frow[jj & 31];
+    } else
     layer1_forward(w1t, b1, frow, h);
     if (dumping) {
         for (int i = 0; i < DEC_IN; ++i) dump[(int64_t)i * total + dcol] = valid ? frow[i] : 0.f;
@@ -442,7 +446,7 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
     for (int j = 0; j < DEC_HID; ++j) dp[j] = 0.f;
     const float dsig = valid ? d_sigma[row] : 0.f;
 #pragma unroll 2
-    for (int o = 0; o < DEC_OUT; ++o) {
+    for (int o = 0; o < ((a.dbg & 4) ? 1 : DEC_OUT); ++o) {
         const float* wr = w2 + o * DEC_HID;
         float acc = b2[o];
 #pragma unroll
@@ -462,7 +466,7 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
         for (int j = 0; j < DEC_HID; ++j) dump[(int64_t)(96 + j) * total + dcol] = dp[j];
     }
 #pragma unroll 2
-    for (int i = 0; i < DEC_IN; ++i) {
+    for (int i = 0; i < ((a.dbg & 4) ? 1 : DEC_IN); ++i) {
         const float* wr = w1t + i * DEC_HID;
         float acc = 0.f;
 #pragma unroll
