@@ -143,6 +143,16 @@ int spi_bias_act(const float* x, const float* b, const float* xref, const float*
                  float* y, int64_t n, int sizeB, int64_t stepB, int grad, int act, float alpha,
                  float gain, float clamp, spi_stream_t stream);
 
+/* Backward of a layer tail  y = clamp(act(z + noise*strength + bias) * gain)  (SynthesisLayer.forward,
+ * networks_stylegan2.py:320-329) in ONE pass over dy [N,C,HW]:
+ *   dz      = dy * d y/d z                (act in {linear, relu, lrelu}; y = saved output; y = NULL: dz = dy, dz may be NULL)
+ *   d_bias[c]   += sum_{n,hw} dz           (NULL to skip; CALLER zeroes)
+ *   d_pixsum[hw] += sum_{n,c} dz           (NULL to skip; CALLER zeroes; d_noise = d_pixsum * strength,
+ *                                           d_strength = sum(d_pixsum * noise))
+ * replaces bias_act(grad=1) + two full-tensor torch reductions of the reference's autograd graph. */
+int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, int N, int C,
+                 int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream);
+
 /* upfirdn2d.cpp:20 `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`.
  *   x [N,C,inH,inW] (dense NCHW), f [fH,fW]; y [N,C,outH,outW] with the reference's output-size rule.
  * Optional fused epilogue (NULL / act = 0 disables): y = bias_act(y + noise[outH,outW]*noise_gain[0], bias[C]). */

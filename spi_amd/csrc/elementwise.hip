@@ -108,6 +108,71 @@ __global__ void bias_act_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Layer-tail backward: activation gradient + bias gradient (sum over n, hw) + noise gradient
+// (sum over n, c) in one pass.  Block = 256 threads x PX consecutive pixels; blockIdx.y picks a chunk
+// of channels.  Per channel the block adds 4 wave-partials to d_bias[c]; the per-pixel sums stay in
+// registers over the channel loop and are added to d_pixsum once.
+// ------------------------------------------------------------------------------------------------
+template <int PX>
+__global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                       float* __restrict__ dz, float* __restrict__ d_bias,
+                                                       float* __restrict__ d_pixsum, int N, int C, int64_t HW, int cchunk,
+                                                       ActParams ap) {
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
+    const int c_beg = blockIdx.y * cchunk, c_end = min(c_beg + cchunk, C);
+    const bool ok = p0 < HW;                               // PX == 4 requires HW % 4 == 0, so a thread is all-in or all-out
+    float pix[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) pix[j] = 0.f;
+    for (int c = c_beg; c < c_end; ++c) {
+        float bsum = 0.f;
+        for (int n = 0; n < N; ++n) {
+            const int64_t off = ((int64_t)n * C + c) * HW + p0;
+            float g[PX], yy[PX];
+            if (ok) {
+                if (PX == 4) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(dy + off);
+                    g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
+                    if (y) { const float4 y4 = *reinterpret_cast<const float4*>(y + off); yy[0] = y4.x; yy[1] = y4.y; yy[2] = y4.z; yy[3] = y4.w; }
+                } else { g[0] = dy[off]; if (y) yy[0] = y[off]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < PX; ++j) g[j] = 0.f;
+            }
+            if (y && ok) {
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const float pre = yy[j] / ap.gain;                         // activation output before the gain (as bias_act grad=1)
+                    float v = g[j];
+                    if (ap.act == SPI_ACT_RELU) v = pre > 0.f ? v : 0.f;
+                    else if (ap.act == SPI_ACT_LRELU) v = pre > 0.f ? v : v * ap.alpha;
+                    v *= ap.gain;
+                    if (ap.clamp >= 0.f) v = (yy[j] > -ap.clamp && yy[j] < ap.clamp) ? v : 0.f;
+                    g[j] = v;
+                }
+                if (dz) {
+                    if (PX == 4) *reinterpret_cast<float4*>(dz + off) = make_float4(g[0], g[1], g[2], g[3]);
+                    else dz[off] = g[0];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PX; ++j) { pix[j] += g[j]; bsum += g[j]; }
+        }
+        if (d_bias) {
+            bsum = wave_sum(bsum);
+            if ((threadIdx.x & 63) == 0) atomicAdd(d_bias + c, bsum);
+        }
+    }
+    if (d_pixsum && ok) {
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            if (gridDim.y == 1) d_pixsum[p0 + j] = pix[j];
+            else atomicAdd(d_pixsum + p0 + j, pix[j]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // upfirdn2d: out[oy,ox] = gain * sum_t k[ty,tx] * U[oy*down + ty, ox*down + tx], U = zero-inserted,
 // padded input; k = f flipped unless `flip` (upfirdn2d.py:168-213).  Only taps that land on a real
 // sample are visited.  Optional pre-bias (filtered_lrelu step 1) and noise/bias/activation epilogue
@@ -583,6 +648,24 @@ static int launch_upfirdn(const float* x, const float* f, float* y, const Upfird
     } else
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
     SPI_LAUNCH_CHECK("spi_upfirdn2d");
+    return SPI_OK;
+}
+
+int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, int N, int C, int64_t HW,
+                 int act, float alpha, float gain, float clamp, spi_stream_t stream) {
+    SPI_REQUIRE(dy && N > 0 && C > 0 && HW > 0, "spi_tail_bwd: bad argument");
+    SPI_REQUIRE(!y || (act >= SPI_ACT_LINEAR && act <= SPI_ACT_LRELU && gain != 0.f), "spi_tail_bwd: activation must be linear / relu / lrelu");
+    SPI_REQUIRE(y || !dz, "spi_tail_bwd: dz without a saved output (dz == dy)");
+    ActParams ap{act, 1, alpha, gain, clamp};
+    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz)) % 16 == 0);
+    const int64_t per_block = vec ? 1024 : 256;
+    const unsigned gx = (unsigned)ceil_div64(HW, per_block);
+    int splits = (int)std::min<int64_t>(C, std::max<int64_t>(1, 1024 / gx));
+    const int cchunk = (C + splits - 1) / splits;
+    splits = (C + cchunk - 1) / cchunk;
+    if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);
+    else hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);
+    SPI_LAUNCH_CHECK("spi_tail_bwd");
     return SPI_OK;
 }
 

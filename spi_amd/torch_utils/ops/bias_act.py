@@ -34,6 +34,29 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
     return y
 
 
+def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise, need_strength, need_bias):
+    """Backward of  y = clamp(act(z + noise*strength + bias)*gain)  for dy [N,C,H,W] in one launch (spi_tail_bwd).
+    ``y`` None: no activation/gain/clamp was applied (dz = dy).  Returns (dz, d_noise, d_strength, d_bias)."""
+    dy = dy.contiguous().float()
+    n, c = dy.shape[0], dy.shape[1]
+    hw = dy[0, 0].numel()
+    want_pix = noise is not None and (need_noise or need_strength)
+    if y is None and not want_pix and not need_bias:
+        return dy, None, None, None
+    dz = torch.empty_like(dy) if y is not None else None
+    d_bias = torch.zeros(c, device=dy.device, dtype=torch.float32) if need_bias else None
+    pix = torch.zeros(dy.shape[2:], device=dy.device, dtype=torch.float32) if want_pix else None
+    hip.call('spi_tail_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), n, c, hw, act_id, alpha, gain, clamp,
+             hip.stream())
+    d_noise = d_strength = None
+    if want_pix:
+        if need_noise:
+            d_noise = pix * strength if strength is not None else pix
+        if need_strength:
+            d_strength = (pix * noise).sum().reshape(())
+    return (dz if dz is not None else dy), d_noise, d_strength, d_bias
+
+
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b, dim, act_id, alpha, gain, clamp, ref):

@@ -59,25 +59,16 @@ class _Conv2d(torch.autograd.Function):
         pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs = ctx.cfg
         n, i, h, wd = x.shape
         o, k = w.shape[-4], w.shape[-2]
-        dz = dy.contiguous().float()
-        if has_epi:
-            dz = _ba._launch(dz, None, None, y, None, 1, 1, act_id, alpha, gain, clamp)
+        dz, d_noise, d_strength, d_bias = _ba.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
+                                                            ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2])
         d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1)
-        dx = dw = d_bias = d_noise = d_strength = None
+        dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w), hip.ptr(dx), hip.stream())
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(dz), hip.ptr(dw), hip.stream())
-        if ctx.needs_input_grad[2]:
-            d_bias = dz.sum([0, 2, 3])
-        if nz is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]):
-            dsum = dz.sum([0, 1])
-            if ctx.needs_input_grad[3]:
-                d_noise = dsum * (ng if ng is not None else 1.0)
-            if ctx.needs_input_grad[4]:
-                d_strength = (dsum * nz).sum().reshape(())
         return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None
 
 

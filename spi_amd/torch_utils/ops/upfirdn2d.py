@@ -161,18 +161,10 @@ class _UpfirdnBiasAct(torch.autograd.Function):
     def backward(ctx, dy):
         y, nz, ng = ctx.saved_tensors
         xs, pad, fgain, act_id, alpha, again, clamp = ctx.cfg
-        dz = _ba._launch(dy.contiguous().float(), None, None, y, None, 1, 1, act_id, alpha, again, clamp)
+        dz, d_noise, d_strength, d_bias = _ba.tail_backward(dy, y, nz, ng, act_id, alpha, again, clamp, ctx.needs_input_grad[2],
+                                                            ctx.needs_input_grad[3], ctx.needs_input_grad[4])
         p = _adjoint_padding(xs, tuple(y.shape), ctx.f, (1, 1), (1, 1), pad)
         dx = _run(dz, ctx.f, (1, 1), (1, 1), p, True, fgain) if ctx.needs_input_grad[0] else None
-        d_noise = d_strength = d_bias = None
-        if nz is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
-            dsum = dz.sum([0, 1])
-            if ctx.needs_input_grad[2]:
-                d_noise = dsum * (ng if ng is not None else 1.0)
-            if ctx.needs_input_grad[3]:
-                d_strength = (dsum * nz).sum().reshape(())
-        if ctx.needs_input_grad[4]:
-            d_bias = dz.sum([0, 2, 3])
         return dx, None, d_noise, d_strength, d_bias, None, None, None, None, None, None
 
 

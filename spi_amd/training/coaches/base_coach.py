@@ -51,6 +51,21 @@ class BaseCoach:
         self.optimizer = None
         self.restart_training()
 
+    def _async_flag(self, cond):
+        """Start copying a 0-dim device boolean to pinned host memory; returns a callable that waits for THAT copy only."""
+        if cond.device.type != 'cuda':
+            return lambda: bool(cond)
+        if getattr(self, '_flag_host', None) is None:
+            self._flag_host = torch.zeros(1, dtype=torch.uint8).pin_memory()
+        self._flag_host.copy_(cond.detach().reshape(1).to(torch.uint8), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+
+        def wait():
+            ev.synchronize()
+            return bool(self._flag_host[0])
+        return wait
+
     def restart_training(self):
         if self.G is None:
             self.G = load_utils.build_generator(self.original_G.init_args, self.original_G.init_kwargs, None, self.device)

@@ -35,9 +35,10 @@ class SingleIDCoach(BaseCoach):
         img = G.synthesis(w_pivot.detach(), camera, noise_mode='const', render_noise=noise)['image']
         loss, loss_lpips = self.calc_loss(img, image, target_feats)
         self.optimizer.zero_grad()
-        if loss_lpips is not None and bool(loss_lpips <= hyperparameters.LPIPS_value_threshold):
+        stop_flag = self._async_flag(loss_lpips <= hyperparameters.LPIPS_value_threshold) if loss_lpips is not None else None
+        loss.backward()                                        # enqueued before the flag is read: the GPU stays busy during the host wait
+        if stop_flag is not None and stop_flag():              # (:95-96) stops before the optimiser step; the extra gradients are discarded
             return True, dict(loss=loss.detach(), lpips=loss_lpips.detach())
-        loss.backward()
         self.optimizer.step()
         return False, dict(loss=loss.detach(), lpips=loss_lpips.detach() if loss_lpips is not None else None)
 

@@ -68,6 +68,7 @@ class RotBboxCoach(BaseCoach):
         if hp.pt_lpips_lambda > 0:
             losses['lpips'] = torch.squeeze(self.lpips_loss(gen['image'], y_feats=ctx['target_feats']))
             loss = loss + losses['lpips'] * hp.pt_lpips_lambda
+        stop_flag = self._async_flag(losses['lpips'] <= hp.LPIPS_value_threshold) if 'lpips' in losses else None
         loss.backward()
         if i % rot_bs == 0:
             depth_main = gen['image_depth'].detach()
@@ -103,7 +104,10 @@ class RotBboxCoach(BaseCoach):
                 from ...criteria.tv_loss import cal_tv_loss
                 losses['tv'] = cal_tv_loss(ws, G) * hp.pt_tv_lambda
                 losses['tv'].backward()
-        if 'lpips' in losses and bool(losses['lpips'] <= hp.LPIPS_value_threshold):       # the loop's one host sync (:148)
+        # the loop's one host read (:148).  The flag was copied to pinned memory right after the main forward, so the
+        # wait ends when the GPU has passed THAT point (not the whole iteration): the backward passes keep the GPU busy
+        # while the host enqueues the optimiser step and the next forward.
+        if stop_flag is not None and stop_flag():
             return True, losses
         self.optimizer.step()
         return False, losses
