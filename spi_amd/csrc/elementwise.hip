@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ dz, float* __restrict__ d_bias,
                                                        float* __restrict__ d_pixsum, int N, int C, int64_t HW, int cchunk,
                                                        ActParams ap) {
+    __shared__ float bpart[512][4];                        // per-channel wave partials of this block (host keeps cchunk <= 512)
     const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
     const int c_beg = blockIdx.y * cchunk, c_end = min(c_beg + cchunk, C);
     const bool ok = p0 < HW;                               // PX == 4 requires HW % 4 == 0, so a thread is all-in or all-out
@@ -160,7 +161,14 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
         }
         if (d_bias) {
             bsum = wave_sum(bsum);
-            if ((threadIdx.x & 63) == 0) atomicAdd(d_bias + c, bsum);
+            if ((threadIdx.x & 63) == 0) bpart[c - c_beg][threadIdx.x >> 6] = bsum;
+        }
+    }
+    if (d_bias) {                                          // one global atomic per channel per block, issued by different lanes
+        __syncthreads();
+        for (int i = threadIdx.x; i < c_end - c_beg; i += 256) {
+            const int cl = (i + blockIdx.x) % (c_end - c_beg);                 // staggered so that blocks do not hit the same address together
+            atomicAdd(d_bias + c_beg + cl, (bpart[cl][0] + bpart[cl][1]) + (bpart[cl][2] + bpart[cl][3]));
         }
     }
     if (d_pixsum && ok) {
@@ -554,7 +562,15 @@ __global__ void __launch_bounds__(1024) lpips_fwd_kernel(const float* __restrict
 #pragma unroll 8
     for (int c = cg; c < C; c += LP_CG) { const float d = a[c * HW] / na - b[c * HW] / nb; val = fmaf(lin[c], d * d, val); }
     val = wave_sum(ok ? val : 0.f);
-    if (px == 0) atomicAdd(out + n, val / (float)HW);
+    __syncthreads();
+    if (px == 0) red[0][cg] = val;                             // same-address global atomics serialise (~10 ns each): one per block
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+#pragma unroll
+        for (int g = 0; g < LP_CG; ++g) tot += red[0][g];
+        atomicAdd(out + n, tot / (float)HW);
+    }
 }
 
 __global__ void __launch_bounds__(1024) lpips_bwd_kernel(const float* __restrict__ fx, const float* __restrict__ fy,
@@ -660,8 +676,8 @@ int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, floa
     const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz)) % 16 == 0);
     const int64_t per_block = vec ? 1024 : 256;
     const unsigned gx = (unsigned)ceil_div64(HW, per_block);
-    int splits = (int)std::min<int64_t>(C, std::max<int64_t>(1, 1024 / gx));
-    const int cchunk = (C + splits - 1) / splits;
+    int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, 1024 / gx));
+    const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
     splits = (C + cchunk - 1) / cchunk;
     if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);
     else hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);

@@ -8,7 +8,9 @@ Per iteration (``train_step``), exactly as the reference's loop body :68-157:
                 depth:      4 random cameras, depth of G vs depth of the frozen original G -> L2 * 1               (:133-141)
   early stop if LPIPS <= 0.05, else ONE optimiser step over the accumulated gradients               (:148-151)
 Result-identical savings: target LPIPS features are cached; the depth branch skips the
-super-resolution network (only ``image_depth`` is consumed, :136-138); w_pivot is detached.
+super-resolution network (only ``image_depth`` is consumed, :136-138); w_pivot is detached; the
+4-view branches pass ONE w with 4 cameras, so the camera-independent StyleGAN2 backbone (46 % of the
+generator's conv FLOPs) and every weight modulation run once instead of on 4 identical rows.
 """
 import os
 import torch
@@ -75,7 +77,7 @@ class RotBboxCoach(BaseCoach):
             if hp.pt_rot_lambda > 0:
                 cams = sample_surrounding_camera(ctx['camera'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                  rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
-                gs = self._synth(G, ws.repeat(rot_bs, 1, 1), cams, rng)
+                gs = self._synth(G, ws, cams, rng)                 # one w, rot_bs cameras: backbone shared (triplane.py)
                 warp_img, warp_mask = rotate(target_camera=cams, target_depth=gs['image_depth'], src_image=ctx['image'].repeat(rot_bs, 1, 1, 1),
                                              src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
                                              src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
@@ -84,7 +86,7 @@ class RotBboxCoach(BaseCoach):
             if hp.pt_mirror_rot_lambda > 0 and ctx['weight_m'] > 0:
                 cams_m = sample_surrounding_camera(ctx['camera_m'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                    rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
-                gm = self._synth(G, ws.repeat(rot_bs, 1, 1), cams_m, rng)
+                gm = self._synth(G, ws, cams_m, rng)
                 warp_m, mask_m = rotate(target_camera=cams_m, target_depth=gm['image_depth'], src_image=ctx['image_m'].repeat(rot_bs, 1, 1, 1),
                                         src_camera=ctx['camera_m'].repeat(rot_bs, 1), src_depth=torch.flip(depth_main, dims=[3]).repeat(rot_bs, 1, 1, 1),
                                         src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
@@ -94,10 +96,9 @@ class RotBboxCoach(BaseCoach):
                 losses['mirror_rot'].backward()
             if hp.pt_depth_lambda > 0:
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
-                ws4 = ws.repeat(4, 1, 1)
-                sample_depth = self._synth(G, ws4, cams_d, rng, skip_superresolution=True)['image_depth']
+                sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True)['image_depth']
                 with torch.no_grad():
-                    stable_depth = self._synth(self.original_G, ws4, cams_d, rng, skip_superresolution=True)['image_depth']
+                    stable_depth = self._synth(self.original_G, ws, cams_d, rng, skip_superresolution=True)['image_depth']
                 losses['depth'] = l2_loss(stable_depth, sample_depth) * hp.pt_depth_lambda
                 losses['depth'].backward()
             if hp.pt_tv_lambda > 0:

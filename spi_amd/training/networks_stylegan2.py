@@ -73,9 +73,13 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     assert down == 1 and up in (1, 2)
     n = x.shape[0]
     oc, ic, kh, kw = weight.shape
-    assert styles.shape == (n, ic)
+    # styles [N, I], or [1, I] shared by the whole batch (same w for every view: the weights are modulated once, the
+    # conv runs with one weight set and its weight gradient is reduced over the batch inside the kernel)
+    assert styles.shape in ((n, ic), (1, ic))
     # modulated (and demodulated) per-sample weights, built directly in the kernels' tap-major layout [N,O,k,k,I]
     w = modulate_weights(weight, styles, demodulate)
+    if styles.shape[0] == 1 and n > 1:
+        w = w[0]
     if up == 1:
         return conv2d_mfma.conv2d(x, w, bias=bias, noise=noise, noise_strength=noise_strength, padding=padding,
                                   flip=not flip_weight, act=act, gain=gain, clamp=clamp, tap_major=True)

@@ -71,8 +71,7 @@ class Projection:
         ws = w_opt + rng.randn(*w_opt.shape) * w_noise_scale
         if self.w_mode == 'w':
             ws = ws.repeat([1, self.num_ws, 1])
-        batch = self.cameras.shape[0]
-        ws = ws.repeat(batch, 1, 1)
+        batch = self.cameras.shape[0]                            # ws stays [1, L, 512]: G.synthesis shares the backbone across the views
         m = G.neural_rendering_resolution ** 2
         rk = G.rendering_kwargs
         noise = (rng.rand(batch, m, int(rk['depth_resolution']), 1), rng.rand(batch * m, max(int(rk['depth_resolution_importance']), 1)))

@@ -84,6 +84,11 @@ class TriPlaneGenerator(torch.nn.Module):
             planes = self._planes(ws, update_emas=update_emas, **synthesis_kwargs)
         if cache_backbone:
             self._last_planes = planes
+        if planes.shape[0] == 1 and n > 1:
+            # one latent, several cameras (SPI's mirror / rot / depth branches repeat the same w per view, e.g.
+            # rot_bbox_cx_coach.py:92): the tri-planes do not depend on the camera, so the backbone runs ONCE and the views
+            # share its output; autograd sums the per-view plane gradients before the single backbone backward pass.
+            planes = planes.expand(n, -1, -1, -1, -1)
         feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs, noise=render_noise)
         r = self.neural_rendering_resolution
         feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()

@@ -76,3 +76,34 @@ def test_mapping_golden(golden):
     G = _narrow_G()
     w = G.mapping(g['map_z'].to(DEV), g['c'][:1].repeat(4, 1).to(DEV))
     assert_close(w[:, 0], g['map_w'], 1e-5, 'mapping')
+
+
+def test_synthesis_shared_w_equals_repeated_w(golden):
+    """One w with several cameras (backbone + modulation run once, conv weight gradients reduced over the batch in-kernel)
+    gives the result of the reference's `ws.repeat(n, 1, 1)` call pattern (rot_bbox_cx_coach.py:92): forward and gradients."""
+    from spi_amd.utils import camera_utils as cu
+    g = golden('synthesis_narrow')
+    G = _narrow_G()
+    G.neural_rendering_resolution = 32
+    names = ['backbone.synthesis.b32.conv0.weight', 'superresolution.block1.conv1.weight', 'superresolution.block0.conv0.bias',
+             'backbone.synthesis.b16.conv1.affine.weight', 'superresolution.block1.torgb.affine.bias', 'decoder.net.0.weight',
+             'backbone.synthesis.b64.conv1.noise_strength']
+    params = dict(G.named_parameters())
+    cams = torch.cat([cu.cal_canonical_c(0.3 * i - 0.4, 0.1 * i).reshape(1, 25) for i in range(3)]).to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    xi, u = torch.rand(3, 1024, 12, 1, generator=gen).to(DEV), torch.rand(3 * 1024, 12, generator=gen).to(DEV)
+    res = []
+    for shared in (True, False):
+        ws = g['ws'][:1].to(DEV).clone().requires_grad_(True)
+        out = G.synthesis(ws if shared else ws.repeat(3, 1, 1), cams, noise_mode='const', render_noise=(xi, u))
+        tgt = torch.Generator().manual_seed(9)
+        d_img = torch.randn(out['image'].shape, generator=tgt).to(DEV)
+        d_dep = torch.randn(out['image_depth'].shape, generator=tgt).to(DEV)
+        loss = (out['image'] * d_img).sum() / 100 + (out['image_depth'] * d_dep).sum()
+        grads = torch.autograd.grad(loss, [ws] + [params[k] for k in names])
+        res.append((out, grads))
+    (oa, ga), (ob, gb) = res
+    assert_close(oa['image'], ob['image'], 2e-5, 'shared-w image')
+    assert_close(oa['image_depth'], ob['image_depth'], 1e-6, 'shared-w depth')
+    for a, b, nm in zip(ga, gb, ['ws'] + names):
+        assert_close(a, b, 5e-4, 'shared-w grad ' + nm)
