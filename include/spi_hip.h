@@ -214,15 +214,16 @@ int spi_rotate_warp(const float* tgt_cam, const float* src_cam_inv, const float*
                     float* warp_rgb, float* warp_mask, spi_stream_t stream);
 
 /* Weight modulation / demodulation of modulated_conv2d (networks_stylegan2.py:62-69, fused path) in one pass:
- *   v[n,o,i,t] = weight[o,i,t] * styles[n,i];  d[n,o] = rsqrt(sum_{i,t} v^2 + 1e-8) (1 if !demodulate);
+ *   v[n,o,i,t] = weight[o,i,t] * styles[n,i] * style_gain;  d[n,o] = rsqrt(sum_{i,t} v^2 + 1e-8) (1 if !demodulate);
  *   w_out[n,o,t,i] = v * d     -- written TAP-MAJOR ([N,O,kh*kw,I]), the layout spi_conv2d_* take with w_tap_major = 1.
  * weight [O,I,T] (T = kh*kw, PyTorch layout), styles [N,I], dcoef [N,O] (output, kept for the backward pass). */
 int spi_modulate_fwd(const float* weight, const float* styles, float* w_out, float* dcoef, int N, int O, int I,
-                     int T, int demodulate, spi_stream_t stream);
+                     int T, int demodulate, float style_gain, spi_stream_t stream);
 /* Adjoint: g = d loss / d w_out [N,O,T,I] -> d_weight [O,I,T] (may be NULL: weights frozen, stage 1) and
  * d_styles [N,I] (accumulated with atomics: the CALLER zeroes it). */
 int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoef, const float* g, float* d_weight,
-                     float* d_styles, int N, int O, int I, int T, int demodulate, spi_stream_t stream);
+                     float* d_styles, int N, int O, int I, int T, int demodulate, float style_gain,
+                     spi_stream_t stream);
 
 /* LPIPS tail, lpips.py:43-65 + utils.py:6-8: per layer, out[n] += mean_hw( sum_c lin[c] *
  * (fx/(|fx|+1e-10) - fy/(|fy|+1e-10))^2 ).  fx, fy [N,C,HW]. */

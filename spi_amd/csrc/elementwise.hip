@@ -745,7 +745,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 
 __global__ void __launch_bounds__(256) modulate_fwd_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
                                                            float* __restrict__ w_out, float* __restrict__ dcoef, int N, int O,
-                                                           int I, int T, int demod) {
+                                                           int I, int T, int demod, float sgain) {
     extern __shared__ float smem[];
     float* Ws = smem;                  // [T][I] tap-major copy of W[o]
     __shared__ float red[4];
@@ -757,20 +757,20 @@ __global__ void __launch_bounds__(256) modulate_fwd_kernel(const float* __restri
         const float* sn = styles + (int64_t)n * I;
         float ss = 0.f;
         if (demod) {
-            for (int e = tid; e < IT; e += 256) { const float v = Ws[e] * sn[e % I]; ss = fmaf(v, v, ss); }
+            for (int e = tid; e < IT; e += 256) { const float v = Ws[e] * (sn[e % I] * sgain); ss = fmaf(v, v, ss); }
             ss = block_sum_256(ss, red);
         }
         const float d = demod ? rsqrtf(ss + 1e-8f) : 1.f;
         if (tid == 0 && dcoef) dcoef[(int64_t)n * O + o] = d;
         float* dst = w_out + ((int64_t)n * O + o) * IT;
-        for (int e = tid; e < IT; e += 256) dst[e] = Ws[e] * sn[e % I] * d;
+        for (int e = tid; e < IT; e += 256) dst[e] = Ws[e] * (sn[e % I] * sgain) * d;
     }
 }
 
 __global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
                                                            const float* __restrict__ dcoef, const float* __restrict__ g,
                                                            float* __restrict__ d_weight, float* __restrict__ d_styles, int N,
-                                                           int O, int I, int T, int demod) {
+                                                           int O, int I, int T, int demod, float sgain) {
     extern __shared__ float smem[];
     const int IT = I * T;
     float* Ws = smem;                  // [T][I] weights
@@ -786,13 +786,13 @@ __global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restri
         const float* gn = g + ((int64_t)n * O + o) * IT;
         float gv = 0.f;
         if (demod) {
-            for (int e = tid; e < IT; e += 256) gv = fmaf(gn[e], Ws[e] * sn[e % I], gv);
+            for (int e = tid; e < IT; e += 256) gv = fmaf(gn[e], Ws[e] * (sn[e % I] * sgain), gv);
             gv = block_sum_256(gv, red);
         }
         const float d = demod ? dcoef[(int64_t)n * O + o] : 1.f;
         const float k3 = demod ? d * d * d * gv : 0.f;
         for (int e = tid; e < IT; e += 256) {
-            const float sv = sn[e % I];
+            const float sv = sn[e % I] * sgain;
             const float dv = d * gn[e] - k3 * (Ws[e] * sv);
             Ds[e] = dv;
             Acc[e] = fmaf(dv, sv, Acc[e]);                           // same thread owns e in every pass: no race
@@ -801,7 +801,7 @@ __global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restri
         for (int i = tid; i < I; i += 256) {
             float a = 0.f;
             for (int t = 0; t < T; ++t) a = fmaf(Ds[t * I + i], Ws[t * I + i], a);
-            atomicAdd(d_styles + (int64_t)n * I + i, a);
+            atomicAdd(d_styles + (int64_t)n * I + i, a * sgain);
         }
         __syncthreads();
     }
@@ -812,23 +812,23 @@ __global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restri
 }
 
 int spi_modulate_fwd(const float* weight, const float* styles, float* w_out, float* dcoef, int N, int O, int I, int T,
-                     int demodulate, spi_stream_t stream) {
+                     int demodulate, float style_gain, spi_stream_t stream) {
     SPI_REQUIRE(weight && styles && w_out, "spi_modulate_fwd: null tensor");
     SPI_REQUIRE(N > 0 && O > 0 && I > 0 && T > 0 && (int64_t)I * T * 12 <= 64 * 1024, "spi_modulate_fwd: bad sizes (I*T must be <= 5461)");
     SPI_REQUIRE(!demodulate || dcoef, "spi_modulate_fwd: demodulation needs the dcoef output");
     hipLaunchKernelGGL(modulate_fwd_kernel, dim3((unsigned)O), dim3(256), (size_t)I * T * 4, as_stream(stream), weight, styles, w_out,
-                       dcoef, N, O, I, T, demodulate);
+                       dcoef, N, O, I, T, demodulate, style_gain);
     SPI_LAUNCH_CHECK("spi_modulate_fwd");
     return SPI_OK;
 }
 
 int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoef, const float* g, float* d_weight,
-                     float* d_styles, int N, int O, int I, int T, int demodulate, spi_stream_t stream) {
+                     float* d_styles, int N, int O, int I, int T, int demodulate, float style_gain, spi_stream_t stream) {
     SPI_REQUIRE(weight && styles && g && d_styles, "spi_modulate_bwd: null tensor");
     SPI_REQUIRE(N > 0 && O > 0 && I > 0 && T > 0 && (int64_t)I * T * 12 <= 64 * 1024, "spi_modulate_bwd: bad sizes (I*T must be <= 5461)");
     SPI_REQUIRE(!demodulate || dcoef, "spi_modulate_bwd: demodulation needs dcoef from the forward pass");
     hipLaunchKernelGGL(modulate_bwd_kernel, dim3((unsigned)O), dim3(256), (size_t)I * T * 12, as_stream(stream), weight, styles, dcoef,
-                       g, d_weight, d_styles, N, O, I, T, demodulate);
+                       g, d_weight, d_styles, N, O, I, T, demodulate, style_gain);
     SPI_LAUNCH_CHECK("spi_modulate_bwd");
     return SPI_OK;
 }

@@ -494,8 +494,17 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
     const float tile_max = __int_as_float(s_acc[4]);
     if (!(tile_max > 0.f)) return;                          // all gradients zero (block-uniform)
     const int e2 = ilogbf(tile_max);
-    const float to_fix = ldexpf(1.f, 40 - e2), from_fix = ldexpf(1.f, e2 - 40);
+    const float to_fix = ldexpf(1.f, 40 - e2);
+    const double from_fix = ldexp(1.0, e2 - 40);
     const int lane = t & 63, wave = t >> 6, half = lane >> 5, ch = lane & 31;
+    int* s_base = reinterpret_cast<int*>(s_x);                 // phase A is over: s_x is free (this thread's x,y,z live in registers)
+    // float -> 64-bit fixed point in 3 instructions: adding 1.5*2^52 in fp64 leaves round(v) in the low mantissa bits
+    // (two's complement for negative v), so bits(v + MAGIC) - bits(MAGIC) is the integer.  |v| < 2^41 here.
+    constexpr double MAGIC = 6755399441055744.0;
+    auto add_fix = [&](long long* p, double dvd, float w) {
+        const double sfx = fma(dvd, (double)w, MAGIC);
+        atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(sfx) - 0x4338000000000000ull);   // ds_add_u64
+    };
     for (int pl = 0; pl < 3; ++pl) {
         __syncthreads();                                   // previous flush done
         if (t < 4) s_acc[t] = 0;
@@ -504,12 +513,19 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
         plane_uv(pl, x, y, z, gx, gy);
         const Corner c = make_corner(gx, gy, a.W, a.H);
         const int cx0 = min(max(c.x0, -2), a.W), cy0 = min(max(c.y0, -2), a.H);     // clamped: far-outside points stay outside
+        // window centred on the mean corner of the tile's valid points (sums are exact in fp32: < 2^24)
+        const float sx = wave_sum(valid ? (float)cx0 : 0.f), sy = wave_sum(valid ? (float)cy0 : 0.f), sc = wave_sum(valid ? 1.f : 0.f);
         __syncthreads();
-        if (valid) { atomicAdd(&s_acc[0], cx0); atomicAdd(&s_acc[1], cy0); atomicAdd(&s_acc[2], 1); }
+        if (lane == 0) { atomicAdd(&s_acc[0], (int)sx); atomicAdd(&s_acc[1], (int)sy); atomicAdd(&s_acc[2], (int)sc); }
         __syncthreads();
         const int cnt = max(s_acc[2], 1);
-        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;    // window centred on the mean corner
-        s_cxy[t] = ((cx0 - wx0 + 0x4000) & 0xffff) | ((cy0 - wy0 + 0x4000) << 16);
+        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;
+        const int lxo = cx0 - wx0, lyo = cy0 - wy0;
+        // fast path: all four corners inside the image AND inside the window -> no per-corner tests in the loop
+        const bool fast = valid && lxo >= 0 && lxo + 1 < WIN && lyo >= 0 && lyo + 1 < WIN &&
+                          c.x0 >= 0 && c.x0 + 1 < a.W && c.y0 >= 0 && c.y0 + 1 < a.H;
+        s_base[t] = fast ? (lyo * WIN + lxo) * DEC_IN : (valid ? -2 : -1);
+        s_cxy[t] = ((lxo + 0x4000) & 0xffff) | ((lyo + 0x4000) << 16);
         s_wx[t] = c.wx1; s_wy[t] = c.wy1;
         __syncthreads();
         float* gplane = d_planes + (int64_t)(n * 3 + pl) * plane_sz;
@@ -517,25 +533,34 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
 #pragma unroll 2
         for (int i = 0; i < 64; i += 2) {
             const int sp = wave * 64 + i + half;
-            if (s_row[sp] < 0) continue;
+            const int base = s_base[sp];
+            if (base == -1) continue;
             const float dv = gbuf[sp * FS + ch];
-            const int pk = s_cxy[sp];
-            const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
             const float fx1 = s_wx[sp], fy1 = s_wy[sp];
             const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
+            if (base >= 0) {
+                if (a.dbg & 32) continue;
+                const double dvd = (double)(dv * to_fix);
+                long long* wp = win + base + ch;
+                add_fix(wp, dvd, fx0 * fy0);
+                add_fix(wp + DEC_IN, dvd, fx1 * fy0);
+                add_fix(wp + WIN * DEC_IN, dvd, fx0 * fy1);
+                add_fix(wp + (WIN + 1) * DEC_IN, dvd, fx1 * fy1);
+                continue;
+            }
+            const int pk = s_cxy[sp];
+            const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int cx = q & 1, cy = q >> 1;
                 const int xl = lx + cx, yl = ly + cy;
                 const int xx = xl + wx0, yy = yl + wy0;
                 if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-                const float v = dv * ((cx ? fx1 : fx0) * (cy ? fy1 : fy0));
+                const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
                 if (!(a.dbg & 2) && xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
-                    if (!(a.dbg & 32))
-                        atomicAdd(reinterpret_cast<unsigned long long*>(&win[(yl * WIN + xl) * DEC_IN + ch]),
-                                  (unsigned long long)__float2ll_rn(v * to_fix));                        // ds_add_u64
+                    if (!(a.dbg & 32)) add_fix(&win[(yl * WIN + xl) * DEC_IN + ch], (double)(dv * to_fix), wq);
                 } else if (!(a.dbg & 16)) {
-                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, v);                        // rare: straight to HBM
+                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dv * wq);                  // rare: straight to HBM
                 }
             }
         }
@@ -546,7 +571,10 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
             const int xx = wx0 + (tex % WIN), yy = wy0 + (tex / WIN);
             if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
             const long long q = win[tex * DEC_IN + ch];
-            if (q != 0) atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, __ll2float_rn(q) * from_fix);
+            if (q != 0) {
+                const double qd = (double)(int)(q >> 32) * 4294967296.0 + (double)(unsigned)q;
+                atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, (float)(qd * from_fix));
+            }
         }
     }
 }

@@ -46,6 +46,7 @@ class RotBboxCoach(BaseCoach):
         ctx['weight_m'] = float(cal_camera_weight(camera)[0])
         ctx['yaw_range'] = float(cal_camera_gauss_weight(camera)[0]) if hyperparameters.use_adapt_yaw_range else 0.2
         ctx['target_feats'] = self.lpips_loss.features(image)
+        self.original_G._last_planes = None                      # per-image backbone cache of the frozen generator (depth branch)
         return ctx
 
     def _synth(self, G, ws, cams, rng, **kw):
@@ -98,7 +99,12 @@ class RotBboxCoach(BaseCoach):
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
                 sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True)['image_depth']
                 with torch.no_grad():
-                    stable_depth = self._synth(self.original_G, ws, cams_d, rng, skip_superresolution=True)['image_depth']
+                    # the frozen generator's tri-planes for this pivot never change: computed on the first use, then
+                    # taken from EG3D's own backbone cache (triplane.py:64-70 cache_backbone / use_cached_backbone)
+                    cached = ctx.get('stable_planes_cached', False)
+                    stable_depth = self._synth(self.original_G, ws, cams_d, rng, skip_superresolution=True, cache_backbone=not cached,
+                                               use_cached_backbone=cached)['image_depth']
+                    ctx['stable_planes_cached'] = True
                 losses['depth'] = l2_loss(stable_depth, sample_depth) * hp.pt_depth_lambda
                 losses['depth'].backward()
             if hp.pt_tv_lambda > 0:

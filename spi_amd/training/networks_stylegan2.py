@@ -31,16 +31,17 @@ class _Modulate(torch.autograd.Function):
     (one HIP launch each way instead of ~12 strided elementwise / reduction launches; reference :62-69)."""
 
     @staticmethod
-    def forward(ctx, weight, styles, demodulate):
+    def forward(ctx, weight, styles, demodulate, style_gain):
         weight = weight.contiguous().float()
         styles = styles.contiguous().float()
         o, i, kh, kw = weight.shape
         n = styles.shape[0]
         w = torch.empty(n, o, kh, kw, i, device=weight.device, dtype=torch.float32)
         dcoef = torch.empty(n, o, device=weight.device, dtype=torch.float32) if demodulate else None
-        hip.call('spi_modulate_fwd', hip.ptr(weight), hip.ptr(styles), hip.ptr(w), hip.ptr(dcoef), n, o, i, kh * kw, int(demodulate), hip.stream())
+        hip.call('spi_modulate_fwd', hip.ptr(weight), hip.ptr(styles), hip.ptr(w), hip.ptr(dcoef), n, o, i, kh * kw, int(demodulate), float(style_gain),
+                 hip.stream())
         ctx.save_for_backward(weight, styles, dcoef)
-        ctx.demodulate = demodulate
+        ctx.demodulate, ctx.style_gain = demodulate, float(style_gain)
         return w
 
     @staticmethod
@@ -52,16 +53,18 @@ class _Modulate(torch.autograd.Function):
         dw = torch.empty_like(weight) if ctx.needs_input_grad[0] else None
         ds = torch.zeros_like(styles)
         hip.call('spi_modulate_bwd', hip.ptr(weight), hip.ptr(styles), hip.ptr(dcoef), hip.ptr(g), hip.ptr(dw), hip.ptr(ds), n, o, i, kh * kw,
-                 int(ctx.demodulate), hip.stream())
-        return dw, ds, None
+                 int(ctx.demodulate), ctx.style_gain, hip.stream())
+        return dw, ds, None, None
 
 
-def modulate_weights(weight, styles, demodulate=True):
-    return _Modulate.apply(weight, styles, bool(demodulate))
+def modulate_weights(weight, styles, demodulate=True, style_gain=1.0):
+    """``style_gain`` multiplies the styles inside the kernel (ToRGBLayer's weight_gain, reference :303)."""
+    return _Modulate.apply(weight, styles, bool(demodulate), float(style_gain))
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
-                     flip_weight=True, fused_modconv=True, noise_strength=None, bias=None, act=None, gain=None, clamp=None):
+                     flip_weight=True, fused_modconv=True, noise_strength=None, bias=None, act=None, gain=None, clamp=None,
+                     style_gain=1.0):
     """Modulate -> (demodulate) -> conv [-> FIR] [-> + noise -> + bias -> act], reference :34-91 (fused path).
 
     ``noise`` may be the final noise tensor (reference style) or, with ``noise_strength`` given, the
@@ -77,7 +80,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     # conv runs with one weight set and its weight gradient is reduced over the batch inside the kernel)
     assert styles.shape in ((n, ic), (1, ic))
     # modulated (and demodulated) per-sample weights, built directly in the kernels' tap-major layout [N,O,k,k,I]
-    w = modulate_weights(weight, styles, demodulate)
+    w = modulate_weights(weight, styles, demodulate, style_gain)
     if styles.shape[0] == 1 and n > 1:
         w = w[0]
     if up == 1:
@@ -102,12 +105,13 @@ class FullyConnectedLayer(torch.nn.Module):
         self.bias_gain = lr_multiplier
 
     def forward(self, x):
-        w = self.weight.to(x.dtype) * self.weight_gain
         b = self.bias
         if b is not None and self.bias_gain != 1:
             b = b * self.bias_gain
         if self.activation == 'linear' and b is not None:
-            return torch.addmm(b.unsqueeze(0), x, w.t())          # plain library GEMM
+            # plain library GEMM; the weight gain rides along as alpha instead of a [out, in] elementwise pass each way
+            return torch.addmm(b.unsqueeze(0), x, self.weight.to(x.dtype).t(), alpha=self.weight_gain)
+        w = self.weight.to(x.dtype) * self.weight_gain
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
     def extra_repr(self):
@@ -202,9 +206,9 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
+        styles = self.affine(w)                                    # * weight_gain happens inside the modulation kernel
         return modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
-                                bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp)
+                                bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp, style_gain=self.weight_gain)
 
 
 class SynthesisBlock(torch.nn.Module):

@@ -95,19 +95,20 @@ def test_modulate_weights_vs_torch(n, o, i, k, demod):
     w = torch.randn(o, i, k, k, generator=gen, dtype=torch.float64, requires_grad=True)
     s = (torch.randn(n, i, generator=gen, dtype=torch.float64) + 1).requires_grad_(True)
     g = torch.randn(n, o, k, k, i, generator=gen, dtype=torch.float64)
-    ref = w.unsqueeze(0) * s.reshape(n, 1, i, 1, 1)
+    sg = 1.0 if demod else 0.37                      # ToRGB folds its weight_gain into the kernel
+    ref = w.unsqueeze(0) * (s * sg).reshape(n, 1, i, 1, 1)
     if demod:
         ref = ref * (ref.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt().reshape(n, o, 1, 1, 1)
     ref = ref.permute(0, 1, 3, 4, 2)
     gw, gs = torch.autograd.grad(ref, [w, s], g)
     wd, sd = w.detach().float().to(DEV).requires_grad_(True), s.detach().float().to(DEV).requires_grad_(True)
-    out = modulate_weights(wd, sd, demod)
+    out = modulate_weights(wd, sd, demod, sg)
     assert out.shape == (n, o, k, k, i) and out.is_contiguous()
     assert_close(out, ref.float(), 2e-5, 'modulate fwd')
     a, b = torch.autograd.grad(out, [wd, sd], g.float().to(DEV))
     assert_close(a, gw.float(), 5e-5, 'modulate dW')
     assert_close(b, gs.float(), 5e-5, 'modulate ds')
     # frozen weights (stage 1): only d_styles
-    out = modulate_weights(wd.detach(), sd, demod)
+    out = modulate_weights(wd.detach(), sd, demod, sg)
     (b2,) = torch.autograd.grad(out, [sd], g.float().to(DEV))
     assert_close(b2, gs.float(), 5e-5, 'modulate ds (weights frozen)')
