@@ -153,10 +153,10 @@ def main():
         tot_bytes = sum(march_rays) * per_ray
         tot_s = sum(march_ms) / 1e3
         achieved = tot_bytes / tot_s / 1e9 if tot_s > 0 else 0.0
-        traffic = None
+        traffic = None                                           # HBM bytes per (average) launch from the committed PMC passes
         pmc = os.path.join(ROOT, 'profiles', 'raymarch_pmc.json')
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get('hbm_bytes_per_16384_rays')
+        if os.path.exists(pmc) and march_rays:
+            traffic = json.load(open(pmc)).get('hbm_bytes_per_16384_rays') / 16384.0 * (sum(march_rays) / len(march_rays))
         out = {
             'metric': 'SPI inversion iters/sec (512^2, 96+96 ray samples)', 'value': world * args.steps / dt, 'unit': 'iters/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
