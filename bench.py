@@ -122,8 +122,15 @@ def main():
         for i in range(n1):
             proj.step(s1_base + i)
         marks['stage1_host_ms_per_step'] = (time.perf_counter() - ta) / max(n1, 1) * 1e3    # stage 1 never syncs: pure host enqueue cost
+        if os.environ.get('SPI_BENCH_SPLIT'):                    # debugging aid: wall time per stage (adds one sync)
+            torch.cuda.synchronize()
+            marks['stage1_ms_per_step'] = (time.perf_counter() - ta) / max(n1, 1) * 1e3
+            tb = time.perf_counter()
         for i in range(n2):
             coach.train_step(s2_base + i, ctx, w_pivot)
+        if os.environ.get('SPI_BENCH_SPLIT'):
+            torch.cuda.synchronize()
+            marks['stage2_ms_per_step'] = (time.perf_counter() - tb) / max(n2, 1) * 1e3
 
     w1, w2 = split_steps(args.warmup)
     k1, k2 = split_steps(args.steps)
@@ -131,12 +138,18 @@ def main():
     rmod.MARCH_EVENTS = []                                       # HIP events around every final-march launch in the timed region
     sdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    if os.environ.get('SPI_TORCH_PROFILE'):                      # debugging aid: per-op device time of the timed region (stderr)
+    if os.environ.get('SPI_TORCH_PROFILE'):                      # debugging aid: per-op device time / launch counts per stage (stderr)
         from torch.profiler import profile, ProfilerActivity
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-            run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
-            torch.cuda.synchronize()
-        print(prof.key_averages().table(sort_by='cuda_time_total', row_limit=70, max_name_column_width=60), file=sys.stderr)
+        for tag, a1, a2 in (('stage 1', k1, 0), ('stage 2', 0, k2)):
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+                run(a1, a2, 25 + w1, ((w2 + 3) // 4) * 4)
+                torch.cuda.synchronize()
+            ka = prof.key_averages()
+            print(f'==== {tag}: {a1 + a2} steps, by device time', file=sys.stderr)
+            print(ka.table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=60), file=sys.stderr)
+            print(f'==== {tag}: by number of calls', file=sys.stderr)
+            for e in sorted(ka, key=lambda e: -e.count)[:45]:
+                print(f'{e.count:7d}  dev {e.device_time_total / 1e3:9.2f} ms  cpu {e.cpu_time_total / 1e3:9.2f} ms  {e.key[:90]}', file=sys.stderr)
     else:
         run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
     t_enq = time.perf_counter() - t0                             # host time to enqueue the K steps (== dt when host-bound)
@@ -161,6 +174,7 @@ def main():
             'metric': 'SPI inversion iters/sec (512^2, 96+96 ray samples)', 'value': world * args.steps / dt, 'unit': 'iters/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
             'stage1_host_enqueue_ms_per_step': marks.get('stage1_host_ms_per_step'),
+            **({k: marks[k] for k in ('stage1_ms_per_step', 'stage2_ms_per_step') if k in marks}),
             'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
             'random-init weights of the ffhqrebalanced512-128 architecture)',

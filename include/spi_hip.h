@@ -225,6 +225,21 @@ int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoe
                      float* d_styles, int N, int O, int I, int T, int demodulate, float style_gain,
                      spi_stream_t stream);
 
+/* Noise regulariser of the stage-1 projectors (mirror_projector.py:106-116, w_plus_projector.py likewise):
+ *   reg = sum_bufs sum_levels  mean(x * roll(x,1,W))^2 + mean(x * roll(x,1,H))^2,   x -> avg_pool2d(x,2) while size > 8
+ * for T square noise buffers in ONE launch (one block per buffer walks its pyramid); the reference's autograd graph is
+ * ~1200 tiny launches per optimisation step.
+ *   bufs: device array of T buffer pointers; res: device int32 [T] (edge lengths, powers of two, <= max_res)
+ *   pyramid: scratch [T * max_res^2 / 2] (pooled levels, kept for the backward); means [T*8*2]; loss [1] (CALLER zeroes). */
+int spi_noise_reg_fwd(const float* const* bufs, const int32_t* res, int T, int max_res, float* pyramid, float* means,
+                      float* loss, spi_stream_t stream);
+/* d reg / d buf_t written to grads + goff[t] (int64 element offsets, device), scaled by the device scalar gout[0]. */
+int spi_noise_reg_bwd(const float* const* bufs, const int32_t* res, int T, int max_res, const float* pyramid,
+                      const float* means, const float* gout, float* grads, const int64_t* goff, float* gpyramid,
+                      spi_stream_t stream);
+/* After the optimiser step (mirror_projector.py:127-131): buf -= mean(buf); buf *= rsqrt(mean(buf^2)), all T in one launch. */
+int spi_noise_renorm(float* const* bufs, const int32_t* res, int T, spi_stream_t stream);
+
 /* LPIPS tail, lpips.py:43-65 + utils.py:6-8: per layer, out[n] += mean_hw( sum_c lin[c] *
  * (fx/(|fx|+1e-10) - fy/(|fy|+1e-10))^2 ).  fx, fy [N,C,HW]. */
 int spi_lpips_layer_fwd(const float* fx, const float* fy, const float* lin, int N, int C, int64_t HW,

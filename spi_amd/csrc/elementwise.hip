@@ -529,6 +529,105 @@ __global__ void rotate_warp_kernel(const float* __restrict__ tgt_cam, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
+// Stage-1 noise regulariser: one 1024-thread block per noise buffer walks the whole pooling pyramid
+// (<= 6 levels of a 256^2 buffer) with block-level reductions; pooled levels live in an L2-resident
+// scratch pyramid so the backward can reuse them.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 block_sum2_1024(float a, float b, float (*red)[2]) {
+    a = wave_sum(a); b = wave_sum(b);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = b; }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sa += red[i][0]; sb += red[i][1]; }
+    return make_float2(sa, sb);
+}
+
+__global__ void __launch_bounds__(1024) noise_reg_fwd_kernel(const float* const* __restrict__ bufs, const int32_t* __restrict__ res,
+                                                             int64_t region, float* __restrict__ pyramid, float* __restrict__ means,
+                                                             float* __restrict__ loss) {
+    __shared__ float red[16][2];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    int R = res[t];
+    const float* x = bufs[t];
+    float* pyr = pyramid + (int64_t)t * region;
+    float total = 0.f;
+    for (int lvl = 0;; ++lvl) {
+        const int n = R * R;
+        float sh = 0.f, sv = 0.f;
+        for (int i = tid; i < n; i += 1024) {
+            const int y = i / R, xx = i - y * R;
+            const float v = x[i];
+            sh = fmaf(v, x[y * R + (xx ? xx - 1 : R - 1)], sh);                  // roll(shifts=1, dims=3): out[x] = in[x-1]
+            sv = fmaf(v, x[(y ? y - 1 : R - 1) * R + xx], sv);
+        }
+        const float2 s2 = block_sum2_1024(sh, sv, red);
+        const float mh = s2.x / (float)n, mv = s2.y / (float)n;
+        if (tid == 0) { means[(t * 8 + lvl) * 2] = mh; means[(t * 8 + lvl) * 2 + 1] = mv; }
+        total += mh * mh + mv * mv;
+        if (R <= 8) break;
+        const int R2 = R >> 1;
+        for (int i = tid; i < R2 * R2; i += 1024) {
+            const int Y = i / R2, X = i - Y * R2;
+            const float* q = x + (2 * Y) * R + 2 * X;
+            pyr[i] = ((q[0] + q[1]) + (q[R] + q[R + 1])) * 0.25f;               // avg_pool2d(kernel_size=2)
+        }
+        __threadfence_block();
+        __syncthreads();
+        x = pyr; pyr += R2 * R2; R = R2;
+    }
+    if (tid == 0) atomicAdd(loss, total);
+}
+
+__global__ void __launch_bounds__(1024) noise_reg_bwd_kernel(const float* const* __restrict__ bufs, const int32_t* __restrict__ res,
+                                                             int64_t region, const float* __restrict__ pyramid,
+                                                             const float* __restrict__ means, const float* __restrict__ gout,
+                                                             float* __restrict__ grads, const int64_t* __restrict__ goff,
+                                                             float* __restrict__ gpyramid) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int R0 = res[t];
+    int L = 1;
+    for (int r = R0; r > 8; r >>= 1) ++L;
+    const float c = gout[0];
+    // level l >= 1 starts at offset sum_{k=1}^{l-1} (R0 >> k)^2 of the buffer's region (same for x and G pyramids)
+    for (int l = L - 1; l >= 0; --l) {
+        const int R = R0 >> l, n = R * R;
+        int64_t off = 0, offp = 0;
+        for (int k = 1; k < l; ++k) off += (int64_t)(R0 >> k) * (R0 >> k);
+        for (int k = 1; k < l + 1; ++k) offp += (int64_t)(R0 >> k) * (R0 >> k);
+        const float* x = l == 0 ? bufs[t] : pyramid + (int64_t)t * region + off;
+        float* G = l == 0 ? grads + goff[t] : gpyramid + (int64_t)t * region + off;
+        const float* Gp = l == L - 1 ? nullptr : gpyramid + (int64_t)t * region + offp;
+        const float a = 2.f * means[(t * 8 + l) * 2] / (float)n * c, b = 2.f * means[(t * 8 + l) * 2 + 1] / (float)n * c;
+        for (int i = tid; i < n; i += 1024) {
+            const int y = i / R, xx = i - y * R;
+            const float hl = x[y * R + (xx ? xx - 1 : R - 1)], hr = x[y * R + (xx + 1 < R ? xx + 1 : 0)];
+            const float vu = x[(y ? y - 1 : R - 1) * R + xx], vd = x[(y + 1 < R ? y + 1 : 0) * R + xx];
+            float g = a * (hl + hr) + b * (vu + vd);
+            if (Gp) g = fmaf(0.25f, Gp[(y >> 1) * (R >> 1) + (xx >> 1)], g);
+            G[i] = g;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(1024) noise_renorm_kernel(float* const* __restrict__ bufs, const int32_t* __restrict__ res) {
+    __shared__ float red[16][2];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int n = res[t] * res[t];
+    float* x = bufs[t];
+    float s = 0.f;
+    for (int i = tid; i < n; i += 1024) s += x[i];
+    const float mu = block_sum2_1024(s, 0.f, red).x / (float)n;
+    float q = 0.f;
+    for (int i = tid; i < n; i += 1024) { const float v = x[i] - mu; x[i] = v; q = fmaf(v, v, q); }     // each thread re-reads only its own elements
+    const float r = rsqrtf(block_sum2_1024(q, 0.f, red).x / (float)n);
+    for (int i = tid; i < n; i += 1024) x[i] *= r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // LPIPS tail (lpips.py:43-65): unit-normalise both feature stacks over channels, squared
 // difference, 1x1 "lin" weights, spatial mean.  A 1024-thread block covers 64 pixels (the lanes:
 // channel reads stay coalesced in NCHW) x 16 channel groups (the waves); channel sums are combined
@@ -830,6 +929,32 @@ int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoe
     hipLaunchKernelGGL(modulate_bwd_kernel, dim3((unsigned)O), dim3(256), (size_t)I * T * 12, as_stream(stream), weight, styles, dcoef,
                        g, d_weight, d_styles, N, O, I, T, demodulate, style_gain);
     SPI_LAUNCH_CHECK("spi_modulate_bwd");
+    return SPI_OK;
+}
+
+int spi_noise_reg_fwd(const float* const* bufs, const int32_t* res, int T, int max_res, float* pyramid, float* means,
+                      float* loss, spi_stream_t stream) {
+    SPI_REQUIRE(bufs && res && pyramid && means && loss && T > 0 && max_res >= 1 && max_res <= 2048, "spi_noise_reg_fwd: bad argument");
+    hipLaunchKernelGGL(noise_reg_fwd_kernel, dim3((unsigned)T), dim3(1024), 0, as_stream(stream), bufs, res, (int64_t)max_res * max_res / 2,
+                       pyramid, means, loss);
+    SPI_LAUNCH_CHECK("spi_noise_reg_fwd");
+    return SPI_OK;
+}
+
+int spi_noise_reg_bwd(const float* const* bufs, const int32_t* res, int T, int max_res, const float* pyramid, const float* means,
+                      const float* gout, float* grads, const int64_t* goff, float* gpyramid, spi_stream_t stream) {
+    SPI_REQUIRE(bufs && res && pyramid && means && gout && grads && goff && gpyramid && T > 0 && max_res >= 1 && max_res <= 2048,
+                "spi_noise_reg_bwd: bad argument");
+    hipLaunchKernelGGL(noise_reg_bwd_kernel, dim3((unsigned)T), dim3(1024), 0, as_stream(stream), bufs, res, (int64_t)max_res * max_res / 2,
+                       pyramid, means, gout, grads, goff, gpyramid);
+    SPI_LAUNCH_CHECK("spi_noise_reg_bwd");
+    return SPI_OK;
+}
+
+int spi_noise_renorm(float* const* bufs, const int32_t* res, int T, spi_stream_t stream) {
+    SPI_REQUIRE(bufs && res && T > 0, "spi_noise_renorm: bad argument");
+    hipLaunchKernelGGL(noise_renorm_kernel, dim3((unsigned)T), dim3(1024), 0, as_stream(stream), bufs, res);
+    SPI_LAUNCH_CHECK("spi_noise_renorm");
     return SPI_OK;
 }
 

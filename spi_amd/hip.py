@@ -50,6 +50,9 @@ _SIGS = {
     'spi_tail_bwd': ([c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_modulate_fwd': ([c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p], c_i),
     'spi_modulate_bwd': ([c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p], c_i),
+    'spi_noise_reg_fwd': ([c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p], c_i),
+    'spi_noise_reg_bwd': ([c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p], c_i),
+    'spi_noise_renorm': ([c_p, c_p, c_i, c_p], c_i),
     'spi_lpips_layer_fwd': ([c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
     'spi_lpips_layer_bwd': ([c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
     'spi_adam_multi': ([c_p, c_p, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p], c_i),

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from ... import hip
 from ...configs import hyperparameters
 from ...utils.rng import DeviceRNG
 from ..optim import Adam
@@ -31,17 +32,67 @@ def w_statistics(G, c, w_avg_samples, device):
     return w_avg, float(w_std)
 
 
-def noise_regulariser(noise_bufs):
-    reg = 0.0
-    for v in noise_bufs:
-        noise = v[None, None, :, :]
-        while True:
-            reg = reg + (noise * torch.roll(noise, shifts=1, dims=3)).mean() ** 2
-            reg = reg + (noise * torch.roll(noise, shifts=1, dims=2)).mean() ** 2
-            if noise.shape[2] <= 8:
-                break
-            noise = F.avg_pool2d(noise, kernel_size=2)
-    return reg
+class _NoiseReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, plan, *bufs):
+        loss = torch.zeros(1, device=bufs[0].device, dtype=torch.float32)
+        pyramid = torch.empty(plan.T * plan.region, device=loss.device, dtype=torch.float32)
+        means = torch.empty(plan.T * 16, device=loss.device, dtype=torch.float32)
+        hip.call('spi_noise_reg_fwd', hip.ptr(plan.ptrs), hip.ptr(plan.res), plan.T, plan.max_res, hip.ptr(pyramid), hip.ptr(means),
+                 hip.ptr(loss), hip.stream())
+        ctx.plan = plan
+        ctx.save_for_backward(pyramid, means)
+        return loss.reshape(())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        plan = ctx.plan
+        pyramid, means = ctx.saved_tensors
+        grads = torch.empty(plan.total, device=pyramid.device, dtype=torch.float32)
+        gpyr = torch.empty_like(pyramid)
+        hip.call('spi_noise_reg_bwd', hip.ptr(plan.ptrs), hip.ptr(plan.res), plan.T, plan.max_res, hip.ptr(pyramid), hip.ptr(means),
+                 hip.ptr(gout.reshape(1).contiguous().float()), hip.ptr(grads), hip.ptr(plan.goff), hip.ptr(gpyr), hip.stream())
+        return (None,) + tuple(g.view(r, r) for g, r in zip(torch.split(grads, plan.sizes), plan.res_list))
+
+
+class NoiseRegulariser:
+    """Multi-scale autocorrelation penalty on the StyleGAN2 noise buffers (mirror_projector.py:106-116) and their
+    re-normalisation after the optimiser step (:127-131), each as ONE launch over all buffers (``spi_noise_reg_*``,
+    ``spi_noise_renorm``) instead of the reference's ~1200 tiny autograd launches per step.  The pointer table is built once:
+    the buffers are optimised in place, their addresses never change."""
+
+    def __init__(self, noise_bufs):
+        self.bufs = list(noise_bufs)
+        dev = self.bufs[0].device
+        assert all(b.ndim == 2 and b.shape[0] == b.shape[1] and b.is_contiguous() and b.dtype == torch.float32 for b in self.bufs)
+        self.res_list = [int(b.shape[0]) for b in self.bufs]
+        self.sizes = [r * r for r in self.res_list]
+        self.T, self.max_res, self.total = len(self.bufs), max(self.res_list), sum(self.sizes)
+        self.region = self.max_res * self.max_res // 2
+        self.ptrs = torch.tensor([b.data_ptr() for b in self.bufs], dtype=torch.int64, device=dev)
+        self.res = torch.tensor(self.res_list, dtype=torch.int32, device=dev)
+        offs = [0]
+        for n in self.sizes[:-1]:
+            offs.append(offs[-1] + n)
+        self.goff = torch.tensor(offs, dtype=torch.int64, device=dev)
+
+    def _check(self):
+        if any(b.data_ptr() != p for b, p in zip(self.bufs, self.ptrs_host())):
+            raise RuntimeError('noise buffers were re-allocated after NoiseRegulariser was built')
+
+    def ptrs_host(self):
+        if not hasattr(self, '_ptrs_host'):
+            self._ptrs_host = [b.data_ptr() for b in self.bufs]
+        return self._ptrs_host
+
+    def __call__(self):
+        self._check()
+        return _NoiseReg.apply(self, *self.bufs)
+
+    def renorm(self):
+        self._check()
+        hip.call('spi_noise_renorm', hip.ptr(self.ptrs), hip.ptr(self.res), self.T, hip.stream())
 
 
 class Projection:
@@ -63,6 +114,7 @@ class Projection:
             buf[:] = self.rng.randn(*buf.shape)
             buf.requires_grad = True
         self.optimizer = Adam([self.w_opt] + list(self.noise_bufs.values()), betas=(0.9, 0.999), lr=hyperparameters.first_inv_lr)
+        self.noise_reg = NoiseRegulariser(self.noise_bufs.values())          # after Adam: it moves the parameters into its flat buffer
 
     def step(self, step):
         G, rng, w_opt = self.G, self.rng, self.w_opt
@@ -77,15 +129,12 @@ class Projection:
         noise = (rng.rand(batch, m, int(rk['depth_resolution']), 1), rng.rand(batch * m, max(int(rk['depth_resolution_importance']), 1)))
         images = G.synthesis(ws, self.cameras, noise_mode='const', render_noise=noise)['image']
         dist = self.dist_fn(images)
-        reg_loss = noise_regulariser(self.noise_bufs.values())
+        reg_loss = self.noise_reg()
         loss = dist + reg_loss * self.reg_weight
         self.optimizer.zero_grad()
         loss.backward()
         self.optimizer.step()
-        with torch.no_grad():
-            for buf in self.noise_bufs.values():
-                buf -= buf.mean()
-                buf *= buf.square().mean().rsqrt()
+        self.noise_reg.renorm()
         return dict(dist=dist.detach(), reg=reg_loss.detach(), loss=loss.detach())
 
 

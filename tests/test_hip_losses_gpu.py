@@ -197,3 +197,34 @@ def test_stage2_rotbbox_iteration_vs_oracle():
         d_gpu = sd[k].cpu() - st.P0[k]
         agree = (torch.sign(d_ref) == torch.sign(d_gpu)).float().mean().item()
         assert agree > 0.97, (k, agree)
+
+
+def test_noise_regulariser_fused_vs_reference_expression():
+    """spi_noise_reg_fwd/bwd + spi_noise_renorm against the reference's expression (mirror_projector.py:106-116,127-131)."""
+    import torch.nn.functional as F
+    from spi_amd.training.projectors.common import NoiseRegulariser
+    gen = torch.Generator().manual_seed(3)
+    sizes = [4, 8, 8, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256]
+    ref_bufs = [(torch.randn(r, r, generator=gen, dtype=torch.float64) * (1 + 0.1 * i) + 0.05 * i).requires_grad_(True) for i, r in enumerate(sizes)]
+    reg = 0.0
+    for v in ref_bufs:
+        noise = v[None, None]
+        while True:
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=3)).mean() ** 2
+            reg = reg + (noise * torch.roll(noise, shifts=1, dims=2)).mean() ** 2
+            if noise.shape[2] <= 8:
+                break
+            noise = F.avg_pool2d(noise, kernel_size=2)
+    gref = torch.autograd.grad(reg * 1e5, ref_bufs)
+    bufs = [b.detach().float().to(DEV).requires_grad_(True) for b in ref_bufs]
+    nr = NoiseRegulariser(bufs)
+    loss = nr()
+    assert abs(loss.item() - reg.item()) <= 1e-5 * abs(reg.item()) + 1e-9
+    g = torch.autograd.grad(loss * 1e5, bufs)
+    for a, b, r in zip(g, gref, sizes):
+        assert_close(a, b.float(), 1e-4, f'noise reg grad {r}')
+    nr.renorm()
+    for b, rb in zip(bufs, ref_bufs):
+        x = rb.detach().clone()
+        x -= x.mean(); x *= x.square().mean().rsqrt()
+        assert_close(b.detach(), x.float(), 1e-5, 'noise renorm')
