@@ -82,17 +82,19 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
  * neighbouring rays (ray m = row * ray_w + col) x 4 consecutive SORTED sample positions; plane-gradient
  * contributions are pre-summed in an LDS window before touching HBM.  Sample (r, k) has depth
  * depths_sorted[r, k] and colour/density/gradient row r*S + perm[r, k] (perm may be NULL = identity).
- * dump_act (optional) must hold 193 * spi_triplane_decode_bwd_sorted_cols(...) floats (column-major as
- * above; padding columns are zero).  d_planes_nhwc is accumulated into. */
+ * The decoder runs on the fp32 matrix cores and its weight gradients are fused in: with dw1 != NULL the call
+ * OVERWRITES dw1 [64,32], db1 [64], dw2 [33,64], db2 [33] (gradients wrt the gained weights w1t^T, b1, w2, b2);
+ * dw1 == NULL (all four) = decoder frozen.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
+ * (weight fragments + per-wave partial sums; contents undefined afterwards).  d_planes_nhwc is accumulated into. */
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d,
                                    const float* depths_sorted, const int32_t* perm, const float* w1t,
                                    const float* b1, const float* w2, const float* b2, const float* d_rgb,
                                    const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
-                                   float box_warp, float* d_planes_nhwc, float* dump_act, int64_t* dump_cols,
-                                   spi_stream_t stream);
-int64_t spi_triplane_decode_bwd_sorted_cols(int N, int M, int S, int ray_w);
+                                   float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1,
+                                   float* dw2, float* db2, spi_stream_t stream);
+int64_t spi_triplane_decode_bwd_sorted_ws(int N, int M, int S, int ray_w);
 
-/* Decoder weight gradients from a dump written by the backward kernels (rows f | h | d_pre1 | d_y, each
+/* Decoder weight gradients from a dump written by spi_triplane_decode_bwd (rows f | h | d_pre1 | d_y, each
  * `cols` long): dw1 [64,32], db1 [64], dw2 [33,64], db2 [33] wrt the gained weights (overwritten). */
 int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, float* dw2, float* db2,
                       spi_stream_t stream);

@@ -329,38 +329,120 @@ __global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const floa
 }
 
 // ------------------------------------------------------------------------------------------------
-// Backward of gather + decoder for the render path, tiled for scatter locality.
+// Backward of gather + decoder for the render path: tiled for scatter locality, decoder on the matrix
+// cores, weight gradients fused in.
 //   A tile is an 8x8 patch of neighbouring rays x 4 consecutive SORTED sample positions: those 256
 //   points land on a few dozen texels per plane, so their plane-gradient contributions are first
-//   summed in a 16x16-texel LDS window (ds_add_f32) and only the window's non-zero texels go to HBM
-//   with global atomics -- instead of 384 global atomics per point.  Corners outside the window
-//   fall back to direct global atomics, so the result never depends on the window placement.
-//   Sample (ray, k) is read through the sort permutation: its colour/density row is perm[ray,k] and
-//   its depth is depths_sorted[ray,k]; the coarse / fine depth arrays are not needed.
+//   summed in a 12x12-texel LDS window and only the window's non-zero texels go to HBM with global
+//   atomics.  Corners outside the window fall back to direct global atomics, so the result never
+//   depends on the window placement.  Sample (ray, k) is read through the sort permutation.
+//
+//   Phase B (the 32-64-33 MLP, forward recompute + backward) runs on v_mfma_f32_32x32x2_f32 with the
+//   POINTS along the MFMA N axis ("orientation 1": accumulator register r of lane (q,h) holds
+//   D[feature rowmap(r,h)][point q]).  In that layout the output of one layer is directly the B
+//   operand of the next (the K index is walked in the accumulator's own (register, half) order and the
+//   weight fragments are pre-permuted to match), so activations never leave registers.
+//   The weight gradients contract over POINTS, which needs activations with the feature in the lane
+//   position ("orientation 2").  Instead of transposing through LDS (no room next to the 72 KB of
+//   feature / gradient rows at 2 blocks per CU) the needed activations are simply computed a second
+//   time in orientation 2 -- H2 = F W1^T, Y2 = H1 W2^T and dH2 = dY1 W2 take their A operand
+//   straight from orientation-1 registers or LDS rows -- and then dW1 += dpre2^T F, dW2 += dY2^T H2 are
+//   MFMAs whose operands are all in registers.  292 MFMAs per 32 points (130 with a frozen decoder)
+//   instead of 8320 VALU FMAs per point + a 772 B/point activation dump + a separate reduction kernel.
+//   The kernel is persistent (grid <= 512): per-wave weight-gradient accumulators live in registers
+//   across tiles and are written once to a scratch row that decoder_partial_reduce_kernel sums.
 // ------------------------------------------------------------------------------------------------
 constexpr int WIN = 12;                       // window edge in texels; WIN*WIN*32 int64 accumulators == DT*FS floats of LDS
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+// weight fragments, one 64-lane row per MFMA k-step (built by decoder_frag_kernel for every call)
+constexpr int FRAG_A1 = 0;                          // [2][16][64]  W1[mt*32+q][2s+h]                      (A of H1, B of H2)
+constexpr int FRAG_A2 = FRAG_A1 + 2 * 16 * 64;      // [32][64]     W2[1+q][mt'*32+rowmap(r',h)]            (A of Y1, B of Y2)
+constexpr int FRAG_A3 = FRAG_A2 + 32 * 64;          // [2][17][64]  W2[1+rowmap(r',h)][mt*32+q]; step 16: sigma row in half 0   (A of dH1, B of dH2)
+constexpr int FRAG_A4 = FRAG_A3 + 2 * 17 * 64;      // [32][64]     W1[mt'*32+rowmap(r',h)][q]              (A of dF)
+constexpr int FRAG_TOTAL = FRAG_A4 + 32 * 64;       // 8320 floats
+constexpr int PART_ROW = 4352;                      // scratch row per wave: dW1 2048 | dW2 2112 | db1 64 | db2 33 | pad
+constexpr int PART_DW2 = 2048, PART_DB1 = 4160, PART_DB2 = 4224;
+constexpr int BWD_MAX_GRID = 512;
+
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // C/D row of accumulator register r in half h
+
+__global__ void decoder_frag_kernel(const float* __restrict__ w1t, const float* __restrict__ w2, float* __restrict__ frag) {
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < FRAG_TOTAL; idx += gridDim.x * blockDim.x) {
+        const int lane = idx & 63, q = lane & 31, h = lane >> 5;
+        float v;
+        if (idx < FRAG_A2) {
+            const int st = idx >> 6, mt = st >> 4, s2 = st & 15;
+            v = w1t[(2 * s2 + h) * DEC_HID + mt * 32 + q];                               // W1[j][i] = w1t[i][j]
+        } else if (idx < FRAG_A3) {
+            const int st = (idx - FRAG_A2) >> 6, mt = st >> 4, r = st & 15;
+            v = w2[(1 + q) * DEC_HID + mt * 32 + rowmap(r, h)];
+        } else if (idx < FRAG_A4) {
+            const int st = (idx - FRAG_A3) >> 6, mt = st / 17, r = st - mt * 17;
+            v = r < 16 ? w2[(1 + rowmap(r, h)) * DEC_HID + mt * 32 + q] : (h == 0 ? w2[mt * 32 + q] : 0.f);
+        } else {
+            const int st = (idx - FRAG_A4) >> 6, mt = st >> 4, r = st & 15;
+            v = w1t[q * DEC_HID + mt * 32 + rowmap(r, h)];
+        }
+        frag[idx] = v;
+    }
+}
+
+// sum the per-wave scratch rows -> dw1 [64,32], db1 [64], dw2 [33,64], db2 [33]
+__global__ void decoder_partial_reduce_kernel(const float* __restrict__ part, int rows, float* __restrict__ dw1, float* __restrict__ db1,
+                                              float* __restrict__ dw2, float* __restrict__ db2) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= PART_DB2 + 33) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+        s0 += part[(int64_t)r * PART_ROW + e]; s1 += part[(int64_t)(r + 1) * PART_ROW + e];
+        s2 += part[(int64_t)(r + 2) * PART_ROW + e]; s3 += part[(int64_t)(r + 3) * PART_ROW + e];
+    }
+    for (; r < rows; ++r) s0 += part[(int64_t)r * PART_ROW + e];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (e < PART_DW2) dw1[e] = v;
+    else if (e < PART_DB1) dw2[e - PART_DW2] = v;
+    else if (e < PART_DB1 + 64) db1[e - PART_DB1] = v;
+    else if (e >= PART_DB2) db2[e - PART_DB2] = v;
+}
 
 struct TiledArgs {
     const float* planes; const float* ray_o; const float* ray_d; const float* depths; const int32_t* perm;
     int N; int M; int S; int H; int W; float scale;
     int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
-    int patches; int kchunks;
-    int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 2 = no LDS window, 4 = skip most of the MLP, 64 = skip the plane gather
+    int patches; int kchunks; int tiles;
+    int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 4 = skip the MLP, 8 = no flush, 32 = no LDS atomics, 64 = skip the plane gather
 };
 
-__global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
-                                                              const float* __restrict__ w2, const float* __restrict__ b2,
-                                                              const float* __restrict__ d_rgb, const float* __restrict__ d_sigma,
-                                                              float* __restrict__ d_planes, float* __restrict__ dump) {
-    __shared__ __attribute__((aligned(16))) float feat[DT * FS];
-    __shared__ __attribute__((aligned(16))) float gbuf[DT * FS];
+#define SPI_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+template <bool WGRAD>
+__global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ frag_g, const float* __restrict__ b1_g,
+                                                                 const float* __restrict__ b2_g, const float* __restrict__ d_rgb,
+                                                                 const float* __restrict__ d_sigma, float* __restrict__ d_planes,
+                                                                 float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float feat[DT * FS];   // rows [point][36]: features 0..31 | d_sigma at col 32; phase B overwrites 0..31 with d_feat
+    __shared__ __attribute__((aligned(16))) float gbuf[DT * FS];   // phase B: the weight fragments (8320 floats); phase C: the scatter window
     __shared__ float s_x[DT], s_y[DT], s_z[DT];
     __shared__ int s_row[DT];                 // row index into the [R*S] sample arrays (-1 = padding point)
+    static_assert(FRAG_TOTAL <= DT * FS, "fragments must fit the second row buffer");
     __shared__ int s_cxy[DT];                 // per plane: window-relative corner (x0 - wx0) | (y0 - wy0) << 16, biased by +0x4000
     __shared__ float s_wx[DT], s_wy[DT];      // per plane: bilinear fractions
     __shared__ int s_acc[8];
     const int t = threadIdx.x;
-    const int tile = blockIdx.x;
+    const int lane = t & 63, wave = t >> 6, q = lane & 31, hh = lane >> 5;
+    const int64_t plane_sz = (int64_t)a.H * a.W * DEC_IN;
+    // Weight-gradient accumulators: the four 32x32 tiles of a wave live in its scratch row in global memory (L2 / MALL) and
+    // are pulled into registers only around their own MFMAs (loaded as the accumulator's initial value, stored back right
+    // after).  Keeping 64 accumulator registers alive across the gather and scatter phases made the compiler spill inside
+    // the scatter loop.
+    float s_sig[2] = {0.f, 0.f}, s_b1[2] = {0.f, 0.f}, s_b2 = 0.f, s_d = 0.f;
+    float* const pr = part + ((int64_t)blockIdx.x * 4 + wave) * PART_ROW;     // this wave's scratch row
+    if (WGRAD)
+        for (int e = lane; e < PART_ROW; e += 64) pr[e] = 0.f;
+    for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
+    __syncthreads();                                           // LDS of the previous tile is no longer in use
     const int n = tile / (a.patches * a.kchunks);
     const int rem = tile - n * (a.patches * a.kchunks);
     const int patch = rem / a.kchunks, kc = rem - patch * a.kchunks;
@@ -387,18 +469,20 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
         x = (o[0] + dpt * d[0]) * a.scale; y = (o[1] + dpt * d[1]) * a.scale; z = (o[2] + dpt * d[2]) * a.scale;
     }
     s_x[t] = x; s_y[t] = y; s_z[t] = z; s_row[t] = row;
+    feat[t * FS + 32] = valid ? d_sigma[row] : 0.f;
+    if (!(a.dbg & 4))
+        for (int i = t; i < FRAG_TOTAL; i += DT) gbuf[i] = frag_g[i];      // weight fragments -> LDS (L2-resident source, same for every tile)
     __syncthreads();
-    // ---- phase A: gather features and stage d_rgb rows, 8 lanes per point
+    // ---- phase A: gather features, 8 lanes per point
+    {
     const int sub = t & 7, grp = t >> 3;
-    const int64_t plane_sz = (int64_t)a.H * a.W * DEC_IN;
 #pragma unroll 2
     for (int pass = 0; pass < DT / 32; ++pass) {
         const int s = pass * 32 + grp;
         const int64_t prow = s_row[s];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), g4 = acc;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (prow >= 0) {
             const float qx = s_x[s], qy = s_y[s], qz = s_z[s];
-            g4 = *reinterpret_cast<const float4*>(d_rgb + prow * DEC_IN + sub * 4);
 #pragma unroll
             for (int pl = 0; pl < ((a.dbg & 64) ? 0 : 3); ++pl) {
                 float gx, gy;
@@ -421,82 +505,187 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
             acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
         }
         *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
-        *reinterpret_cast<float4*>(gbuf + s * FS + sub * 4) = g4;
+    }
     }
     __syncthreads();
-    // ---- phase B: decoder forward + backward for this thread's point
-    const int64_t total = (int64_t)gridDim.x * DT;            // dump columns: tile-linear index
-    const int64_t dcol = (int64_t)tile * DT + t;
-    const bool dumping = (dump != nullptr);
-    float* frow = feat + t * FS;
-    float* grow = gbuf + t * FS;
-    float h[DEC_HID];
-    if (a.dbg & 4) {
+    // ---- phase B: decoder forward + backward on the matrix cores, 32 points (one MFMA N tile) at a time per wave.
+    //      Everything below touches only this wave's 64 rows of feat / gbuf.
+    if (!(a.dbg & 4)) {
+#pragma unroll 1
+    for (int nt = 0; nt < 2; ++nt) {
+        const int pbase = wave * 64 + nt * 32;
+        // The bias loads do not depend on the tile: without this opaque zero LICM hoists them out of the tile loop and keeps
+        // them in registers for the whole kernel.
+        int opq = 0;
+        asm volatile("" : "+s"(opq));
+        int q_ = q, hh_ = hh;                                   // opaque per iteration: keeps ~70 lane_-derived address terms from being
+        asm volatile("" : "+v"(q_), "+v"(hh_));                 // hoisted out of the tile loop and parked in (spilled) registers
+        const int lane_ = q_ + 32 * hh_;
+        const float* frag = gbuf;                              // LDS copy: one conflict-free 64-lane_ row per k-step
+        const float* b1 = b1_g + opq;
+        const float* b2 = b2_g + opq;
+        float* frow = feat + (pbase + q_) * FS;                 // the lane_'s own point (orientation 1: lane_ <-> point)
+        const float dsq = hh_ == 0 ? frow[32] : 0.f;            // d_sigma of the lane_'s point, counted once (half 0)
+        // d_rgb of the lane_'s point straight from HBM (its row is 128 contiguous bytes; each half takes 4 x 16 B), requested
+        // now and consumed after the two forward layers
+        const int myrow = s_row[pbase + q_];
+        float4 dr[4];
 #pragma unroll
-        for (int jj = 0; jj < DEC_HID; ++jj) h[jj] = frow[jj & 31];
-    } else
-    layer1_forward(w1t, b1, frow, h);
-    if (dumping) {
-        for (int i = 0; i < DEC_IN; ++i) dump[(int64_t)i * total + dcol] = valid ? frow[i] : 0.f;
+        for (int g = 0; g < 4; ++g)
+            dr[g] = myrow >= 0 ? *reinterpret_cast<const float4*>(d_rgb + (int64_t)myrow * DEC_IN + 8 * g + 4 * hh_) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // H1[j][p] = softplus(W1 F + b1)
+        f32x16_t H1[2];
 #pragma unroll
-        for (int j = 0; j < DEC_HID; ++j) dump[(int64_t)(32 + j) * total + dcol] = valid ? h[j] : 0.f;
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H1[mt][r] = b1[mt * 32 + rowmap(r, hh_)];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const float fb = frow[2 * s + hh_];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) H1[mt] = SPI_MFMA(frag[FRAG_A1 + (mt * 16 + s) * 64 + lane_], fb, H1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) H1[mt][r] = softplus_fast(H1[mt][r]);
+        // Y1[o][p] (orientation 1) and, for the weight gradients, Y2[p][o] (orientation 2) from the same fragments
+        f32x16_t Y1, Y2;
+        float dr2[16];                                         // orientation 2: d_rgb[point rowmap(r,h)][channel q_], coalesced over q_
+        if (WGRAD) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int prow2 = s_row[pbase + rowmap(r, hh_)];
+                dr2[r] = prow2 >= 0 ? d_rgb[(int64_t)prow2 * DEC_IN + q_] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Y1[r] = b2[1 + rowmap(r, hh_)]; Y2[r] = b2[1 + q_]; }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float wf = frag[FRAG_A2 + (mt * 16 + r) * 64 + lane_];
+                Y1 = SPI_MFMA(wf, H1[mt][r], Y1);
+                if (WGRAD) Y2 = SPI_MFMA(H1[mt][r], wf, Y2);
+            }
+        // dY = d_rgb * d(sigmoid * 1.002 - 0.001)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float sg = sigmoid_fast(Y1[r]);
+            const float4 d4 = dr[r >> 2];
+            const float dv1 = (r & 3) == 0 ? d4.x : ((r & 3) == 1 ? d4.y : ((r & 3) == 2 ? d4.z : d4.w));      // channel rowmap(r,hh_) = (r&3) + 8(r>>2) + 4hh
+            Y1[r] = dv1 * 1.002f * sg * (1.f - sg);
+            if (WGRAD) {
+                const float sg2 = sigmoid_fast(Y2[r]);
+                Y2[r] = dr2[r] * 1.002f * sg2 * (1.f - sg2);
+            }
+        }
+        // dH1[j][p] = W2^T dY1 (+ sigma row) -> dpre1 -> dF[i][p] = W1^T dpre1
+        f32x16_t dH1[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dH1[mt][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 17; ++r) {
+            const float bv = r < 16 ? Y1[r & 15] : dsq;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) dH1[mt] = SPI_MFMA(frag[FRAG_A3 + (mt * 17 + r) * 64 + lane_], bv, dH1[mt]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dH1[mt][r] *= (H1[mt][r] > 20.f) ? 1.f : (1.f - exp_fast(-H1[mt][r]));
+        f32x16_t dF;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dF[r] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dF = SPI_MFMA(frag[FRAG_A4 + (mt * 16 + r) * 64 + lane_], dH1[mt][r], dF);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (WGRAD) {
+            // per j-half i: dH2[p][j] = dY W2 (+ sigma row), H2[p][j] = softplus(F W1^T + b1), dpre2 = dH2 * softplus'
+            // then dW2[:, j-half] += dY2^T H2 and dW1[j-half, :] += dpre2^T F (contraction over the tile's 32 points)
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                f32x16_t dH2, H2, aW1, aW2;
+                float ls = 0.f, lb = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {             // running sums of this wave's dW tiles: arrive while dH2 / H2 are computed
+                    aW1[r] = pr[(i * 32 + rowmap(r, hh_)) * DEC_IN + q_];                            // dW1[j][c]: j = i*32 + row, c = q_
+                    aW2[r] = pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_];             // dW2[o][j]: o = 1 + row, j = i*32 + q_
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { dH2[r] = 0.f; H2[r] = b1[i * 32 + q_]; }
+#pragma unroll
+                for (int r = 0; r < 17; ++r) {
+                    const float av = r < 16 ? Y1[r & 15] : dsq;
+                    dH2 = SPI_MFMA(av, frag[FRAG_A3 + (i * 17 + r) * 64 + lane_], dH2);
+                    }
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    H2 = SPI_MFMA(frow[2 * s + hh_], frag[FRAG_A1 + (i * 16 + s) * 64 + lane_], H2);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float hv = softplus_fast(H2[r]);
+                    H2[r] = hv;
+                    dH2[r] *= (hv > 20.f) ? 1.f : (1.f - exp_fast(-hv));               // -> dpre2
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int prow = (pbase + rowmap(r, hh_)) * FS;
+                    aW2 = SPI_MFMA(Y2[r], H2[r], aW2);
+                    aW1 = SPI_MFMA(dH2[r], feat[prow + q_], aW1);
+                    ls = fmaf(feat[prow + 32], H2[r], ls);
+                    lb += dH2[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    pr[(i * 32 + rowmap(r, hh_)) * DEC_IN + q_] = aW1[r];
+                    pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_] = aW2[r];
+                }
+                s_sig[0] += i == 0 ? ls : 0.f; s_sig[1] += i == 0 ? 0.f : ls;
+                s_b1[0] += i == 0 ? lb : 0.f; s_b1[1] += i == 0 ? 0.f : lb;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s_b2 += Y2[r];
+            s_d += dsq;
+        }
+        // this tile's feature rows are dead now (both orientations are done with them): d_feat takes their place
+#pragma unroll
+        for (int r = 0; r < 16; ++r) frow[rowmap(r, hh_)] = dF[r] / 3.f;           // the plane mean contributes the 1/3
     }
-    float dp[DEC_HID];
-#pragma unroll
-    for (int j = 0; j < DEC_HID; ++j) dp[j] = 0.f;
-    const float dsig = valid ? d_sigma[row] : 0.f;
-#pragma unroll 2
-    for (int o = 0; o < ((a.dbg & 4) ? 1 : DEC_OUT); ++o) {
-        const float* wr = w2 + o * DEC_HID;
-        float acc = b2[o];
-#pragma unroll
-        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], h[j], acc);
-        float dyo;
-        if (o == 0) dyo = dsig;
-        else { const float sg = sigmoid_fast(acc); dyo = grow[o - 1] * 1.002f * sg * (1.f - sg); }
-        if (!valid) dyo = 0.f;
-        if (dumping) dump[(int64_t)(160 + o) * total + dcol] = dyo;
-#pragma unroll
-        for (int j = 0; j < DEC_HID; ++j) dp[j] = fmaf(wr[j], dyo, dp[j]);
     }
-#pragma unroll
-    for (int j = 0; j < DEC_HID; ++j) dp[j] *= (h[j] > 20.f) ? 1.f : (1.f - exp_fast(-h[j]));
-    if (dumping) {
-#pragma unroll
-        for (int j = 0; j < DEC_HID; ++j) dump[(int64_t)(96 + j) * total + dcol] = dp[j];
-    }
-#pragma unroll 2
-    for (int i = 0; i < ((a.dbg & 4) ? 1 : DEC_IN); ++i) {
-        const float* wr = w1t + i * DEC_HID;
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], dp[j], acc);
-        grow[i] = acc / 3.f;
-    }
-    // ---- phase C: per plane, accumulate in an LDS window (reusing `feat`), then flush it.
+    // ---- phase C: per plane, accumulate in an LDS window (reusing `gbuf`), then flush it.
     // LDS float atomics are ~30x slower than integer ones on gfx950 (ds_add_f32: ~190 cycles per
     // wave-instruction, ds_add_u64: ~10; tools/ubench/lds_atomic.hip), so the window holds 64-bit
     // fixed-point sums scaled by a per-tile power of two: every fp32 product is represented exactly
     // (down to 2^-40 of the tile's largest |gradient|), the sum is order-independent, and it is
     // converted back to fp32 once at the flush.
-    if (a.dbg & 1) return;
-    static_assert(WIN * WIN * DEC_IN * 8 <= DT * FS * 4, "window must fit the feature buffer");
-    long long* win = reinterpret_cast<long long*>(feat);
+    if (a.dbg & 1) continue;
+    static_assert(WIN * WIN * DEC_IN * 8 <= DT * FS * 4, "window must fit the fragment buffer");
+    long long* win = reinterpret_cast<long long*>(gbuf);
+    __syncthreads();                                       // phase B done in every wave: fragments dead, feat rows = d_feat
+    const float* growt = feat + t * FS;
     float amax = 0.f;
 #pragma unroll
-    for (int i = 0; i < DEC_IN; ++i) amax = fmaxf(amax, fabsf(grow[i]));
+    for (int i = 0; i < DEC_IN; ++i) amax = fmaxf(amax, fabsf(growt[i]));
     amax = wave_max(amax);
-    __syncthreads();                                       // feat free (phase B done); gbuf complete
     if (t < 8) s_acc[t] = 0;
     __syncthreads();
     if ((t & 63) == 0) atomicMax(&s_acc[4], __float_as_int(amax));        // amax >= 0: int order == float order
     __syncthreads();
     const float tile_max = __int_as_float(s_acc[4]);
-    if (!(tile_max > 0.f)) return;                          // all gradients zero (block-uniform)
+    if (!(tile_max > 0.f)) continue;                        // all gradients zero (block-uniform)
     const int e2 = ilogbf(tile_max);
     const float to_fix = ldexpf(1.f, 40 - e2);
     const double from_fix = ldexp(1.0, e2 - 40);
-    const int lane = t & 63, wave = t >> 6, half = lane >> 5, ch = lane & 31;
+    const int half = lane >> 5, ch = lane & 31;
     int* s_base = reinterpret_cast<int*>(s_x);                 // phase A is over: s_x is free (this thread's x,y,z live in registers)
     // float -> 64-bit fixed point in 3 instructions: adding 1.5*2^52 in fp64 leaves round(v) in the low mantissa bits
     // (two's complement for negative v), so bits(v + MAGIC) - bits(MAGIC) is the integer.  |v| < 2^41 here.
@@ -535,7 +724,7 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
             const int sp = wave * 64 + i + half;
             const int base = s_base[sp];
             if (base == -1) continue;
-            const float dv = gbuf[sp * FS + ch];
+            const float dv = feat[sp * FS + ch];
             const float fx1 = s_wx[sp], fy1 = s_wy[sp];
             const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
             if (base >= 0) {
@@ -551,15 +740,15 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
             const int pk = s_cxy[sp];
             const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cx = q & 1, cy = q >> 1;
+            for (int qq = 0; qq < 4; ++qq) {
+                const int cx = qq & 1, cy = qq >> 1;
                 const int xl = lx + cx, yl = ly + cy;
                 const int xx = xl + wx0, yy = yl + wy0;
                 if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
                 const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
-                if (!(a.dbg & 2) && xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
+                if (xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
                     if (!(a.dbg & 32)) add_fix(&win[(yl * WIN + xl) * DEC_IN + ch], (double)(dv * to_fix), wq);
-                } else if (!(a.dbg & 16)) {
+                } else {
                     atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dv * wq);                  // rare: straight to HBM
                 }
             }
@@ -570,12 +759,26 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
             const int tex = j * 8 + wave * 2 + half;
             const int xx = wx0 + (tex % WIN), yy = wy0 + (tex / WIN);
             if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-            const long long q = win[tex * DEC_IN + ch];
-            if (q != 0) {
-                const double qd = (double)(int)(q >> 32) * 4294967296.0 + (double)(unsigned)q;
+            const long long qv = win[tex * DEC_IN + ch];
+            if (qv != 0) {
+                const double qd = (double)(int)(qv >> 32) * 4294967296.0 + (double)(unsigned)qv;
                 atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, (float)(qd * from_fix));
             }
         }
+    }
+    }   // tile loop
+    if (WGRAD) {
+        // bias / sigma-row sums -> the wave's scratch row (the dW tiles are already there); decoder_partial_reduce_kernel sums the rows
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float sg = s_sig[i] + __shfl_xor(s_sig[i], 32, WAVE);
+            const float sb = s_b1[i] + __shfl_xor(s_b1[i], 32, WAVE);
+            if (hh == 0) { pr[PART_DW2 + i * 32 + q] = sg; pr[PART_DB1 + i * 32 + q] = sb; }     // sigma row of dW2, db1
+        }
+        const float sb2 = s_b2 + __shfl_xor(s_b2, 32, WAVE);
+        if (hh == 0) pr[PART_DB2 + 1 + q] = sb2;
+        const float sd = wave_sum(s_d);
+        if (lane == 0) pr[PART_DB2] = sd;
     }
 }
 
@@ -589,7 +792,6 @@ __global__ void __launch_bounds__(DT) decode_bwd_tiled_kernel(TiledArgs a, const
 //   sums ride along on the VALU while the tiles are staged.  Blocks own point chunks and add their
 //   partial results to the (pre-zeroed) outputs with global atomics.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
 constexpr int WG_BK = 16;                  // points per slab
 constexpr int WG_LD = 192 + 4;             // LDS row: [dpre 64 | dy_rgb 32 | f 32 | h 64] + pad
 
@@ -1118,10 +1320,13 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d, const float* depths_sorted,
                                    const int32_t* perm, const float* w1t, const float* b1, const float* w2, const float* b2,
                                    const float* d_rgb, const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
-                                   float box_warp, float* d_planes_nhwc, float* dump_act, int64_t* dump_cols, spi_stream_t stream) {
-    SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_rgb && d_sigma && d_planes_nhwc,
+                                   float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1, float* dw2,
+                                   float* db2, spi_stream_t stream) {
+    SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_rgb && d_sigma && d_planes_nhwc && workspace,
                 "spi_triplane_decode_bwd_sorted: null tensor");
     SPI_REQUIRE(N > 0 && M > 0 && S > 0 && H > 0 && W > 0 && box_warp > 0.f && ray_w > 0, "spi_triplane_decode_bwd_sorted: bad size");
+    const bool wgrad = dw1 != nullptr;
+    SPI_REQUIRE(!wgrad || (db1 && dw2 && db2), "spi_triplane_decode_bwd_sorted: the four decoder gradient outputs come together");
     TiledArgs a;
     a.planes = planes_nhwc; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths_sorted; a.perm = perm;
     a.N = N; a.M = M; a.S = S; a.H = H; a.W = W; a.scale = 2.f / box_warp; a.ray_w = ray_w;
@@ -1130,18 +1335,28 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     a.kchunks = (S + 3) / 4;
     a.dbg = g_spi_debug;
     const int64_t tiles = (int64_t)N * a.patches * a.kchunks;
-    if (dump_cols) *dump_cols = tiles * DT;
-    if (d_rgb == nullptr) return SPI_OK;
-    hipLaunchKernelGGL(decode_bwd_tiled_kernel, dim3((unsigned)tiles), dim3(DT), 0, as_stream(stream), a, w1t, b1, w2, b2, d_rgb, d_sigma,
-                       d_planes_nhwc, dump_act);
+    SPI_REQUIRE(tiles < (int64_t)1 << 31, "spi_triplane_decode_bwd_sorted: too many tiles");
+    a.tiles = (int)tiles;
+    const unsigned grid = (unsigned)std::min<int64_t>(tiles, BWD_MAX_GRID);
+    hipStream_t st = as_stream(stream);
+    float* frag = workspace;
+    float* part = workspace + FRAG_TOTAL;
+    hipLaunchKernelGGL(decoder_frag_kernel, dim3(9), dim3(1024), 0, st, w1t, w2, frag);
+    if (wgrad) {
+        hipLaunchKernelGGL(decode_bwd_tiled_kernel<true>, dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part);
+        hipLaunchKernelGGL(decoder_partial_reduce_kernel, dim3((PART_DB2 + 33 + 255) / 256), dim3(256), 0, st, part, (int)grid * 4, dw1, db1, dw2, db2);
+    } else {
+        hipLaunchKernelGGL(decode_bwd_tiled_kernel<false>, dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part);
+    }
     SPI_LAUNCH_CHECK("spi_triplane_decode_bwd_sorted");
     return SPI_OK;
 }
 
-int64_t spi_triplane_decode_bwd_sorted_cols(int N, int M, int S, int ray_w) {
+int64_t spi_triplane_decode_bwd_sorted_ws(int N, int M, int S, int ray_w) {
     const bool p2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
     const int64_t patches = p2d ? M / 64 : (M + 63) / 64;
-    return (int64_t)N * patches * ((S + 3) / 4) * DT;
+    const int64_t tiles = (int64_t)N * patches * ((S + 3) / 4);
+    return FRAG_TOTAL + std::min<int64_t>(tiles, BWD_MAX_GRID) * 4 * PART_ROW;
 }
 
 int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, float* dw2, float* db2, spi_stream_t stream) {

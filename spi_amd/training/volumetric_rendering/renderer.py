@@ -184,14 +184,13 @@ class _Render(torch.autograd.Function):
         _, _, hh, ww, _ = planes_nhwc.shape
         res = int(round(math.sqrt(m)))
         ray_w = res if res * res == m else m
-        dump = None
-        if want_w:
-            cols = hip.lib().spi_triplane_decode_bwd_sorted_cols(n, m, s, ray_w)
-            dump = torch.empty(DEC_DUMP_ROWS, cols, device=dev, dtype=torch.float32)
+        ws = torch.empty(hip.lib().spi_triplane_decode_bwd_sorted_ws(n, m, s, ray_w), device=dev, dtype=torch.float32)
+        gw = None
+        if want_w:                               # decoder weight gradients come out of the same kernel (no activation dump)
+            gw = (torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev))
         hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes_nhwc), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(d_all), hip.ptr(perm),
                  hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_col), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
-                 hip.ptr(d_planes), hip.ptr(dump), None, hip.stream())
-        gw = _decoder_wgrad(dump) if want_w else None
+                 hip.ptr(d_planes), hip.ptr(ws), *([hip.ptr(g) for g in gw] if want_w else [None] * 4), hip.stream())
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
         if want_w:
