@@ -775,7 +775,8 @@ int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, floa
     const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz)) % 16 == 0);
     const int64_t per_block = vec ? 1024 : 256;
     const unsigned gx = (unsigned)ceil_div64(HW, per_block);
-    int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, 1024 / gx));
+    // channel splits: enough blocks to spread the work, but every split adds one same-address atomic per pixel to d_pixsum
+    int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, (d_pixsum ? 128 : 1024) / gx));
     const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
     splits = (C + cchunk - 1) / cchunk;
     if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);

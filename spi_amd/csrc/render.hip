@@ -388,23 +388,25 @@ __global__ void decoder_frag_kernel(const float* __restrict__ w1t, const float* 
     }
 }
 
-// sum the per-wave scratch rows -> dw1 [64,32], db1 [64], dw2 [33,64], db2 [33]
+// sum the per-wave scratch rows -> dw1 [64,32], db1 [64], dw2 [33,64], db2 [33] (pre-zeroed): blockIdx.y owns a slice of rows
 __global__ void decoder_partial_reduce_kernel(const float* __restrict__ part, int rows, float* __restrict__ dw1, float* __restrict__ db1,
                                               float* __restrict__ dw2, float* __restrict__ db2) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= PART_DB2 + 33) return;
+    const int per = (rows + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(r0 + per, rows);
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
+    int r = r0;
+    for (; r + 3 < r1; r += 4) {
         s0 += part[(int64_t)r * PART_ROW + e]; s1 += part[(int64_t)(r + 1) * PART_ROW + e];
         s2 += part[(int64_t)(r + 2) * PART_ROW + e]; s3 += part[(int64_t)(r + 3) * PART_ROW + e];
     }
-    for (; r < rows; ++r) s0 += part[(int64_t)r * PART_ROW + e];
+    for (; r < r1; ++r) s0 += part[(int64_t)r * PART_ROW + e];
     const float v = (s0 + s1) + (s2 + s3);
-    if (e < PART_DW2) dw1[e] = v;
-    else if (e < PART_DB1) dw2[e - PART_DW2] = v;
-    else if (e < PART_DB1 + 64) db1[e - PART_DB1] = v;
-    else if (e >= PART_DB2) db2[e - PART_DB2] = v;
+    if (e < PART_DW2) atomicAdd(dw1 + e, v);
+    else if (e < PART_DB1) atomicAdd(dw2 + e - PART_DW2, v);
+    else if (e < PART_DB1 + 64) atomicAdd(db1 + e - PART_DB1, v);
+    else if (e >= PART_DB2) atomicAdd(db2 + e - PART_DB2, v);
 }
 
 struct TiledArgs {
@@ -1344,7 +1346,9 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     hipLaunchKernelGGL(decoder_frag_kernel, dim3(9), dim3(1024), 0, st, w1t, w2, frag);
     if (wgrad) {
         hipLaunchKernelGGL(decode_bwd_tiled_kernel<true>, dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part);
-        hipLaunchKernelGGL(decoder_partial_reduce_kernel, dim3((PART_DB2 + 33 + 255) / 256), dim3(256), 0, st, part, (int)grid * 4, dw1, db1, dw2, db2);
+        hipMemsetAsync(dw1, 0, 64 * 32 * sizeof(float), st); hipMemsetAsync(db1, 0, 64 * sizeof(float), st);
+        hipMemsetAsync(dw2, 0, 33 * 64 * sizeof(float), st); hipMemsetAsync(db2, 0, 33 * sizeof(float), st);
+        hipLaunchKernelGGL(decoder_partial_reduce_kernel, dim3((PART_DB2 + 33 + 255) / 256, 32), dim3(256), 0, st, part, (int)grid * 4, dw1, db1, dw2, db2);
     } else {
         hipLaunchKernelGGL(decode_bwd_tiled_kernel<false>, dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part);
     }
