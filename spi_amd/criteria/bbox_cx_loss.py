@@ -29,39 +29,65 @@ def get_landmark_bbox(lm, scale=1):
     return boxes
 
 
-def roi_align(x, boxes, output_size=80):
-    """x [N,C,H,W]; boxes [N,4] float (x1,y1,x2,y2), box i applies to image i.  Differentiable wrt x."""
-    n, c, h, w = x.shape
+def _axis(t, size):
+    valid = ((t >= -1.0) & (t <= size)).float()
+    t = t.clamp(min=0)
+    lo = t.floor().long()
+    edge = lo >= size - 1
+    lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
+    hi = torch.where(edge, lo, lo + 1)
+    t = torch.where(edge, lo.float(), t)
+    return lo, hi, t - lo.float(), valid
+
+
+def roi_plan(boxes, h, w, device, output_size=80):
+    """Sampling geometry of ``roi_align`` for boxes [N,4] (x1,y1,x2,y2), one box per image: a list of per-image index / weight
+    tensors on ``device``.  This is the only host-side part (the sampling grid size depends on the box size); for SPI the
+    landmarks are fixed per image, so the coach builds the plan once per image and the loss itself never synchronises."""
     out = output_size
-    bx = boxes.detach().float().cpu()            # box geometry is host data (landmarks), like the reference's .long() math
-    res = []
-    for i in range(n):
+    bx = boxes.detach().float().cpu()
+    plans = []
+    for i in range(bx.shape[0]):
         x1, y1, x2, y2 = [float(v) for v in bx[i]]
         rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
         gw, gh = int(math.ceil(rw / out)), int(math.ceil(rh / out))
         bw, bh = rw / out, rh / out
         ar = torch.arange(out, dtype=torch.float32).view(-1, 1)
-        xs = (ar * bw + (torch.arange(gw, dtype=torch.float32).view(1, -1) + 0.5) * bw / gw + x1).reshape(-1).to(x.device)
-        ys = (ar * bh + (torch.arange(gh, dtype=torch.float32).view(1, -1) + 0.5) * bh / gh + y1).reshape(-1).to(x.device)
+        xs = (ar * bw + (torch.arange(gw, dtype=torch.float32).view(1, -1) + 0.5) * bw / gw + x1).reshape(-1)
+        ys = (ar * bh + (torch.arange(gh, dtype=torch.float32).view(1, -1) + 0.5) * bh / gh + y1).reshape(-1)
+        key = (x1, y1, x2, y2)
+        if plans and plans[-1]['key'] == key:            # SPI repeats one landmark set over the batch: share the tensors
+            plans.append(plans[-1])
+            continue
+        xl, xh, xf, xv = _axis(xs, w)
+        yl, yh, yf, yv = _axis(ys, h)
+        plans.append(dict(key=key, gw=gw, gh=gh, xl=xl.to(device), xh=xh.to(device), xf=xf.to(device), xv=xv.to(device),
+                          yl=yl.to(device), yh=yh.to(device), yf=yf.to(device), yv=yv.to(device)))
+    return plans
 
-        def axis(t, size):
-            valid = ((t >= -1.0) & (t <= size)).float()
-            t = t.clamp(min=0)
-            lo = t.floor().long()
-            edge = lo >= size - 1
-            lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
-            hi = torch.where(edge, lo, lo + 1)
-            t = torch.where(edge, lo.float(), t)
-            return lo, hi, t - lo.float(), valid
-        xl, xh, xf, xv = axis(xs, w)
-        yl, yh, yf, yv = axis(ys, h)
-        img = x[i]
-        top, bot = img[:, yl, :], img[:, yh, :]
-        val = ((top[:, :, xl] * (1 - xf) + top[:, :, xh] * xf) * (1 - yf).view(1, -1, 1)
-               + (bot[:, :, xl] * (1 - xf) + bot[:, :, xh] * xf) * yf.view(1, -1, 1))
-        val = val * yv.view(1, -1, 1) * xv.view(1, 1, -1)
-        res.append(val.reshape(c, out, gh, out, gw).mean(dim=(2, 4)))
-    return torch.stack(res)
+
+def roi_align(x, boxes, output_size=80, plan=None):
+    """x [N,C,H,W]; boxes [N,4] float (x1,y1,x2,y2), box i applies to image i.  Differentiable wrt x.
+    ``plan`` (from ``roi_plan``) skips the host-side geometry; images that share a plan entry are gathered together."""
+    n, c, h, w = x.shape
+    out = output_size
+    if plan is None:
+        plan = roi_plan(boxes, h, w, x.device, output_size)
+    res, i = [], 0
+    while i < n:
+        pl = plan[i]
+        j = i
+        while j + 1 < n and plan[j + 1] is pl:
+            j += 1
+        img = x[i:j + 1]
+        xf, yf = pl['xf'], pl['yf']
+        top, bot = img[:, :, pl['yl'], :], img[:, :, pl['yh'], :]
+        val = ((top[..., pl['xl']] * (1 - xf) + top[..., pl['xh']] * xf) * (1 - yf).view(1, 1, -1, 1)
+               + (bot[..., pl['xl']] * (1 - xf) + bot[..., pl['xh']] * xf) * yf.view(1, 1, -1, 1))
+        val = val * pl['yv'].view(1, 1, -1, 1) * pl['xv'].view(1, 1, 1, -1)
+        res.append(val.reshape(j + 1 - i, c, out, pl['gh'], out, pl['gw']).mean(dim=(3, 5)))
+        i = j + 1
+    return torch.cat(res)
 
 
 def compute_cosine_distance(x, y):
@@ -89,7 +115,11 @@ class BoxCXLoss(torch.nn.Module):
         self.register_buffer('vgg_mean', torch.tensor([[[0.485]], [[0.456]], [[0.406]]]))
         self.register_buffer('vgg_std', torch.tensor([[[0.229]], [[0.224]], [[0.225]]]))
 
-    def forward(self, x, y, lm):
+    def plan(self, lm, device):
+        """Host-side box geometry for ``forward(..., plan=)``: build once per image (the landmarks do not change)."""
+        return [roi_plan(box.float(), 256, 256, device) for box in get_landmark_bbox(lm)[:3]]
+
+    def forward(self, x, y, lm, plan=None):
         if x.shape[-1] > 256:
             x = F.interpolate(x, (256, 256), mode='bilinear', align_corners=False)
         if y.shape[-1] > 256:
@@ -97,9 +127,13 @@ class BoxCXLoss(torch.nn.Module):
         x = (x - self.vgg_mean) / self.vgg_std
         y = (y - self.vgg_mean) / self.vgg_std
         loss = 0
-        for box in get_landmark_bbox(lm)[:3]:
-            fx = self.vgg_model(roi_align(x, box.float()))
-            fy = self.vgg_model(roi_align(y, box.float()))
+        if plan is not None and tuple(x.shape[-2:]) != (256, 256):
+            plan = None                                      # the plan is built for the 256^2 working resolution
+        boxes = get_landmark_bbox(lm)[:3] if plan is None else [None] * 3
+        for bi, box in enumerate(boxes):
+            pl = plan[bi] if plan is not None else roi_plan(box.float(), x.shape[-2], x.shape[-1], x.device)
+            fx = self.vgg_model(roi_align(x, box, plan=pl))
+            fy = self.vgg_model(roi_align(y, box, plan=pl))
             cx = compute_cx(compute_relative_distance(compute_cosine_distance(fx, fy)), self.band_width)
             cx = torch.mean(torch.max(cx, dim=1)[0], dim=1)
             loss = loss + torch.mean(-torch.log(cx + 1e-5))

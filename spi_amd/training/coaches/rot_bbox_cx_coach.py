@@ -46,6 +46,7 @@ class RotBboxCoach(BaseCoach):
         ctx['weight_m'] = float(cal_camera_weight(camera)[0])
         ctx['yaw_range'] = float(cal_camera_gauss_weight(camera)[0]) if hyperparameters.use_adapt_yaw_range else 0.2
         ctx['target_feats'] = self.lpips_loss.features(image)
+        ctx['box_plan'] = self.box_cx_loss.plan(ctx['lm'].repeat(self.rot_bs, 1, 1), dev)      # host-side RoI geometry, once per image
         self.original_G._last_planes = None                      # per-image backbone cache of the frozen generator (depth branch)
         return ctx
 
@@ -93,7 +94,7 @@ class RotBboxCoach(BaseCoach):
                                         src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
                 flip_warp, flip_mask = torch.flip(warp_m, dims=[3]), torch.flip(mask_m, dims=[3])
                 losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
-                                                        ctx['lm'].repeat(rot_bs, 1, 1)) * hp.pt_mirror_rot_lambda * rot_bs
+                                                        ctx['lm'].repeat(rot_bs, 1, 1), plan=ctx.get('box_plan')) * hp.pt_mirror_rot_lambda * rot_bs
                 losses['mirror_rot'].backward()
             if hp.pt_depth_lambda > 0:
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
