@@ -84,7 +84,8 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
  * depths_sorted[r, k] and colour/density/gradient row r*S + perm[r, k] (perm may be NULL = identity).
  * The decoder runs on the fp32 matrix cores and its weight gradients are fused in: with dw1 != NULL the call
  * OVERWRITES dw1 [64,32], db1 [64], dw2 [33,64], db2 [33] (gradients wrt the gained weights w1t^T, b1, w2, b2);
- * dw1 == NULL (all four) = decoder frozen.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
+ * dw1 == NULL (all four) = decoder frozen.  d_rgb == NULL = the colour gradient is zero (depth-only loss): the colour
+ * layer is skipped.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
  * (weight fragments + per-wave partial sums; contents undefined afterwards).  d_planes_nhwc is accumulated into. */
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d,
                                    const float* depths_sorted, const int32_t* perm, const float* w1t,
@@ -114,7 +115,8 @@ int spi_raymarch_fwd(const float* colors, const float* densities, const float* d
                      int white_back, float* rgb, float* depth, float* weights, float* wsum,
                      spi_stream_t stream);
 
-/* Backward: d_rgb [R,C], d_depth [R] (NULL = 0), d_weights [R,S-1] (NULL = 0) ->
+/* Backward: d_rgb [R,C] (NULL = 0: only the depth map is differentiated -- colors / d_colors are then not touched
+ * and may be NULL), d_depth [R] (NULL = 0), d_weights [R,S-1] (NULL = 0) ->
  * d_colors [R,S,C], d_densities [R,S] written through perm like the forward reads. */
 int spi_raymarch_bwd(const float* colors, const float* densities, const float* depths,
                      const int32_t* perm, const float* clamp2, const float* d_rgb, const float* d_depth,

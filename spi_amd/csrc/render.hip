@@ -419,7 +419,7 @@ struct TiledArgs {
 
 #define SPI_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
-template <bool WGRAD>
+template <bool WGRAD, bool RGB>
 __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ frag_g, const float* __restrict__ b1_g,
                                                                  const float* __restrict__ b2_g, const float* __restrict__ d_rgb,
                                                                  const float* __restrict__ d_sigma, float* __restrict__ d_planes,
@@ -532,9 +532,11 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         // now and consumed after the two forward layers
         const int myrow = s_row[pbase + q_];
         float4 dr[4];
+        if (RGB) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            dr[g] = myrow >= 0 ? *reinterpret_cast<const float4*>(d_rgb + (int64_t)myrow * DEC_IN + 8 * g + 4 * hh_) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < 4; ++g)
+                dr[g] = myrow >= 0 ? *reinterpret_cast<const float4*>(d_rgb + (int64_t)myrow * DEC_IN + 8 * g + 4 * hh_) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         // H1[j][p] = softplus(W1 F + b1)
         f32x16_t H1[2];
 #pragma unroll
@@ -554,13 +556,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         // Y1[o][p] (orientation 1) and, for the weight gradients, Y2[p][o] (orientation 2) from the same fragments
         f32x16_t Y1, Y2;
         float dr2[16];                                         // orientation 2: d_rgb[point rowmap(r,h)][channel q_], coalesced over q_
-        if (WGRAD) {
+        // RGB == false: only the density gradient is non-zero (SPI's depth branch) -> the whole colour layer drops out
+        if (WGRAD && RGB) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int prow2 = s_row[pbase + rowmap(r, hh_)];
                 dr2[r] = prow2 >= 0 ? d_rgb[(int64_t)prow2 * DEC_IN + q_] : 0.f;
             }
         }
+        if (RGB) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Y1[r] = b2[1 + rowmap(r, hh_)]; Y2[r] = b2[1 + q_]; }
 #pragma unroll
@@ -571,9 +575,10 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 Y1 = SPI_MFMA(wf, H1[mt][r], Y1);
                 if (WGRAD) Y2 = SPI_MFMA(H1[mt][r], wf, Y2);
             }
+        }
         // dY = d_rgb * d(sigmoid * 1.002 - 0.001)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int r = 0; RGB && r < 16; ++r) {
             const float sg = sigmoid_fast(Y1[r]);
             const float4 d4 = dr[r >> 2];
             const float dv1 = (r & 3) == 0 ? d4.x : ((r & 3) == 1 ? d4.y : ((r & 3) == 2 ? d4.z : d4.w));      // channel rowmap(r,hh_) = (r&3) + 8(r>>2) + 4hh
@@ -590,7 +595,7 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) dH1[mt][r] = 0.f;
 #pragma unroll
-        for (int r = 0; r < 17; ++r) {
+        for (int r = RGB ? 0 : 16; r < 17; ++r) {
             const float bv = r < 16 ? Y1[r & 15] : dsq;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) dH1[mt] = SPI_MFMA(frag[FRAG_A3 + (mt * 17 + r) * 64 + lane_], bv, dH1[mt]);
@@ -619,15 +624,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {             // running sums of this wave's dW tiles: arrive while dH2 / H2 are computed
                     aW1[r] = pr[(i * 32 + rowmap(r, hh_)) * DEC_IN + q_];                            // dW1[j][c]: j = i*32 + row, c = q_
-                    aW2[r] = pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_];             // dW2[o][j]: o = 1 + row, j = i*32 + q_
+                    if (RGB) aW2[r] = pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_];    // dW2[o][j]: o = 1 + row, j = i*32 + q_
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { dH2[r] = 0.f; H2[r] = b1[i * 32 + q_]; }
 #pragma unroll
-                for (int r = 0; r < 17; ++r) {
+                for (int r = RGB ? 0 : 16; r < 17; ++r) {
                     const float av = r < 16 ? Y1[r & 15] : dsq;
                     dH2 = SPI_MFMA(av, frag[FRAG_A3 + (i * 17 + r) * 64 + lane_], dH2);
-                    }
+                }
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     H2 = SPI_MFMA(frow[2 * s + hh_], frag[FRAG_A1 + (i * 16 + s) * 64 + lane_], H2);
@@ -641,7 +646,7 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int prow = (pbase + rowmap(r, hh_)) * FS;
-                    aW2 = SPI_MFMA(Y2[r], H2[r], aW2);
+                    if (RGB) aW2 = SPI_MFMA(Y2[r], H2[r], aW2);
                     aW1 = SPI_MFMA(dH2[r], feat[prow + q_], aW1);
                     ls = fmaf(feat[prow + 32], H2[r], ls);
                     lb += dH2[r];
@@ -649,13 +654,13 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     pr[(i * 32 + rowmap(r, hh_)) * DEC_IN + q_] = aW1[r];
-                    pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_] = aW2[r];
+                    if (RGB) pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_] = aW2[r];
                 }
                 s_sig[0] += i == 0 ? ls : 0.f; s_sig[1] += i == 0 ? 0.f : ls;
                 s_b1[0] += i == 0 ? lb : 0.f; s_b1[1] += i == 0 ? 0.f : lb;
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s_b2 += Y2[r];
+            for (int r = 0; RGB && r < 16; ++r) s_b2 += Y2[r];
             s_d += dsq;
         }
         // this tile's feature rows are dead now (both orientations are done with them): d_feat takes their place
@@ -1069,7 +1074,11 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
     __builtin_amdgcn_wave_barrier();
     // pass 1 over the colour rows: q_k = <d_rgb, c_k>; write d_colors rows = d_rgb * (w_{k-1} + w_k)
     const int sub = lane & 7, rg = lane >> 3;
-    const float4 g4 = *reinterpret_cast<const float4*>(d_rgb + r * 32 + sub * 4);
+    const float4 g4 = d_rgb ? *reinterpret_cast<const float4*>(d_rgb + r * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!d_rgb) {                     // only the depth map is differentiated (SPI's depth branch): no colour traffic at all
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) if (c * 64 + lane < S) L.q[c * 64 + lane] = 0.f;
+    } else
 #pragma unroll 4
     for (int k0 = 0; k0 < S; k0 += 8) {
         const int k = k0 + rg;
@@ -1324,7 +1333,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
                                    const float* d_rgb, const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
                                    float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1, float* dw2,
                                    float* db2, spi_stream_t stream) {
-    SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_rgb && d_sigma && d_planes_nhwc && workspace,
+    SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_sigma && d_planes_nhwc && workspace,
                 "spi_triplane_decode_bwd_sorted: null tensor");
     SPI_REQUIRE(N > 0 && M > 0 && S > 0 && H > 0 && W > 0 && box_warp > 0.f && ray_w > 0, "spi_triplane_decode_bwd_sorted: bad size");
     const bool wgrad = dw1 != nullptr;
@@ -1344,14 +1353,16 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     float* frag = workspace;
     float* part = workspace + FRAG_TOTAL;
     hipLaunchKernelGGL(decoder_frag_kernel, dim3(9), dim3(1024), 0, st, w1t, w2, frag);
+#define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part)
     if (wgrad) {
-        hipLaunchKernelGGL(decode_bwd_tiled_kernel<true>, dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part);
+        if (d_rgb) SPI_BWD_LAUNCH(true, true); else SPI_BWD_LAUNCH(true, false);
         hipMemsetAsync(dw1, 0, 64 * 32 * sizeof(float), st); hipMemsetAsync(db1, 0, 64 * sizeof(float), st);
         hipMemsetAsync(dw2, 0, 33 * 64 * sizeof(float), st); hipMemsetAsync(db2, 0, 33 * sizeof(float), st);
         hipLaunchKernelGGL(decoder_partial_reduce_kernel, dim3((PART_DB2 + 33 + 255) / 256, 32), dim3(256), 0, st, part, (int)grid * 4, dw1, db1, dw2, db2);
     } else {
-        hipLaunchKernelGGL(decode_bwd_tiled_kernel<false>, dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part);
+        if (d_rgb) SPI_BWD_LAUNCH(false, true); else SPI_BWD_LAUNCH(false, false);
     }
+#undef SPI_BWD_LAUNCH
     SPI_LAUNCH_CHECK("spi_triplane_decode_bwd_sorted");
     return SPI_OK;
 }
@@ -1409,10 +1420,11 @@ int spi_raymarch_bwd(const float* colors, const float* densities, const float* d
                      const float* clamp2, const float* d_rgb, const float* d_depth, const float* d_weights, int64_t R,
                      int S, int S_store, int C, int white_back, float* d_colors, float* d_densities, spi_stream_t stream) {
     SPI_REQUIRE(S_store >= S, "spi_raymarch_bwd: S_store must be >= S");
-    SPI_REQUIRE(colors && densities && depths && d_rgb && d_colors && d_densities && R > 0, "spi_raymarch_bwd: null tensor");
+    SPI_REQUIRE(densities && depths && d_densities && R > 0 && (d_rgb == nullptr || colors != nullptr), "spi_raymarch_bwd: null tensor");
     SPI_REQUIRE(S >= 2 && S <= MAXS, "spi_raymarch_bwd: need 2 <= S <= %d, got %d", MAXS, S);
     SPI_REQUIRE(C == 32, "spi_raymarch_bwd: only C = 32 feature channels are supported, got %d", C);
     SPI_REQUIRE(d_depth == nullptr || clamp2 != nullptr, "spi_raymarch_bwd: d_depth given without clamp range");
+    SPI_REQUIRE(d_rgb == nullptr || d_colors != nullptr, "spi_raymarch_bwd: d_rgb given without a d_colors output");
     dim3 grid((unsigned)ceil_div64(R, RM_WAVES)), block(64 * RM_WAVES);
     const int nch = (S + 63) / 64;
 #define LAUNCH_BWD(NCH) hipLaunchKernelGGL(raymarch_bwd_kernel<NCH>, grid, block, 0, as_stream(stream), colors, densities, \

@@ -161,6 +161,7 @@ class _Render(torch.autograd.Function):
         ctx.meta = (n, m, sc, sf, box_warp, white_back, gains)
         ctx.aux = dict(depths_coarse=d_c, depths_fine=d_f, depths_sorted=d_all, perm=perm)
         ctx.mark_non_differentiable(wsum)
+        ctx.set_materialize_grads(False)          # an unused output arrives as None in backward (depth-only / image-only losses)
         return rgb, depth, wsum
 
     @staticmethod
@@ -172,9 +173,12 @@ class _Render(torch.autograd.Function):
         s = sc + sf
         r = n * m
         dev = planes_nhwc.device
-        d_rgb = d_rgb.contiguous().float() if d_rgb is not None else torch.zeros(n, m, 32, device=dev)
+        if d_rgb is None and d_depth is None:
+            return (None,) * 11
+        # d_rgb None: only the depth map feeds the loss (SPI's depth branch) -> no colour gradient buffers or traffic at all
+        d_rgb = d_rgb.contiguous().float() if d_rgb is not None else None
         dd = d_depth.contiguous().float() if d_depth is not None else None
-        d_col = torch.empty_like(rgb_all)
+        d_col = torch.empty_like(rgb_all) if d_rgb is not None else None
         d_sig = torch.empty_like(sig_all)
         hip.call('spi_raymarch_bwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), hip.ptr(d_rgb),
                  hip.ptr(dd), None, r, s, s, 32, white_back, hip.ptr(d_col), hip.ptr(d_sig), hip.stream())

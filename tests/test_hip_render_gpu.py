@@ -163,3 +163,30 @@ def test_full_render_config_size_vs_oracle():
     # north_star tolerance: 1e-3 relative on rendered RGB / depth
     assert_close(x, a, 1e-3, 'rgb'); assert_close(y, b, 1e-3, 'depth'); assert_close(z, cc, 1e-3, 'weight sum')
     assert rel_err(x, a) < 2e-4 and rel_err(y, b) < 2e-5      # what the kernels actually achieve
+
+
+@pytest.mark.parametrize('frozen', [False, True])
+def test_depth_only_and_rgb_only_backward(golden, frozen):
+    """A loss that uses only one renderer output takes the short paths (no colour gradient buffers for a depth-only loss,
+    `d_rgb = NULL` kernels): same gradients as the full path fed with an explicit zero gradient for the unused output."""
+    from spi_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    g = golden('renderer')
+    dec = _decoder(_P(g))
+    for p in dec.parameters():
+        p.requires_grad_(not frozen)
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12)
+    c = g['cam']
+    ro, rd = orr.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 8)
+    planes = g['planes'].to(DEV).requires_grad_(True)
+    wrt = [planes] + ([] if frozen else list(dec.parameters()))
+    rgb, depth, _ = ImportanceRenderer()(planes, dec, ro.to(DEV), rd.to(DEV), opts, noise=(g['fr_xi'], g['fr_u']))
+    drgb, ddep = g['fr_drgb'].to(DEV), g['fr_ddepth'].to(DEV)
+    full_d = torch.autograd.grad([rgb, depth], wrt, [torch.zeros_like(drgb), ddep], retain_graph=True)
+    only_d = torch.autograd.grad([depth], wrt, [ddep], retain_graph=True, allow_unused=True)
+    full_c = torch.autograd.grad([rgb, depth], wrt, [drgb, torch.zeros_like(ddep)], retain_graph=True)
+    only_c = torch.autograd.grad([rgb], wrt, [drgb], retain_graph=True)
+    names = ['planes'] + ([] if frozen else [k for k, _ in dec.named_parameters()])
+    for a, b, nm in zip(only_d, full_d, names):
+        assert_close(a if a is not None else torch.zeros_like(b), b, 2e-5, 'depth-only grad ' + nm)
+    for a, b, nm in zip(only_c, full_c, names):
+        assert_close(a, b, 2e-5, 'rgb-only grad ' + nm)
