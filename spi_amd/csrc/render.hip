@@ -621,10 +621,16 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
             for (int i = 0; i < 2; ++i) {
                 f32x16_t dH2, H2, aW1, aW2;
                 float ls = 0.f, lb = 0.f;
+                // running sums of this wave's dW tiles: arrive while dH2 / H2 are computed.  One base pointer per tile + compile-time
+                // offsets (global_load ... offset:imm): with per-element 64-bit addresses the 32 address pairs stay live from the
+                // loads to the stores and cost 64 VGPRs.
+                float* const pw1 = pr + (i * 32 + 4 * hh_) * DEC_IN + q_;                             // dW1[j][c]: j = i*32 + rowmap(r,h), c = q_
+                float* const pw2 = pr + PART_DW2 + (1 + 4 * hh_) * DEC_HID + i * 32 + q_;              // dW2[o][j]: o = 1 + rowmap(r,h), j = i*32 + q_
+                float* const pw2b = pw2 + 16 * DEC_HID;                                               // rows 16.. (keeps every offset < 4 KB)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {             // running sums of this wave's dW tiles: arrive while dH2 / H2 are computed
-                    aW1[r] = pr[(i * 32 + rowmap(r, hh_)) * DEC_IN + q_];                            // dW1[j][c]: j = i*32 + row, c = q_
-                    if (RGB) aW2[r] = pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_];    // dW2[o][j]: o = 1 + row, j = i*32 + q_
+                for (int r = 0; r < 16; ++r) {
+                    aW1[r] = pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN];
+                    if (RGB) aW2[r] = r < 8 ? pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] : pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID];
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { dH2[r] = 0.f; H2[r] = b1[i * 32 + q_]; }
@@ -653,8 +659,8 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    pr[(i * 32 + rowmap(r, hh_)) * DEC_IN + q_] = aW1[r];
-                    if (RGB) pr[PART_DW2 + (1 + rowmap(r, hh_)) * DEC_HID + i * 32 + q_] = aW2[r];
+                    pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN] = aW1[r];
+                    if (RGB) { if (r < 8) pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] = aW2[r]; else pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID] = aW2[r]; }
                 }
                 s_sig[0] += i == 0 ? ls : 0.f; s_sig[1] += i == 0 ? 0.f : ls;
                 s_b1[0] += i == 0 ? lb : 0.f; s_b1[1] += i == 0 ? 0.f : lb;
