@@ -577,12 +577,13 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxT = std::max(maxT, P.cls[c].taps.T); }
     auto blocks = [&](int bm, int bn) { return (int64_t)((maxpix + bn - 1) / bn) * ((P.Mo + bm - 1) / bm) * P.N * P.ncls; };
     const int nslab = maxT * ((P.Ci + BK - 1) / BK);
-    int cfg;                    // 0: 32x128, 1: 128x128, 2: 64x64, 3: 32x32
+    int cfg;                    // 0: 32x128, 1: 128x128, 2: 64x64, 3: 32x32, 4: 64x256 (64 output channels: same 64x64 wave tile as cfg 1)
     if (P.Mo <= 32) cfg = 0;
+    else if (P.Mo <= 64 && blocks(64, 256) >= 384) cfg = 4;
     else if (blocks(128, 128) >= 384) cfg = 1;
     else if (P.Mo >= 64 && maxpix >= 64) cfg = 2;
     else cfg = 3;
-    static const int bm_of[4] = {32, 128, 64, 32}, bn_of[4] = {128, 128, 64, 32};
+    static const int bm_of[5] = {32, 128, 64, 32, 64}, bn_of[5] = {128, 128, 64, 32, 256};
     const int64_t nb = blocks(bm_of[cfg], bn_of[cfg]);
     int nsplit = 1;
     if (nb < 512 && nslab >= 8) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);
@@ -594,6 +595,7 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     case 0: launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, nsplit, st); break;
     case 1: launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, nsplit, st); break;
     case 2: launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, nsplit, st); break;
+    case 4: launch_igemm<1, 4, 2, 2>(P, in, w, out, ep, nsplit, st); break;
     default: launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, nsplit, st); break;
     }
     if (nsplit > 1 && (ep.bias || ep.noise || ep.act)) {
