@@ -142,8 +142,10 @@ def test_full_render_golden_fwd_bwd(golden):
         assert_close(gv, g['fr_g_' + k], 5e-5, 'render grad ' + k)
 
 
-def test_full_render_config_size_vs_oracle():
-    """BASELINE config 2 sizes on a ray subset: 256^2 planes, 96+96 samples (oracle finishes in seconds on 1024 rays)."""
+@pytest.mark.parametrize('depth', [96, 128])
+def test_full_render_config_size_vs_oracle(depth):
+    """BASELINE config 2 (96+96) and config 5 (128+128 = the kernels' 256-sample limit) on a ray subset: 256^2 planes,
+    forward and gradients wrt planes and decoder (oracle finishes in seconds on 1024 rays)."""
     from spi_amd.training.volumetric_rendering.renderer import ImportanceRenderer
     from spi_amd.utils import camera_utils as cu
     from synth_weights import synth_tensor
@@ -156,13 +158,22 @@ def test_full_render_config_size_vs_oracle():
     ro, rd = orr.ray_sampler(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 128)
     sel = torch.randperm(128 * 128, generator=gen)[:1024]
     ro, rd = ro[:, sel].contiguous(), rd[:, sel].contiguous()
-    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=96, depth_resolution_importance=96)
-    xi, u = torch.rand(1, 1024, 96, 1, generator=gen), torch.rand(1024, 96, generator=gen)
-    a, b, cc = orr.render(P, planes, ro, rd, opts, xi=xi, u=u)
-    x, y, z = ImportanceRenderer()(planes.to(DEV), dec, ro.to(DEV), rd.to(DEV), opts, noise=(xi, u))
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=depth, depth_resolution_importance=depth)
+    xi, u = torch.rand(1, 1024, depth, 1, generator=gen), torch.rand(1024, depth, generator=gen)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    pl_ref = planes.clone().requires_grad_(True)
+    a, b, cc = orr.render(Pg, pl_ref, ro, rd, opts, xi=xi, u=u)
+    pl = planes.to(DEV).requires_grad_(True)
+    x, y, z = ImportanceRenderer()(pl, dec, ro.to(DEV), rd.to(DEV), opts, noise=(xi, u))
     # north_star tolerance: 1e-3 relative on rendered RGB / depth
     assert_close(x, a, 1e-3, 'rgb'); assert_close(y, b, 1e-3, 'depth'); assert_close(z, cc, 1e-3, 'weight sum')
     assert rel_err(x, a) < 2e-4 and rel_err(y, b) < 2e-5      # what the kernels actually achieve
+    d1, d2 = torch.randn(a.shape, generator=gen), torch.randn(b.shape, generator=gen)
+    gref = torch.autograd.grad([a, b], [pl_ref] + [Pg[k] for k in sorted(Pg)], [d1, d2])
+    names = {f'decoder.net.{i}.{k}': getattr(dec.net[i], k) for i in (0, 2) for k in ('weight', 'bias')}
+    ggpu = torch.autograd.grad([x, y], [pl] + [names[k] for k in sorted(Pg)], [d1.to(DEV), d2.to(DEV)])
+    for gg, gr, nm in zip(ggpu, gref, ['planes'] + sorted(Pg)):
+        assert_close(gg, gr, 1e-3, f'config-size grad {nm}')
 
 
 @pytest.mark.parametrize('frozen', [False, True])
