@@ -13,6 +13,9 @@ SOURCES = ['elementwise.hip', 'render.hip', 'conv.hip']
 LIB = os.path.join(HERE, 'libspi_hip.so')
 STAMP = os.path.join(HERE, '.build_stamp')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-comment',
+         # MFMA results stay in VGPRs: the default AGPR form costs 2 v_accvgpr moves per MFMA across the igemm loop back-edge, and on
+         # gfx950 every VALU instruction beside an fp32 MFMA steals ~2.6 matrix-pipe cycles (tools/ubench/mfma_valu.hip)
+         '-mllvm', '-amdgpu-mfma-vgpr-form=1',
          '-Wno-pass-failed', '-I' + os.path.join(ROOT, 'include'), '-I' + HERE]
 
 
