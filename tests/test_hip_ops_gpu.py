@@ -99,6 +99,28 @@ def test_filtered_lrelu_golden(golden):
         assert_close(y, g[f'fl_y{i}'], 2e-6, f'filtered_lrelu[{i}]')
 
 
+@pytest.mark.parametrize('up,down,pad', [(2, 2, [5, 4, 5, 4]), (1, 2, [3, 3, 3, 3]), (2, 1, [2, 1, 2, 1])])
+def test_filtered_lrelu_gradients_vs_oracle(up, down, pad):
+    """filtered_lrelu with gradients (the differentiable HIP decomposition) against the oracle's autograd, and the fused
+    forward-only kernel against the same values."""
+    from spi_amd.torch_utils.ops import filtered_lrelu
+    gen = torch.Generator().manual_seed(up * 10 + down)
+    x = torch.randn(2, 6, 18, 20, generator=gen, requires_grad=True)
+    b = torch.randn(6, generator=gen, requires_grad=True)
+    fu, fd = osg.fir_filter() * 1.0, osg.fir_filter().flip(0) * 0.9 + 0.01
+    ref = osg.filtered_lrelu(x, fu, fd, b, up=up, down=down, padding=pad, gain=1.3, slope=0.15, clamp=0.9)
+    dy = torch.randn(ref.shape, generator=gen)
+    gx, gb = torch.autograd.grad(ref, [x, b], dy)
+    xd, bd = x.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    y = filtered_lrelu.filtered_lrelu(xd, fu.to(DEV), fd.to(DEV), bd, up=up, down=down, padding=pad, gain=1.3, slope=0.15, clamp=0.9)
+    assert_close(y, ref, 3e-6, 'filtered_lrelu fwd (differentiable path)')
+    ax, ab = torch.autograd.grad(y, [xd, bd], dy.to(DEV))
+    assert_close(ax, gx, 1e-5, 'filtered_lrelu dx'); assert_close(ab, gb, 1e-5, 'filtered_lrelu db')
+    with torch.no_grad():
+        y2 = filtered_lrelu.filtered_lrelu(xd, fu.to(DEV), fd.to(DEV), bd, up=up, down=down, padding=pad, gain=1.3, slope=0.15, clamp=0.9)
+    assert_close(y2, ref, 3e-6, 'filtered_lrelu fwd (fused kernels)')
+
+
 @pytest.mark.parametrize('inh,pad', [(201, 1), (199, 2), (130, 1), (113, 2)])
 def test_upfirdn2d_tiled_ragged_vs_oracle(inh, pad):
     """LDS-tiled 4x4 FIR (outputs >= 100 px): ragged tile edges, unaligned rows (scalar stores) and the fused tail + gradients."""
