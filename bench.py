@@ -35,6 +35,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--depth', type=int, default=96, help='coarse = fine samples per ray')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sr-fp16', action='store_true', help='NOT the benchmark configuration: fp16 MFMA in the super-resolution blocks '
+                                                           '(BASELINE config 5); the JSON line then says dtype f32+f16sr')
     ap.add_argument('--narrow', action='store_true', help='debug: reduced-width generator (NOT the benchmark configuration)')
     return ap.parse_args()
 
@@ -95,6 +97,7 @@ def main():
     import tempfile
 
     global_config.device = str(dev)
+    global_config.enable_fp16_blocks = bool(args.sr_fp16)
     tmp = tempfile.mkdtemp(prefix='spi_bench_')
     for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
         setattr(paths_config, k, f'{tmp}/{k}/')
@@ -176,7 +179,7 @@ def main():
                        'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
                        'note': 'rank 0; stage 2 amortises the every-4th-iteration rot / mirror-rot / depth branches over whole super-cycles'},
             'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32+f16sr' if args.sr_fp16 else 'f32', 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
             'random-init weights of the ffhqrebalanced512-128 architecture)',
             'config': {'workload': 'configs[1]: 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
                                    f'{args.depth}+{args.depth} samples', 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},

@@ -189,6 +189,9 @@ typedef struct spi_conv_desc {
     int flip;                 /* 1: spatially flip the kernel (true convolution)                       */
     int w_tap_major;          /* 0: weights [O, I, kh, kw] (PyTorch);  1: [O, kh, kw, I] (channels innermost:  */
                               /*    contiguous slab loads and contiguous weight-gradient writes)        */
+    int compute_f16;          /* 1: operands rounded to fp16, fp16 MFMA with fp32 accumulation (the reference's */
+                              /*    use_fp16 super-resolution blocks); tensors stay fp32 in memory.  Needs      */
+                              /*    I % 16 == 0, otherwise the fp32 kernels run                                 */
     int64_t w_batch_stride;   /* elements between per-sample weights; 0 = weights shared by the batch  */
     /* fused epilogue of the forward (all optional): y = clamp(act(acc + noise*noise_gain + bias)*gain) */
     const float* bias;        /* [O] */

@@ -10,3 +10,7 @@ log_snapshot = 500
 pivotal_training_steps = 0
 model_snapshot_interval = 400
 run_name = ''
+
+# fp16 MFMA in the generator blocks that the checkpoint marks `use_fp16` (the super-resolution blocks: sr_num_fp16_res = 4).
+# Off by default: fp32 everywhere reproduces the reference's CPU path, the parity target.  `--sr_fp16` / BASELINE config 5.
+enable_fp16_blocks = False

@@ -16,6 +16,7 @@
 //     conflicts, conflict-free fragment reads), register-prefetched double buffer
 //   - epilogue (noise, bias, activation, gain, clamp) applied to the accumulators in registers
 #include "common.hpp"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -73,7 +74,11 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 // -------------------------------------------------------------------------------------------------
 //   AMF (needs BUF): the A-tile loader runs its lanes along m instead of k -- for the dgrad of tap-major
 //   weights (m = input channel is the contiguous axis) that turns 16 scattered 4-byte reads into one line.
-template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF, bool AMF = false>
+//   F16 (needs BUF, no SPLITK): operands are rounded to fp16 when they are staged in LDS ([k/4][m][4] halves, one 8-byte
+//   fragment per lane) and multiplied on v_mfma_f32_32x32x8_f16 with fp32 accumulation -- the precision of the reference's
+//   `use_fp16` super-resolution blocks (superresolution.py:271), at 16x the fp32 matrix rate.
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF, bool AMF = false, bool F16 = false>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ wgt, float* __restrict__ out,
                                                             Epilogue ep, int nsplit) {
@@ -85,6 +90,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     constexpr int B_KSTEP = NT / BN;          // k rows covered per pass (p fastest)
     static_assert(NT >= BN && NT % BK == 0 && NT % BN == 0 && A_PER >= 1 && B_PER >= 1, "tile/threads mismatch");
     static_assert(!AMF || (BUF && NT % BM == 0), "m-fast A loads need the buffer path");
+    static_assert(!F16 || (BUF && !SPLITK), "fp16 operands: buffer path, no split-K");
     constexpr int A_KSTEP = AMF ? NT / BM : 0; // AMF: k rows covered per pass (m fastest)
     __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
@@ -193,10 +199,18 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         for (int j = 0; j < B_PER; ++j) load_b(S, q, j);
     };
     auto store_a = [&](const Stage& S, int buf, int j) {
-        if (AMF) As[buf][(a_k + j * A_KSTEP) * LDA + a_m] = S.ra[j];
+        if constexpr (F16) {
+            const int k = AMF ? a_k + j * A_KSTEP : a_k, m = AMF ? a_m : a_m + j * A_MSTEP;
+            reinterpret_cast<_Float16*>(As[buf])[((k >> 2) * LDA + m) * 4 + (k & 3)] = (_Float16)S.ra[j];
+        } else if (AMF) As[buf][(a_k + j * A_KSTEP) * LDA + a_m] = S.ra[j];
         else As[buf][a_k * LDA + a_m + j * A_MSTEP] = (BUF || ((S.am >> j) & 1u)) ? S.ra[j] : 0.f;
     };
-    auto store_b = [&](const Stage& S, int buf, int j) { Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? S.rb[j] : 0.f; };
+    auto store_b = [&](const Stage& S, int buf, int j) {
+        if constexpr (F16) {
+            const int k = b_k + j * B_KSTEP;
+            reinterpret_cast<_Float16*>(Bs[buf])[((k >> 2) * LDB + b_p) * 4 + (k & 3)] = (_Float16)S.rb[j];
+        } else Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? S.rb[j] : 0.f;
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -209,14 +223,16 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     const int fr = lane & 31, fk = lane >> 5;
     // one pipeline step: MFMAs of slab s from LDS[buf]; issue loads of slab s+2 into L; write slab s+1 from W to LDS[buf^1]
     auto step = [&](int s, int buf, Stage& L, const Stage& W) {
-        const float* Ab = As[buf] + wm * TM * 32 + fr;
-        const float* Bb = Bs[buf] + wn * TN * 32 + fr;
         L.am = L.bm = 0;
         const SlabAddr q2 = slab_setup(s + 2);
-        constexpr int NK = BK / 2;
+        constexpr int NK = F16 ? BK / 8 : BK / 2;
+        // one body for both operand types: FragT = float (one k per lane half) or 4 halves (k = 4*half .. 4*half+3)
+        using FragT = typename std::conditional<F16, half4_t, float>::type;
+        const FragT* Ab = reinterpret_cast<const FragT*>(As[buf]) + wm * TM * 32 + fr;
+        const FragT* Bb = reinterpret_cast<const FragT*>(Bs[buf]) + wn * TN * 32 + fr;
         // fragments are read one MFMA group ahead (two register sets), so the lgkmcnt wait in front of a
         // group never exposes the LDS latency
-        float af[2][TM], bf[2][TN];
+        FragT af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = Ab[fk * LDA + i * 32];
 #pragma unroll
@@ -232,8 +248,10 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
             if (kk < NK / 2) {               // first half of the MFMA groups: request slab s+2
 #pragma unroll
@@ -315,7 +333,7 @@ __global__ void conv_epilogue_kernel(float* __restrict__ y, int64_t total, int O
 //   raw-buffer loads (hardware zero-fill out of range, no masks), two register stages, loads of slab
 //   s+2 issued and slab s+1 written to LDS behind the MFMA groups, fragments read one group ahead.
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool F16 = false>
 __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ dout, float* __restrict__ dw,
                                                             int pix_per_block) {
@@ -390,8 +408,14 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
             }
         }
     };
-    auto store_a = [&](const Stage& S, int buf, int q) { As[buf][l_p * LDA + l_r + q * ROWSTEP] = S.ra[q]; };
-    auto store_b = [&](const Stage& S, int buf, int q) { Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = S.rb[q]; };
+    auto store_a = [&](const Stage& S, int buf, int q) {
+        if constexpr (F16) reinterpret_cast<_Float16*>(As[buf])[((l_p >> 2) * LDA + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.ra[q];
+        else As[buf][l_p * LDA + l_r + q * ROWSTEP] = S.ra[q];
+    };
+    auto store_b = [&](const Stage& S, int buf, int q) {
+        if constexpr (F16) reinterpret_cast<_Float16*>(Bs[buf])[((l_p >> 2) * LDB + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.rb[q];
+        else Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = S.rb[q];
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -403,10 +427,11 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     const int nslab = (pend - pbeg + BK - 1) / BK;
     const int fr = lane & 31, fk = lane >> 5;
     auto step = [&](int s, int buf, Stage& L, const Stage& W) {
-        const float* Ab = As[buf] + wm * TM * 32 + fr;
-        const float* Bb = Bs[buf] + wn * TN * 32 + fr;
-        constexpr int NK = BK / 2;
-        float af[2][TM], bf[2][TN];
+        constexpr int NK = F16 ? BK / 8 : BK / 2;
+        using FragT = typename std::conditional<F16, half4_t, float>::type;
+        const FragT* Ab = reinterpret_cast<const FragT*>(As[buf]) + wm * TM * 32 + fr;
+        const FragT* Bb = reinterpret_cast<const FragT*>(Bs[buf]) + wn * TN * 32 + fr;
+        FragT af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[0][i] = Ab[fk * LDA + i * 32];
 #pragma unroll
@@ -422,8 +447,10 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
             if (kk == 0) load_all(L, pbeg + (s + 2) * BK);      // slab s+2 (beyond pend: every element out of range -> zeros)
             if (kk >= NK / 2) {
@@ -554,7 +581,7 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, int nsplit, hipStream_t st) {
+static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, int nsplit, hipStream_t st, bool f16) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     int maxpix = 0;
     for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
@@ -565,6 +592,9 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
         if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
         else if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
         else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
+    } else if (f16 && buf) {
+        if (P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
+        else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, false, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
     } else {
         if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
         else if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
@@ -572,7 +602,7 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
     }
 }
 
-static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st) {
+static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st, bool f16 = false) {
     int maxpix = 0, maxT = 0;
     for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxT = std::max(maxT, P.cls[c].taps.T); }
     auto blocks = [&](int bm, int bn) { return (int64_t)((maxpix + bn - 1) / bn) * ((P.Mo + bm - 1) / bm) * P.N * P.ncls; };
@@ -586,17 +616,18 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     static const int bm_of[5] = {32, 128, 64, 32, 64}, bn_of[5] = {128, 128, 64, 32, 256};
     const int64_t nb = blocks(bm_of[cfg], bn_of[cfg]);
     int nsplit = 1;
-    if (nb < 512 && nslab >= 8) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);
+    const bool f16_ok = f16 && (P.Ci % BK == 0) && (P.in_bs * 4 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31));
+    if (nb < 512 && nslab >= 8 && !f16_ok) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);      // fp16 operands: never split (one precision per call)
     if (nsplit > 1) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)P.N * P.out_bs * sizeof(float), st);
         if (e != hipSuccess) { spi_set_error("conv: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
     }
     switch (cfg) {
-    case 0: launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, nsplit, st); break;
-    case 1: launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, nsplit, st); break;
-    case 2: launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, nsplit, st); break;
-    case 4: launch_igemm<1, 4, 2, 2>(P, in, w, out, ep, nsplit, st); break;
-    default: launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, nsplit, st); break;
+    case 0: launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
+    case 1: launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, nsplit, st, f16); break;
+    case 2: launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
+    case 4: launch_igemm<1, 4, 2, 2>(P, in, w, out, ep, nsplit, st, f16); break;
+    default: launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
     }
     if (nsplit > 1 && (ep.bias || ep.noise || ep.act)) {
         const int64_t total = (int64_t)P.N * P.out_bs;
@@ -617,7 +648,7 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
                 "spi_conv2d_fwd: no fused epilogue in transposed mode (the FIR pass owns it)");
     IGemmParams P; make_forward(d, P);
     Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
-    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream)); if (rc) return rc;
+    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16 != 0); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_fwd");
     return SPI_OK;
 }
@@ -627,7 +658,7 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     SPI_REQUIRE(dy && w && dx, "spi_conv2d_dgrad: null tensor");
     IGemmParams P; make_dgrad(d, P);
     Epilogue ep{nullptr, nullptr, nullptr, 0, 0.f, 1.f, -1.f};
-    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream)); if (rc) return rc;
+    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16 != 0); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_dgrad");
     return SPI_OK;
 }
@@ -652,7 +683,8 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     int ppb = (int)((maxpix + splits - 1) / splits);
     ppb = std::max(64, ((ppb + BK - 1) / BK) * BK);
     dim3 grid((unsigned)((maxpix + ppb - 1) / ppb), (unsigned)tiles, (unsigned)(P.N * P.ncls));
-    hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb);
+    if (d->compute_f16) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb);
+    else hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb);
     SPI_LAUNCH_CHECK("spi_conv2d_wgrad");
     return SPI_OK;
 }

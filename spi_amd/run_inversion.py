@@ -46,7 +46,9 @@ def parse_args(argv=None):
     parser.add_argument('--network_pkl', type=str, default=None)
     parser.add_argument('--depth_resolution', type=int, default=None)
     parser.add_argument('--depth_resolution_importance', type=int, default=None)
+    parser.add_argument('--sr_fp16', action='store_true', help='fp16 MFMA in the super-resolution blocks (BASELINE config 5); default fp32')
     args = parser.parse_args(argv)
+    global_config.enable_fp16_blocks = bool(args.sr_fp16)
 
     for k in ('use_encoder', 'use_G_avg', 'first_inv_type', 'first_inv_steps', 'G_1_step', 'G_1_type', 'G_2_step',
               'load_embedding_coach_name', 'use_adapt_yaw_range', 'description', 'pt_rot_lambda', 'pt_mirror_rot_lambda',

@@ -20,8 +20,9 @@ from ... import hip
 from . import bias_act as _ba
 
 
-def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0, tap_major=0):
-    return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
+def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0, tap_major=0,
+          f16=0):
+    return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), int(f16), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
                         act, alpha, gain, clamp)
 
 
@@ -31,7 +32,7 @@ def out_size(h, k, pad, transposed):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp):
+    def forward(ctx, x, w, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, f16=False):
         # w is TAP-MAJOR here: [O, k, k, I] or [N, O, k, k, I]
         x = x.contiguous().float()
         w = w.contiguous().float()
@@ -45,23 +46,23 @@ class _Conv2d(torch.autograd.Function):
         bb = bias.contiguous().float() if bias is not None else None
         nz = noise.contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
         ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)
-        ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs)
+        ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, w, y, nz, ng = ctx.saved_tensors
-        pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs = ctx.cfg
+        pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16 = ctx.cfg
         n, i, h, wd = x.shape
         o, k = w.shape[-4], w.shape[-2]
         dz, d_noise, d_strength, d_bias = _ba.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
                                                             ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2])
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -69,7 +70,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(dz), hip.ptr(dw), hip.stream())
-        return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None
+        return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None, None
 
 
 def to_tap_major(w):
@@ -78,9 +79,10 @@ def to_tap_major(w):
 
 
 def conv2d(x, w, bias=None, noise=None, noise_strength=None, padding=0, transposed=False, flip=False, act=None, alpha=None,
-           gain=None, clamp=None, tap_major=False):
+           gain=None, clamp=None, tap_major=False, fp16=False):
     """x [N,I,H,W]; w [O,I,k,k] (shared) or [N,O,I,k,k] (per sample) -- or already [.., O,k,k,I] with tap_major=True.
-    act=None -> no activation/gain/clamp."""
+    act=None -> no activation/gain/clamp.  fp16: operands rounded to fp16 on their way into the matrix cores (fp32 accumulate,
+    fp32 tensors) in all three passes -- the reference's `use_fp16` blocks."""
     if not tap_major:
         w = to_tap_major(w)
     if act is None:
@@ -91,4 +93,4 @@ def conv2d(x, w, bias=None, noise=None, noise_strength=None, padding=0, transpos
         a = float(d_alpha if alpha is None else alpha)
         g = float(d_gain if gain is None else gain)
         c = float(-1 if clamp is None else clamp)
-    return _Conv2d.apply(x, w, bias, noise, noise_strength, int(padding), bool(transposed), bool(flip), act_id, a, g, c)
+    return _Conv2d.apply(x, w, bias, noise, noise_strength, int(padding), bool(transposed), bool(flip), act_id, a, g, c, bool(fp16))

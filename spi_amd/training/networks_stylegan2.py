@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from .. import hip
+from ..configs import global_config
 from ..torch_utils.ops import bias_act, upfirdn2d, conv2d_mfma
 
 
@@ -64,7 +65,7 @@ def modulate_weights(weight, styles, demodulate=True, style_gain=1.0):
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                      flip_weight=True, fused_modconv=True, noise_strength=None, bias=None, act=None, gain=None, clamp=None,
-                     style_gain=1.0):
+                     style_gain=1.0, fp16=False):
     """Modulate -> (demodulate) -> conv [-> FIR] [-> + noise -> + bias -> act], reference :34-91 (fused path).
 
     ``noise`` may be the final noise tensor (reference style) or, with ``noise_strength`` given, the
@@ -85,10 +86,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         w = w[0]
     if up == 1:
         return conv2d_mfma.conv2d(x, w, bias=bias, noise=noise, noise_strength=noise_strength, padding=padding,
-                                  flip=not flip_weight, act=act, gain=gain, clamp=clamp, tap_major=True)
+                                  flip=not flip_weight, act=act, gain=gain, clamp=clamp, tap_major=True, fp16=fp16)
     # up = 2: stride-2 transposed conv, then the 4x4 low-pass (gain up^2) with the layer tail fused in
     assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
-    z = conv2d_mfma.conv2d(x, w, transposed=True, flip=flip_weight, tap_major=True)
+    z = conv2d_mfma.conv2d(x, w, transposed=True, flip=flip_weight, tap_major=True, fp16=fp16)
     return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
                                         padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
 
@@ -175,7 +176,7 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, fp16=False):
         assert noise_mode in ['random', 'const', 'none']
         styles = self.affine(w)
         noise = strength = None
@@ -190,7 +191,7 @@ class SynthesisLayer(torch.nn.Module):
         return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, noise_strength=strength, up=self.up,
                                 padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1),
                                 fused_modconv=fused_modconv, bias=self.bias, act=self.activation, gain=self.act_gain * gain,
-                                clamp=clamp)
+                                clamp=clamp, fp16=fp16)
 
     def extra_repr(self):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, resolution={self.resolution:d}, up={self.up}'
@@ -205,10 +206,10 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True):
+    def forward(self, x, w, fused_modconv=True, fp16=False):
         styles = self.affine(w)                                    # * weight_gain happens inside the modulation kernel
         return modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
-                                bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp, style_gain=self.weight_gain)
+                                bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp, style_gain=self.weight_gain, fp16=fp16)
 
 
 class SynthesisBlock(torch.nn.Module):
@@ -240,17 +241,21 @@ class SynthesisBlock(torch.nn.Module):
             fused_modconv = self.fused_modconv_default
         if fused_modconv == 'inference_only':
             fused_modconv = not self.training
+        # reference rule (:421-423): fp16 iff use_fp16 and not force_fp32 and the tensor is on 'cuda'.  Here it is opt-in
+        # (global_config.enable_fp16_blocks, `--sr_fp16`): default fp32 everywhere = the reference's CPU path, which is the
+        # parity target.  fp16 blocks keep fp32 tensors and round the conv operands to fp16 on their way into the MFMAs.
+        f16 = bool(self.use_fp16 and not force_fp32 and global_config.enable_fp16_blocks)
         wi = 0
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
         else:
-            x = self.conv0(x.float(), ws[:, wi], fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv0(x.float(), ws[:, wi], fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
             wi += 1
-        x = self.conv1(x, ws[:, wi], fused_modconv=fused_modconv, **layer_kwargs)
+        x = self.conv1(x, ws[:, wi], fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
         wi += 1
         if img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        y = self.torgb(x, ws[:, wi], fused_modconv=fused_modconv)
+        y = self.torgb(x, ws[:, wi], fused_modconv=fused_modconv, fp16=f16)
         img = img + y if img is not None else y
         return x, img
 

@@ -3,7 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import assert_close
+from conftest import assert_close, rel_err
 from oracle import stylegan_ref as osg
 
 pytestmark = pytest.mark.gpu
@@ -112,3 +112,48 @@ def test_modulate_weights_vs_torch(n, o, i, k, demod):
     out = modulate_weights(wd.detach(), sd, demod, sg)
     (b2,) = torch.autograd.grad(out, [sd], g.float().to(DEV))
     assert_close(b2, gs.float(), 5e-5, 'modulate ds (weights frozen)')
+
+
+@pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 24, 3, False), (1, 64, 128, 40, 3, False), (2, 16, 32, 33, 1, False),
+                                                  (1, 32, 64, 12, 3, True)])
+def test_conv2d_fp16_operands_vs_rounded_reference(n, i, o, h, k, transposed):
+    """fp16 MFMA mode (BASELINE config 5 / the reference's use_fp16 SR blocks): every pass equals the fp32-accumulated
+    convolution of fp16-ROUNDED operands (products of two fp16 values are exact in fp32)."""
+    import torch.nn.functional as F
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(n * 100 + i)
+    x = torch.randn(n, i, h, h, generator=gen)
+    w = torch.randn(n, o, i, k, k, generator=gen) * 0.2
+    r = lambda t: t.half().double()
+    pad = 0 if transposed else k // 2
+    outs, dxs, dws = [], [], []
+    for b in range(n):
+        xb, wb = r(x[b:b + 1]), r(w[b])
+        if transposed:
+            yb = F.conv_transpose2d(xb, wb.transpose(0, 1), stride=2)                       # out[o,2y+ky,2x+kx] += x[i,y,x] w[o,i,ky,kx]
+        else:
+            yb = F.conv2d(xb, wb.flip([2, 3]), padding=pad)                                  # flip=True: true convolution
+        outs.append(yb)
+    ref = torch.cat(outs)
+    dy = torch.randn(ref.shape, generator=gen)
+    for b in range(n):
+        xb, wb, db = r(x[b:b + 1]), r(w[b]), r(dy[b:b + 1])
+        if transposed:
+            xx, ww = x[b:b + 1].double().requires_grad_(True), w[b].double().requires_grad_(True)
+            (gx,) = torch.autograd.grad(F.conv_transpose2d(xx, wb.transpose(0, 1), stride=2), xx, db)
+            (gw,) = torch.autograd.grad(F.conv_transpose2d(xb, ww.transpose(0, 1), stride=2), ww, db)
+        else:
+            xx, ww = x[b:b + 1].double().requires_grad_(True), w[b].double().requires_grad_(True)
+            (gx,) = torch.autograd.grad(F.conv2d(xx, wb.flip([2, 3]), padding=pad), xx, db)
+            (gw,) = torch.autograd.grad(F.conv2d(xb, ww.flip([2, 3]), padding=pad), ww, db)
+        dxs.append(gx); dws.append(gw)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = conv2d_mfma.conv2d(xd, wd, padding=pad, transposed=transposed, flip=not transposed, fp16=True)
+    assert_close(y, ref.float(), 2e-5, 'fp16-operand conv fwd')
+    gx, gw = torch.autograd.grad(y, [xd, wd], dy.to(DEV))
+    assert_close(gx, torch.cat(dxs).float(), 2e-5, 'fp16-operand conv dgrad')
+    assert_close(gw, torch.stack(dws).float(), 2e-5, 'fp16-operand conv wgrad')
+    # and it differs from the fp32 path by about fp16 rounding, not more
+    y32 = conv2d_mfma.conv2d(xd, wd, padding=pad, transposed=transposed, flip=not transposed)
+    e = rel_err(y, y32)
+    assert 1e-5 < e < 5e-3, e

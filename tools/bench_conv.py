@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the MFMA conv kernels on the generator's layer shapes (TFLOP/s per direction)."""
-import ctypes, os, sys, time
+import ctypes, os, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spi_amd import hip
@@ -49,7 +49,7 @@ def main():
         y = torch.empty(N, O, oh, oh, device=dev)
         dx = torch.empty_like(x); dw = torch.empty_like(w)
         wbs = O * I * k * k if per else 0
-        d = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1)
+        d = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
         s = hip.stream()
         flops = 2.0 * N * O * I * k * k * (H * H if tr else oh * oh)
         reps = 3 if flops > 2e10 else 10
