@@ -145,6 +145,14 @@ class BaseCoach:
         self.save(w, c, G, path=os.path.join(paths_config.checkpoints_dir, self.coach_name, f'{name}.pt'))
         self.log_image(w, c, G, path=os.path.join(paths_config.images_output_dir, self.coach_name, name + '.jpg'))
         self.log_image(w, cal_mirror_c(c), G, path=os.path.join(paths_config.mirror_images_output_dir, self.coach_name, name + '.jpg'))
+        if getattr(hyperparameters, 'log_video', True):
+            self.log_video(w, G, path=os.path.join(paths_config.video_output_dir, self.coach_name, f'{name}.mp4'))
+
+    def log_video(self, w, G, path):
+        """120-frame novel-view orbit of the inverted latent (base_coach.py:236-237 -> video_utils.gen_interp_video)."""
+        from ...utils.video_utils import gen_interp_video
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        return gen_interp_video(G, {'w': w.detach().clone()}, mp4=path)
 
     def build_name(self):
         hp = hyperparameters

@@ -1,0 +1,116 @@
+"""Novel-view orbit and shape export after the inversion (drop-in surface of spi/utils/video_utils.py:14-230).
+
+``gen_interp_video(G, {'w': w}, mp4=path)`` is what ``BaseCoach.log_video`` calls (base_coach.py:236-237): 120 frames on a
+yaw +-0.7 / pitch +-0.4 orbit around the look-at point (0, 0, 0.2), radius 2.7, FFHQ intrinsics.  The reference evaluates
+``G.synthesis`` once per frame, i.e. runs the StyleGAN2 backbone 120 times on the same ``w``; here the frames go through the
+generator in batches with ONE ``w`` (``TriPlaneGenerator.synthesis`` shares the backbone and the weight modulation across the
+views), under ``no_grad``.  Only the single-latent 1x1 grid SPI uses is implemented; keyframe interpolation over several
+latents (the reference's scipy ``interp1d`` over seeds) is not.
+Output: ``imageio`` is not a dependency -- frames are written as ``<mp4 stem>_frames/%04d.jpg`` (PIL), plus the mp4 when
+imageio happens to be importable.  ``gen_shapes`` saves the raw 'sigma' grid as ``.npy`` (the reference's marching-cubes
+``.ply`` needs scikit-image / mrcfile).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import camera_utils as cu
+
+
+def orbit_cameras(num_frames, yaw_range=0.7, pitch_range=0.4, lookat=(0.0, 0.0, 0.2), radius=2.7, device='cpu'):
+    """[F,25] cameras of the reference's orbit (video_utils.py:155-160).  It writes 3.14, not pi: kept, the path is part of
+    what a user sees."""
+    t = torch.arange(num_frames, dtype=torch.float32, device=device).view(-1, 1)
+    h = 3.14 / 2 + yaw_range * torch.sin(2 * 3.14 * t / num_frames)
+    v = 3.14 / 2 - 0.05 + pitch_range * torch.cos(2 * 3.14 * t / num_frames)
+    ext = cu.look_at_pose(h, v, torch.tensor(lookat, device=device), radius)
+    return torch.cat([ext.reshape(-1, 16), cu._intrinsics(num_frames, device)], dim=1)
+
+
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0):
+    """Regular N^3 grid of query points, x fastest (video_utils.py:41-70).  -> ([1, N^3, 3], origin, voxel size)"""
+    origin = np.array(voxel_origin, dtype=np.float32) - cube_length / 2
+    voxel = cube_length / (N - 1)
+    idx = torch.arange(N ** 3, dtype=torch.int64)
+    s = torch.zeros(N ** 3, 3)
+    s[:, 2] = idx % N
+    s[:, 1] = (idx // N) % N
+    s[:, 0] = (idx // N // N) % N
+    s[:, 0] = s[:, 0] * voxel + origin[2]
+    s[:, 1] = s[:, 1] * voxel + origin[1]
+    s[:, 2] = s[:, 2] * voxel + origin[0]
+    return s.unsqueeze(0), origin, voxel
+
+
+def to_uint8(img, image_mode='image'):
+    """[N,C,H,W] in [-1,1] -> uint8 [N,H,W,3] like layout_grid (video_utils.py:26-38)."""
+    if image_mode == 'image_depth':
+        img = -img
+        lo, hi = img.amin(dim=(1, 2, 3), keepdim=True), img.amax(dim=(1, 2, 3), keepdim=True)
+        img = (img - lo) / (hi - lo) * 2 - 1
+    if img.shape[1] == 1:
+        img = img.repeat(1, 3, 1, 1)
+    return (img * 127.5 + 128).clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1)
+
+
+@torch.no_grad()
+def sigma_grid(G, w, resolution=128, max_batch=1 << 22):
+    """Density on a resolution^3 grid over the tri-plane box through ``G.sample_mixed`` (video_utils.py:177-196), with the
+    reference's border clean-up (:198-207).  -> float32 [R,R,R] numpy."""
+    dev = w.device
+    samples, _, _ = create_samples(N=resolution, voxel_origin=[0, 0, 0], cube_length=G.rendering_kwargs['box_warp'])
+    samples = samples.to(dev)
+    sig = torch.zeros(1, samples.shape[1], 1, device=dev)
+    dirs = torch.zeros(1, min(max_batch, samples.shape[1]), 3, device=dev)
+    dirs[..., -1] = -1
+    head = 0
+    while head < samples.shape[1]:
+        chunk = samples[:, head:head + max_batch]
+        sig[:, head:head + max_batch] = G.sample_mixed(chunk, dirs[:, :chunk.shape[1]], w, noise_mode='const')['sigma']
+        head += max_batch
+    s = np.flip(sig.reshape(resolution, resolution, resolution).cpu().numpy(), 0).copy()
+    pad, pad_top = int(30 * resolution / 256), int(38 * resolution / 256)
+    if pad:
+        s[:pad] = 0; s[-pad:] = 0; s[:, :pad] = 0; s[:, :, :pad] = 0; s[:, :, -pad:] = 0
+    if pad_top:
+        s[:, -pad_top:] = 0
+    return s
+
+
+@torch.no_grad()
+def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_shapes=False, batch=4, device=None,
+                     voxel_resolution=128, save_frames=True, **_unused):
+    """Orbit video of ONE latent.  Returns the frames as uint8 [F,H,W,3] (numpy)."""
+    w = G_kwargs['w']
+    if w.ndim == 2:
+        w = w.unsqueeze(0)
+    if w.shape[0] != 1:
+        raise NotImplementedError('keyframe interpolation over several latents is not implemented (SPI renders one latent per video)')
+    device = device or w.device
+    cams = orbit_cameras(w_frames, device=device)
+    frames = []
+    for i in range(0, w_frames, batch):
+        c = cams[i:i + batch]
+        out = G.synthesis(w.to(device), c, noise_mode='const')[image_mode]          # one w, len(c) cameras: backbone shared
+        frames.append(to_uint8(out, image_mode).cpu())
+    frames = torch.cat(frames).numpy()
+    stem = os.path.splitext(mp4)[0]
+    if save_frames:
+        from PIL import Image
+        os.makedirs(stem + '_frames', exist_ok=True)
+        for i, f in enumerate(frames):
+            Image.fromarray(f).save(os.path.join(stem + '_frames', f'{i:04d}.jpg'))
+        try:                                                                         # the container itself only if imageio exists
+            import imageio
+            with imageio.get_writer(mp4, mode='I', fps=60, codec='libx264') as vw:
+                for f in frames:
+                    vw.append_data(f)
+        except ImportError:
+            pass
+    if gen_shapes:
+        os.makedirs(os.path.join(os.path.dirname(mp4) or '.', 'interpolation_shape'), exist_ok=True)
+        np.save(os.path.join(os.path.dirname(mp4) or '.', 'interpolation_shape', '0000_sigma.npy'), sigma_grid(G, w.to(device), voxel_resolution))
+        np.save(stem + '_trajectory.npy', cams[:, :16].reshape(-1, 4, 4).cpu().numpy())
+    return frames

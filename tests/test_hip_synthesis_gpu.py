@@ -133,3 +133,28 @@ def test_synthesis_fp16_superresolution_close_to_fp32(golden):
     e = rel_err(o16['image'], o32['image'])
     assert 1e-6 < e < 3e-3, e                       # really a different arithmetic, and within the north-star 1e-3-ish band
     assert rel_err(g16, g32) < 2e-2
+
+
+def test_orbit_video_and_sigma_grid(tmp_path):
+    """Post-process novel-view rendering: batched frames with ONE latent equal per-frame synthesis with the
+    latent repeated (the reference's call pattern); frames land on disk; the density grid comes out of `sample_mixed`."""
+    from spi_amd.utils import video_utils as vu
+    G = _narrow_G()
+    G.neural_rendering_resolution = 32
+    w = torch.randn(1, 14, 512, generator=torch.Generator().manual_seed(2)).to(DEV) * 0.3
+    mp4 = str(tmp_path / 'v' / 'face.mp4')
+    import os
+    os.makedirs(os.path.dirname(mp4))
+    frames = vu.gen_interp_video(G, {'w': w}, mp4=mp4, w_frames=6, batch=4, gen_shapes=True, voxel_resolution=16)
+    assert frames.shape == (6, 512, 512, 3) and frames.dtype.name == 'uint8'
+    assert sorted(os.listdir(mp4[:-4] + '_frames')) == [f'{i:04d}.jpg' for i in range(6)]
+    cams = vu.orbit_cameras(6, device=DEV)
+    with torch.no_grad():
+        one = G.synthesis(w, cams[4:5], noise_mode='const')['image']
+    ref = vu.to_uint8(one).cpu().numpy()[0].astype(int)
+    # same picture up to the renderer's random stratified jitter (fresh torch.rand draws per call, as in the reference)
+    assert abs(frames[4].astype(int) - ref).mean() < 2.0 and abs(frames[3].astype(int) - ref).mean() > abs(frames[4].astype(int) - ref).mean()
+    sig = __import__('numpy').load(os.path.join(os.path.dirname(mp4), 'interpolation_shape', '0000_sigma.npy'))
+    assert sig.shape == (16, 16, 16) and __import__('numpy').isfinite(sig).all()
+    traj = __import__('numpy').load(mp4[:-4] + '_trajectory.npy')
+    assert traj.shape == (6, 4, 4)

@@ -150,3 +150,25 @@ def test_projector_w_statistics_and_schedule_host_math():
     lr_mid, _ = stage1_schedule(250, 500, 2.0)
     assert abs(lr_mid - 0.01) < 1e-12
     assert stage1_schedule(499, 500, 2.0)[1] == 0.0
+
+
+def test_orbit_cameras_geometry():
+    """Novel-view orbit of the post-process video (video_utils.py:155-160): look-at cameras on a radius-2.7 sphere looking at
+    (0, 0, 0.2), yaw +-0.7 / pitch +-0.4 swept once over the frames, FFHQ intrinsics."""
+    import math
+    from spi_amd.utils.video_utils import orbit_cameras, create_samples
+    c = orbit_cameras(120)
+    assert c.shape == (120, 25)
+    ext = c[:, :16].reshape(-1, 4, 4)
+    origin, fwd = ext[:, :3, 3], ext[:, :3, 2]
+    lookat = torch.tensor([0.0, 0.0, 0.2])
+    assert torch.allclose(origin.norm(dim=1), torch.full((120,), 2.7), atol=1e-5)      # LookAtPoseSampler: sphere around the ORIGIN, looking at the pivot
+    to_target = torch.nn.functional.normalize(lookat - origin, dim=1)
+    assert torch.allclose(fwd, to_target, atol=1e-5)                      # camera z axis looks at the pivot
+    assert torch.allclose(c[:, 16:], torch.tensor([4.2647, 0, 0.5, 0, 4.2647, 0.5, 0, 0, 1]).repeat(120, 1))
+    yaw = torch.atan2(origin[:, 0], origin[:, 2])
+    assert 0.6 < yaw.max() < 0.8 and -0.8 < yaw.min() < -0.6             # ~ +-0.7 rad
+    assert abs(float(yaw[0])) < 2e-3 and abs(float(yaw[60])) < 5e-3      # starts and crosses at the frontal view (3.14 != pi)
+    s, o, v = create_samples(N=4, cube_length=1.0)
+    assert s.shape == (1, 64, 3) and abs(v - 1 / 3) < 1e-6 and torch.allclose(s[0, 0], torch.tensor([-0.5, -0.5, -0.5]))
+    assert torch.allclose(s[0, 1], torch.tensor([-0.5, -0.5, -0.5 + 1 / 3]))   # the LAST coordinate runs fastest (:57-66)
