@@ -103,6 +103,9 @@ def run(argv=None):
         coach = SingleIDCoach(loader, use_wandb, G=G)
     elif args.G_1_type == 'RotBbox':
         coach = RotBboxCoach(loader, use_wandb, G=G)
+    elif args.G_1_type == 'Inference':
+        from .training.coaches.inference_coach import InferenceCoach
+        coach = InferenceCoach(loader, use_wandb, G=G)
     else:
         raise NotImplementedError(args.G_1_type)
     sdist.barrier()

@@ -124,6 +124,40 @@ class BaseCoach:
     def train(self):
         pass
 
+    def cal_metric(self, fake, gt, name, fake_m=None):
+        """L2 / LPIPS / ID of a synthesised view (and of the mirrored view against the flipped photo), base_coach.py:141-152."""
+        if getattr(self, 'metric', None) is None:
+            from ...utils.metric_utils import Metric
+            self.metric = Metric(lpips_loss=self.lpips_loss)
+        d = self.metric_dic.setdefault(name, {'l2': [], 'lpips': [], 'id': [], 'l2_m': [], 'lpips_m': [], 'id_m': []})
+        for key, (a, b) in (('', (gt, fake)), ('_m', (torch.flip(gt, dims=[3]), fake_m))):
+            if b is None:
+                continue
+            l2, lp, ids = self.metric.run(a, b)
+            d['l2' + key].append(l2); d['lpips' + key].append(lp); d['id' + key].append(ids)
+
+    def log_metric(self):
+        """Append the per-image table and averages to <experiments_output_dir>/metric_log.txt (format of base_coach.py:154-198)."""
+        hp = hyperparameters
+        with open(os.path.join(paths_config.experiments_output_dir, 'metric_log.txt'), 'a') as f:
+            f.write(f'Coach name: {self.coach_name}\nhyperparameters.use_encoder: {hp.use_encoder}\n'
+                    f'hyperparameters.first_inv_type: {hp.first_inv_type}\nhyperparameters.first_inv_steps: {hp.first_inv_steps}\n'
+                    f'hyperparameters.G_1_step: {hp.G_1_step}\nhyperparameters.G_2_step: {hp.G_2_step}\n\n')
+            for key, cur in self.metric_dic.items():
+                msg = f'Mode: {key}\n'
+                cnt = len(cur['l2'])
+                tot = [0.0] * 6
+                cols = ('l2', 'lpips', 'id', 'l2_m', 'lpips_m', 'id_m')
+                for i in range(cnt):
+                    v = [cur[c][i] if i < len(cur[c]) else float('nan') for c in cols]
+                    msg += (f'ID: {i} L2: {v[0]:.6f}; Lpips: {v[1]:.6f}; ID Sim: {v[2]:.6f}; L2 M: {v[3]:.6f}; Lpips M: {v[4]:.6f}; '
+                            f'ID Sim M: {v[5]:.6f};\n')
+                    tot = [t + x for t, x in zip(tot, v)]
+                tot = [t / max(cnt, 1) for t in tot]
+                msg += (f'Mode: {key} AVG\nL2: {tot[0]:.6f}; Lpips: {tot[1]:.6f}; ID Sim: {tot[2]:.6f}; L2 M: {tot[3]:.6f}; '
+                        f'Lpips M: {tot[4]:.6f}; ID Sim M: {tot[5]:.6f};\n')
+                f.write(msg + '\n')
+
     def save(self, w, c, G, path):
         torch.save({'w': w.detach().cpu(), 'c': c.detach().cpu(), 'G': {k: v.detach().cpu() for k, v in G.state_dict().items()}}, path)
 
