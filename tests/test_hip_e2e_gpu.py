@@ -9,6 +9,20 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _restore_global_configs():
+    """run_inversion writes the reference's module-level config objects; put them back for the tests that follow."""
+    from spi_amd.configs import hyperparameters, paths_config, global_config
+    mods = (hyperparameters, paths_config, global_config)
+    saved = [{k: v for k, v in vars(m).items() if not k.startswith('__')} for m in mods]
+    yield
+    for m, sv in zip(mods, saved):
+        for k in [k for k in vars(m) if not k.startswith('__') and k not in sv]:
+            delattr(m, k)
+        for k, v in sv.items():
+            setattr(m, k, v)
+
+
 def test_cli_pti_then_inference_and_metrics(tmp_path, capsys):
     from spi_amd import run_inversion
     from spi_amd.configs import hyperparameters as hp, paths_config
