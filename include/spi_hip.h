@@ -157,6 +157,15 @@ int spi_bias_act(const float* x, const float* b, const float* xref, const float*
 int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, int N, int C,
                  int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream);
 
+/* out[r] += sum_p a[r,p] * b'[r,p] for r < rows (= N*C), p < HW  (out: CALLER zeroes).  With act != 0, b is a layer
+ * OUTPUT y = clamp(act(z + noise*noise_gain + bias)*gain) and b' is the reconstructed conv result z (act in {linear,
+ * lrelu}; clamped pixels carry a zero gradient in `a`, so their irrecoverable z does not matter); act == 0: b' = b.
+ * Used for the style gradient of a modulated conv whose weights are frozen (SPI stage 1):
+ *   d s_i = <x_i, dx_i> / s_i  -  s_i * gain^2 * sum_o d_o^2 <dz_o, z_o> sum_t W[o,i,t]^2
+ * -- two per-channel dot products and a GEMV instead of the O*I*k*k weight-gradient GEMM. */
+int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C, int64_t HW, const float* bias,
+                 const float* noise, const float* noise_gain, int act, float alpha, float gain, spi_stream_t stream);
+
 /* upfirdn2d.cpp:20 `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`.
  *   x [N,C,inH,inW] (dense NCHW), f [fH,fW]; y [N,C,outH,outW] with the reference's output-size rule.
  * Optional fused epilogue (NULL / act = 0 disables): y = bias_act(y + noise[outH,outW]*noise_gain[0], bias[C]). */

@@ -181,6 +181,40 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-row dot products  out[r] += sum_p a[r,p] * b'[r,p]  (b' = b, or the conv result reconstructed from a layer output)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) chan_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                       int C, int64_t HW, int64_t per_block, const float* __restrict__ bias,
+                                                       const float* __restrict__ noise, const float* __restrict__ noise_gain,
+                                                       int act, float alpha, float gain) {
+    const int64_t r = blockIdx.y;
+    const int c = (int)(r % C);
+    const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = min(p0 + per_block, HW);
+    const float* ar = a + r * HW; const float* br = b + r * HW;
+    const float bv = (act && bias) ? bias[c] : 0.f;
+    const float ng = (act && noise) ? (noise_gain ? noise_gain[0] : 1.f) : 0.f;
+    const float inv_gain = act ? 1.f / gain : 1.f;
+    const float inv_alpha = (act == SPI_ACT_LRELU) ? 1.f / alpha : 1.f;
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += 512) {
+        float v = br[p];
+        if (act) { v *= inv_gain; v = (v > 0.f ? v : v * inv_alpha) - bv - (noise ? noise[p] * ng : 0.f); }
+        s0 = fmaf(ar[p], v, s0);
+        const int64_t p2 = p + 256;
+        if (p2 < p1) {
+            float w = br[p2];
+            if (act) { w *= inv_gain; w = (w > 0.f ? w : w * inv_alpha) - bv - (noise ? noise[p2] * ng : 0.f); }
+            s1 = fmaf(ar[p2], w, s1);
+        }
+    }
+    __shared__ float red[4];
+    const float s = wave_sum(s0 + s1);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + r, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// ------------------------------------------------------------------------------------------------
 // upfirdn2d: out[oy,ox] = gain * sum_t k[ty,tx] * U[oy*down + ty, ox*down + tx], U = zero-inserted,
 // padded input; k = f flipped unless `flip` (upfirdn2d.py:168-213).  Only taps that land on a real
 // sample are visited.  Optional pre-bias (filtered_lrelu step 1) and noise/bias/activation epilogue
@@ -782,6 +816,20 @@ int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, floa
     if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);
     else hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);
     SPI_LAUNCH_CHECK("spi_tail_bwd");
+    return SPI_OK;
+}
+
+int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
+                 const float* noise_gain, int act, float alpha, float gain, spi_stream_t stream) {
+    SPI_REQUIRE(a && b && out && rows > 0 && rows < 65536 && C > 0 && HW > 0, "spi_chan_dot: bad argument");
+    SPI_REQUIRE(act == 0 || ((act == SPI_ACT_LINEAR || act == SPI_ACT_LRELU) && gain != 0.f && (act != SPI_ACT_LRELU || alpha != 0.f)),
+                "spi_chan_dot: only linear / lrelu outputs can be inverted");
+    // ~1024 blocks in total, at least 2048 pixels per block
+    const int64_t want = std::max<int64_t>(1, 1024 / rows);
+    const int64_t per_block = std::max<int64_t>(2048, ((HW + want - 1) / want + 511) / 512 * 512);
+    dim3 grid((unsigned)ceil_div64(HW, per_block), (unsigned)rows);
+    hipLaunchKernelGGL(chan_dot_kernel, grid, dim3(256), 0, as_stream(stream), a, b, out, C, HW, per_block, bias, noise, noise_gain, act, alpha, gain);
+    SPI_LAUNCH_CHECK("spi_chan_dot");
     return SPI_OK;
 }
 

@@ -63,6 +63,79 @@ def modulate_weights(weight, styles, demodulate=True, style_gain=1.0):
     return _Modulate.apply(weight, styles, bool(demodulate), float(style_gain))
 
 
+class _ModConvFrozen(torch.autograd.Function):
+    """Modulated conv whose WEIGHTS are frozen but whose styles need a gradient (SPI stage 1: G.requires_grad_(False), W+ is
+    optimised).  The reference's autograd graph computes the full O*I*k*k weight gradient only to contract it with dw''/ds;
+    algebraically (v = W s g, d = rsqrt(|v|^2), w'' = v d, z = conv(x, w'')):
+        d s_i = <x_i, dx_i> / s_i  -  s_i g^2 sum_o d_o^2 <dz_o, z_o> sum_t W[o,i,t]^2
+    i.e. two per-channel dot products over activations that already exist (dx comes out of dgrad anyway) and a GEMV --
+    the weight-gradient GEMM (20 % of a stage-1 step) disappears.  Same value up to fp32 rounding."""
+
+    @staticmethod
+    def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16):
+        import ctypes
+        from ..torch_utils.ops.conv2d_mfma import _desc, out_size
+        x = x.contiguous().float()
+        weight = weight.detach().contiguous().float()
+        st = styles.detach().contiguous().float()
+        o, i, kh, kw = weight.shape
+        n, ns = x.shape[0], st.shape[0]
+        w2 = torch.empty(ns, o, kh, kw, i, device=x.device, dtype=torch.float32)
+        dcoef = torch.empty(ns, o, device=x.device, dtype=torch.float32) if demodulate else None
+        hip.call('spi_modulate_fwd', hip.ptr(weight), hip.ptr(st), hip.ptr(w2), hip.ptr(dcoef), ns, o, i, kh * kw, int(demodulate),
+                 float(style_gain), hip.stream())
+        h, wd = x.shape[2], x.shape[3]
+        wbs = o * i * kh * kw if ns == n and n > 1 else (0 if ns == 1 else o * i * kh * kw)
+        if ns == 1:
+            wbs = 0
+        oh, ow = out_size(h, kh, pad, transposed), out_size(wd, kh, pad, transposed)
+        y = torch.empty(n, o, oh, ow, device=x.device, dtype=torch.float32)
+        bb = bias.detach().contiguous().float() if bias is not None else None
+        nz = noise.detach().contiguous().float() if noise is not None else None
+        ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
+        d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16)
+        hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w2), hip.ptr(y), hip.stream())
+        has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0 or bb is not None or nz is not None)
+        ctx.save_for_backward(x, weight, st, w2, dcoef, y, bb, nz, ng)
+        ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, demodulate, float(style_gain), f16)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        import ctypes
+        from ..torch_utils.ops.conv2d_mfma import _desc
+        x, weight, st, w2, dcoef, y, bb, nz, ng = ctx.saved_tensors
+        pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, demodulate, sgain, f16 = ctx.cfg
+        o, i, kh, kw = weight.shape
+        n, ns = x.shape[0], st.shape[0]
+        h, wd = x.shape[2], x.shape[3]
+        dz, d_noise, d_strength, d_bias = bias_act.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
+                                                                 ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3])
+        d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, tap_major=1, f16=f16)
+        dx = torch.empty_like(x)
+        hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w2), hip.ptr(dx), hip.stream())
+        a = torch.zeros(n, i, device=x.device, dtype=torch.float32)
+        hip.call('spi_chan_dot', hip.ptr(x), hip.ptr(dx), hip.ptr(a), n * i, i, h * wd, None, None, None, 0, 0.0, 1.0, hip.stream())
+        if ns == 1 and n > 1:
+            a = a.sum(0, keepdim=True)
+        ds = torch.where(st.abs() > 1e-20, a / st, torch.zeros_like(a))
+        if demodulate:
+            cv = torch.zeros(n, o, device=x.device, dtype=torch.float32)
+            hw_out = y.shape[2] * y.shape[3]
+            if has_epi:
+                hip.call('spi_chan_dot', hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, hip.ptr(bb), hip.ptr(nz), hip.ptr(ng), act_id, alpha,
+                         gain, hip.stream())
+            else:
+                hip.call('spi_chan_dot', hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, None, None, None, 0, 0.0, 1.0, hip.stream())
+            if ns == 1 and n > 1:
+                cv = cv.sum(0, keepdim=True)
+            ww = weight.square().sum(dim=(2, 3))                                   # [O, I]
+            ds = ds - st * (sgain * sgain) * ((dcoef.square() * cv) @ ww)
+        return (dx if ctx.needs_input_grad[0] else None, None, ds, d_bias, d_noise, d_strength,
+                None, None, None, None, None, None, None, None, None, None)
+
+
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                      flip_weight=True, fused_modconv=True, noise_strength=None, bias=None, act=None, gain=None, clamp=None,
                      style_gain=1.0, fp16=False):
@@ -81,6 +154,23 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     # conv runs with one weight set and its weight gradient is reduced over the batch inside the kernel)
     assert styles.shape in ((n, ic), (1, ic))
     # modulated (and demodulated) per-sample weights, built directly in the kernels' tap-major layout [N,O,k,k,I]
+    frozen = torch.is_grad_enabled() and not weight.requires_grad and styles.requires_grad
+    if frozen:                      # stage 1: no weight-gradient GEMM, the style gradient comes from two channel dot products
+        from ..torch_utils.ops import bias_act as _ba
+        if up == 1:
+            if act is None:
+                act_id, a_, g_, c_ = (1 if (bias is not None or noise is not None) else 0), 0.0, 1.0, -1.0
+            else:
+                act_id, d_alpha, d_gain, _ = _ba.activation_funcs[act]
+                assert act_id in (1, 3), 'fused epilogue of the frozen-weight path supports linear / lrelu'
+                a_, g_, c_ = float(d_alpha), float(d_gain if gain is None else gain), float(-1 if clamp is None else clamp)
+            return _ModConvFrozen.apply(x, weight, styles, bias, noise, noise_strength, int(padding), False, not flip_weight, act_id, a_, g_, c_,
+                                        bool(demodulate), float(style_gain), bool(fp16))
+        assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
+        z = _ModConvFrozen.apply(x, weight, styles, None, None, None, 0, True, flip_weight, 0, 0.0, 1.0, -1.0, bool(demodulate),
+                                 float(style_gain), bool(fp16))
+        return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
+                                            padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
     w = modulate_weights(weight, styles, demodulate, style_gain)
     if styles.shape[0] == 1 and n > 1:
         w = w[0]

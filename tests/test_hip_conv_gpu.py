@@ -157,3 +157,34 @@ def test_conv2d_fp16_operands_vs_rounded_reference(n, i, o, h, k, transposed):
     y32 = conv2d_mfma.conv2d(xd, wd, padding=pad, transposed=transposed, flip=not transposed)
     e = rel_err(y, y32)
     assert 1e-5 < e < 5e-3, e
+
+
+@pytest.mark.parametrize('up,demod,shared,n', [(1, True, False, 2), (1, True, True, 3), (2, True, False, 1), (2, True, True, 2), (1, False, False, 2)])
+def test_frozen_weight_modconv_style_gradient(up, demod, shared, n):
+    """Stage-1 path (weights frozen): d styles from  <x,dx>/s - s g^2 sum_o d_o^2 <dz_o,z_o> sum_t W^2  equals the autograd
+    gradient of the ordinary path (weight-gradient GEMM -> modulate backward); dx / d noise unchanged."""
+    from spi_amd.training.networks_stylegan2 import modulated_conv2d
+    from spi_amd.torch_utils.ops import upfirdn2d
+    gen = torch.Generator().manual_seed(up * 7 + n)
+    i, o, h, k = 32, 48, 20, (3 if demod else 1)
+    x = torch.randn(n, i, h, h, generator=gen).to(DEV).requires_grad_(True)
+    st = (torch.randn(1 if shared else n, i, generator=gen) * 0.5 + 1).to(DEV).requires_grad_(True)
+    w = torch.randn(o, i, k, k, generator=gen).to(DEV)
+    oh = h * up
+    noise = torch.randn(oh, oh, generator=gen).to(DEV).requires_grad_(True) if demod else None
+    strength = torch.tensor(0.4, device=DEV) if demod else None
+    bias = torch.randn(o, generator=gen).to(DEV)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    kw = dict(noise=noise, noise_strength=strength, up=up, padding=k // 2, resample_filter=f, demodulate=demod, flip_weight=(up == 1),
+              bias=bias, act=('lrelu' if demod else 'linear'), gain=(1.3 if demod else 1), clamp=(2.5 if demod else 256), style_gain=(1.0 if demod else 0.2))
+    res = []
+    for frozen in (False, True):
+        wt = w.clone().requires_grad_(not frozen)
+        y = modulated_conv2d(x=x, weight=wt, styles=st, **kw)
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(99)).to(DEV)
+        wrt = [x, st] + ([noise] if noise is not None else [])
+        res.append((y, torch.autograd.grad(y, wrt, dy)))
+    (ya, ga), (yb, gb) = res
+    assert_close(yb, ya, 1e-6, 'frozen-weight fwd')
+    for a, b, nm in zip(gb, ga, ('dx', 'dstyles', 'dnoise')):
+        assert_close(a, b, 2e-4, 'frozen-weight ' + nm)
