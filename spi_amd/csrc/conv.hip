@@ -333,7 +333,7 @@ __global__ void conv_epilogue_kernel(float* __restrict__ y, int64_t total, int O
 //   raw-buffer loads (hardware zero-fill out of range, no masks), two register stages, loads of slab
 //   s+2 issued and slab s+1 written to LDS behind the MFMA groups, fragments read one group ahead.
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool F16 = false>
+template <int WM, int WN, int TM, int TN, bool F16 = false, bool FAST = false>
 __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ dout, float* __restrict__ dw,
                                                             int pix_per_block) {
@@ -381,11 +381,38 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     }
     // one tap for the whole tile?  (block-uniform: channel counts that are multiples of the tile width)
     const bool uni = (P.Ci % BN == 0);
+    // FAST (host: Ci % BN == 0, Mo % BM == 0, every class row holds >= BK pixels): the per-q part of every address is a multiple
+    // of ROWSTEP planes, i.e. wave-uniform -> it rides in the buffer instruction's scalar offset, and the pixel cursor advances
+    // incrementally (no division per slab): ~25 vector instructions per slab instead of ~100, all branch-free selects (on
+    // gfx950 each VALU instruction beside the fp32 MFMAs costs ~2.6 matrix-pipe cycles).  The scalar offset is not
+    // range-checked by the hardware, hence the "all rows / channels exist" condition.
+    const int sstepA = __builtin_amdgcn_readfirstlane(ROWSTEP * P.OH * P.OW * 4);
+    const int sstepB = __builtin_amdgcn_readfirstlane(ROWSTEP * P.IH * P.IW * 4);
     struct Stage { float ra[A_PER]; float rb[B_PER]; };
     Stage st0, st1;
+    int curY = 0, curX = 0;                    // FAST: pixel of the next slab to load (load_all is called with pk = pbeg, +BK, +2BK, ...)
+    if (FAST) { const int p0 = min(pbeg + l_p, npix - 1); curY = p0 / C.OWp; curX = p0 - curY * C.OWp; }
     auto load_all = [&](Stage& S, int pk) {
         const int p = pk + l_p;
         const bool pvld = p < pend;
+        if constexpr (FAST) {
+            const int Y = curY, X = curX;
+            const int nx = curX + BK;
+            const bool wrap = nx >= C.OWp;
+            curX = wrap ? nx - C.OWp : nx;
+            curY += wrap ? 1 : 0;
+            const unsigned pixA = pvld ? (unsigned)(((Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox)) * 4) : OOB;
+            const int iy = Y * P.isy + bdy[0], ix = X * P.isx + bdx[0];
+            const bool inb = pvld & (iy >= 0) & (iy < P.IH) & (ix >= 0) & (ix < P.IW);
+            const unsigned pixB = inb ? (unsigned)((iy * P.IW + ix) * 4) : OOB;
+            const unsigned voA = pixA + rowA[0], voB = pixB + chanB[0];
+#pragma unroll
+            for (int q = 0; q < A_PER; ++q)
+                S.ra[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, (int)voA, q * sstepA, 0));
+#pragma unroll
+            for (int q = 0; q < B_PER; ++q)
+                S.rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)voB, q * sstepB, 0));
+        } else {
         const int pc = min(p, npix - 1);
         const int Y = pc / C.OWp, X = pc - Y * C.OWp;
         const unsigned pixA = pvld ? (unsigned)(((Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox)) * 4) : OOB;
@@ -406,6 +433,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
                 const unsigned pixB = (pvld && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) ? (unsigned)((iy * P.IW + ix) * 4) : OOB;
                 S.rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)(chanB[q] + pixB), 0, 0));
             }
+        }
         }
     };
     auto store_a = [&](const Stage& S, int buf, int q) {
@@ -683,8 +711,13 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     int ppb = (int)((maxpix + splits - 1) / splits);
     ppb = std::max(64, ((ppb + BK - 1) / BK) * BK);
     dim3 grid((unsigned)((maxpix + ppb - 1) / ppb), (unsigned)tiles, (unsigned)(P.N * P.ncls));
-    if (d->compute_f16) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, true>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb);
-    else hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb);
+    // measured: the scalar-offset variant wins when a tap is ONE column tile (Ci == 128: +6 %) and loses for Ci >= 256 (-10 %)
+    bool fastw = (P.Ci == BN) && (P.Mo % BM == 0);
+    for (int c = 0; c < P.ncls; ++c) fastw = fastw && P.cls[c].OWp >= BK;
+#define SPI_WG_LAUNCH(F16F, FASTF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, F16F, FASTF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
+    if (d->compute_f16) { if (fastw) SPI_WG_LAUNCH(true, true); else SPI_WG_LAUNCH(true, false); }
+    else { if (fastw) SPI_WG_LAUNCH(false, true); else SPI_WG_LAUNCH(false, false); }
+#undef SPI_WG_LAUNCH
     SPI_LAUNCH_CHECK("spi_conv2d_wgrad");
     return SPI_OK;
 }
