@@ -917,7 +917,13 @@ __global__ void minmax_kernel(const float* __restrict__ x, int64_t n, float* __r
         lo = fminf(lo, v); hi = fmaxf(hi, v);
     }
     lo = wave_min(lo); hi = wave_max(hi);
-    if ((threadIdx.x & 63) == 0) { atomic_min_f(out2, lo); atomic_max_f(out2 + 1, hi); }
+    __shared__ float red[2][4];                  // same-address global atomics serialise (~10 ns each): one pair per block
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = lo; red[1][threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomic_min_f(out2, fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3])));
+        atomic_max_f(out2 + 1, fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1397,7 +1403,7 @@ int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, f
 int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream) {
     SPI_REQUIRE(x && out2 && n > 0, "spi_minmax: bad argument");
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, as_stream(stream), out2);
-    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n, 256 * 8), 1024);
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n, 256 * 8), 512);
     hipLaunchKernelGGL(minmax_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, n, out2);
     SPI_LAUNCH_CHECK("spi_minmax");
     return SPI_OK;
