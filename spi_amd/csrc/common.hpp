@@ -46,6 +46,42 @@ constexpr unsigned BUF_OOB = 0x80000000u;        // beyond any num_records we cr
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int64_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
+// Four 16-byte buffer loads in flight, one wait.  (hipcc 7.2 miscompiles __builtin_amdgcn_raw_buffer_load_b64 / _b128 into a
+// single buffer_load_dword -- only the first component arrives -- hence the inline assembly; the compiler does not track
+// vmcnt for assembly, so the wait has to sit inside the block.)
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+// twelve loads (the 3 x 4 bilinear corners of a tri-plane sample), one wait
+__device__ __forceinline__ void buf_load12_f32x4(__amdgpu_buffer_rsrc_t rs, const unsigned (&o)[12], f32x4_t (&v)[12]) {
+    asm volatile("buffer_load_dwordx4 %0, %12, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %1, %13, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %2, %14, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %3, %15, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %4, %16, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %5, %17, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %6, %18, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %7, %19, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %8, %20, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %9, %21, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %10, %22, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %11, %23, %24, 0 offen\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+                   "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
+                 : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]), "v"(o[8]), "v"(o[9]), "v"(o[10]),
+                   "v"(o[11]), "s"(rs)
+                 : "memory");
+}
+__device__ __forceinline__ void buf_load4_f32x4(__amdgpu_buffer_rsrc_t rs, unsigned o0, unsigned o1, unsigned o2, unsigned o3,
+                                               f32x4_t& v0, f32x4_t& v1, f32x4_t& v2, f32x4_t& v3) {
+    asm volatile("buffer_load_dwordx4 %0, %4, %8, 0 offen\n\t"
+                 "buffer_load_dwordx4 %1, %5, %8, 0 offen\n\t"
+                 "buffer_load_dwordx4 %2, %6, %8, 0 offen\n\t"
+                 "buffer_load_dwordx4 %3, %7, %8, 0 offen\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                 : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rs)
+                 : "memory");
+}
 __device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 0));
 }

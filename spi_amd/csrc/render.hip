@@ -141,9 +141,61 @@ __device__ __forceinline__ void plane_uv(int pl, float x, float y, float z, floa
     gy = (pl == 0) ? y : ((pl == 1) ? z : x);
 }
 
+// Bilinear corner offsets (bytes) into the channels-last planes tensor for the 16-byte piece `sub` of a texel row; corners
+// outside the plane get the out-of-range offset, for which a raw buffer load returns zeros -- no predication, no
+// exec-masked regions, all 12 loads of a point in flight together.
+struct CornerOff { unsigned o00, o01, o10, o11; float w00, w01, w10, w11; };
+__device__ __forceinline__ CornerOff corner_offsets(const Corner& c, int W, int H, unsigned plane_byte_base, int sub) {
+    const bool x0ok = (c.x0 >= 0) & (c.x0 < W), x1ok = (c.x0 + 1 >= 0) & (c.x0 + 1 < W);
+    const bool y0ok = (c.y0 >= 0) & (c.y0 < H), y1ok = (c.y0 + 1 >= 0) & (c.y0 + 1 < H);
+    const unsigned o = plane_byte_base + (unsigned)(((c.y0 * W + c.x0) * DEC_IN + sub * 4) * 4);       // wraps harmlessly when unused
+    CornerOff r;
+    r.o00 = (x0ok & y0ok) ? o : BUF_OOB;
+    r.o01 = (x1ok & y0ok) ? o + DEC_IN * 4 : BUF_OOB;
+    r.o10 = (x0ok & y1ok) ? o + (unsigned)(W * DEC_IN * 4) : BUF_OOB;
+    r.o11 = (x1ok & y1ok) ? o + (unsigned)((W + 1) * DEC_IN * 4) : BUF_OOB;
+    r.w00 = c.wx0 * c.wy0; r.w01 = c.wx1 * c.wy0; r.w10 = c.wx0 * c.wy1; r.w11 = c.wx1 * c.wy1;
+    return r;
+}
+__device__ __forceinline__ void corner_accumulate(float4& acc, __amdgpu_buffer_rsrc_t rs, const CornerOff& k) {
+    f32x4_t v00, v01, v10, v11;
+    buf_load4_f32x4(rs, k.o00, k.o01, k.o10, k.o11, v00, v01, v10, v11);
+    acc.x += v00.x * k.w00 + v01.x * k.w01 + v10.x * k.w10 + v11.x * k.w11;
+    acc.y += v00.y * k.w00 + v01.y * k.w01 + v10.y * k.w10 + v11.y * k.w11;
+    acc.z += v00.z * k.w00 + v01.z * k.w01 + v10.z * k.w10 + v11.z * k.w11;
+    acc.w += v00.w * k.w00 + v01.w * k.w01 + v10.w * k.w10 + v11.w * k.w11;
+}
+
+// One tri-plane sample: 12 corner rows requested together, combined with the bilinear weights, mean over the planes.
+__device__ __forceinline__ float4 gather_point(__amdgpu_buffer_rsrc_t rs, int n, float x, float y, float z, int W, int H, unsigned plane_bytes, int sub) {
+    unsigned o[12]; float w[12];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        float gx, gy;
+        plane_uv(pl, x, y, z, gx, gy);
+        const CornerOff k = corner_offsets(make_corner(gx, gy, W, H), W, H, (unsigned)(n * 3 + pl) * plane_bytes, sub);
+        o[4 * pl] = k.o00; o[4 * pl + 1] = k.o01; o[4 * pl + 2] = k.o10; o[4 * pl + 3] = k.o11;
+        w[4 * pl] = k.w00; w[4 * pl + 1] = k.w01; w[4 * pl + 2] = k.w10; w[4 * pl + 3] = k.w11;
+    }
+    f32x4_t v[12];
+    buf_load12_f32x4(rs, o, v);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {                       // same summation order as before: per plane, then across planes
+        acc.x += v[4 * pl].x * w[4 * pl] + v[4 * pl + 1].x * w[4 * pl + 1] + v[4 * pl + 2].x * w[4 * pl + 2] + v[4 * pl + 3].x * w[4 * pl + 3];
+        acc.y += v[4 * pl].y * w[4 * pl] + v[4 * pl + 1].y * w[4 * pl + 1] + v[4 * pl + 2].y * w[4 * pl + 2] + v[4 * pl + 3].y * w[4 * pl + 3];
+        acc.z += v[4 * pl].z * w[4 * pl] + v[4 * pl + 1].z * w[4 * pl + 1] + v[4 * pl + 2].z * w[4 * pl + 2] + v[4 * pl + 3].z * w[4 * pl + 3];
+        acc.w += v[4 * pl].w * w[4 * pl] + v[4 * pl + 1].w * w[4 * pl + 1] + v[4 * pl + 2].w * w[4 * pl + 2] + v[4 * pl + 3].w * w[4 * pl + 3];
+    }
+    acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+    return acc;
+}
+
 // Phase A shared by forward and backward: feat[s][0..31] = mean over planes of the bilinear samples.
 __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, int64_t total, float* feat) {
     const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);          // host: < 2 GiB
 #pragma unroll 2
     for (int pass = 0; pass < DT / 32; ++pass) {
         const int s = pass * 32 + grp;
@@ -152,26 +204,7 @@ __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, i
         if (g < total) {
             int n; float x, y, z;
             point_xyz(a, g, n, x, y, z);
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                float gx, gy;
-                plane_uv(pl, x, y, z, gx, gy);
-                const Corner c = make_corner(gx, gy, a.W, a.H);
-                const float* pb = a.planes + ((int64_t)(n * 3 + pl) * a.H * a.W) * DEC_IN + sub * 4;
-                const bool x0ok = (c.x0 >= 0) & (c.x0 < a.W), x1ok = (c.x0 + 1 >= 0) & (c.x0 + 1 < a.W);
-                const bool y0ok = (c.y0 >= 0) & (c.y0 < a.H), y1ok = (c.y0 + 1 >= 0) & (c.y0 + 1 < a.H);
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v00 = (x0ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0) * DEC_IN) : z4;
-                const float4 v01 = (x1ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0 + 1) * DEC_IN) : z4;
-                const float4 v10 = (x0ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0) * DEC_IN) : z4;
-                const float4 v11 = (x1ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0 + 1) * DEC_IN) : z4;
-                const float w00 = c.wx0 * c.wy0, w01 = c.wx1 * c.wy0, w10 = c.wx0 * c.wy1, w11 = c.wx1 * c.wy1;
-                acc.x += v00.x * w00 + v01.x * w01 + v10.x * w10 + v11.x * w11;
-                acc.y += v00.y * w00 + v01.y * w01 + v10.y * w10 + v11.y * w11;
-                acc.z += v00.z * w00 + v01.z * w01 + v10.z * w10 + v11.z * w11;
-                acc.w += v00.w * w00 + v01.w * w01 + v10.w * w10 + v11.w * w11;
-            }
-            acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+            acc = gather_point(rs, n, x, y, z, a.W, a.H, plane_bytes, sub);
         }
         *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
     }
@@ -478,6 +511,8 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     // ---- phase A: gather features, 8 lanes per point
     {
     const int sub = t & 7, grp = t >> 3;
+    const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
+    const __amdgpu_buffer_rsrc_t rs_planes = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);  // host: < 2 GiB
 #pragma unroll 2
     for (int pass = 0; pass < DT / 32; ++pass) {
         const int s = pass * 32 + grp;
@@ -485,26 +520,7 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (prow >= 0) {
             const float qx = s_x[s], qy = s_y[s], qz = s_z[s];
-#pragma unroll
-            for (int pl = 0; pl < ((a.dbg & 64) ? 0 : 3); ++pl) {
-                float gx, gy;
-                plane_uv(pl, qx, qy, qz, gx, gy);
-                const Corner c = make_corner(gx, gy, a.W, a.H);
-                const float* pb = a.planes + (int64_t)(n * 3 + pl) * plane_sz + sub * 4;
-                const bool x0ok = (c.x0 >= 0) & (c.x0 < a.W), x1ok = (c.x0 + 1 >= 0) & (c.x0 + 1 < a.W);
-                const bool y0ok = (c.y0 >= 0) & (c.y0 < a.H), y1ok = (c.y0 + 1 >= 0) & (c.y0 + 1 < a.H);
-                const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v00 = (x0ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0) * DEC_IN) : z4;
-                const float4 v01 = (x1ok & y0ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)c.y0 * a.W + c.x0 + 1) * DEC_IN) : z4;
-                const float4 v10 = (x0ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0) * DEC_IN) : z4;
-                const float4 v11 = (x1ok & y1ok) ? *reinterpret_cast<const float4*>(pb + ((int64_t)(c.y0 + 1) * a.W + c.x0 + 1) * DEC_IN) : z4;
-                const float w00 = c.wx0 * c.wy0, w01 = c.wx1 * c.wy0, w10 = c.wx0 * c.wy1, w11 = c.wx1 * c.wy1;
-                acc.x += v00.x * w00 + v01.x * w01 + v10.x * w10 + v11.x * w11;
-                acc.y += v00.y * w00 + v01.y * w01 + v10.y * w10 + v11.y * w11;
-                acc.z += v00.z * w00 + v01.z * w01 + v10.z * w10 + v11.z * w11;
-                acc.w += v00.w * w00 + v01.w * w01 + v10.w * w10 + v11.w * w11;
-            }
-            acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+            if (!(a.dbg & 64)) acc = gather_point(rs_planes, n, qx, qy, qz, a.W, a.H, plane_bytes, sub);
         }
         *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
     }
@@ -1303,6 +1319,7 @@ static int fill_decode_args(DecodeArgs& a, const float* planes, const float* coo
     SPI_REQUIRE(planes && w1 && b1 && w2 && b2, "spi_triplane_decode: null tensor");
     SPI_REQUIRE(out_S == 0 || (ray_o != nullptr && out_off >= 0 && out_off + S <= out_S), "spi_triplane_decode: bad out_S/out_off");
     SPI_REQUIRE(N > 0 && P > 0 && H > 0 && W > 0 && box_warp > 0.f, "spi_triplane_decode: bad size");
+    SPI_REQUIRE((int64_t)N * 3 * H * W * DEC_IN * 4 < ((int64_t)1 << 31), "spi_triplane_decode: the planes tensor must be < 2 GiB (one buffer descriptor)");
     if (ray_o == nullptr) SPI_REQUIRE(coords != nullptr, "spi_triplane_decode: need coords or rays");
     else SPI_REQUIRE(ray_d && depths && S > 0 && P % S == 0, "spi_triplane_decode: rays mode needs ray_d, depths, P %% S == 0");
     a.planes = planes; a.coords = coords; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths;
@@ -1348,6 +1365,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_sigma && d_planes_nhwc && workspace,
                 "spi_triplane_decode_bwd_sorted: null tensor");
     SPI_REQUIRE(N > 0 && M > 0 && S > 0 && H > 0 && W > 0 && box_warp > 0.f && ray_w > 0, "spi_triplane_decode_bwd_sorted: bad size");
+    SPI_REQUIRE((int64_t)N * 3 * H * W * DEC_IN * 4 < ((int64_t)1 << 31), "spi_triplane_decode_bwd_sorted: the planes tensor must be < 2 GiB (one buffer descriptor)");
     const bool wgrad = dw1 != nullptr;
     SPI_REQUIRE(!wgrad || (db1 && dw2 && db2), "spi_triplane_decode_bwd_sorted: the four decoder gradient outputs come together");
     TiledArgs a;
