@@ -961,14 +961,22 @@ __device__ __forceinline__ int64_t row_of(const int32_t* perm, int64_t r, int S,
 template <int NCH>
 __device__ __forceinline__ void march_load(MarchLds& L, const float* __restrict__ densities, const float* __restrict__ depths,
                                            const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane) {
+    // Unconditional loads on clamped indices, in two waves: all permutation entries + depths first, then the densities they
+    // point to.  (Guarded loads compile to one exec-masked region each with a wait in between: 2 * NCH serialised round trips
+    // at the head of every ray.)
+    int pk[NCH]; float dp[NCH], sg[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int k = min(c * 64 + lane, S - 1);
+        pk[c] = perm ? perm[r * S + k] : k;                       // row of sample k inside the ray's S_store rows
+        dp[c] = depths[r * S + k];
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) sg[c] = densities[r * S_store + pk[c]];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int k = c * 64 + lane;
-        if (k < S) {
-            const int pk = perm ? perm[r * S + k] : k;          // row of sample k inside the ray's S_store rows
-            L.row[k] = pk;
-            L.sig[k] = densities[r * S_store + pk]; L.dep[k] = depths[r * S + k];
-        }
+        if (k < S) { L.row[k] = pk[c]; L.sig[k] = sg[c]; L.dep[k] = dp[c]; }
     }
     __builtin_amdgcn_wave_barrier();
 }
