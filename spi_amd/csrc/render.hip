@@ -547,11 +547,14 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         // d_rgb of the lane_'s point straight from HBM (its row is 128 contiguous bytes; each half takes 4 x 16 B), requested
         // now and consumed after the two forward layers
         const int myrow = s_row[pbase + q_];
+        // (unconditional loads on a clamped row, zeroed afterwards: a guarded load `ok ? *p : 0` becomes an exec-masked region
+        // that ends in s_waitcnt vmcnt(0) -- 4 + 16 serialised HBM round trips per 32 points before this was changed)
         float4 dr[4];
         if (RGB) {
+            const float4* drp = reinterpret_cast<const float4*>(d_rgb + (int64_t)max(myrow, 0) * DEC_IN + 4 * hh_);
+            const float keep = myrow >= 0 ? 1.f : 0.f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                dr[g] = myrow >= 0 ? *reinterpret_cast<const float4*>(d_rgb + (int64_t)myrow * DEC_IN + 8 * g + 4 * hh_) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < 4; ++g) { float4 v = drp[2 * g]; dr[g] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep); }
         }
         // H1[j][p] = softplus(W1 F + b1)
         f32x16_t H1[2];
@@ -577,7 +580,8 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int prow2 = s_row[pbase + rowmap(r, hh_)];
-                dr2[r] = prow2 >= 0 ? d_rgb[(int64_t)prow2 * DEC_IN + q_] : 0.f;
+                const float v = d_rgb[(int64_t)max(prow2, 0) * DEC_IN + q_];
+                dr2[r] = prow2 >= 0 ? v : 0.f;
             }
         }
         if (RGB) {
@@ -1119,9 +1123,10 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
     for (int k0 = 0; k0 < S; k0 += 8) {
         const int k = k0 + rg;
         float part = 0.f;
+        // the load is unconditional (clamped row): guarded loads serialise, one exec-masked region + full wait per row group
+        const int64_t row = r * S_store + L.row[min(k, S - 1)];
+        const float4 c = *reinterpret_cast<const float4*>(colors + row * 32 + sub * 4);
         if (k < S) {
-            const int64_t row = r * S_store + L.row[k];
-            const float4 c = *reinterpret_cast<const float4*>(colors + row * 32 + sub * 4);
             part = g4.x * c.x + g4.y * c.y + g4.z * c.z + g4.w * c.w;
             const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
             *reinterpret_cast<float4*>(d_colors + row * 32 + sub * 4) = make_float4(g4.x * v, g4.y * v, g4.z * v, g4.w * v);
