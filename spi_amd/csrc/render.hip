@@ -1028,18 +1028,40 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
     const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
     if (r >= R) return;
     MarchLds& L = lds[wave];
-    march_load<NCH>(L, densities, depths, perm, r, S, S_store, lane);
-    // All colour rows of the ray (NCH*8 float4 per lane, 8 rows = 1 KB per wave-instruction) are requested
-    // BEFORE the scalar phase, so the ~24 KB stream is in flight while the scans and exponentials run.
+    // Round trip 1: the ray's sort permutation and depths.  Round trip 2: the densities they point to AND all colour rows of
+    // the ray (NCH*8 float4 per lane, 8 rows = 1 KB per wave-instruction), requested together so that the ~24 KB stream is in
+    // flight while the densities arrive and the scans and exponentials run.  All loads are unconditional on clamped indices.
     const int sub = lane & 7, rg = lane >> 3;
     float4 creg[NCH * 8];
-    if (rgb != nullptr) {
+    {
+        int pk[NCH]; float dp[NCH], sg[NCH];
 #pragma unroll
-        for (int it = 0; it < NCH * 8; ++it) {
-            const int k = it * 8 + rg;
-            creg[it] = (k < S) ? *reinterpret_cast<const float4*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int c = 0; c < NCH; ++c) {
+            const int k = min(c * 64 + lane, S - 1);
+            pk[c] = perm ? perm[r * S + k] : k;
+            dp[c] = depths[r * S + k];
         }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            if (k < S) { L.row[k] = pk[c]; L.dep[k] = dp[c]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) sg[c] = densities[r * S_store + pk[c]];
+        if (rgb != nullptr) {
+#pragma unroll
+            for (int it = 0; it < NCH * 8; ++it) {
+                const int k = min(it * 8 + rg, S - 1);
+                creg[it] = *reinterpret_cast<const float4*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            if (k < S) L.sig[k] = sg[c];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
     march_scan<NCH>(L, S, lane, alpha, trans, delta, smid);

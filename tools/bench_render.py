@@ -56,6 +56,14 @@ def main():
     t = timeit(lambda: hip.call('spi_raymarch_fwd', hip.ptr(col), hip.ptr(den), hip.ptr(dep), None, hip.ptr(cl), N * 16384, S, S, 32, 0, hip.ptr(rgb), hip.ptr(d), hip.ptr(w), None, hip.stream()), 20)
     by = N * 16384 * (S * 34 * 4 + (33 + S - 1) * 4)
     print(f'  raymarch fwd S=192: {t * 1e3:.1f} us  -> {by / t / 1e6:.0f} GB/s ({by / t / 1e6 / 80:.1f} % of 8 TB/s)')
+    # through a sort permutation like the renderer's (two ascending runs of 96 merged), rgb only (what bench.py times)
+    dc = torch.sort(torch.rand(N * 16384, 96, device=dev), 1)[0]; df = torch.sort(torch.rand(N * 16384, 96, device=dev), 1)[0]
+    dep2, perm = torch.sort(torch.cat([dc, df], 1) + 2.25, 1)
+    perm = perm.int().contiguous(); dep2 = dep2.contiguous()
+    ws = torch.empty(N * 16384, device=dev)
+    t = timeit(lambda: hip.call('spi_raymarch_fwd', hip.ptr(col), hip.ptr(den), hip.ptr(dep2), hip.ptr(perm), hip.ptr(cl), N * 16384, S, S, 32, 0, hip.ptr(rgb), hip.ptr(d), None, hip.ptr(ws), hip.stream()), 20)
+    by = N * 16384 * (S * 34 * 4 + 34 * 4)
+    print(f'  raymarch fwd S=192 via perm, no weights: {t * 1e3:.1f} us  -> {by / t / 1e6:.0f} GB/s ({by / t / 1e6 / 80:.1f} % of 8 TB/s)')
 
 
 if __name__ == '__main__':
