@@ -23,6 +23,7 @@ SHAPES = [  # name, N, I, O, H, k, transposed, per_sample
     ('sr1.torgb 128->3 @512', 1, 128, 3, 512, 1, False, True),
     ('b64.conv1 N=4', 4, 512, 512, 64, 3, False, True),
     ('sr1.conv1 N=4', 4, 128, 128, 512, 3, False, True),
+    ('vgg 3->64 @256 N=4', 4, 3, 64, 256, 3, False, False),
     ('vgg 64->64 @256 N=4', 4, 64, 64, 256, 3, False, False),
     ('vgg 512->512 @32 N=4', 4, 512, 512, 32, 3, False, False),
 ]
