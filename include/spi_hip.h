@@ -85,14 +85,15 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
  * The decoder runs on the fp32 matrix cores and its weight gradients are fused in: with dw1 != NULL the call
  * OVERWRITES dw1 [64,32], db1 [64], dw2 [33,64], db2 [33] (gradients wrt the gained weights w1t^T, b1, w2, b2);
  * dw1 == NULL (all four) = decoder frozen.  d_rgb == NULL = the colour gradient is zero (depth-only loss): the colour
- * layer is skipped.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
+ * layer is skipped.  ray_active (optional, int32 [N*M] from spi_raymarch_bwd): rays flagged 0 are skipped, 8x8 patches
+ * without any active ray cost nothing.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
  * (weight fragments + per-wave partial sums; contents undefined afterwards).  d_planes_nhwc is accumulated into. */
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d,
                                    const float* depths_sorted, const int32_t* perm, const float* w1t,
                                    const float* b1, const float* w2, const float* b2, const float* d_rgb,
                                    const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
                                    float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1,
-                                   float* dw2, float* db2, spi_stream_t stream);
+                                   float* dw2, float* db2, const int32_t* ray_active, spi_stream_t stream);
 int64_t spi_triplane_decode_bwd_sorted_ws(int N, int M, int S, int ray_w);
 
 /* Decoder weight gradients from a dump written by spi_triplane_decode_bwd (rows f | h | d_pre1 | d_y, each
@@ -117,11 +118,13 @@ int spi_raymarch_fwd(const float* colors, const float* densities, const float* d
 
 /* Backward: d_rgb [R,C] (NULL = 0: only the depth map is differentiated -- colors / d_colors are then not touched
  * and may be NULL), d_depth [R] (NULL = 0), d_weights [R,S-1] (NULL = 0) ->
- * d_colors [R,S,C], d_densities [R,S] written through perm like the forward reads. */
+ * d_colors [R,S,C], d_densities [R,S] written through perm like the forward reads.
+ * ray_active (optional, int32 [R]): set to 0 for rays whose incoming gradient is exactly zero -- their rows of d_colors /
+ * d_densities are then NOT written (all zero by definition); pass the same array to spi_triplane_decode_bwd_sorted. */
 int spi_raymarch_bwd(const float* colors, const float* densities, const float* depths,
                      const int32_t* perm, const float* clamp2, const float* d_rgb, const float* d_depth,
                      const float* d_weights, int64_t R, int S, int S_store, int C, int white_back,
-                     float* d_colors, float* d_densities, spi_stream_t stream);
+                     float* d_colors, float* d_densities, int32_t* ray_active, spi_stream_t stream);
 
 /* sample_importance + sample_pdf, renderer.py:194-253.  depths [R,S], weights [R,S-1], u [R,Sf]
  * -> fine depths [R,Sf]: in draw order like the reference (sort_out = 0) or ascending per ray (sort_out = 1;

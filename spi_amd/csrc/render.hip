@@ -444,6 +444,7 @@ __global__ void decoder_partial_reduce_kernel(const float* __restrict__ part, in
 
 struct TiledArgs {
     const float* planes; const float* ray_o; const float* ray_d; const float* depths; const int32_t* perm;
+    const int32_t* ray_active;                // optional per-ray flags from spi_raymarch_bwd: 0 = the ray's gradient rows are all zero (and unwritten)
     int N; int M; int S; int H; int W; float scale;
     int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
     int patches; int kchunks; int tiles;
@@ -492,7 +493,9 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         m = patch * 64 + rl;
     }
     const int k = kc * 4 + kk;
-    const bool valid = (m < a.M) && (k < a.S);
+    bool valid = (m < a.M) && (k < a.S);
+    if (valid && a.ray_active) valid = a.ray_active[(int64_t)n * a.M + m] != 0;
+    if (!__syncthreads_or(valid)) continue;                    // no ray of this patch carries a gradient: nothing to do (block-uniform)
     int row = -1;
     float x = 0.f, y = 0.f, z = 0.f;
     if (valid) {
@@ -552,9 +555,9 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         float4 dr[4];
         if (RGB) {
             const float4* drp = reinterpret_cast<const float4*>(d_rgb + (int64_t)max(myrow, 0) * DEC_IN + 4 * hh_);
-            const float keep = myrow >= 0 ? 1.f : 0.f;
+            const bool keep = myrow >= 0;              // select, not multiply: the clamped row may be an unwritten (inactive-ray) row
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { float4 v = drp[2 * g]; dr[g] = make_float4(v.x * keep, v.y * keep, v.z * keep, v.w * keep); }
+            for (int g = 0; g < 4; ++g) { float4 v = drp[2 * g]; dr[g] = make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f); }
         }
         // H1[j][p] = softplus(W1 F + b1)
         f32x16_t H1[2];
@@ -1116,11 +1119,21 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
         const int32_t* __restrict__ perm, const float* __restrict__ clamp2, const float* __restrict__ d_rgb,
         const float* __restrict__ d_depth, const float* __restrict__ d_weights, int64_t R, int S, int S_store, int white_back,
-        float* __restrict__ d_colors, float* __restrict__ d_densities) {
+        float* __restrict__ d_colors, float* __restrict__ d_densities, int32_t* __restrict__ ray_active) {
     __shared__ MarchLds lds[RM_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
     if (r >= R) return;
+    if (ray_active) {
+        // A ray whose incoming gradient is exactly zero contributes exactly zero everywhere downstream: it is only flagged
+        // (its d_colors / d_densities rows are NOT written and must not be read -- spi_triplane_decode_bwd_sorted takes the
+        // same flags).  SPI's masked pseudo-view losses leave 65-90 % of the rays of those views in this state.
+        bool nz = d_rgb && lane < 32 && d_rgb[r * 32 + lane] != 0.f;
+        if (d_depth && lane == 32) nz = d_depth[r] != 0.f;
+        const bool any = __any(nz) || d_weights != nullptr;
+        if (lane == 0) ray_active[r] = any ? 1 : 0;
+        if (!any) return;
+    }
     MarchLds& L = lds[wave];
     float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
     march_scalars<NCH>(L, densities, depths, perm, r, S, S_store, lane, alpha, trans, delta, smid);
@@ -1396,7 +1409,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
                                    const int32_t* perm, const float* w1t, const float* b1, const float* w2, const float* b2,
                                    const float* d_rgb, const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
                                    float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1, float* dw2,
-                                   float* db2, spi_stream_t stream) {
+                                   float* db2, const int32_t* ray_active, spi_stream_t stream) {
     SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_sigma && d_planes_nhwc && workspace,
                 "spi_triplane_decode_bwd_sorted: null tensor");
     SPI_REQUIRE(N > 0 && M > 0 && S > 0 && H > 0 && W > 0 && box_warp > 0.f && ray_w > 0, "spi_triplane_decode_bwd_sorted: bad size");
@@ -1404,7 +1417,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     const bool wgrad = dw1 != nullptr;
     SPI_REQUIRE(!wgrad || (db1 && dw2 && db2), "spi_triplane_decode_bwd_sorted: the four decoder gradient outputs come together");
     TiledArgs a;
-    a.planes = planes_nhwc; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths_sorted; a.perm = perm;
+    a.planes = planes_nhwc; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths_sorted; a.perm = perm; a.ray_active = ray_active;
     a.N = N; a.M = M; a.S = S; a.H = H; a.W = W; a.scale = 2.f / box_warp; a.ray_w = ray_w;
     a.patch2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
     a.patches = a.patch2d ? M / 64 : (M + 63) / 64;
@@ -1483,7 +1496,8 @@ int spi_raymarch_fwd(const float* colors, const float* densities, const float* d
 
 int spi_raymarch_bwd(const float* colors, const float* densities, const float* depths, const int32_t* perm,
                      const float* clamp2, const float* d_rgb, const float* d_depth, const float* d_weights, int64_t R,
-                     int S, int S_store, int C, int white_back, float* d_colors, float* d_densities, spi_stream_t stream) {
+                     int S, int S_store, int C, int white_back, float* d_colors, float* d_densities, int32_t* ray_active,
+                     spi_stream_t stream) {
     SPI_REQUIRE(S_store >= S, "spi_raymarch_bwd: S_store must be >= S");
     SPI_REQUIRE(densities && depths && d_densities && R > 0 && (d_rgb == nullptr || colors != nullptr), "spi_raymarch_bwd: null tensor");
     SPI_REQUIRE(S >= 2 && S <= MAXS, "spi_raymarch_bwd: need 2 <= S <= %d, got %d", MAXS, S);
@@ -1493,7 +1507,7 @@ int spi_raymarch_bwd(const float* colors, const float* densities, const float* d
     dim3 grid((unsigned)ceil_div64(R, RM_WAVES)), block(64 * RM_WAVES);
     const int nch = (S + 63) / 64;
 #define LAUNCH_BWD(NCH) hipLaunchKernelGGL(raymarch_bwd_kernel<NCH>, grid, block, 0, as_stream(stream), colors, densities, \
-                                          depths, perm, clamp2, d_rgb, d_depth, d_weights, R, S, S_store, white_back, d_colors, d_densities)
+                                          depths, perm, clamp2, d_rgb, d_depth, d_weights, R, S, S_store, white_back, d_colors, d_densities, ray_active)
     switch (nch) { case 1: LAUNCH_BWD(1); break; case 2: LAUNCH_BWD(2); break; case 3: LAUNCH_BWD(3); break; default: LAUNCH_BWD(4); }
 #undef LAUNCH_BWD
     SPI_LAUNCH_CHECK("spi_raymarch_bwd");

@@ -32,12 +32,12 @@ _SIGS = {
     'spi_nhwc_to_nchw': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     'spi_triplane_decode_fwd': ([c_p] * 9 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_triplane_decode_bwd': ([c_p] * 11 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
-    'spi_triplane_decode_bwd_sorted': ([c_p] * 11 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f] + [c_p] * 7, c_i),
+    'spi_triplane_decode_bwd_sorted': ([c_p] * 11 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f] + [c_p] * 8, c_i),
     'spi_triplane_decode_bwd_sorted_ws': ([c_i, c_i, c_i, c_i], c_l),
     'spi_decoder_wgrad': ([c_p, c_l, c_p, c_p, c_p, c_p, c_p], c_i),
     'spi_minmax': ([c_p, c_l, c_p, c_p], c_i),
     'spi_raymarch_fwd': ([c_p] * 5 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 5, c_i),
-    'spi_raymarch_bwd': ([c_p] * 8 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 3, c_i),
+    'spi_raymarch_bwd': ([c_p] * 8 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 4, c_i),
     'spi_importance_sample': ([c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p], c_i),
     'spi_merge_sort_depths': ([c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_bias_act': ([c_p] * 6 + [c_l, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p], c_i),

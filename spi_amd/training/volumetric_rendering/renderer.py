@@ -19,6 +19,7 @@ Only the scalar ``ray_start``/``ray_end`` branch (renderer.py:188-190) is implem
 the FFHQ configuration takes; 'auto' ray limits and disparity-space sampling raise.
 """
 import math
+import os
 import torch
 
 from ... import hip
@@ -175,13 +176,23 @@ class _Render(torch.autograd.Function):
         dev = planes_nhwc.device
         if d_rgb is None and d_depth is None:
             return (None,) * 11
+        if os.environ.get('SPI_DEBUG_SPARSITY'):                  # debugging aid: how many rays carry a gradient at all
+            z = torch.ones(n, m, dtype=torch.bool, device=dev)
+            if d_rgb is not None:
+                z &= (d_rgb.reshape(n, m, -1) == 0).all(-1)
+            if d_depth is not None:
+                z &= (d_depth.reshape(n, m) == 0)
+            print(f'[sparsity] render backward N={n}: {float(z.float().mean()) * 100:.1f} % of rays have an all-zero gradient', flush=True)
         # d_rgb None: only the depth map feeds the loss (SPI's depth branch) -> no colour gradient buffers or traffic at all
         d_rgb = d_rgb.contiguous().float() if d_rgb is not None else None
         dd = d_depth.contiguous().float() if d_depth is not None else None
         d_col = torch.empty_like(rgb_all) if d_rgb is not None else None
         d_sig = torch.empty_like(sig_all)
+        # rays with an exactly-zero incoming gradient (SPI's masked pseudo-view losses: 65-90 % of those views) are flagged by
+        # the march backward and skipped by the decoder backward; their rows of d_col / d_sig stay unwritten
+        active = torch.empty(r, device=dev, dtype=torch.int32)
         hip.call('spi_raymarch_bwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), hip.ptr(d_rgb),
-                 hip.ptr(dd), None, r, s, s, 32, white_back, hip.ptr(d_col), hip.ptr(d_sig), hip.stream())
+                 hip.ptr(dd), None, r, s, s, 32, white_back, hip.ptr(d_col), hip.ptr(d_sig), hip.ptr(active), hip.stream())
         want_w = any(ctx.needs_input_grad[1:5])
         d_planes = torch.zeros_like(planes_nhwc)
         # one pass over all Sc+Sf samples in sorted order, 8x8 ray patches (LDS-aggregated scatter)
@@ -194,7 +205,7 @@ class _Render(torch.autograd.Function):
             gw = (torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev))
         hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes_nhwc), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(d_all), hip.ptr(perm),
                  hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_col), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
-                 hip.ptr(d_planes), hip.ptr(ws), *([hip.ptr(g) for g in gw] if want_w else [None] * 4), hip.stream())
+                 hip.ptr(d_planes), hip.ptr(ws), *([hip.ptr(g) for g in gw] if want_w else [None] * 4), hip.ptr(active), hip.stream())
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
         if want_w:

@@ -34,7 +34,7 @@ for wgrad in (False, True):
     gw = [torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev)]
     hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(depths), None, hip.ptr(w1t), hip.ptr(b1),
              hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), hip.ptr(d_sig), N, M, S, res, H, H, 1.0, hip.ptr(dp), hip.ptr(ws),
-             *([hip.ptr(g) for g in gw] if wgrad else [None] * 4), hip.stream())
+             *([hip.ptr(g) for g in gw] if wgrad else [None] * 4), None, hip.stream())
     torch.cuda.synchronize()
     e = (dp - dp_ref).abs()
     print(f'wgrad={wgrad}: d_planes max|ref| {dp_ref.abs().max():.4e} max err {e.max():.4e} mean err {e.mean():.4e} frac>1e-4*max {(e > 1e-4 * dp_ref.abs().max()).float().mean():.4f}')
