@@ -169,6 +169,11 @@ int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, floa
 int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C, int64_t HW, const float* bias,
                  const float* noise, const float* noise_gain, int act, float alpha, float gain, spi_stream_t stream);
 
+/* flags[n, s] = 1 if any x[n, c, 16 s .. 16 s + 15] != 0 over all channels c (flat pixel index over H*W), else 0;
+ * flags holds N * ceil(HW / 16) entries.  Feeds spi_conv_desc.dy_seg_flags. */
+#define SPI_SEG_PIXELS 16
+int spi_seg_flags(const float* x, int32_t* flags, int N, int C, int64_t HW, spi_stream_t stream);
+
 /* upfirdn2d.cpp:20 `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`.
  *   x [N,C,inH,inW] (dense NCHW), f [fH,fW]; y [N,C,outH,outW] with the reference's output-size rule.
  * Optional fused epilogue (NULL / act = 0 disables): y = bias_act(y + noise[outH,outW]*noise_gain[0], bias[C]). */
@@ -210,6 +215,11 @@ typedef struct spi_conv_desc {
     const float* noise;       /* [OH,OW] */
     const float* noise_gain;  /* [1] device scalar */
     int act; float alpha, gain, clamp;
+    /* backward passes only (optional, NULL = dense): spi_seg_flags() of the output gradient `dy`.  Masked losses leave whole
+     * regions of dy exactly zero; dgrad then skips output tiles whose receptive field holds no flagged segment (writing
+     * zeros) and wgrad reduces over the flagged 16-pixel slabs only -- the results are those of the dense kernels up to
+     * the order of the fp32 sums. */
+    const int32_t* dy_seg_flags;
 } spi_conv_desc;
 /* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
  * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).

@@ -41,6 +41,8 @@ struct IGemmParams {
     int64_t w_elems;        // elements of one sample's weight tensor (buffer-descriptor range)
     int ncls;
     ClassParams cls[4];
+    // optional zero-segment map of the backward passes' gradient operand (spi_conv_desc.dy_seg_flags): [N, nseg] over flat pixels / 16
+    const int32_t* seg_flags; int nseg;
 };
 
 // k -> (channel, tap) for k = c*T + t.  T == 1 is special-cased (ceil(2^32/1) does not fit 32 bits).
@@ -117,6 +119,35 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     const float* inb = in + (int64_t)n * P.in_bs;
     const float* wb = wgt + (int64_t)n * P.wbs;
     const int64_t chs = (int64_t)P.IH * P.IW;
+
+    // ---- sparse gradient operand (dgrad only; host guarantees ncls == 1, unit output strides, no split-K): when no flagged segment
+    //      intersects the tile's receptive field the accumulators would stay exactly 0 -> write the zeros and leave.
+    if (!SPLITK && P.seg_flags) {
+        const int pl = min(p0 + BN, npix) - 1;
+        const int Y0 = p0 / C.OWp, Y1 = pl / C.OWp;
+        int dymin = 0, dymax = 0, dxmin = 0, dxmax = 0;
+        for (int t = 0; t < T; ++t) {
+            dymin = min(dymin, C.taps.dy[t]); dymax = max(dymax, C.taps.dy[t]);
+            dxmin = min(dxmin, C.taps.dx[t]); dxmax = max(dxmax, C.taps.dx[t]);
+        }
+        int xlo = 0, xhi = P.IW - 1;
+        if (Y0 == Y1) { xlo = max((p0 - Y0 * C.OWp) * P.isx + dxmin, 0); xhi = min((pl - Y0 * C.OWp) * P.isx + dxmax, P.IW - 1); }
+        const int ylo = max(Y0 * P.isy + dymin, 0), yhi = min(Y1 * P.isy + dymax, P.IH - 1);
+        const int32_t* fl = P.seg_flags + (int64_t)n * P.nseg;
+        int any = 0;
+        for (int iy = ylo; iy <= yhi; ++iy) {
+            const int s1 = (iy * P.IW + xhi) >> 4;
+            for (int sg = ((iy * P.IW + xlo) >> 4) + tid; sg <= s1; sg += NT) any |= fl[sg];
+        }
+        if (!__syncthreads_or(any)) {
+            float* ob = out + (int64_t)n * P.out_bs;
+            for (int e = tid; e < BM * BN; e += NT) {
+                const int m = m0 + e / BN, pp = p0 + e % BN;
+                if (m < P.Mo && pp < npix) ob[(int64_t)m * npix + pp] = 0.f;
+            }
+            return;
+        }
+    }
 
     // ---- per-thread load coordinates
     const int a_k = AMF ? tid / BM : tid % BK, a_m = AMF ? tid % BM : tid / BK;
@@ -333,7 +364,11 @@ __global__ void conv_epilogue_kernel(float* __restrict__ y, int64_t total, int O
 //   raw-buffer loads (hardware zero-fill out of range, no masks), two register stages, loads of slab
 //   s+2 issued and slab s+1 written to LDS behind the MFMA groups, fragments read one group ahead.
 // -------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, bool F16 = false, bool FAST = false>
+//   SPARSE: P.seg_flags marks the 16-pixel segments of dOut that hold a non-zero; a block first compacts the slabs of its pixel
+//   range whose dOut segments are flagged into an LDS list and then runs the pipeline over that list only (masked losses: most
+//   slabs multiply by an all-zero A operand).
+constexpr int WG_LISTMAX = 2048;
+template <int WM, int WN, int TM, int TN, bool F16 = false, bool FAST = false, bool SPARSE = false>
 __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ dout, float* __restrict__ dw,
                                                             int pix_per_block) {
@@ -452,7 +487,42 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nslab = (pend - pbeg + BK - 1) / BK;
+    static_assert(!(SPARSE && FAST), "the incremental cursor of FAST needs consecutive slabs");
+    int nslab = (pend - pbeg + BK - 1) / BK;
+    __shared__ unsigned short s_list[SPARSE ? WG_LISTMAX : 1];
+    __shared__ int s_nnz;
+    if constexpr (SPARSE) {
+        if (wave == 0) {
+            const int32_t* fl = P.seg_flags + (int64_t)n * P.nseg;
+            // is any segment of dOut flat pixels [lo, hi] flagged?
+            auto range_nz = [&](int lo, int hi) { int a = 0; for (int sg = lo >> 4; sg <= (hi >> 4); ++sg) a |= fl[sg]; return a != 0; };
+            int cnt = 0;
+            for (int b = 0; b < nslab; b += 64) {
+                const int k = b + lane;
+                bool nz = false;
+                if (k < nslab) {
+                    const int pa = pbeg + k * BK, pb = min(pa + BK, pend) - 1;
+                    const int Ya = pa / C.OWp, Xa = pa - Ya * C.OWp, Yb = pb / C.OWp, Xb = pb - Yb * C.OWp;
+                    const int ra = (Ya * P.osy + C.ooy) * P.OW + C.oox, rb = (Yb * P.osy + C.ooy) * P.OW + C.oox;
+                    if (Ya == Yb) nz = range_nz(ra + Xa * P.osx, ra + Xb * P.osx);
+                    else if (Yb == Ya + 1) nz = range_nz(ra + Xa * P.osx, ra + (C.OWp - 1) * P.osx) || range_nz(rb, rb + Xb * P.osx);
+                    else nz = true;                                  // rows shorter than a slab: no filtering
+                }
+                const unsigned long long mk = __ballot(nz);
+                if (nz) s_list[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)k;
+                cnt += __popcll(mk);
+            }
+            if (lane == 0) s_nnz = cnt;
+        }
+        __syncthreads();
+        nslab = s_nnz;
+        if (nslab == 0) return;                                      // dw was zeroed by the host
+    }
+    // pixel index of the i-th slab this block reduces (past the end: pend -> every element out of range -> zeros)
+    auto slab_pk = [&](int i) {
+        if constexpr (SPARSE) return i < nslab ? pbeg + (int)s_list[i] * BK : pend;
+        else return pbeg + i * BK;
+    };
     const int fr = lane & 31, fk = lane >> 5;
     auto step = [&](int s, int buf, Stage& L, const Stage& W) {
         constexpr int NK = F16 ? BK / 8 : BK / 2;
@@ -480,7 +550,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
                     else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (kk == 0) load_all(L, pbeg + (s + 2) * BK);      // slab s+2 (beyond pend: every element out of range -> zeros)
+            if (kk == 0) load_all(L, slab_pk(s + 2));           // slab s+2 (beyond pend: every element out of range -> zeros)
             if (kk >= NK / 2) {
 #pragma unroll
                 for (int q = 0; q < A_PER; ++q) if (q * (NK / 2) / A_PER == kk - NK / 2) store_a(W, buf ^ 1, q);
@@ -491,12 +561,12 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
         }
         __syncthreads();
     };
-    load_all(st0, pbeg);
+    load_all(st0, slab_pk(0));
 #pragma unroll
     for (int q = 0; q < A_PER; ++q) store_a(st0, 0, q);
 #pragma unroll
     for (int q = 0; q < B_PER; ++q) store_b(st0, 0, q);
-    load_all(st1, pbeg + BK);
+    load_all(st1, slab_pk(1));
     __syncthreads();
     for (int s = 0; s < nslab; s += 2) {
         step(s, 0, st0, st1);
@@ -552,6 +622,7 @@ static void make_forward(const spi_conv_desc* d, IGemmParams& P) {
     int OH, OW; out_dims(d, OH, OW);
     const int kk = d->kh * d->kw;
     P.N = d->N; P.Mo = d->O; P.Ci = d->I; P.IH = d->H; P.IW = d->W; P.OH = OH; P.OW = OW;
+    P.seg_flags = nullptr; P.nseg = 0;
     P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->I * d->H * d->W; P.out_bs = (int64_t)d->O * OH * OW;
     P.w_elems = (int64_t)d->O * d->I * kk;
     if (!d->transposed) {
@@ -586,6 +657,7 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
     int OH, OW; out_dims(d, OH, OW);
     const int kk = d->kh * d->kw;
     P.N = d->N; P.Mo = d->I; P.Ci = d->O; P.IH = OH; P.IW = OW; P.OH = d->H; P.OW = d->W;
+    P.seg_flags = d->dy_seg_flags; P.nseg = (int)(((int64_t)OH * OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS);
     P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->O * OH * OW; P.out_bs = (int64_t)d->I * d->H * d->W;
     P.w_elems = (int64_t)d->O * d->I * kk;
     P.osy = P.osx = 1; P.ncls = 1;
@@ -714,9 +786,12 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     // measured: the scalar-offset variant wins when a tap is ONE column tile (Ci == 128: +6 %) and loses for Ci >= 256 (-10 %)
     bool fastw = (P.Ci == BN) && (P.Mo % BM == 0);
     for (int c = 0; c < P.ncls; ++c) fastw = fastw && P.cls[c].OWp >= BK;
-#define SPI_WG_LAUNCH(F16F, FASTF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, F16F, FASTF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
-    if (d->compute_f16) { if (fastw) SPI_WG_LAUNCH(true, true); else SPI_WG_LAUNCH(true, false); }
-    else { if (fastw) SPI_WG_LAUNCH(false, true); else SPI_WG_LAUNCH(false, false); }
+    const bool sparse = d->dy_seg_flags != nullptr && ppb / BK <= WG_LISTMAX;
+    if (sparse) { P.seg_flags = d->dy_seg_flags; P.nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
+#define SPI_WG_LAUNCH(F16F, FASTF, SPF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, F16F, FASTF, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
+    if (sparse) { if (d->compute_f16) SPI_WG_LAUNCH(true, false, true); else SPI_WG_LAUNCH(false, false, true); }
+    else if (d->compute_f16) { if (fastw) SPI_WG_LAUNCH(true, true, false); else SPI_WG_LAUNCH(true, false, false); }
+    else { if (fastw) SPI_WG_LAUNCH(false, true, false); else SPI_WG_LAUNCH(false, false, false); }
 #undef SPI_WG_LAUNCH
     SPI_LAUNCH_CHECK("spi_conv2d_wgrad");
     return SPI_OK;

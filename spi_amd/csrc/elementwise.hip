@@ -759,6 +759,42 @@ __global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t*
 }
 
 // ================================================================================================
+// flags[n, s] = any(x[n, :, 16 s .. 16 s + 15] != 0): one block per 1024 pixels of one sample, lanes along pixels (coalesced rows),
+// every thread ORs the bit patterns of its 4 pixels over all channels, segments are combined through LDS.
+__global__ void __launch_bounds__(256) seg_flags_kernel(const float* __restrict__ x, int32_t* __restrict__ flags, int C, int64_t HW, int nseg) {
+    __shared__ int s_f[64];
+    const int tid = threadIdx.x, n = blockIdx.y;
+    const int64_t base = (int64_t)blockIdx.x * 1024;
+    if (tid < 64) s_f[tid] = 0;
+    __syncthreads();
+    const unsigned* xb = reinterpret_cast<const unsigned*>(x) + (int64_t)n * C * HW;
+    int64_t pix[4]; bool ok[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int64_t p = base + tid + 256 * k; ok[k] = p < HW; pix[k] = ok[k] ? p : HW - 1; }
+    unsigned acc[4] = {0u, 0u, 0u, 0u};
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {
+        unsigned v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[u][k] = xb[(int64_t)(c + u) * HW + pix[k]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[k] |= v[u][k];
+    }
+    for (; c < C; ++c)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[k] |= xb[(int64_t)c * HW + pix[k]];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (ok[k] && (acc[k] << 1) != 0u) s_f[(tid + 256 * k) >> 4] = 1;      // << 1: -0.0 counts as zero
+    __syncthreads();
+    const int seg = blockIdx.x * 64 + tid;
+    if (tid < 64 && seg < nseg) flags[(int64_t)n * nseg + seg] = s_f[tid];
+}
+
 extern "C" {
 
 int spi_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y, int64_t n,
@@ -830,6 +866,14 @@ int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C
     dim3 grid((unsigned)ceil_div64(HW, per_block), (unsigned)rows);
     hipLaunchKernelGGL(chan_dot_kernel, grid, dim3(256), 0, as_stream(stream), a, b, out, C, HW, per_block, bias, noise, noise_gain, act, alpha, gain);
     SPI_LAUNCH_CHECK("spi_chan_dot");
+    return SPI_OK;
+}
+
+int spi_seg_flags(const float* x, int32_t* flags, int N, int C, int64_t HW, spi_stream_t stream) {
+    SPI_REQUIRE(x && flags && N > 0 && N < 65536 && C > 0 && HW > 0 && HW < (1ll << 31), "spi_seg_flags: bad argument");
+    const int nseg = (int)ceil_div64(HW, SPI_SEG_PIXELS);
+    hipLaunchKernelGGL(seg_flags_kernel, dim3((unsigned)ceil_div64(HW, 1024), (unsigned)N), dim3(256), 0, as_stream(stream), x, flags, C, HW, nseg);
+    SPI_LAUNCH_CHECK("spi_seg_flags");
     return SPI_OK;
 }
 

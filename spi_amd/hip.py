@@ -21,7 +21,7 @@ c_p = ctypes.c_void_p
 class ConvDesc(ctypes.Structure):
     _fields_ = [('N', c_i), ('I', c_i), ('O', c_i), ('H', c_i), ('W', c_i), ('kh', c_i), ('kw', c_i), ('pad', c_i),
                 ('transposed', c_i), ('flip', c_i), ('w_tap_major', c_i), ('compute_f16', c_i), ('w_batch_stride', c_l), ('bias', c_p), ('noise', c_p),
-                ('noise_gain', c_p), ('act', c_i), ('alpha', c_f), ('gain', c_f), ('clamp', c_f)]
+                ('noise_gain', c_p), ('act', c_i), ('alpha', c_f), ('gain', c_f), ('clamp', c_f), ('dy_seg_flags', c_p)]
 
 
 _SIGS = {
@@ -40,6 +40,7 @@ _SIGS = {
     'spi_raymarch_bwd': ([c_p] * 8 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 4, c_i),
     'spi_importance_sample': ([c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p], c_i),
     'spi_merge_sort_depths': ([c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p], c_i),
+    'spi_seg_flags': ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     'spi_bias_act': ([c_p] * 6 + [c_l, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_upfirdn2d': ([c_p] * 3 + [c_i] * 15 + [c_f, c_i, c_i] + [c_p] * 3 + [c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_filtered_lrelu': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f, c_i, c_i, c_i, c_p], c_i),

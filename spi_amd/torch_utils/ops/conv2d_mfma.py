@@ -14,16 +14,43 @@ Replaces what the reference gets from cuDNN through ``conv2d_gradfix.conv2d`` / 
 An optional fused epilogue applies ``+ noise * strength``, ``+ bias``, activation, gain, clamp to the
 accumulators (SynthesisLayer.forward tail, networks_stylegan2.py:320-329) for stride-1 convs.
 """
+import contextlib
 import ctypes
 import torch
 from ... import hip
 from . import bias_act as _ba
 
+# Sparse output gradients.  SPI's pseudo-view losses are masked (visibility / foreground masks, rot_bbox_cx_coach.py:94-140 of the
+# reference): most pixels of d(image) are exactly zero, and so are the gradients arriving at the super-resolution convolutions.
+# Inside ``with sparse_gradients():`` the backward of large convs first maps the all-zero 16-pixel segments of dy
+# (spi_seg_flags) and hands the map to dgrad / wgrad, which skip them.  Results equal the dense kernels' up to fp32 summation order.
+_sparse = [False]
+SPARSE_MIN_PIXELS = 128 * 128
+
+
+@contextlib.contextmanager
+def sparse_gradients(enabled=True):
+    old = _sparse[0]
+    _sparse[0] = bool(enabled)
+    try:
+        yield
+    finally:
+        _sparse[0] = old
+
+
+def seg_flags(x):
+    """[N, C, H, W] -> int32 [N, ceil(H*W/16)]: 1 where the 16-pixel segment (flat index) holds a non-zero in any channel."""
+    n, c = x.shape[0], x.shape[1]
+    hw = x[0, 0].numel()
+    flags = torch.empty(n, (hw + 15) // 16, device=x.device, dtype=torch.int32)
+    hip.call('spi_seg_flags', hip.ptr(x), hip.ptr(flags), n, c, hw, hip.stream())
+    return flags
+
 
 def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0, tap_major=0,
-          f16=0):
+          f16=0, dy_flags=None):
     return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), int(f16), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
-                        act, alpha, gain, clamp)
+                        act, alpha, gain, clamp, hip.ptr(dy_flags))
 
 
 def out_size(h, k, pad, transposed):
@@ -32,7 +59,7 @@ def out_size(h, k, pad, transposed):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, f16=False):
+    def forward(ctx, x, w, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, f16=False, may_be_sparse=False):
         # w is TAP-MAJOR here: [O, k, k, I] or [N, O, k, k, I]
         x = x.contiguous().float()
         w = w.contiguous().float()
@@ -50,19 +77,21 @@ class _Conv2d(torch.autograd.Function):
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
         ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)
-        ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16)
+        ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16, may_be_sparse)
         return y
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, w, y, nz, ng = ctx.saved_tensors
-        pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16 = ctx.cfg
+        pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16, may_be_sparse = ctx.cfg
         n, i, h, wd = x.shape
         o, k = w.shape[-4], w.shape[-2]
         dz, d_noise, d_strength, d_bias = _ba.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
                                                             ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2])
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16)
+        # (only convs that opted in -- the generator's; the loss networks behind the masks see dense gradients)
+        flags = seg_flags(dz) if (_sparse[0] and may_be_sparse and dz.shape[2] * dz.shape[3] >= SPARSE_MIN_PIXELS) else None
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16, dy_flags=flags)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
@@ -70,7 +99,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(dz), hip.ptr(dw), hip.stream())
-        return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None, None
+        return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None, None, None
 
 
 def to_tap_major(w):
@@ -79,10 +108,11 @@ def to_tap_major(w):
 
 
 def conv2d(x, w, bias=None, noise=None, noise_strength=None, padding=0, transposed=False, flip=False, act=None, alpha=None,
-           gain=None, clamp=None, tap_major=False, fp16=False):
+           gain=None, clamp=None, tap_major=False, fp16=False, sparse_grad=False):
     """x [N,I,H,W]; w [O,I,k,k] (shared) or [N,O,I,k,k] (per sample) -- or already [.., O,k,k,I] with tap_major=True.
     act=None -> no activation/gain/clamp.  fp16: operands rounded to fp16 on their way into the matrix cores (fp32 accumulate,
-    fp32 tensors) in all three passes -- the reference's `use_fp16` blocks."""
+    fp32 tensors) in all three passes -- the reference's `use_fp16` blocks.  sparse_grad: this conv's output gradient may hold large
+    exactly-zero regions; its backward maps and skips them when run inside ``with sparse_gradients():``."""
     if not tap_major:
         w = to_tap_major(w)
     if act is None:
@@ -93,4 +123,4 @@ def conv2d(x, w, bias=None, noise=None, noise_strength=None, padding=0, transpos
         a = float(d_alpha if alpha is None else alpha)
         g = float(d_gain if gain is None else gain)
         c = float(-1 if clamp is None else clamp)
-    return _Conv2d.apply(x, w, bias, noise, noise_strength, int(padding), bool(transposed), bool(flip), act_id, a, g, c, bool(fp16))
+    return _Conv2d.apply(x, w, bias, noise, noise_strength, int(padding), bool(transposed), bool(flip), act_id, a, g, c, bool(fp16), bool(sparse_grad))

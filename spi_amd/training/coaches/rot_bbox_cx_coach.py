@@ -22,6 +22,7 @@ from ...utils.rotate import rotate
 from ...utils.mask_utils import calculate_face_mask
 from ...utils.camera_utils import cal_mirror_c, cal_camera_weight, sample_surrounding_camera, sample_camera, cal_camera_gauss_weight
 from ...utils.rng import DeviceRNG
+from ...torch_utils.ops.conv2d_mfma import sparse_gradients
 from .base_coach import BaseCoach
 
 
@@ -84,7 +85,8 @@ class RotBboxCoach(BaseCoach):
                                              src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
                                              src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
                 losses['rot'] = self.lpips_loss(gs['image'] * warp_mask, warp_img) * hp.pt_rot_lambda * rot_bs
-                losses['rot'].backward()
+                with sparse_gradients():                            # d(image) is zero outside warp_mask
+                    losses['rot'].backward()
             if hp.pt_mirror_rot_lambda > 0 and ctx['weight_m'] > 0:
                 cams_m = sample_surrounding_camera(ctx['camera_m'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                    rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
@@ -95,7 +97,8 @@ class RotBboxCoach(BaseCoach):
                 flip_warp, flip_mask = torch.flip(warp_m, dims=[3]), torch.flip(mask_m, dims=[3])
                 losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
                                                         ctx['lm'].repeat(rot_bs, 1, 1), plan=ctx.get('box_plan')) * hp.pt_mirror_rot_lambda * rot_bs
-                losses['mirror_rot'].backward()
+                with sparse_gradients():
+                    losses['mirror_rot'].backward()
             if hp.pt_depth_lambda > 0:
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
                 sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True)['image_depth']

@@ -176,10 +176,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
         w = w[0]
     if up == 1:
         return conv2d_mfma.conv2d(x, w, bias=bias, noise=noise, noise_strength=noise_strength, padding=padding,
-                                  flip=not flip_weight, act=act, gain=gain, clamp=clamp, tap_major=True, fp16=fp16)
+                                  flip=not flip_weight, act=act, gain=gain, clamp=clamp, tap_major=True, fp16=fp16, sparse_grad=True)
     # up = 2: stride-2 transposed conv, then the 4x4 low-pass (gain up^2) with the layer tail fused in
     assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
-    z = conv2d_mfma.conv2d(x, w, transposed=True, flip=flip_weight, tap_major=True, fp16=fp16)
+    z = conv2d_mfma.conv2d(x, w, transposed=True, flip=flip_weight, tap_major=True, fp16=fp16, sparse_grad=True)
     return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
                                         padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
 

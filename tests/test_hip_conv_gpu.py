@@ -188,3 +188,64 @@ def test_frozen_weight_modconv_style_gradient(up, demod, shared, n):
     assert_close(yb, ya, 1e-6, 'frozen-weight fwd')
     for a, b, nm in zip(gb, ga, ('dx', 'dstyles', 'dnoise')):
         assert_close(a, b, 2e-4, 'frozen-weight ' + nm)
+
+
+def _masked_gradient(shape, gen, kind):
+    """dy with exactly-zero regions like the masked pseudo-view losses leave: blobs / a box / everything / nothing."""
+    n, o, h, w = shape
+    dy = torch.randn(shape, generator=gen)
+    m = torch.zeros(n, 1, h, w)
+    if kind == 'box':
+        m[:, :, h // 3: h // 3 + max(h // 5, 2), w // 4: w // 4 + max(w // 3, 2)] = 1
+    elif kind == 'blobs':
+        m = (F.avg_pool2d(torch.rand(n, 1, h, w, generator=gen), 9, 1, 4) > 0.56).float()
+    elif kind == 'pixel':
+        m[0, 0, h - 1, w - 1] = 1
+        m[-1, 0, 0, 0] = 1
+    elif kind == 'dense':
+        m[:] = 1
+    return dy * m                                                                     # kind == 'empty': all zero
+
+
+def test_seg_flags_vs_torch():
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(5)
+    for shape in [(2, 5, 37, 41), (1, 3, 128, 128), (3, 17, 33, 64)]:
+        x = _masked_gradient(shape, gen, 'blobs')
+        x[0, 0, 0, 3] = -0.0                                                          # a negative zero is still zero
+        fl = conv2d_mfma.seg_flags(x.to(DEV)).cpu()
+        hw = shape[2] * shape[3]
+        nz = (x != 0).any(1).reshape(shape[0], hw).float()
+        nz = F.pad(nz, (0, (-hw) % 16)).reshape(shape[0], -1, 16).amax(2).int()
+        assert torch.equal(fl, nz)
+
+
+@pytest.mark.parametrize('kind', ['box', 'blobs', 'pixel', 'dense', 'empty'])
+@pytest.mark.parametrize('n,i,o,h,k,transposed,fp16', [(2, 32, 48, 128, 3, False, False), (1, 128, 3, 130, 1, False, False),
+                                                      (2, 32, 128, 64, 3, True, False), (1, 128, 128, 128, 3, False, True),
+                                                      (1, 16, 16, 131, 3, False, False)])
+def test_conv_backward_sparse_gradient_equals_dense(kind, n, i, o, h, k, transposed, fp16):
+    """`with sparse_gradients()`: dgrad / wgrad skip the all-zero 16-pixel segments of dy -> same gradients as the dense kernels
+    (up to the order of the fp32 sums), and exact zeros where the dense result is exactly zero."""
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(h + k)
+    wd = h + 16 if not transposed else h
+    x = torch.randn(n, i, h, wd, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(n, o, i, k, k, generator=gen) / (i * k * k) ** 0.5).to(DEV).requires_grad_(True)
+    bias = torch.randn(o, generator=gen).to(DEV).requires_grad_(True) if not transposed else None
+    kw = dict(padding=(0 if transposed else k // 2), transposed=transposed, flip=not transposed, fp16=fp16)
+    if not transposed:
+        kw.update(bias=bias, act='lrelu', clamp=256)
+    y = conv2d_mfma.conv2d(x, w, sparse_grad=True, **kw)
+    dy = _masked_gradient(tuple(y.shape), gen, kind).to(DEV)
+    wrt = [x, w] + ([bias] if bias is not None else [])
+    dense = torch.autograd.grad(y, wrt, dy, retain_graph=True)
+    with conv2d_mfma.sparse_gradients():
+        sparse = torch.autograd.grad(y, wrt, dy)
+    assert_close(sparse[0], dense[0], 1e-6 if not fp16 else 1e-5, 'sparse dgrad')
+    assert torch.equal(sparse[0] == 0, dense[0] == 0)
+    assert_close(sparse[1], dense[1], 2e-6 if not fp16 else 1e-5, 'sparse wgrad')
+    if kind == 'empty':
+        assert float(sparse[1].abs().max()) == 0
+    if bias is not None:
+        assert_close(sparse[2], dense[2], 1e-6, 'bias gradient')
