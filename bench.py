@@ -76,6 +76,40 @@ def cpu_baseline(depth, narrow):
                        f'torch {torch.__version__} CPU fp32, {cores} threads of {os.cpu_count()}')
 
 
+def conv_roofline(dev, f16):
+    """Second roofline line: the matrix-core kernels that hold most of the step's GPU time (igemm_kernel / wgrad_kernel).  Times the
+    largest convolution of the loop -- superresolution b512.conv1, 128 -> 128, 3x3 at 512^2, one image -- with HIP events on the
+    launch stream, outside the timed region: forward, data gradient, weight gradient."""
+    from spi_amd.torch_utils.ops import conv2d_mfma as cm
+    from spi_amd import hip
+    import ctypes
+    n, i, o, h, k = 1, 128, 128, 512, 3
+    x = torch.randn(n, i, h, h, device=dev)
+    w = torch.randn(n, o, k, k, i, device=dev) * 0.03
+    y = torch.empty(n, o, h, h, device=dev)
+    dx, dw = torch.empty_like(x), torch.empty_like(w)
+    d = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1, f16=int(f16))
+    flop = 2.0 * n * o * i * k * k * h * h
+    peak = 2500.0 if f16 else 157.3                              # dense MFMA peaks (TFLOP/s): fp16 / fp32, MI355X_MICROARCH.md
+    res = {}
+    for name, fn in (('fwd', lambda: hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())),
+                     ('dgrad', lambda: hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(y), hip.ptr(w), hip.ptr(dx), hip.stream())),
+                     ('wgrad', lambda: hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(y), hip.ptr(dw), hip.stream()))):
+        for _ in range(3):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ms = sorted(a.elapsed_time(b) for a, b in ev)
+        avg = sum(ms) / len(ms)
+        res[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12}
+    worst = min(v['achieved'] for v in res.values())
+    return {'kernel': 'igemm_kernel / wgrad_kernel on SR b512.conv1 (128->128, 3x3, 512^2, N=1)', 'bound': 'mfma', 'achieved': worst, 'peak': peak,
+            'unit': 'TFLOP/s', 'frac': worst / peak, 'flop_per_launch': flop, 'passes': res,
+            'note': 'achieved = slowest of the three passes; wgrad includes its memset of dw'}
+
+
 def main():
     args = parse()
     from spi_amd import dist as sdist
@@ -189,6 +223,7 @@ def main():
                          'launches': len(march_ms), 'avg_launch_us': (sum(march_ms) / max(len(march_ms), 1)) * 1e3,
                          'bytes_per_ray': per_ray, 'rays_per_launch': (sum(march_rays) / max(len(march_rays), 1))},
         }
+        out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow)
         print(json.dumps(out), flush=True)
