@@ -228,3 +228,50 @@ def test_noise_regulariser_fused_vs_reference_expression():
         x = rb.detach().clone()
         x -= x.mean(); x *= x.square().mean().rsqrt()
         assert_close(b.detach(), x.float(), 1e-5, 'noise renorm')
+
+
+def test_idloss_irse50_vs_oracle_and_reference_golden():
+    """Identity metric: the HIP-conv IR-SE50 backbone + IDLoss against the CPU oracle and against the features the
+    reference's own Backbone produced for the same synthetic weights (tests/golden/idloss.npz).  Tolerance 1e-3 relative on the unit
+    feature vectors (54 convolutions deep), 1e-4 absolute on the cosine similarity."""
+    import os
+    import numpy as np
+    from conftest import ROOT
+    from oracle import irse_ref
+    from spi_amd.criteria.id_loss import IDLoss, Backbone
+    from spi_amd.criteria.id_loss.model_irse import get_blocks
+    assert get_blocks(50) == irse_ref.UNITS
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'idloss.npz'))
+    g = torch.Generator().manual_seed(77)
+    faces = torch.rand(2, 3, 112, 112, generator=g) * 2 - 1
+    img_a = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    img_b = (img_a + 0.3 * torch.randn(1, 3, 512, 512, generator=g)).clamp(-1, 1)
+    sd = irse_ref.synthetic_state_dict(int(gold['seed']))
+    loss = IDLoss(None, state_dict=sd).to(DEV)
+    feats = loss.facenet(faces.to(DEV))
+    assert_close(feats, torch.from_numpy(gold['feats']), 1e-3, 'IR-SE50 features vs reference golden')
+    with torch.no_grad():
+        assert_close(feats, irse_ref.backbone_forward(sd, faces), 1e-3, 'IR-SE50 features vs oracle')
+    assert_close(loss.extract_feats(img_b.to(DEV)), torch.from_numpy(gold['feat_b']), 1e-3, 'extract_feats')
+    sim = loss.calculate_similarity(img_a.to(DEV), img_b.to(DEV))
+    assert abs(float(sim) - float(gold['similarity'])) < 1e-4
+    assert abs(float(loss(img_a.to(DEV), img_b.to(DEV))) - (1 - float(gold['similarity']))) < 1e-4
+    assert abs(float(loss.calculate_batch_similarity(img_a.to(DEV), img_a.to(DEV))) - 1) < 1e-5
+    with pytest.raises(FileNotFoundError):
+        IDLoss('/nonexistent/model_ir_se50.pth')
+    with pytest.raises(RuntimeError):
+        Backbone(112, 50, 'ir_se').train()
+    # Metric picks the checkpoint up from paths_config.IDLOSS_PATH when the file exists
+    import tempfile
+    from spi_amd.configs import paths_config
+    from spi_amd.utils.metric_utils import Metric
+    old = paths_config.IDLOSS_PATH
+    with tempfile.TemporaryDirectory() as td:
+        paths_config.IDLOSS_PATH = os.path.join(td, 'model_ir_se50.pth')
+        torch.save(sd, paths_config.IDLOSS_PATH)
+        try:
+            m = Metric(lpips_loss=lambda a, b: torch.zeros(()), device=DEV)
+            l2, lp, ids = m.run(img_a.to(DEV), img_b.to(DEV))
+        finally:
+            paths_config.IDLOSS_PATH = old
+    assert abs(ids - float(gold['similarity'])) < 1e-4 and lp == 0

@@ -227,3 +227,24 @@ def test_c_oracle_against_golden(golden):
     L.ref_importance(ctypes.c_void_p(_fp(dep)), ctypes.c_void_p(_fp(w)), ctypes.c_void_p(_fp(u)), ctypes.c_int64(nn * m), s, 20,
                      ctypes.c_void_p(_fp(fine)))
     assert (fine.reshape(nn, m, 20) - g['is_fine'][..., 0]).abs().max() < 5e-6
+
+
+def _idloss_inputs():
+    g = torch.Generator().manual_seed(77)                       # same recipe as tests/golden/make_idloss_golden.py
+    faces = torch.rand(2, 3, 112, 112, generator=g) * 2 - 1
+    img_a = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    img_b = (img_a + 0.3 * torch.randn(1, 3, 512, 512, generator=g)).clamp(-1, 1)
+    return faces, img_a, img_b
+
+
+def test_oracle_idloss_against_reference_golden():
+    """oracle/irse_ref.py against features / similarity computed by the reference's own Backbone (golden/idloss.npz)."""
+    from oracle import irse_ref
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', 'idloss.npz'))
+    faces, img_a, img_b = _idloss_inputs()
+    assert abs(float(faces.double().sum()) - float(gold['faces_checksum'])) < 1e-6
+    sd = irse_ref.synthetic_state_dict(int(gold['seed']))
+    with torch.no_grad():
+        assert_close(irse_ref.backbone_forward(sd, faces), torch.from_numpy(gold['feats']), 1e-5, 'IR-SE50 features')
+        assert_close(irse_ref.extract_feats(sd, img_a), torch.from_numpy(gold['feat_a']), 1e-5, 'extract_feats')
+        assert abs(float(irse_ref.calculate_similarity(sd, img_a, img_b)) - float(gold['similarity'])) < 1e-5
