@@ -51,6 +51,12 @@ class RotBboxCoach(BaseCoach):
         self.original_G._last_planes = None                      # per-image backbone cache of the frozen generator (depth branch)
         return ctx
 
+    def _trainable_params(self):
+        key = id(self.G)
+        if getattr(self, '_params_of', None) != key:
+            self._params_of, self._params = key, [p for p in self.G.parameters() if p.requires_grad]
+        return self._params
+
     def _synth(self, G, ws, cams, rng, **kw):
         n, m = cams.shape[0], G.neural_rendering_resolution ** 2
         rk = G.rendering_kwargs
@@ -74,7 +80,16 @@ class RotBboxCoach(BaseCoach):
             losses['lpips'] = torch.squeeze(self.lpips_loss(gen['image'], y_feats=ctx['target_feats']))
             loss = loss + losses['lpips'] * hp.pt_lpips_lambda
         stop_flag = self._async_flag(losses['lpips'] <= hp.LPIPS_value_threshold) if 'lpips' in losses else None
-        loss.backward()
+        # The reference calls backward() once per loss (:69,85,105,131): every parameter's .grad is read-modify-written once per
+        # call (~150 tiny add_ launches each).  Here each call returns its gradients as fresh tensors (autograd.grad) and they are
+        # folded into .grad in the reference's order with one multi-tensor add per call: the same sums.
+        params = self._trainable_params()
+        pending = []
+
+        def branch_backward(branch_loss, sparse):
+            with sparse_gradients(sparse):                          # sparse: d(image) is exactly zero outside the warp mask
+                pending.append(torch.autograd.grad(branch_loss, params, allow_unused=True))
+        branch_backward(loss, False)
         if i % rot_bs == 0:
             depth_main = gen['image_depth'].detach()
             if hp.pt_rot_lambda > 0:
@@ -85,8 +100,7 @@ class RotBboxCoach(BaseCoach):
                                              src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
                                              src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
                 losses['rot'] = self.lpips_loss(gs['image'] * warp_mask, warp_img) * hp.pt_rot_lambda * rot_bs
-                with sparse_gradients():                            # d(image) is zero outside warp_mask
-                    losses['rot'].backward()
+                branch_backward(losses['rot'], True)
             if hp.pt_mirror_rot_lambda > 0 and ctx['weight_m'] > 0:
                 cams_m = sample_surrounding_camera(ctx['camera_m'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                    rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
@@ -97,8 +111,7 @@ class RotBboxCoach(BaseCoach):
                 flip_warp, flip_mask = torch.flip(warp_m, dims=[3]), torch.flip(mask_m, dims=[3])
                 losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
                                                         ctx['lm'].repeat(rot_bs, 1, 1), plan=ctx.get('box_plan')) * hp.pt_mirror_rot_lambda * rot_bs
-                with sparse_gradients():
-                    losses['mirror_rot'].backward()
+                branch_backward(losses['mirror_rot'], True)
             if hp.pt_depth_lambda > 0:
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
                 sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True)['image_depth']
@@ -110,11 +123,19 @@ class RotBboxCoach(BaseCoach):
                                                use_cached_backbone=cached)['image_depth']
                     ctx['stable_planes_cached'] = True
                 losses['depth'] = l2_loss(stable_depth, sample_depth) * hp.pt_depth_lambda
-                losses['depth'].backward()
+                branch_backward(losses['depth'], False)
             if hp.pt_tv_lambda > 0:
                 from ...criteria.tv_loss import cal_tv_loss
                 losses['tv'] = cal_tv_loss(ws, G) * hp.pt_tv_lambda
                 losses['tv'].backward()
+        for grads in pending:
+            have = [(p, g) for p, g in zip(params, grads) if g is not None]
+            both = [(p.grad, g) for p, g in have if p.grad is not None]
+            if both:
+                torch._foreach_add_([a for a, _ in both], [b for _, b in both])
+            for p, g in have:
+                if p.grad is None:
+                    p.grad = g
         # the loop's one host read (:148).  The flag was copied to pinned memory right after the main forward, so the
         # wait ends when the GPU has passed THAT point (not the whole iteration): the backward passes keep the GPU busy
         # while the host enqueues the optimiser step and the next forward.
