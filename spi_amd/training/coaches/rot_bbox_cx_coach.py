@@ -12,6 +12,7 @@ super-resolution network (only ``image_depth`` is consumed, :136-138); w_pivot i
 4-view branches pass ONE w with 4 cameras, so the camera-independent StyleGAN2 backbone (46 % of the
 generator's conv FLOPs) and every weight modulation run once instead of on 4 identical rows.
 """
+import contextlib
 import os
 import torch
 
@@ -51,6 +52,11 @@ class RotBboxCoach(BaseCoach):
         self.original_G._last_planes = None                      # per-image backbone cache of the frozen generator (depth branch)
         return ctx
 
+    def _side_streams(self):
+        if getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream(device=self.device) for _ in range(3)]
+        return self._streams
+
     def _trainable_params(self):
         key = id(self.G)
         if getattr(self, '_params_of', None) != key:
@@ -89,10 +95,25 @@ class RotBboxCoach(BaseCoach):
         def branch_backward(branch_loss, sparse):
             with sparse_gradients(sparse):                          # sparse: d(image) is exactly zero outside the warp mask
                 pending.append(torch.autograd.grad(branch_loss, params, allow_unused=True))
+        # The three pseudo-view branches depend on the main FORWARD only (depth_main) and on nothing of each other: each runs on its
+        # own HIP stream beside the main backward, so their launch-bound stretches (4^2..64^2 backbone layers, tiny elementwise
+        # kernels) fill the CUs the other chains leave idle.  Gradients meet again in the ordered multi-tensor adds below.
+        side = self._side_streams() if (i % rot_bs == 0 and global_config.concurrent_branches and gen['image'].is_cuda) else None
+        if side:
+            main_stream = torch.cuda.current_stream()
+            fwd_done = torch.cuda.Event()
+            fwd_done.record(main_stream)                            # before the main backward is enqueued
         branch_backward(loss, False)
         if i % rot_bs == 0:
             depth_main = gen['image_depth'].detach()
-            if hp.pt_rot_lambda > 0:
+
+            def on_stream(k):
+                if not side:
+                    return contextlib.nullcontext()
+                side[k].wait_event(fwd_done)
+                return torch.cuda.stream(side[k])
+
+            def rot_branch():
                 cams = sample_surrounding_camera(ctx['camera'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                  rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
                 gs = self._synth(G, ws, cams, rng)                 # one w, rot_bs cameras: backbone shared (triplane.py)
@@ -101,7 +122,8 @@ class RotBboxCoach(BaseCoach):
                                              src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
                 losses['rot'] = self.lpips_loss(gs['image'] * warp_mask, warp_img) * hp.pt_rot_lambda * rot_bs
                 branch_backward(losses['rot'], True)
-            if hp.pt_mirror_rot_lambda > 0 and ctx['weight_m'] > 0:
+
+            def mirror_branch():
                 cams_m = sample_surrounding_camera(ctx['camera_m'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                    rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
                 gm = self._synth(G, ws, cams_m, rng)
@@ -112,7 +134,8 @@ class RotBboxCoach(BaseCoach):
                 losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
                                                         ctx['lm'].repeat(rot_bs, 1, 1), plan=ctx.get('box_plan')) * hp.pt_mirror_rot_lambda * rot_bs
                 branch_backward(losses['mirror_rot'], True)
-            if hp.pt_depth_lambda > 0:
+
+            def depth_branch():
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
                 sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True)['image_depth']
                 with torch.no_grad():
@@ -124,6 +147,19 @@ class RotBboxCoach(BaseCoach):
                     ctx['stable_planes_cached'] = True
                 losses['depth'] = l2_loss(stable_depth, sample_depth) * hp.pt_depth_lambda
                 branch_backward(losses['depth'], False)
+
+            if hp.pt_rot_lambda > 0:
+                with on_stream(0):
+                    rot_branch()
+            if hp.pt_mirror_rot_lambda > 0 and ctx['weight_m'] > 0:
+                with on_stream(1):
+                    mirror_branch()
+            if hp.pt_depth_lambda > 0:
+                with on_stream(2):
+                    depth_branch()
+            if side:
+                for st in side:
+                    main_stream.wait_stream(st)
             if hp.pt_tv_lambda > 0:
                 from ...criteria.tv_loss import cal_tv_loss
                 losses['tv'] = cal_tv_loss(ws, G) * hp.pt_tv_lambda
