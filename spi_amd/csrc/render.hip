@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const floa
 //   The kernel is persistent (grid <= 512): per-wave weight-gradient accumulators live in registers
 //   across tiles and are written once to a scratch row that decoder_partial_reduce_kernel sums.
 // ------------------------------------------------------------------------------------------------
-constexpr int WIN = 12;                       // window edge in texels; WIN*WIN*32 int64 accumulators == DT*FS floats of LDS
+constexpr int WIN = 16;                       // window edge in texels; WIN*WIN*32 int32 accumulators <= DT*FS floats of LDS
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 // weight fragments, one 64-lane row per MFMA k-step (built by decoder_frag_kernel for every call)
@@ -448,7 +448,7 @@ struct TiledArgs {
     int N; int M; int S; int H; int W; float scale;
     int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
     int patches; int kchunks; int tiles;
-    int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 4 = skip the MLP, 8 = no flush, 32 = no LDS atomics, 64 = skip the plane gather
+    int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 4 = skip the MLP, 8 = no flush, 16 = skip points that leave the window, 32 = no LDS atomics, 64 = skip the plane gather
 };
 
 #define SPI_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -699,13 +699,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     }
     // ---- phase C: per plane, accumulate in an LDS window (reusing `gbuf`), then flush it.
     // LDS float atomics are ~30x slower than integer ones on gfx950 (ds_add_f32: ~190 cycles per
-    // wave-instruction, ds_add_u64: ~10; tools/ubench/lds_atomic.hip), so the window holds 64-bit
-    // fixed-point sums scaled by a per-tile power of two: every fp32 product is represented exactly
-    // (down to 2^-40 of the tile's largest |gradient|), the sum is order-independent, and it is
-    // converted back to fp32 once at the flush.
+    // wave-instruction, ds_add_u32/u64: ~10; tools/ubench/lds_atomic.hip), so the window holds 32-bit
+    // fixed-point sums scaled by a per-tile power of two (resolution 2^-21 of the tile's largest |gradient|,
+    // headroom for 256 full-weight contributions per texel); the sum is order-independent and is converted
+    // back to fp32 once at the flush.  32-bit cells make the window 16 x 16 texels in the LDS that held 12 x 12
+    // 64-bit ones: an 8 x 8 ray patch spans ~15 texels, and every point that leaves the window costs four
+    // tested corners and global atomics (0.8 of 2.65 ms per image with the 12-texel window).
     if (a.dbg & 1) continue;
-    static_assert(WIN * WIN * DEC_IN * 8 <= DT * FS * 4, "window must fit the fragment buffer");
-    long long* win = reinterpret_cast<long long*>(gbuf);
+    static_assert(WIN * WIN * DEC_IN * 4 <= DT * FS * 4, "window must fit the fragment buffer");
+    int* win = reinterpret_cast<int*>(gbuf);
     __syncthreads();                                       // phase B done in every wave: fragments dead, feat rows = d_feat
     const float* growt = feat + t * FS;
     float amax = 0.f;
@@ -719,21 +721,20 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     const float tile_max = __int_as_float(s_acc[4]);
     if (!(tile_max > 0.f)) continue;                        // all gradients zero (block-uniform)
     const int e2 = ilogbf(tile_max);
-    const float to_fix = ldexpf(1.f, 40 - e2);
-    const double from_fix = ldexp(1.0, e2 - 40);
+    const float to_fix = ldexpf(1.f, 21 - e2);              // |dv * to_fix| < 2^22
+    const float from_fix = ldexpf(1.f, e2 - 21);
     const int half = lane >> 5, ch = lane & 31;
     int* s_base = reinterpret_cast<int*>(s_x);                 // phase A is over: s_x is free (this thread's x,y,z live in registers)
-    // float -> 64-bit fixed point in 3 instructions: adding 1.5*2^52 in fp64 leaves round(v) in the low mantissa bits
-    // (two's complement for negative v), so bits(v + MAGIC) - bits(MAGIC) is the integer.  |v| < 2^41 here.
-    constexpr double MAGIC = 6755399441055744.0;
-    auto add_fix = [&](long long* p, double dvd, float w) {
-        const double sfx = fma(dvd, (double)w, MAGIC);
-        atomicAdd(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(sfx) - 0x4338000000000000ull);   // ds_add_u64
+    // float -> fixed point in 2 instructions: fma(v, w, 1.5*2^23) leaves round-to-nearest-even(v*w) in the low mantissa bits
+    // (two's complement for negative values), so bits(.) - bits(1.5*2^23) is the integer.  |v*w| < 2^22 here.
+    constexpr float MAGIC = 12582912.f;
+    auto add_fix = [&](int* p, float dvs, float w) {
+        atomicAdd(p, __float_as_int(fmaf(dvs, w, MAGIC)) - 0x4B400000);                                   // ds_add_u32
     };
     for (int pl = 0; pl < 3; ++pl) {
         __syncthreads();                                   // previous flush done
         if (t < 4) s_acc[t] = 0;
-        for (int i = t; i < WIN * WIN * DEC_IN; i += DT) win[i] = 0;
+        for (int i = t; i < WIN * WIN * DEC_IN / 4; i += DT) reinterpret_cast<int4*>(win)[i] = make_int4(0, 0, 0, 0);
         float gx, gy;
         plane_uv(pl, x, y, z, gx, gy);
         const Corner c = make_corner(gx, gy, a.W, a.H);
@@ -765,14 +766,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
             const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
             if (base >= 0) {
                 if (a.dbg & 32) continue;
-                const double dvd = (double)(dv * to_fix);
-                long long* wp = win + base + ch;
-                add_fix(wp, dvd, fx0 * fy0);
-                add_fix(wp + DEC_IN, dvd, fx1 * fy0);
-                add_fix(wp + WIN * DEC_IN, dvd, fx0 * fy1);
-                add_fix(wp + (WIN + 1) * DEC_IN, dvd, fx1 * fy1);
+                const float dvs = dv * to_fix;
+                int* wp = win + base + ch;
+                add_fix(wp, dvs, fx0 * fy0);
+                add_fix(wp + DEC_IN, dvs, fx1 * fy0);
+                add_fix(wp + WIN * DEC_IN, dvs, fx0 * fy1);
+                add_fix(wp + (WIN + 1) * DEC_IN, dvs, fx1 * fy1);
                 continue;
             }
+            if (a.dbg & 16) continue;
             const int pk = s_cxy[sp];
             const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
 #pragma unroll
@@ -783,8 +785,8 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
                 const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
                 if (xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
-                    if (!(a.dbg & 32)) add_fix(&win[(yl * WIN + xl) * DEC_IN + ch], (double)(dv * to_fix), wq);
-                } else {
+                    if (!(a.dbg & 32)) add_fix(&win[(yl * WIN + xl) * DEC_IN + ch], dv * to_fix, wq);
+                } else if (!(a.dbg & 128)) {
                     atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dv * wq);                  // rare: straight to HBM
                 }
             }
@@ -795,11 +797,8 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
             const int tex = j * 8 + wave * 2 + half;
             const int xx = wx0 + (tex % WIN), yy = wy0 + (tex / WIN);
             if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-            const long long qv = win[tex * DEC_IN + ch];
-            if (qv != 0) {
-                const double qd = (double)(int)(qv >> 32) * 4294967296.0 + (double)(unsigned)qv;
-                atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, (float)(qd * from_fix));
-            }
+            const int qv = win[tex * DEC_IN + ch];
+            if (qv != 0) atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, (float)qv * from_fix);
         }
     }
     }   // tile loop

@@ -41,7 +41,7 @@ def main():
     for frozen in (True, False):
         for p in dec.parameters():
             p.requires_grad_(not frozen)
-        for flags, tag in ((0, 'full'), (1, 'no scatter'), (1 + 4, 'no scatter, no MLP'), (1 + 4 + 64, 'no scatter, no MLP, no gather'), (1 + 64, 'no scatter, no gather'), (8 + 16 + 32, 'scatter loop without atomics'), (8, 'no flush'), (32, 'no LDS atomics')):
+        for flags, tag in ((0, 'full'), (1, 'no scatter'), (1 + 4, 'no scatter, no MLP'), (1 + 4 + 64, 'no scatter, no MLP, no gather'), (1 + 64, 'no scatter, no gather'), (8 + 16 + 32, 'scatter loop without atomics'), (8, 'no flush'), (32, 'no LDS atomics'), (16, 'no slow path'), (128, 'no global atomics from the slow path')):
             lib.spi_debug_set(flags)
             rgb, depth, _ = fwd()
             g1, g2 = torch.randn_like(rgb), torch.randn_like(depth)
