@@ -738,9 +738,11 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         float gx, gy;
         plane_uv(pl, x, y, z, gx, gy);
         const Corner c = make_corner(gx, gy, a.W, a.H);
-        const int cx0 = min(max(c.x0, -2), a.W), cy0 = min(max(c.y0, -2), a.H);     // clamped: far-outside points stay outside
-        // window centred on the mean corner of the tile's valid points (sums are exact in fp32: < 2^24)
-        const float sx = wave_sum(valid ? (float)cx0 : 0.f), sy = wave_sum(valid ? (float)cy0 : 0.f), sc = wave_sum(valid ? 1.f : 0.f);
+        // points whose four corners all lie outside the plane image contribute nothing to this plane (padding_mode zeros)
+        const bool vin = valid && c.x0 + 1 >= 0 && c.x0 < a.W && c.y0 + 1 >= 0 && c.y0 < a.H;
+        const int cx0 = c.x0, cy0 = c.y0;
+        // window centred on the mean corner of the tile's contributing points (sums are exact in fp32: < 2^24)
+        const float sx = wave_sum(vin ? (float)cx0 : 0.f), sy = wave_sum(vin ? (float)cy0 : 0.f), sc = wave_sum(vin ? 1.f : 0.f);
         __syncthreads();
         if (lane == 0) { atomicAdd(&s_acc[0], (int)sx); atomicAdd(&s_acc[1], (int)sy); atomicAdd(&s_acc[2], (int)sc); }
         __syncthreads();
@@ -748,9 +750,9 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;
         const int lxo = cx0 - wx0, lyo = cy0 - wy0;
         // fast path: all four corners inside the image AND inside the window -> no per-corner tests in the loop
-        const bool fast = valid && lxo >= 0 && lxo + 1 < WIN && lyo >= 0 && lyo + 1 < WIN &&
+        const bool fast = vin && lxo >= 0 && lxo + 1 < WIN && lyo >= 0 && lyo + 1 < WIN &&
                           c.x0 >= 0 && c.x0 + 1 < a.W && c.y0 >= 0 && c.y0 + 1 < a.H;
-        s_base[t] = fast ? (lyo * WIN + lxo) * DEC_IN : (valid ? -2 : -1);
+        s_base[t] = fast ? (lyo * WIN + lxo) * DEC_IN : (vin ? -2 : -1);
         s_cxy[t] = ((lxo + 0x4000) & 0xffff) | ((lyo + 0x4000) << 16);
         s_wx[t] = c.wx1; s_wy[t] = c.wy1;
         __syncthreads();
