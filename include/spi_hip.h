@@ -220,6 +220,10 @@ typedef struct spi_conv_desc {
      * zeros) and wgrad reduces over the flagged 16-pixel slabs only -- the results are those of the dense kernels up to
      * the order of the fp32 sums. */
     const int32_t* dy_seg_flags;
+    /* forward only (optional, NULL = dense): spi_seg_flags()-style map over the OUTPUT pixels [N, ceil(OH*OW/16)]: output tiles
+     * that hold no flagged segment are not computed (zeros are written).  For consumers that read the output only inside a
+     * known region (masked losses): flag that region, dilated by what the layers in between need. */
+    const int32_t* out_seg_flags;
 } spi_conv_desc;
 /* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
  * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).

@@ -43,6 +43,8 @@ struct IGemmParams {
     ClassParams cls[4];
     // optional zero-segment map of the backward passes' gradient operand (spi_conv_desc.dy_seg_flags): [N, nseg] over flat pixels / 16
     const int32_t* seg_flags; int nseg;
+    // optional "needed output" map of the forward pass (spi_conv_desc.out_seg_flags): [N, out_nseg] over flat output pixels / 16
+    const int32_t* out_flags; int out_nseg;
 };
 
 // k -> (channel, tap) for k = c*T + t.  T == 1 is special-cased (ceil(2^32/1) does not fit 32 bits).
@@ -119,6 +121,31 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     const float* inb = in + (int64_t)n * P.in_bs;
     const float* wb = wgt + (int64_t)n * P.wbs;
     const int64_t chs = (int64_t)P.IH * P.IW;
+
+    // ---- needed-output map (forward only; host guarantees no split-K): tiles without a flagged output segment are not computed
+    if (!SPLITK && P.out_flags) {
+        const int pl = min(p0 + BN, npix) - 1;
+        const int Y0 = p0 / C.OWp, Y1 = pl / C.OWp;
+        const int32_t* fl = P.out_flags + (int64_t)n * P.out_nseg;
+        int any = 0;
+        for (int Yr = Y0; Yr <= Y1; ++Yr) {
+            const int xa = (Yr == Y0) ? p0 - Y0 * C.OWp : 0, xb = (Yr == Y1) ? pl - Y1 * C.OWp : C.OWp - 1;
+            const int row = (Yr * P.osy + C.ooy) * P.OW + C.oox;
+            const int s1 = (row + xb * P.osx) >> 4;
+            for (int sg = ((row + xa * P.osx) >> 4) + tid; sg <= s1; sg += NT) any |= fl[sg];
+        }
+        if (!__syncthreads_or(any)) {
+            float* ob = out + (int64_t)n * P.out_bs;
+            for (int e = tid; e < BM * BN; e += NT) {
+                const int m = m0 + e / BN, pp = p0 + e % BN;
+                if (m < P.Mo && pp < npix) {
+                    const int Yo = pp / C.OWp, Xo = pp - Yo * C.OWp;
+                    ob[(int64_t)m * P.OH * P.OW + (int64_t)(Yo * P.osy + C.ooy) * P.OW + (Xo * P.osx + C.oox)] = 0.f;
+                }
+            }
+            return;
+        }
+    }
 
     // ---- sparse gradient operand (dgrad only; host guarantees ncls == 1, unit output strides, no split-K): when no flagged segment
     //      intersects the tile's receptive field the accumulators would stay exactly 0 -> write the zeros and leave.
@@ -623,6 +650,7 @@ static void make_forward(const spi_conv_desc* d, IGemmParams& P) {
     const int kk = d->kh * d->kw;
     P.N = d->N; P.Mo = d->O; P.Ci = d->I; P.IH = d->H; P.IW = d->W; P.OH = OH; P.OW = OW;
     P.seg_flags = nullptr; P.nseg = 0;
+    P.out_flags = nullptr; P.out_nseg = 0;
     P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->I * d->H * d->W; P.out_bs = (int64_t)d->O * OH * OW;
     P.w_elems = (int64_t)d->O * d->I * kk;
     if (!d->transposed) {
@@ -658,6 +686,7 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
     const int kk = d->kh * d->kw;
     P.N = d->N; P.Mo = d->I; P.Ci = d->O; P.IH = OH; P.IW = OW; P.OH = d->H; P.OW = d->W;
     P.seg_flags = d->dy_seg_flags; P.nseg = (int)(((int64_t)OH * OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS);
+    P.out_flags = nullptr; P.out_nseg = 0;
     P.wbs = d->w_batch_stride; P.in_bs = (int64_t)d->O * OH * OW; P.out_bs = (int64_t)d->I * d->H * d->W;
     P.w_elems = (int64_t)d->O * d->I * kk;
     P.osy = P.osx = 1; P.ncls = 1;
@@ -747,6 +776,7 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     SPI_REQUIRE(!(d->transposed && (d->bias || d->noise || d->act > SPI_ACT_LINEAR)),
                 "spi_conv2d_fwd: no fused epilogue in transposed mode (the FIR pass owns it)");
     IGemmParams P; make_forward(d, P);
+    if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
     Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
     rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16 != 0); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_fwd");

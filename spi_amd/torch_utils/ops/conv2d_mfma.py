@@ -38,6 +38,23 @@ def sparse_gradients(enabled=True):
         _sparse[0] = old
 
 
+# Needed-output regions.  When the consumer of a generator forward looks at the image only inside a known region (the warp mask of
+# the pseudo-view losses), the convs that opted in (sparse_grad=True) skip the output tiles that hold no flagged 16-pixel segment:
+# ``with needed_output({(OH, OW): int32 flags [N, ceil(OH*OW/16)]})`` -- the caller provides one map per output resolution, dilated by
+# what the layers between that conv and the consumer read (superresolution.needed_output_maps).
+_needed = [None]
+
+
+@contextlib.contextmanager
+def needed_output(flags_by_shape):
+    old = _needed[0]
+    _needed[0] = flags_by_shape
+    try:
+        yield
+    finally:
+        _needed[0] = old
+
+
 def seg_flags(x):
     """[N, C, H, W] -> int32 [N, ceil(H*W/16)]: 1 where the 16-pixel segment (flat index) holds a non-zero in any channel."""
     n, c = x.shape[0], x.shape[1]
@@ -48,9 +65,9 @@ def seg_flags(x):
 
 
 def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0, tap_major=0,
-          f16=0, dy_flags=None):
+          f16=0, dy_flags=None, out_flags=None):
     return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), int(f16), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
-                        act, alpha, gain, clamp, hip.ptr(dy_flags))
+                        act, alpha, gain, clamp, hip.ptr(dy_flags), hip.ptr(out_flags))
 
 
 def out_size(h, k, pad, transposed):
@@ -73,7 +90,10 @@ class _Conv2d(torch.autograd.Function):
         bb = bias.contiguous().float() if bias is not None else None
         nz = noise.contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16)
+        of = _needed[0].get((oh, ow)) if (may_be_sparse and _needed[0]) else None
+        if of is not None:
+            assert of.dtype == torch.int32 and tuple(of.shape) == (n, (oh * ow + 15) // 16), 'needed_output: flags must be int32 [N, ceil(OH*OW/16)]'
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16, out_flags=of)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
         ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)

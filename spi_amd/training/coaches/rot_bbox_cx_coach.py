@@ -116,21 +116,32 @@ class RotBboxCoach(BaseCoach):
             def rot_branch():
                 cams = sample_surrounding_camera(ctx['camera'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                  rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
-                gs = self._synth(G, ws, cams, rng)                 # one w, rot_bs cameras: backbone shared (triplane.py)
-                warp_img, warp_mask = rotate(target_camera=cams, target_depth=gs['image_depth'], src_image=ctx['image'].repeat(rot_bs, 1, 1, 1),
-                                             src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
-                                             src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
-                losses['rot'] = self.lpips_loss(gs['image'] * warp_mask, warp_img) * hp.pt_rot_lambda * rot_bs
+                warp = {}
+
+                def region(out):
+                    # the warp needs the rendered depth only, so it runs between the renderer and the super-resolution network: the
+                    # loss looks at image * warp_mask, and the SR convs skip the tiles no visible pixel depends on (triplane.synthesis)
+                    warp['img'], warp['mask'] = rotate(target_camera=cams, target_depth=out['image_depth'], src_image=ctx['image'].repeat(rot_bs, 1, 1, 1),
+                                                       src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
+                                                       src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
+                    return warp['mask']
+                gs = self._synth(G, ws, cams, rng, sr_region_fn=region)   # one w, rot_bs cameras: backbone shared (triplane.py)
+                losses['rot'] = self.lpips_loss(gs['image'] * warp['mask'], warp['img']) * hp.pt_rot_lambda * rot_bs
                 branch_backward(losses['rot'], True)
 
             def mirror_branch():
                 cams_m = sample_surrounding_camera(ctx['camera_m'], batch_size=rot_bs, yaw_range=ctx['yaw_range'], pitch_range=0.1,
                                                    rand=(rng.rand(rot_bs, 1), rng.rand(rot_bs, 1)))
-                gm = self._synth(G, ws, cams_m, rng)
-                warp_m, mask_m = rotate(target_camera=cams_m, target_depth=gm['image_depth'], src_image=ctx['image_m'].repeat(rot_bs, 1, 1, 1),
-                                        src_camera=ctx['camera_m'].repeat(rot_bs, 1), src_depth=torch.flip(depth_main, dims=[3]).repeat(rot_bs, 1, 1, 1),
-                                        src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
-                flip_warp, flip_mask = torch.flip(warp_m, dims=[3]), torch.flip(mask_m, dims=[3])
+                warp = {}
+
+                def region(out):
+                    warp['img'], warp['mask'] = rotate(target_camera=cams_m, target_depth=out['image_depth'], src_image=ctx['image_m'].repeat(rot_bs, 1, 1, 1),
+                                                       src_camera=ctx['camera_m'].repeat(rot_bs, 1),
+                                                       src_depth=torch.flip(depth_main, dims=[3]).repeat(rot_bs, 1, 1, 1),
+                                                       src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
+                    return warp['mask']
+                gm = self._synth(G, ws, cams_m, rng, sr_region_fn=region)
+                flip_warp, flip_mask = torch.flip(warp['img'], dims=[3]), torch.flip(warp['mask'], dims=[3])
                 losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
                                                         ctx['lm'].repeat(rot_bs, 1, 1), plan=ctx.get('box_plan')) * hp.pt_mirror_rot_lambda * rot_bs
                 branch_backward(losses['mirror_rot'], True)

@@ -24,6 +24,22 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
         self.block1 = SynthesisBlock(256, 128, w_dim=512, resolution=512, img_channels=3, is_last=True, use_fp16=use_fp16,
                                      conv_clamp=clamp, **block_kwargs)
 
+    @staticmethod
+    @torch.no_grad()
+    def needed_output_maps(region):
+        """region [N,1,512,512] (non-zero = the caller reads this image pixel) -> {(OH, OW): int32 segment flags} for
+        ``conv2d_mfma.needed_output``: per conv output resolution of the two blocks, the region dilated by what the layers between
+        that conv and the image read (3x3 convs: 1 px; the 4x4 up-sampling FIR: [-1, +2] px; torgb / skip up-sampling: the FIR).
+        The margins are generous (4 px at 512^2 and again 4 px at 256^2) -- a tile of the implicit GEMM is 128+ pixels wide anyway."""
+        from ..torch_utils.ops import conv2d_mfma
+        F = torch.nn.functional
+        assert region.ndim == 4 and region.shape[1] == 1 and region.shape[-1] == 512 and region.shape[-2] == 512
+        m = (region != 0).float()
+        m512 = F.max_pool2d(m, 9, 1, 4)                                   # block1.conv1 / torgb outputs (512^2)
+        m513 = F.max_pool2d(F.pad(m512, (0, 1, 0, 1)), 5, 1, 2)           # block1.conv0's transposed conv (513^2), read through the FIR
+        m256 = F.max_pool2d(F.max_pool2d(m513[:, :, :512, :512], 2), 9, 1, 4)   # block0.conv1 / torgb outputs (256^2)
+        return {(512, 512): conv2d_mfma.seg_flags(m512), (513, 513): conv2d_mfma.seg_flags(m513.contiguous()), (256, 256): conv2d_mfma.seg_flags(m256)}
+
     def forward(self, rgb, x, ws, **block_kwargs):
         ws = ws[:, -1:, :].repeat(1, 3, 1)
         if x.shape[-1] != self.input_resolution:      # only reduced-size test configurations get here

@@ -69,7 +69,10 @@ class TriPlaneGenerator(torch.nn.Module):
         return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
 
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
-                  use_cached_backbone=False, render_noise=None, skip_superresolution=False, **synthesis_kwargs):
+                  use_cached_backbone=False, render_noise=None, skip_superresolution=False, sr_region_fn=None, **synthesis_kwargs):
+        """sr_region_fn (extension, optional): called as ``sr_region_fn(out)`` with ``{'image_raw', 'image_depth'}`` once the renderer is
+        done; returns a ``[N,1,512,512]`` mask of the image pixels the caller will look at (None = all).  The super-resolution convs
+        then skip the output tiles that no such pixel depends on -- ``out['image']`` is the full forward's inside the mask and unspecified outside."""
         cam2world = c[:, :16].view(-1, 4, 4)
         intrinsics = c[:, 16:25].view(-1, 3, 3)
         if neural_rendering_resolution is None:
@@ -97,8 +100,15 @@ class TriPlaneGenerator(torch.nn.Module):
         out = {'image_raw': rgb_image, 'image_depth': depth_image}
         if not skip_superresolution:
             sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != 'noise_mode'}
-            out['image'] = self.superresolution(rgb_image, feature_image, ws,
-                                                noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **sr_kwargs)
+            region = sr_region_fn(out) if sr_region_fn is not None else None
+            if region is not None and hasattr(self.superresolution, 'needed_output_maps'):
+                from ..torch_utils.ops import conv2d_mfma
+                with conv2d_mfma.needed_output(self.superresolution.needed_output_maps(region)):
+                    out['image'] = self.superresolution(rgb_image, feature_image, ws,
+                                                        noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **sr_kwargs)
+            else:
+                out['image'] = self.superresolution(rgb_image, feature_image, ws,
+                                                    noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **sr_kwargs)
         return out
 
     def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):

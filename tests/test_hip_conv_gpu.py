@@ -249,3 +249,35 @@ def test_conv_backward_sparse_gradient_equals_dense(kind, n, i, o, h, k, transpo
         assert float(sparse[1].abs().max()) == 0
     if bias is not None:
         assert_close(sparse[2], dense[2], 1e-6, 'bias gradient')
+
+
+@pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 128, 3, False), (1, 128, 3, 130, 1, False), (2, 32, 128, 64, 3, True), (1, 16, 16, 131, 3, False)])
+def test_conv_forward_needed_output_region(n, i, o, h, k, transposed):
+    """`with needed_output({(OH, OW): flags})`: output tiles without a flagged segment may be skipped (zeros); every flagged pixel is
+    bit-identical to the dense forward, and the backward still works on the region."""
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(h + k + 1)
+    wd = h + 16 if not transposed else h
+    x = torch.randn(n, i, h, wd, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(o, i, k, k, generator=gen) / (i * k * k) ** 0.5).to(DEV).requires_grad_(True)       # shared weights (one w, several views)
+    kw = dict(padding=(0 if transposed else k // 2), transposed=transposed, flip=not transposed, sparse_grad=True)
+    dense = conv2d_mfma.conv2d(x, w, **kw)
+    oh, ow = dense.shape[2:]
+    for kind in ('box', 'blobs', 'pixel', 'empty', 'dense'):
+        m = (_masked_gradient((n, 1, oh, ow), gen, kind) != 0).float().to(DEV)
+        flags = conv2d_mfma.seg_flags(m)
+        with conv2d_mfma.needed_output({(oh, ow): flags}):
+            y = conv2d_mfma.conv2d(x, w, **kw)
+        assert torch.equal(y * m, dense * m), kind
+        big = k == 3 and not transposed and h == 128                    # small problems run split-K: dense, flags ignored
+        if kind == 'empty' and big:
+            assert float(y.detach().abs().max()) == 0
+        if kind == 'box':
+            if big:
+                assert float((y.detach() == 0).float().mean()) > 0.3     # something was actually skipped (small problems run split-K, dense)
+            gx, gw = torch.autograd.grad((y * m).square().sum(), [x, w])
+            hx, hw = torch.autograd.grad((dense * m).square().sum(), [x, w], retain_graph=True)
+            assert_close(gx, hx, 1e-6, 'dgrad through a region forward')
+            assert_close(gw, hw, 2e-6, 'wgrad through a region forward')
+    with conv2d_mfma.needed_output({(oh + 1, ow): flags}):              # other resolutions are untouched
+        assert torch.equal(conv2d_mfma.conv2d(x, w, **kw), dense)
