@@ -224,6 +224,8 @@ typedef struct spi_conv_desc {
      * that hold no flagged segment are not computed (zeros are written).  For consumers that read the output only inside a
      * known region (masked losses): flag that region, dilated by what the layers in between need. */
     const int32_t* out_seg_flags;
+    int dw_zeroed;            /* spi_conv2d_wgrad only: 1 = the caller already zeroed dw (saves the memset launch when dw is a slice of
+                               * a buffer that was cleared together with other small gradients) */
 } spi_conv_desc;
 /* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
  * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).

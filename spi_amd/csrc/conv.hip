@@ -802,8 +802,10 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     SPI_REQUIRE(P.in_bs * 4 < (1ll << 30) && P.out_bs * 4 < (1ll << 30), "spi_conv2d_wgrad: a per-sample activation must be < 1 GiB");
     const int64_t wsz = (int64_t)d->O * d->I * d->kh * d->kw;
     const int64_t nw = (d->w_batch_stride == 0) ? 1 : d->N;
-    hipError_t e = hipMemsetAsync(dw, 0, (size_t)(nw * wsz) * sizeof(float), as_stream(stream));
-    if (e != hipSuccess) { spi_set_error("spi_conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+    if (!d->dw_zeroed) {
+        hipError_t e = hipMemsetAsync(dw, 0, (size_t)(nw * wsz) * sizeof(float), as_stream(stream));
+        if (e != hipSuccess) { spi_set_error("spi_conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+    }
     // tile 128 x 128; split the pixel reduction so the grid has ~>= 1024 blocks
     constexpr int BM = 128, BN = 128;
     int maxpix = 0, maxcols = 0;

@@ -34,9 +34,16 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
     return y
 
 
-def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise, need_strength, need_bias):
+def tail_zero_elems(dy, noise, need_noise, need_strength, need_bias):
+    """floats of zeroed scratch tail_backward needs for this call (its caller may provide them as ``zero_buf``)"""
+    want_pix = noise is not None and (need_noise or need_strength)
+    return (dy.shape[1] if need_bias else 0) + (dy[0, 0].numel() if want_pix else 0)
+
+
+def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise, need_strength, need_bias, zero_buf=None):
     """Backward of  y = clamp(act(z + noise*strength + bias)*gain)  for dy [N,C,H,W] in one launch (spi_tail_bwd).
-    ``y`` None: no activation/gain/clamp was applied (dz = dy).  Returns (dz, d_noise, d_strength, d_bias)."""
+    ``y`` None: no activation/gain/clamp was applied (dz = dy).  Returns (dz, d_noise, d_strength, d_bias).
+    ``zero_buf``: optional zeroed 1-D fp32 tensor whose first ``tail_zero_elems(...)`` entries become d_bias / the pixel sums."""
     dy = dy.contiguous().float()
     n, c = dy.shape[0], dy.shape[1]
     hw = dy[0, 0].numel()
@@ -44,8 +51,11 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
     if y is None and not want_pix and not need_bias:
         return dy, None, None, None
     dz = torch.empty_like(dy) if y is not None else None
-    d_bias = torch.zeros(c, device=dy.device, dtype=torch.float32) if need_bias else None
-    pix = torch.zeros(dy.shape[2:], device=dy.device, dtype=torch.float32) if want_pix else None
+    if zero_buf is None:
+        zero_buf = torch.zeros((c if need_bias else 0) + (hw if want_pix else 0), device=dy.device, dtype=torch.float32)
+    nb = c if need_bias else 0
+    d_bias = zero_buf[:nb] if need_bias else None
+    pix = zero_buf[nb:nb + hw].view(dy.shape[2:]) if want_pix else None
     hip.call('spi_tail_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), n, c, hw, act_id, alpha, gain, clamp,
              hip.stream())
     d_noise = d_strength = None

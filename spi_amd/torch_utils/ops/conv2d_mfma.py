@@ -65,9 +65,9 @@ def seg_flags(x):
 
 
 def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0, tap_major=0,
-          f16=0, dy_flags=None, out_flags=None):
+          f16=0, dy_flags=None, out_flags=None, dw_zeroed=0):
     return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), int(f16), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
-                        act, alpha, gain, clamp, hip.ptr(dy_flags), hip.ptr(out_flags))
+                        act, alpha, gain, clamp, hip.ptr(dy_flags), hip.ptr(out_flags), int(dw_zeroed))
 
 
 def out_size(h, k, pad, transposed):
@@ -107,17 +107,23 @@ class _Conv2d(torch.autograd.Function):
         pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16, may_be_sparse = ctx.cfg
         n, i, h, wd = x.shape
         o, k = w.shape[-4], w.shape[-2]
+        # every small accumulator of this backward (bias gradient, per-pixel noise sums, weight gradient) is carved from ONE zeroed
+        # buffer: one fill launch instead of three
+        n_tail = _ba.tail_zero_elems(dy, nz, ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2])
+        n_dw = w.numel() if ctx.needs_input_grad[1] else 0
+        zbuf = torch.zeros(n_tail + n_dw, device=x.device, dtype=torch.float32) if n_tail + n_dw else None
         dz, d_noise, d_strength, d_bias = _ba.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
-                                                            ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2])
+                                                            ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2],
+                                                            zero_buf=zbuf)
         # (only convs that opted in -- the generator's; the loss networks behind the masks see dense gradients)
         flags = seg_flags(dz) if (_sparse[0] and may_be_sparse and dz.shape[2] * dz.shape[3] >= SPARSE_MIN_PIXELS) else None
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16, dy_flags=flags)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16, dy_flags=flags, dw_zeroed=1)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w), hip.ptr(dx), hip.stream())
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
+            dw = zbuf[n_tail:].view(w.shape)
             hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(dz), hip.ptr(dw), hip.stream())
         return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None, None, None
 
