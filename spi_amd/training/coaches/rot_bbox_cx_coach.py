@@ -58,9 +58,12 @@ class RotBboxCoach(BaseCoach):
         return self._streams
 
     def _trainable_params(self):
+        """(backbone parameters, all other trainable parameters) of G"""
         key = id(self.G)
         if getattr(self, '_params_of', None) != key:
-            self._params_of, self._params = key, [p for p in self.G.parameters() if p.requires_grad]
+            named = [(k, p) for k, p in self.G.named_parameters() if p.requires_grad]
+            self._params_of = key
+            self._params = ([p for k, p in named if k.startswith('backbone.')], [p for k, p in named if not k.startswith('backbone.')])
         return self._params
 
     def _synth(self, G, ws, cams, rng, **kw):
@@ -76,7 +79,17 @@ class RotBboxCoach(BaseCoach):
         G, rot_bs = self.G, self.rot_bs
         ws = w_pivot.detach()
         self.optimizer.zero_grad()
-        gen = self._synth(G, ws, ctx['camera'], rng)
+        # ONE backbone pass per iteration.  The reference re-runs G.synthesis -- backbone included -- for the main view and for each
+        # pseudo-view branch (:60,92,112,133) and back-propagates each loss through it; w and G do not change inside an iteration,
+        # so the tri-planes are the same tensor every time.  They are computed once, every view renders from them (EG3D's own
+        # use_cached_backbone switch, triplane.py:64-70), each loss is back-propagated down to the planes, and the summed plane
+        # gradient goes through the backbone once at the end: the same gradient (the backbone backward is linear in d planes),
+        # 3 backbone forward + 3 backward passes fewer on every 4th iteration.
+        bb_params, params = self._trainable_params()
+        planes = G._planes(ws, noise_mode='const')
+        leaf = planes.detach().requires_grad_(True)
+        G._last_planes = leaf
+        gen = self._synth(G, ws, ctx['camera'], rng, use_cached_backbone=True)
         losses = {}
         loss = 0.0
         if hp.pt_l2_lambda > 0:
@@ -89,12 +102,14 @@ class RotBboxCoach(BaseCoach):
         # The reference calls backward() once per loss (:69,85,105,131): every parameter's .grad is read-modify-written once per
         # call (~150 tiny add_ launches each).  Here each call returns its gradients as fresh tensors (autograd.grad) and they are
         # folded into .grad in the reference's order with one multi-tensor add per call: the same sums.
-        params = self._trainable_params()
         pending = []
+        d_planes = []
 
         def branch_backward(branch_loss, sparse):
             with sparse_gradients(sparse):                          # sparse: d(image) is exactly zero outside the warp mask
-                pending.append(torch.autograd.grad(branch_loss, params, allow_unused=True))
+                g = torch.autograd.grad(branch_loss, [leaf] + params, allow_unused=True)
+            d_planes.append(g[0])
+            pending.append(g[1:])
         # The three pseudo-view branches depend on the main FORWARD only (depth_main) and on nothing of each other: each runs on its
         # own HIP stream beside the main backward, so their launch-bound stretches (4^2..64^2 backbone layers, tiny elementwise
         # kernels) fill the CUs the other chains leave idle.  Gradients meet again in the ordered multi-tensor adds below.
@@ -125,7 +140,7 @@ class RotBboxCoach(BaseCoach):
                                                        src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
                                                        src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
                     return warp['mask']
-                gs = self._synth(G, ws, cams, rng, sr_region_fn=region)   # one w, rot_bs cameras: backbone shared (triplane.py)
+                gs = self._synth(G, ws, cams, rng, sr_region_fn=region, use_cached_backbone=True)
                 losses['rot'] = self.lpips_loss(gs['image'] * warp['mask'], warp['img']) * hp.pt_rot_lambda * rot_bs
                 branch_backward(losses['rot'], True)
 
@@ -140,7 +155,7 @@ class RotBboxCoach(BaseCoach):
                                                        src_depth=torch.flip(depth_main, dims=[3]).repeat(rot_bs, 1, 1, 1),
                                                        src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
                     return warp['mask']
-                gm = self._synth(G, ws, cams_m, rng, sr_region_fn=region)
+                gm = self._synth(G, ws, cams_m, rng, sr_region_fn=region, use_cached_backbone=True)
                 flip_warp, flip_mask = torch.flip(warp['img'], dims=[3]), torch.flip(warp['mask'], dims=[3])
                 losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
                                                         ctx['lm'].repeat(rot_bs, 1, 1), plan=ctx.get('box_plan')) * hp.pt_mirror_rot_lambda * rot_bs
@@ -148,7 +163,7 @@ class RotBboxCoach(BaseCoach):
 
             def depth_branch():
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
-                sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True)['image_depth']
+                sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True, use_cached_backbone=True)['image_depth']
                 with torch.no_grad():
                     # the frozen generator's tri-planes for this pivot never change: computed on the first use, then
                     # taken from EG3D's own backbone cache (triplane.py:64-70 cache_backbone / use_cached_backbone)
@@ -175,8 +190,14 @@ class RotBboxCoach(BaseCoach):
                 from ...criteria.tv_loss import cal_tv_loss
                 losses['tv'] = cal_tv_loss(ws, G) * hp.pt_tv_lambda
                 losses['tv'].backward()
+        G._last_planes = None
+        dpl = d_planes[0]
+        for g in d_planes[1:]:
+            dpl = dpl + g
+        pending.append(torch.autograd.grad(planes, bb_params, grad_outputs=dpl, allow_unused=True))
         for grads in pending:
-            have = [(p, g) for p, g in zip(params, grads) if g is not None]
+            plist = bb_params if grads is pending[-1] else params
+            have = [(p, g) for p, g in zip(plist, grads) if g is not None]
             both = [(p.grad, g) for p, g in have if p.grad is not None]
             if both:
                 torch._foreach_add_([a for a, _ in both], [b for _, b in both])
