@@ -59,7 +59,8 @@ int spi_nhwc_to_nchw(const float* src, float* dst, int NP, int C, int H, int W, 
  *   multiplied by their weight_gain / bias_gain (networks_stylegan2.py:115-120).
  *   out: rgb / sigma rows.  Plain mode (out_S = 0): rgb [N,P,32], sigma [N,P].  Rays mode with
  *   out_S > 0: the point (ray r, sample k) goes to row r*out_S + out_off + k, so the coarse and
- *   fine passes fill one [R, Sc+Sf, .] buffer (the torch.cat of renderer.py:158-160 never happens). */
+ *   fine passes fill one [R, Sc+Sf, .] buffer (the torch.cat of renderer.py:158-160 never happens).
+ *   rgb may be NULL: only the densities are evaluated (depth-only rendering). */
 int spi_triplane_decode_fwd(const float* planes_nhwc, const float* coords, const float* ray_o,
                             const float* ray_d, const float* depths, const float* w1t, const float* b1,
                             const float* w2, const float* b2, int N, int64_t P, int S, int H, int W,

@@ -242,9 +242,11 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
     float* frow = feat + t * FS;
     float h[DEC_HID];
     layer1_forward(w1t, b1, frow, h);
-    // layer 2, one output per iteration; the rgb row overwrites this thread's own feature row
+    // layer 2, one output per iteration; the rgb row overwrites this thread's own feature row.  rgb == NULL (depth-only rendering):
+    // only the density row of W2 is evaluated and nothing but sigma is written.
+    const int nout = rgb ? DEC_OUT : 1;
 #pragma unroll 2
-    for (int o = 0; o < DEC_OUT; ++o) {
+    for (int o = 0; o < nout; ++o) {
         const float* wr = w2 + o * DEC_HID;
         float acc = b2[o];
 #pragma unroll
@@ -252,6 +254,7 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
         if (o == 0) { if (base + t < total) sigma[out_row(a, base + t)] = acc; }
         else frow[o - 1] = sigmoid_fast(acc) * 1.002f - 0.001f;
     }
+    if (!rgb) return;
     __syncthreads();
     // the tile's rgb block is contiguous in global memory: 256 points x 32 floats
 #pragma unroll
@@ -1384,7 +1387,7 @@ int spi_triplane_decode_fwd(const float* planes_nhwc, const float* coords, const
     DecodeArgs a;
     int rc = fill_decode_args(a, planes_nhwc, coords, ray_o, ray_d, depths, w1, b1, w2, b2, N, P, S, H, W, box_warp, out_S, out_off);
     if (rc) return rc;
-    SPI_REQUIRE(rgb && sigma, "spi_triplane_decode_fwd: null output");
+    SPI_REQUIRE(sigma, "spi_triplane_decode_fwd: null output");          // rgb may be NULL: densities only
     const int64_t total = (int64_t)N * P;
     hipLaunchKernelGGL(decode_fwd_kernel, dim3((unsigned)ceil_div64(total, DT)), dim3(DT), 0, as_stream(stream), a, w1, b1, w2, b2, rgb, sigma);
     SPI_LAUNCH_CHECK("spi_triplane_decode_fwd");

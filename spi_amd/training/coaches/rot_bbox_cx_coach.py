@@ -163,12 +163,12 @@ class RotBboxCoach(BaseCoach):
 
             def depth_branch():
                 cams_d = sample_camera(batch_size=4, yaw_range=0.7, pitch_range=0.4, device=self.device, rand=(rng.rand(4, 1), rng.rand(4, 1)))
-                sample_depth = self._synth(G, ws, cams_d, rng, skip_superresolution=True, use_cached_backbone=True)['image_depth']
+                sample_depth = self._synth(G, ws, cams_d, rng, depth_only=True, use_cached_backbone=True)['image_depth']
                 with torch.no_grad():
                     # the frozen generator's tri-planes for this pivot never change: computed on the first use, then
                     # taken from EG3D's own backbone cache (triplane.py:64-70 cache_backbone / use_cached_backbone)
                     cached = ctx.get('stable_planes_cached', False)
-                    stable_depth = self._synth(self.original_G, ws, cams_d, rng, skip_superresolution=True, cache_backbone=not cached,
+                    stable_depth = self._synth(self.original_G, ws, cams_d, rng, depth_only=True, cache_backbone=not cached,
                                                use_cached_backbone=cached)['image_depth']
                     ctx['stable_planes_cached'] = True
                 losses['depth'] = l2_loss(stable_depth, sample_depth) * hp.pt_depth_lambda

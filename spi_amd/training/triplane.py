@@ -69,10 +69,12 @@ class TriPlaneGenerator(torch.nn.Module):
         return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
 
     def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
-                  use_cached_backbone=False, render_noise=None, skip_superresolution=False, sr_region_fn=None, **synthesis_kwargs):
+                  use_cached_backbone=False, render_noise=None, skip_superresolution=False, sr_region_fn=None, depth_only=False,
+                  **synthesis_kwargs):
         """sr_region_fn (extension, optional): called as ``sr_region_fn(out)`` with ``{'image_raw', 'image_depth'}`` once the renderer is
         done; returns a ``[N,1,512,512]`` mask of the image pixels the caller will look at (None = all).  The super-resolution convs
-        then skip the output tiles that no such pixel depends on -- ``out['image']`` is the full forward's inside the mask and unspecified outside."""
+        then skip the output tiles that no such pixel depends on -- ``out['image']`` is the full forward's inside the mask and unspecified outside.
+        depth_only (extension): return ``{'image_depth'}`` alone; the renderer skips the colour half of the decoder and of the composite."""
         cam2world = c[:, :16].view(-1, 4, 4)
         intrinsics = c[:, 16:25].view(-1, 3, 3)
         if neural_rendering_resolution is None:
@@ -92,8 +94,10 @@ class TriPlaneGenerator(torch.nn.Module):
             # rot_bbox_cx_coach.py:92): the tri-planes do not depend on the camera, so the backbone runs ONCE and the views
             # share its output; autograd sums the per-view plane gradients before the single backbone backward pass.
             planes = planes.expand(n, -1, -1, -1, -1)
-        feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs, noise=render_noise)
+        feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs, noise=render_noise, depth_only=depth_only)
         r = self.neural_rendering_resolution
+        if depth_only:
+            return {'image_depth': depth.permute(0, 2, 1).reshape(n, 1, r, r)}
         feature_image = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
         depth_image = depth.permute(0, 2, 1).reshape(n, 1, r, r)
         rgb_image = feature_image[:, :3]

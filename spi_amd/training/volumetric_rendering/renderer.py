@@ -129,7 +129,9 @@ class _Render(torch.autograd.Function):
         d_c = torch.empty(n, m, sc, device=dev, dtype=torch.float32)
         xi = xi.reshape(n, m, sc).contiguous().float()
         hip.call('spi_coarse_depths', hip.ptr(xi), r, sc, float(opts['ray_start']), float(opts['ray_end']), hip.ptr(d_c), hip.stream())
-        rgb_all = torch.empty(n, m, s, 32, device=dev, dtype=torch.float32)
+        # depth_only (SPI's depth-regularisation branch reads nothing but image_depth): no colour rows are decoded, stored or composited
+        depth_only = bool(opts.get('depth_only', False))
+        rgb_all = torch.empty(n, m, s, 32, device=dev, dtype=torch.float32) if not depth_only else None
         sig_all = torch.empty(n, m, s, device=dev, dtype=torch.float32)
         _decode_fwd(planes_nhwc, dec, rays=(ray_o, ray_d), depths=d_c, box_warp=box_warp, out=(rgb_all, sig_all), out_S=s, out_off=0)
         if sf > 0:
@@ -146,15 +148,15 @@ class _Render(torch.autograd.Function):
         else:
             d_f, d_all, perm = None, d_c, None
         clamp2 = depth_range(d_all)
-        rgb = torch.empty(n, m, 32, device=dev, dtype=torch.float32)
+        rgb = torch.empty(n, m, 32, device=dev, dtype=torch.float32) if not depth_only else None
         depth = torch.empty(n, m, 1, device=dev, dtype=torch.float32)
         wsum = torch.empty(n, m, 1, device=dev, dtype=torch.float32)
-        if MARCH_EVENTS is not None:
+        if MARCH_EVENTS is not None and not depth_only:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         hip.call('spi_raymarch_fwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), r, s, s, 32,
                  white_back, hip.ptr(rgb), hip.ptr(depth), None, hip.ptr(wsum), hip.stream())
-        if MARCH_EVENTS is not None:
+        if MARCH_EVENTS is not None and not depth_only:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             MARCH_EVENTS.append((e0, e1, r))
@@ -270,7 +272,8 @@ class ImportanceRenderer(torch.nn.Module):
         if opts.get('density_noise', 0) > 0:
             raise NotImplementedError('density_noise > 0 is not on the SPI path (renderer.py:146-147)')
 
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, noise=None):
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, noise=None, depth_only=False):
+        """depth_only (extension): returns (None, depth, weight sums) -- the colour half of the decoder and of the composite is skipped."""
         self._check(rendering_options)
         n, m, _ = ray_origins.shape
         sc, sf = int(rendering_options['depth_resolution']), int(rendering_options['depth_resolution_importance'])
@@ -281,7 +284,7 @@ class ImportanceRenderer(torch.nn.Module):
             xi, u = noise
             xi, u = xi.to(planes.device), u.to(planes.device)
         params, gains = _decoder_params(decoder)
-        rgb, depth, wsum = _Render.apply(planes, *params, gains, ray_origins, ray_directions, xi, u, dict(rendering_options))
+        rgb, depth, wsum = _Render.apply(planes, *params, gains, ray_origins, ray_directions, xi, u, dict(rendering_options, depth_only=bool(depth_only)))
         return rgb, depth, wsum
 
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):

@@ -242,3 +242,32 @@ def test_render_backward_skips_zero_gradient_rays(frozen):
     # everything masked: exact zeros, no NaN from unwritten rows
     g0 = torch.autograd.grad([x, y], wrt, [torch.zeros_like(x), torch.zeros_like(y)])
     assert all(float(g.abs().max()) == 0.0 for g in g0)
+
+
+def test_depth_only_rendering_equals_full_depth():
+    """renderer(..., depth_only=True): same depth map and the same plane / decoder gradients of a depth loss as the full render
+    (whose colour half is then simply unused)."""
+    from spi_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    from spi_amd.training.volumetric_rendering.ray_sampler import RaySampler
+    from spi_amd.training.triplane import OSGDecoder
+    from spi_amd.utils import camera_utils as cu
+    torch.manual_seed(11)
+    n = 2
+    dec = OSGDecoder(32, {'decoder_lr_mul': 1, 'decoder_output_dim': 32}).to(DEV)
+    planes = (torch.randn(n, 3, 32, 64, 64, device=DEV) * 0.5).requires_grad_(True)
+    c = torch.cat([cu.cal_canonical_c(0.3, 0.1), cu.cal_canonical_c(-0.2, 0.0)]).to(DEV)
+    ro, rd = RaySampler()(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 32)
+    opts = dict(depth_resolution=24, depth_resolution_importance=24, ray_start=2.25, ray_end=3.3, box_warp=1, white_back=False)
+    noise = (torch.rand(n, 1024, 24, 1, device=DEV), torch.rand(n * 1024, 24, device=DEV))
+    ren = ImportanceRenderer()
+    rgb, depth, _ = ren(planes, dec, ro, rd, opts, noise=noise)
+    none, depth_o, _ = ren(planes, dec, ro, rd, opts, noise=noise, depth_only=True)
+    assert none is None and torch.equal(depth_o, depth)
+    g = torch.randn_like(depth)
+    wrt = [planes] + list(dec.parameters())
+    full = torch.autograd.grad(depth, wrt, g, allow_unused=True)
+    only = torch.autograd.grad(depth_o, wrt, g, allow_unused=True)
+    for a, b in zip(only, full):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert_close(a, b, 1e-5, 'depth-only gradient')
