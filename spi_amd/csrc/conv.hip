@@ -416,7 +416,8 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     const int Kc = P.Ci * T;                               // columns of this class
     const int ntile_n = (Kc + BN - 1) / BN;
     const int m0 = (blockIdx.y / ntile_n) * BM, j0 = (blockIdx.y % ntile_n) * BN;
-    const int pbeg = blockIdx.x * pix_per_block, pend = min(pbeg + pix_per_block, npix);
+    // dense: blockIdx.x owns a pixel range; SPARSE: an equal share of the class's flagged slabs (ranked below)
+    const int pbeg = SPARSE ? 0 : blockIdx.x * pix_per_block, pend = SPARSE ? npix : min(pbeg + pix_per_block, npix);
     if (pbeg >= npix) return;
     const float* inb = in + (int64_t)n * P.in_bs;
     const float* dob = dout + (int64_t)n * P.out_bs;
@@ -517,37 +518,54 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     static_assert(!(SPARSE && FAST), "the incremental cursor of FAST needs consecutive slabs");
     int nslab = (pend - pbeg + BK - 1) / BK;
     __shared__ unsigned short s_list[SPARSE ? WG_LISTMAX : 1];
-    __shared__ int s_nnz;
+    __shared__ int s_scan[SPARSE ? NT : 1];
     if constexpr (SPARSE) {
-        if (wave == 0) {
-            const int32_t* fl = P.seg_flags + (int64_t)n * P.nseg;
-            // is any segment of dOut flat pixels [lo, hi] flagged?
-            auto range_nz = [&](int lo, int hi) { int a = 0; for (int sg = lo >> 4; sg <= (hi >> 4); ++sg) a |= fl[sg]; return a != 0; };
-            int cnt = 0;
-            for (int b = 0; b < nslab; b += 64) {
-                const int k = b + lane;
-                bool nz = false;
-                if (k < nslab) {
-                    const int pa = pbeg + k * BK, pb = min(pa + BK, pend) - 1;
-                    const int Ya = pa / C.OWp, Xa = pa - Ya * C.OWp, Yb = pb / C.OWp, Xb = pb - Yb * C.OWp;
-                    const int ra = (Ya * P.osy + C.ooy) * P.OW + C.oox, rb = (Yb * P.osy + C.ooy) * P.OW + C.oox;
-                    if (Ya == Yb) nz = range_nz(ra + Xa * P.osx, ra + Xb * P.osx);
-                    else if (Yb == Ya + 1) nz = range_nz(ra + Xa * P.osx, ra + (C.OWp - 1) * P.osx) || range_nz(rb, rb + Xb * P.osx);
-                    else nz = true;                                  // rows shorter than a slab: no filtering
-                }
-                const unsigned long long mk = __ballot(nz);
-                if (nz) s_list[cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (unsigned short)k;
-                cnt += __popcll(mk);
+        // Every block ranks ALL slabs of its (sample, class) that touch a flagged dOut segment (the flag map is a few KB, L2-resident)
+        // and takes an equal share of the ranked list: blockIdx.x-th of gridDim.x parts.  Splitting the pixel RANGE instead leaves the
+        // blocks of the masked-out rows idle and the ones inside the mask with the whole work.
+        const int32_t* fl = P.seg_flags + (int64_t)n * P.nseg;
+        auto range_nz = [&](int lo, int hi) { int a = 0; for (int sg = lo >> 4; sg <= (hi >> 4); ++sg) a |= fl[sg]; return a != 0; };
+        const int nsl = (npix + BK - 1) / BK;
+        const int per = (nsl + NT - 1) / NT;                     // host: <= 64
+        const int k0 = tid * per;
+        unsigned long long bits = 0ull;
+        for (int j = 0; j < per; ++j) {
+            const int k = k0 + j;
+            bool nz = false;
+            if (k < nsl) {
+                const int pa = k * BK, pb = min(pa + BK, npix) - 1;
+                const int Ya = pa / C.OWp, Xa = pa - Ya * C.OWp, Yb = pb / C.OWp, Xb = pb - Yb * C.OWp;
+                const int ra = (Ya * P.osy + C.ooy) * P.OW + C.oox, rb = (Yb * P.osy + C.ooy) * P.OW + C.oox;
+                if (Ya == Yb) nz = range_nz(ra + Xa * P.osx, ra + Xb * P.osx);
+                else if (Yb == Ya + 1) nz = range_nz(ra + Xa * P.osx, ra + (C.OWp - 1) * P.osx) || range_nz(rb, rb + Xb * P.osx);
+                else nz = true;                                  // rows shorter than a slab: no filtering
             }
-            if (lane == 0) s_nnz = cnt;
+            bits |= (unsigned long long)nz << j;
+        }
+        s_scan[tid] = __popcll(bits);
+        __syncthreads();
+        for (int off = 1; off < NT; off <<= 1) {                 // inclusive scan of the per-thread counts
+            const int v = tid >= off ? s_scan[tid - off] : 0;
+            __syncthreads();
+            s_scan[tid] += v;
+            __syncthreads();
+        }
+        const int total = s_scan[NT - 1];
+        const int beg = (int)((int64_t)blockIdx.x * total / gridDim.x), end = (int)((int64_t)(blockIdx.x + 1) * total / gridDim.x);
+        int rank = s_scan[tid] - __popcll(bits);
+        while (bits) {
+            const int j = __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            if (rank >= beg && rank < end) s_list[rank - beg] = (unsigned short)(k0 + j);
+            ++rank;
         }
         __syncthreads();
-        nslab = s_nnz;
-        if (nslab == 0) return;                                      // dw was zeroed by the host
+        nslab = end - beg;
+        if (nslab == 0) return;                                  // dw was zeroed by the host
     }
     // pixel index of the i-th slab this block reduces (past the end: pend -> every element out of range -> zeros)
     auto slab_pk = [&](int i) {
-        if constexpr (SPARSE) return i < nslab ? pbeg + (int)s_list[i] * BK : pend;
+        if constexpr (SPARSE) return i < nslab ? (int)s_list[i] * BK : pend;
         else return pbeg + i * BK;
     };
     const int fr = lane & 31, fk = lane >> 5;
@@ -818,7 +836,7 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     // measured: the scalar-offset variant wins when a tap is ONE column tile (Ci == 128: +6 %) and loses for Ci >= 256 (-10 %)
     bool fastw = (P.Ci == BN) && (P.Mo % BM == 0);
     for (int c = 0; c < P.ncls; ++c) fastw = fastw && P.cls[c].OWp >= BK;
-    const bool sparse = d->dy_seg_flags != nullptr && ppb / BK <= WG_LISTMAX;
+    const bool sparse = d->dy_seg_flags != nullptr && ppb / BK + 1 <= WG_LISTMAX && (maxpix + BK - 1) / BK <= 64 * 256;
     if (sparse) { P.seg_flags = d->dy_seg_flags; P.nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
 #define SPI_WG_LAUNCH(F16F, FASTF, SPF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, F16F, FASTF, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
     if (sparse) { if (d->compute_f16) SPI_WG_LAUNCH(true, false, true); else SPI_WG_LAUNCH(false, false, true); }
