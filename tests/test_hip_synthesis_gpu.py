@@ -103,10 +103,12 @@ def test_synthesis_shared_w_equals_repeated_w(golden):
         grads = torch.autograd.grad(loss, [ws] + [params[k] for k in names])
         res.append((out, grads))
     (oa, ga), (ob, gb) = res
-    assert_close(oa['image'], ob['image'], 2e-5, 'shared-w image')
-    assert_close(oa['image_depth'], ob['image_depth'], 1e-6, 'shared-w depth')
+    # (the batched and the single backbone pass pick different split-K shapes and their atomics are not run-to-run bit-stable:
+    #  tolerances sit an order of magnitude above the usual differences)
+    assert_close(oa['image'], ob['image'], 5e-5, 'shared-w image')
+    assert_close(oa['image_depth'], ob['image_depth'], 1e-5, 'shared-w depth')
     for a, b, nm in zip(ga, gb, ['ws'] + names):
-        assert_close(a, b, 5e-4, 'shared-w grad ' + nm)
+        assert_close(a, b, 1e-3, 'shared-w grad ' + nm)
 
 
 def test_synthesis_fp16_superresolution_close_to_fp32(golden):
