@@ -1060,7 +1060,9 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
 #pragma unroll
             for (int it = 0; it < NCH * 8; ++it) {
                 const int k = min(it * 8 + rg, S - 1);
-                creg[it] = *reinterpret_cast<const float4*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4);
+                // read once, never again: non-temporal (keeps the 400 MB colour stream from evicting what the next kernels reuse)
+                const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4));
+                creg[it] = make_float4(cv.x, cv.y, cv.z, cv.w);
             }
         }
 #pragma unroll
