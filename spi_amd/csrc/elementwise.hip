@@ -132,9 +132,9 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
             float g[PX], yy[PX];
             if (ok) {
                 if (PX == 4) {
-                    const float4 g4 = *reinterpret_cast<const float4*>(dy + off);
+                    const f32x4_t g4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dy + off));      // dy and y are read once
                     g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
-                    if (y) { const float4 y4 = *reinterpret_cast<const float4*>(y + off); yy[0] = y4.x; yy[1] = y4.y; yy[2] = y4.z; yy[3] = y4.w; }
+                    if (y) { const f32x4_t y4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(y + off)); yy[0] = y4.x; yy[1] = y4.y; yy[2] = y4.z; yy[3] = y4.w; }
                 } else { g[0] = dy[off]; if (y) yy[0] = y[off]; }
             } else {
 #pragma unroll

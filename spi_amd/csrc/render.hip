@@ -1166,7 +1166,7 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
         float part = 0.f;
         // the load is unconditional (clamped row): guarded loads serialise, one exec-masked region + full wait per row group
         const int64_t row = r * S_store + L.row[min(k, S - 1)];
-        const float4 c = *reinterpret_cast<const float4*>(colors + row * 32 + sub * 4);
+        const f32x4_t c = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(colors + row * 32 + sub * 4));   // last use of the colour rows
         if (k < S) {
             part = g4.x * c.x + g4.y * c.y + g4.z * c.z + g4.w * c.w;
             const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
