@@ -262,7 +262,8 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
         const int e = it * DT + t;                 // float4 index within the tile
         const int s = e >> 3, q = e & 7;
         if (base + s < total)
-            *reinterpret_cast<float4*>(rgb + out_row(a, base + s) * DEC_IN + q * 4) = *reinterpret_cast<const float4*>(feat + s * FS + q * 4);
+            __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(feat + s * FS + q * 4),
+                                        reinterpret_cast<f32x4_t*>(rgb + out_row(a, base + s) * DEC_IN + q * 4));    // 400 MB per image, read back once
     }
 }
 
