@@ -757,6 +757,7 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     int cfg;                    // 0: 32x128, 1: 128x128, 2: 64x64, 3: 32x32, 4: 64x256 (64 output channels: same 64x64 wave tile as cfg 1)
     if (P.Mo <= 32) cfg = 0;
     else if (P.Mo <= 64 && blocks(64, 256) >= 384) cfg = 4;
+    else if (P.Mo > 32 && P.Mo <= 64 && maxpix >= 4096) cfg = 2;       // 64 output channels, too few 64x256 tiles: 64x64 tiles waste nothing (a 128-row tile is half empty)
     else if (blocks(128, 128) >= 384) cfg = 1;
     else if (P.Mo >= 64 && maxpix >= 64) cfg = 2;
     else cfg = 3;

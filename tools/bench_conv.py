@@ -26,6 +26,17 @@ SHAPES = [  # name, N, I, O, H, k, transposed, per_sample
     ('vgg 3->64 @256 N=4', 4, 3, 64, 256, 3, False, False),
     ('vgg 64->64 @256 N=4', 4, 64, 64, 256, 3, False, False),
     ('vgg 512->512 @32 N=4', 4, 512, 512, 32, 3, False, False),
+    ('vgg 64->64 @256 N=1', 1, 64, 64, 256, 3, False, False),
+    ('vgg 64->128 @128 N=1', 1, 64, 128, 128, 3, False, False),
+    ('vgg 128->128 @128 N=1', 1, 128, 128, 128, 3, False, False),
+    ('vgg 128->256 @64 N=1', 1, 128, 256, 64, 3, False, False),
+    ('vgg 256->256 @64 N=1', 1, 256, 256, 64, 3, False, False),
+    ('vgg 256->512 @32 N=1', 1, 256, 512, 32, 3, False, False),
+    ('vgg 512->512 @32 N=1', 1, 512, 512, 32, 3, False, False),
+    ('vgg 512->512 @16 N=1', 1, 512, 512, 16, 3, False, False),
+    ('vgg 64->64 @256 N=2', 2, 64, 64, 256, 3, False, False),
+    ('vgg 128->128 @128 N=2', 2, 128, 128, 128, 3, False, False),
+    ('vgg 256->256 @64 N=2', 2, 256, 256, 64, 3, False, False),
 ]
 
 
