@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     const int Kc = P.Ci * T;                               // columns of this class
     const int ntile_n = (Kc + BN - 1) / BN;
     const int m0 = (blockIdx.y / ntile_n) * BM, j0 = (blockIdx.y % ntile_n) * BN;
+    if (m0 >= P.Mo) return;                                 // a class with fewer column tiles than the widest one (transposed convs)
     // dense: blockIdx.x owns a pixel range; SPARSE: an equal share of the class's flagged slabs (ranked below)
     const int pbeg = SPARSE ? 0 : blockIdx.x * pix_per_block, pend = SPARSE ? npix : min(pbeg + pix_per_block, npix);
     if (pbeg >= npix) return;
@@ -830,7 +831,10 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     int maxpix = 0, maxcols = 0;
     for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxcols = std::max(maxcols, P.Ci * P.cls[c].taps.T); }
     const int tiles = ((P.Mo + BM - 1) / BM) * ((maxcols + BN - 1) / BN);
-    int64_t splits = std::max<int64_t>(1, 1024 / std::max<int64_t>(1, (int64_t)tiles * P.N * P.ncls));
+    // blocks that do work: the classes of a transposed conv hold 4 / 2 / 2 / 1 taps, i.e. different numbers of column tiles
+    int64_t active = 0;
+    for (int c = 0; c < P.ncls; ++c) active += (int64_t)((P.Mo + BM - 1) / BM) * ((P.Ci * P.cls[c].taps.T + BN - 1) / BN);
+    int64_t splits = std::max<int64_t>(1, 1024 / std::max<int64_t>(1, active * P.N));
     int ppb = (int)((maxpix + splits - 1) / splits);
     ppb = std::max(64, ((ppb + BK - 1) / BK) * BK);
     dim3 grid((unsigned)((maxpix + ppb - 1) / ppb), (unsigned)tiles, (unsigned)(P.N * P.ncls));
