@@ -827,7 +827,10 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
         if (e != hipSuccess) { spi_set_error("spi_conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
     }
     // tile 128 x 128; split the pixel reduction so the grid has ~>= 1024 blocks
-    constexpr int BM = 128, BN = 128;
+    // (a 32-row tile for layers with <= 32 output channels -- the 3-channel torgb layers: a 128-row tile spends 97 % of its MFMAs on
+    //  rows that do not exist and the kernel should be memory-bound there)
+    constexpr int BN = 128;
+    const int BM = P.Mo <= 32 ? 32 : 128;
     int maxpix = 0, maxcols = 0;
     for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxcols = std::max(maxcols, P.Ci * P.cls[c].taps.T); }
     const int tiles = ((P.Mo + BM - 1) / BM) * ((maxcols + BN - 1) / BN);
@@ -836,15 +839,21 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     for (int c = 0; c < P.ncls; ++c) active += (int64_t)((P.Mo + BM - 1) / BM) * ((P.Ci * P.cls[c].taps.T + BN - 1) / BN);
     int64_t splits = std::max<int64_t>(1, 1024 / std::max<int64_t>(1, active * P.N));
     int ppb = (int)((maxpix + splits - 1) / splits);
-    ppb = std::max(64, ((ppb + BK - 1) / BK) * BK);
+    ppb = std::max(256, ((ppb + BK - 1) / BK) * BK);     // >= 16 slabs per block: below that the 16 K atomics of a tile cost more than its MFMAs
     dim3 grid((unsigned)((maxpix + ppb - 1) / ppb), (unsigned)tiles, (unsigned)(P.N * P.ncls));
     // measured: the scalar-offset variant wins when a tap is ONE column tile (Ci == 128: +6 %) and loses for Ci >= 256 (-10 %)
-    bool fastw = (P.Ci == BN) && (P.Mo % BM == 0);
+    bool fastw = (P.Ci == BN) && (P.Mo % 128 == 0);
     for (int c = 0; c < P.ncls; ++c) fastw = fastw && P.cls[c].OWp >= BK;
     const bool sparse = d->dy_seg_flags != nullptr && ppb / BK + 1 <= WG_LISTMAX && (maxpix + BK - 1) / BK <= 64 * 256;
     if (sparse) { P.seg_flags = d->dy_seg_flags; P.nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
 #define SPI_WG_LAUNCH(F16F, FASTF, SPF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, F16F, FASTF, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
-    if (sparse) { if (d->compute_f16) SPI_WG_LAUNCH(true, false, true); else SPI_WG_LAUNCH(false, false, true); }
+    if (BM == 32) {
+#define SPI_WG_SKINNY(F16F, SPF) hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1, F16F, false, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
+        if (sparse) { if (d->compute_f16) SPI_WG_SKINNY(true, true); else SPI_WG_SKINNY(false, true); }
+        else { if (d->compute_f16) SPI_WG_SKINNY(true, false); else SPI_WG_SKINNY(false, false); }
+#undef SPI_WG_SKINNY
+    }
+    else if (sparse) { if (d->compute_f16) SPI_WG_LAUNCH(true, false, true); else SPI_WG_LAUNCH(false, false, true); }
     else if (d->compute_f16) { if (fastw) SPI_WG_LAUNCH(true, true, false); else SPI_WG_LAUNCH(true, false, false); }
     else { if (fastw) SPI_WG_LAUNCH(false, true, false); else SPI_WG_LAUNCH(false, false, false); }
 #undef SPI_WG_LAUNCH
