@@ -943,19 +943,27 @@ __global__ void __launch_bounds__(256) modulate_fwd_kernel(const float* __restri
     __shared__ float red[4];
     const int o = blockIdx.x, tid = threadIdx.x, IT = I * T;
     const float* wr = weight + (int64_t)o * IT;
-    for (int e = tid; e < IT; e += 256) { const int i = e / T, t = e - i * T; Ws[t * I + i] = wr[e]; }
+    // loops are (tap, channel) nests: no per-element division by T or modulo I (each costs ~30 VALU instructions on gfx950)
+    for (int i = tid; i < I; i += 256)
+        for (int t = 0; t < T; ++t) Ws[t * I + i] = wr[i * T + t];
     __syncthreads();
     for (int n = 0; n < N; ++n) {
         const float* sn = styles + (int64_t)n * I;
         float ss = 0.f;
         if (demod) {
-            for (int e = tid; e < IT; e += 256) { const float v = Ws[e] * (sn[e % I] * sgain); ss = fmaf(v, v, ss); }
+            for (int i = tid; i < I; i += 256) {
+                const float sv = sn[i] * sgain;
+                for (int t = 0; t < T; ++t) { const float v = Ws[t * I + i] * sv; ss = fmaf(v, v, ss); }
+            }
             ss = block_sum_256(ss, red);
         }
         const float d = demod ? rsqrtf(ss + 1e-8f) : 1.f;
         if (tid == 0 && dcoef) dcoef[(int64_t)n * O + o] = d;
         float* dst = w_out + ((int64_t)n * O + o) * IT;
-        for (int e = tid; e < IT; e += 256) dst[e] = Ws[e] * (sn[e % I] * sgain) * d;
+        for (int i = tid; i < I; i += 256) {
+            const float sv = sn[i] * sgain * d;
+            for (int t = 0; t < T; ++t) dst[t * I + i] = Ws[t * I + i] * sv;
+        }
     }
 }
 
@@ -966,40 +974,44 @@ __global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restri
     extern __shared__ float smem[];
     const int IT = I * T;
     float* Ws = smem;                  // [T][I] weights
-    float* Ds = smem + IT;             // [T][I] dv of the current sample
-    float* Acc = smem + 2 * IT;        // [T][I] running dW (tap-major)
+    float* Acc = smem + IT;            // [T][I] running dW (tap-major)
     __shared__ float red[4];
     const int o = blockIdx.x, tid = threadIdx.x;
     const float* wr = weight + (int64_t)o * IT;
-    for (int e = tid; e < IT; e += 256) { const int i = e / T, t = e - i * T; Ws[t * I + i] = wr[e]; Acc[t * I + i] = 0.f; }
+    // (tap, channel) loop nests: thread `tid` owns channels tid, tid + 256, ... in every pass -- no division / modulo per element, no
+    // race on Acc, and the d_styles sum of a channel is finished by the thread that produced its dv (no second pass over LDS)
+    for (int i = tid; i < I; i += 256)
+        for (int t = 0; t < T; ++t) { Ws[t * I + i] = wr[i * T + t]; Acc[t * I + i] = 0.f; }
     __syncthreads();
     for (int n = 0; n < N; ++n) {
         const float* sn = styles + (int64_t)n * I;
         const float* gn = g + ((int64_t)n * O + o) * IT;
         float gv = 0.f;
         if (demod) {
-            for (int e = tid; e < IT; e += 256) gv = fmaf(gn[e], Ws[e] * (sn[e % I] * sgain), gv);
+            for (int i = tid; i < I; i += 256) {
+                const float sv = sn[i] * sgain;
+                for (int t = 0; t < T; ++t) gv = fmaf(gn[t * I + i], Ws[t * I + i] * sv, gv);
+            }
             gv = block_sum_256(gv, red);
         }
         const float d = demod ? dcoef[(int64_t)n * O + o] : 1.f;
         const float k3 = demod ? d * d * d * gv : 0.f;
-        for (int e = tid; e < IT; e += 256) {
-            const float sv = sn[e % I] * sgain;
-            const float dv = d * gn[e] - k3 * (Ws[e] * sv);
-            Ds[e] = dv;
-            Acc[e] = fmaf(dv, sv, Acc[e]);                           // same thread owns e in every pass: no race
-        }
-        __syncthreads();
         for (int i = tid; i < I; i += 256) {
+            const float sv = sn[i] * sgain;
             float a = 0.f;
-            for (int t = 0; t < T; ++t) a = fmaf(Ds[t * I + i], Ws[t * I + i], a);
+            for (int t = 0; t < T; ++t) {
+                const float wv = Ws[t * I + i];
+                const float dv = d * gn[t * I + i] - k3 * (wv * sv);
+                Acc[t * I + i] = fmaf(dv, sv, Acc[t * I + i]);
+                a = fmaf(dv, wv, a);
+            }
             atomicAdd(d_styles + (int64_t)n * I + i, a * sgain);
         }
-        __syncthreads();
     }
     if (d_weight) {
         float* dst = d_weight + (int64_t)o * IT;
-        for (int e = tid; e < IT; e += 256) { const int i = e / T, t = e - i * T; dst[e] = Acc[t * I + i]; }
+        for (int i = tid; i < I; i += 256)
+            for (int t = 0; t < T; ++t) dst[i * T + t] = Acc[t * I + i];
     }
 }
 
@@ -1019,7 +1031,7 @@ int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoe
     SPI_REQUIRE(weight && styles && g && d_styles, "spi_modulate_bwd: null tensor");
     SPI_REQUIRE(N > 0 && O > 0 && I > 0 && T > 0 && (int64_t)I * T * 12 <= 64 * 1024, "spi_modulate_bwd: bad sizes (I*T must be <= 5461)");
     SPI_REQUIRE(!demodulate || dcoef, "spi_modulate_bwd: demodulation needs dcoef from the forward pass");
-    hipLaunchKernelGGL(modulate_bwd_kernel, dim3((unsigned)O), dim3(256), (size_t)I * T * 12, as_stream(stream), weight, styles, dcoef,
+    hipLaunchKernelGGL(modulate_bwd_kernel, dim3((unsigned)O), dim3(256), (size_t)I * T * 8, as_stream(stream), weight, styles, dcoef,
                        g, d_weight, d_styles, N, O, I, T, demodulate, style_gain);
     SPI_LAUNCH_CHECK("spi_modulate_bwd");
     return SPI_OK;
