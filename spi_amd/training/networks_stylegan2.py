@@ -335,17 +335,15 @@ class SynthesisBlock(torch.nn.Module):
         # (global_config.enable_fp16_blocks, `--sr_fp16`): default fp32 everywhere = the reference's CPU path, which is the
         # parity target.  fp16 blocks keep fp32 tensors and round the conv operands to fp16 on their way into the MFMAs.
         f16 = bool(self.use_fp16 and not force_fp32 and global_config.enable_fp16_blocks)
-        wi = 0
+        w_iter = iter(ws.unbind(dim=1))               # (:432) one unbind -> one stack in the backward instead of a zero-fill + copy per row
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
         else:
-            x = self.conv0(x.float(), ws[:, wi], fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
-            wi += 1
-        x = self.conv1(x, ws[:, wi], fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
-        wi += 1
+            x = self.conv0(x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
+        x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
         if img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        y = self.torgb(x, ws[:, wi], fused_modconv=fused_modconv, fp16=f16)
+        y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16)
         img = img + y if img is not None else y
         return x, img
 
