@@ -175,6 +175,14 @@ int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C
 #define SPI_SEG_PIXELS 16
 int spi_seg_flags(const float* x, int32_t* flags, int N, int C, int64_t HW, spi_stream_t stream);
 
+/* Last step of the frozen-weight style gradient (see spi_chan_dot):
+ *   ds[s,i] = A_i / st[s,i]  -  st[s,i] * gain^2 * sum_o dcoef[s,o]^2 * C_o * ww[o,i],     A_i = sum_n a[n,i],  C_o = sum_n cv[n,o]
+ * a [N,I] = <x_i, dx_i>, cv [N,O] = <dz_o, z_o> (NULL without demodulation: second term dropped), st [NS,I] styles (NS = N, or 1
+ * = one style row shared by the batch: then the sums run over n), dcoef [NS,O], ww [O,I] = sum_t W[o,i,t]^2.  |st| <= 1e-20 gives 0
+ * for the first term.  One launch instead of ~15 elementwise / reduction / GEMV launches per layer. */
+int spi_style_grad(const float* a, const float* cv, const float* st, const float* dcoef, const float* ww, float* ds, int N, int NS,
+                   int I, int O, float style_gain, spi_stream_t stream);
+
 /* upfirdn2d.cpp:20 `upfirdn2d(x,f,upx,upy,downx,downy,padx0,padx1,pady0,pady1,flip,gain)`.
  *   x [N,C,inH,inW] (dense NCHW), f [fH,fW]; y [N,C,outH,outW] with the reference's output-size rule.
  * Optional fused epilogue (NULL / act = 0 disables): y = bias_act(y + noise[outH,outW]*noise_gain[0], bias[C]). */

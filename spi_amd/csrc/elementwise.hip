@@ -795,6 +795,38 @@ __global__ void __launch_bounds__(256) seg_flags_kernel(const float* __restrict_
     if (tid < 64 && seg < nseg) flags[(int64_t)n * nseg + seg] = s_f[tid];
 }
 
+// ds[s,i] = A_i / st[s,i] - st[s,i] g^2 sum_o dcoef[s,o]^2 C_o ww[o,i]   (frozen-weight style gradient, see spi_style_grad)
+__global__ void __launch_bounds__(256) style_grad_kernel(const float* __restrict__ a, const float* __restrict__ cv, const float* __restrict__ st,
+                                                         const float* __restrict__ dcoef, const float* __restrict__ ww, float* __restrict__ ds,
+                                                         int N, int NS, int I, int O, float g2) {
+    extern __shared__ float coef[];                       // [O]: dcoef[s,o]^2 * C_o
+    const int s = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const bool shared = (NS == 1 && N > 1);
+    if (cv) {
+        for (int o = threadIdx.x; o < O; o += 256) {
+            float c = 0.f;
+            if (shared) for (int n = 0; n < N; ++n) c += cv[(int64_t)n * O + o];
+            else c = cv[(int64_t)s * O + o];
+            const float d = dcoef[(int64_t)s * O + o];
+            coef[o] = d * d * c;
+        }
+        __syncthreads();
+    }
+    if (i >= I) return;
+    float av = 0.f;
+    if (shared) for (int n = 0; n < N; ++n) av += a[(int64_t)n * I + i];
+    else av = a[(int64_t)s * I + i];
+    const float sv = st[(int64_t)s * I + i];
+    float r = fabsf(sv) > 1e-20f ? av / sv : 0.f;
+    if (cv) {
+        float acc = 0.f;
+#pragma unroll 4
+        for (int o = 0; o < O; ++o) acc = fmaf(coef[o], ww[(int64_t)o * I + i], acc);
+        r -= sv * g2 * acc;
+    }
+    ds[(int64_t)s * I + i] = r;
+}
+
 extern "C" {
 
 int spi_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y, int64_t n,
@@ -866,6 +898,16 @@ int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C
     dim3 grid((unsigned)ceil_div64(HW, per_block), (unsigned)rows);
     hipLaunchKernelGGL(chan_dot_kernel, grid, dim3(256), 0, as_stream(stream), a, b, out, C, HW, per_block, bias, noise, noise_gain, act, alpha, gain);
     SPI_LAUNCH_CHECK("spi_chan_dot");
+    return SPI_OK;
+}
+
+int spi_style_grad(const float* a, const float* cv, const float* st, const float* dcoef, const float* ww, float* ds, int N, int NS,
+                   int I, int O, float style_gain, spi_stream_t stream) {
+    SPI_REQUIRE(a && st && ds && N > 0 && (NS == N || NS == 1) && I > 0 && O > 0 && O <= 8192, "spi_style_grad: bad argument");
+    SPI_REQUIRE(cv == nullptr || (dcoef && ww), "spi_style_grad: the demodulation term needs dcoef and ww");
+    hipLaunchKernelGGL(style_grad_kernel, dim3((unsigned)((I + 255) / 256), (unsigned)NS), dim3(256), (size_t)O * sizeof(float), as_stream(stream),
+                       a, cv, st, dcoef, ww, ds, N, NS, I, O, style_gain * style_gain);
+    SPI_LAUNCH_CHECK("spi_style_grad");
     return SPI_OK;
 }
 

@@ -40,6 +40,7 @@ _SIGS = {
     'spi_raymarch_bwd': ([c_p] * 8 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 4, c_i),
     'spi_importance_sample': ([c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p], c_i),
     'spi_merge_sort_depths': ([c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p], c_i),
+    'spi_style_grad': ([c_p] * 6 + [c_i, c_i, c_i, c_i, c_f, c_p], c_i),
     'spi_seg_flags': ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     'spi_bias_act': ([c_p] * 6 + [c_l, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_upfirdn2d': ([c_p] * 3 + [c_i] * 15 + [c_f, c_i, c_i] + [c_p] * 3 + [c_i, c_f, c_f, c_f, c_p], c_i),

@@ -63,6 +63,17 @@ def modulate_weights(weight, styles, demodulate=True, style_gain=1.0):
     return _Modulate.apply(weight, styles, bool(demodulate), float(style_gain))
 
 
+def _tap_energy(weight):
+    """sum_t W[o,i,t]^2 [O, I] of a FROZEN conv weight.  Cached ON the parameter object (so it lives and dies with it) and recomputed
+    when the tensor has been written since (``_version``): stage 1 evaluates it 500 times per image on unchanged weights."""
+    hit = getattr(weight, '_spi_tap_energy', None)
+    if hit is None or hit[0] != weight._version or hit[1].device != weight.device:
+        with torch.no_grad():
+            hit = (weight._version, weight.detach().float().square().sum(dim=(2, 3)).contiguous())
+        weight._spi_tap_energy = hit
+    return hit[1]
+
+
 class _ModConvFrozen(torch.autograd.Function):
     """Modulated conv whose WEIGHTS are frozen but whose styles need a gradient (SPI stage 1: G.requires_grad_(False), W+ is
     optimised).  The reference's autograd graph computes the full O*I*k*k weight gradient only to contract it with dw''/ds;
@@ -72,7 +83,7 @@ class _ModConvFrozen(torch.autograd.Function):
     the weight-gradient GEMM (20 % of a stage-1 step) disappears.  Same value up to fp32 rounding."""
 
     @staticmethod
-    def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16):
+    def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16, ww=None):
         import ctypes
         from ..torch_utils.ops.conv2d_mfma import _desc, out_size
         x = x.contiguous().float()
@@ -96,7 +107,7 @@ class _ModConvFrozen(torch.autograd.Function):
         d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w2), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0 or bb is not None or nz is not None)
-        ctx.save_for_backward(x, weight, st, w2, dcoef, y, bb, nz, ng)
+        ctx.save_for_backward(x, weight, st, w2, dcoef, y, bb, nz, ng, ww)
         ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, demodulate, float(style_gain), f16)
         return y
 
@@ -105,35 +116,37 @@ class _ModConvFrozen(torch.autograd.Function):
     def backward(ctx, dy):
         import ctypes
         from ..torch_utils.ops.conv2d_mfma import _desc
-        x, weight, st, w2, dcoef, y, bb, nz, ng = ctx.saved_tensors
+        x, weight, st, w2, dcoef, y, bb, nz, ng, ww = ctx.saved_tensors
         pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, demodulate, sgain, f16 = ctx.cfg
         o, i, kh, kw = weight.shape
         n, ns = x.shape[0], st.shape[0]
         h, wd = x.shape[2], x.shape[3]
+        # one zeroed buffer for every accumulator of this backward: layer-tail sums | <x_i, dx_i> | <dz_o, z_o>
+        n_tail = bias_act.tail_zero_elems(dy, nz, ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3])
+        zb = torch.zeros(n_tail + n * i + (n * o if demodulate else 0), device=x.device, dtype=torch.float32)
         dz, d_noise, d_strength, d_bias = bias_act.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
-                                                                 ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3])
+                                                                 ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3],
+                                                                 zero_buf=zb)
         d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, tap_major=1, f16=f16)
         dx = torch.empty_like(x)
         hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w2), hip.ptr(dx), hip.stream())
-        a = torch.zeros(n, i, device=x.device, dtype=torch.float32)
+        a = zb[n_tail:n_tail + n * i]
         hip.call('spi_chan_dot', hip.ptr(x), hip.ptr(dx), hip.ptr(a), n * i, i, h * wd, None, None, None, 0, 0.0, 1.0, hip.stream())
-        if ns == 1 and n > 1:
-            a = a.sum(0, keepdim=True)
-        ds = torch.where(st.abs() > 1e-20, a / st, torch.zeros_like(a))
+        cv = None
         if demodulate:
-            cv = torch.zeros(n, o, device=x.device, dtype=torch.float32)
+            cv = zb[n_tail + n * i:]
             hw_out = y.shape[2] * y.shape[3]
             if has_epi:
                 hip.call('spi_chan_dot', hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, hip.ptr(bb), hip.ptr(nz), hip.ptr(ng), act_id, alpha,
                          gain, hip.stream())
             else:
                 hip.call('spi_chan_dot', hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, None, None, None, 0, 0.0, 1.0, hip.stream())
-            if ns == 1 and n > 1:
-                cv = cv.sum(0, keepdim=True)
-            ww = weight.square().sum(dim=(2, 3))                                   # [O, I]
-            ds = ds - st * (sgain * sgain) * ((dcoef.square() * cv) @ ww)
+            if ww is None:
+                ww = weight.square().sum(dim=(2, 3)).contiguous()                  # [O, I]
+        ds = torch.empty(ns, i, device=x.device, dtype=torch.float32)
+        hip.call('spi_style_grad', hip.ptr(a), hip.ptr(cv), hip.ptr(st), hip.ptr(dcoef), hip.ptr(ww), hip.ptr(ds), n, ns, i, o, sgain, hip.stream())
         return (dx if ctx.needs_input_grad[0] else None, None, ds, d_bias, d_noise, d_strength,
-                None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None)
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
@@ -165,10 +178,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                 assert act_id in (1, 3), 'fused epilogue of the frozen-weight path supports linear / lrelu'
                 a_, g_, c_ = float(d_alpha), float(d_gain if gain is None else gain), float(-1 if clamp is None else clamp)
             return _ModConvFrozen.apply(x, weight, styles, bias, noise, noise_strength, int(padding), False, not flip_weight, act_id, a_, g_, c_,
-                                        bool(demodulate), float(style_gain), bool(fp16))
+                                        bool(demodulate), float(style_gain), bool(fp16), _tap_energy(weight) if demodulate else None)
         assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
         z = _ModConvFrozen.apply(x, weight, styles, None, None, None, 0, True, flip_weight, 0, 0.0, 1.0, -1.0, bool(demodulate),
-                                 float(style_gain), bool(fp16))
+                                 float(style_gain), bool(fp16), _tap_energy(weight) if demodulate else None)
         return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
                                             padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
     w = modulate_weights(weight, styles, demodulate, style_gain)
