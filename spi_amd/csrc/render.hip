@@ -215,19 +215,26 @@ __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, i
 // the per-point vector that is indexed by the loop variable lives in LDS, the 64 accumulators in
 // registers.  (A fully unrolled version makes the compiler hoist all 4160 weights into SGPRs and
 // spill them through v_writelane/v_readlane.)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+// Packed fp32 (v_pk_fma_f32: two FMAs per lane and cycle -- the 157 TFLOP/s vector peak assumes it): hidden units are processed in
+// pairs, the weight pair comes from SGPRs, the per-point input is broadcast into both halves.
 __device__ __forceinline__ void layer1_forward(const float* __restrict__ w1t, const float* __restrict__ b1,
                                                const float* frow, float (&h)[DEC_HID]) {
+    f32x2_t h2[DEC_HID / 2];
+    const f32x2_t* b2v = reinterpret_cast<const f32x2_t*>(b1);
 #pragma unroll
-    for (int j = 0; j < DEC_HID; ++j) h[j] = b1[j];
+    for (int j = 0; j < DEC_HID / 2; ++j) h2[j] = b2v[j];
 #pragma unroll 2
     for (int i = 0; i < DEC_IN; ++i) {
         const float fi = frow[i];
-        const float* wr = w1t + i * DEC_HID;
+        const f32x2_t f2 = {fi, fi};
+        const f32x2_t* wr = reinterpret_cast<const f32x2_t*>(w1t + i * DEC_HID);
 #pragma unroll
-        for (int j = 0; j < DEC_HID; ++j) h[j] = fmaf(wr[j], fi, h[j]);
+        for (int j = 0; j < DEC_HID / 2; ++j) h2[j] = __builtin_elementwise_fma(wr[j], f2, h2[j]);
     }
 #pragma unroll
-    for (int j = 0; j < DEC_HID; ++j) h[j] = softplus_fast(h[j]);
+    for (int j = 0; j < DEC_HID / 2; ++j) { h[2 * j] = softplus_fast(h2[j].x); h[2 * j + 1] = softplus_fast(h2[j].y); }
 }
 
 __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
@@ -247,10 +254,11 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
     const int nout = rgb ? DEC_OUT : 1;
 #pragma unroll 2
     for (int o = 0; o < nout; ++o) {
-        const float* wr = w2 + o * DEC_HID;
-        float acc = b2[o];
+        const f32x2_t* wr = reinterpret_cast<const f32x2_t*>(w2 + o * DEC_HID);
+        f32x2_t acc2 = {b2[o], 0.f};
 #pragma unroll
-        for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], h[j], acc);
+        for (int j = 0; j < DEC_HID / 2; ++j) acc2 = __builtin_elementwise_fma(wr[j], f32x2_t{h[2 * j], h[2 * j + 1]}, acc2);
+        const float acc = acc2.x + acc2.y;
         if (o == 0) { if (base + t < total) sigma[out_row(a, base + t)] = acc; }
         else frow[o - 1] = sigmoid_fast(acc) * 1.002f - 0.001f;
     }
