@@ -275,3 +275,49 @@ def test_idloss_irse50_vs_oracle_and_reference_golden():
         finally:
             paths_config.IDLOSS_PATH = old
     assert abs(ids - float(gold['similarity'])) < 1e-4 and lp == 0
+
+
+def test_stage2_concurrent_branches_equal_sequential():
+    """global_config.concurrent_branches (rot / mirror-rot / depth on their own HIP streams) gives the sequential loop's losses and
+    parameter updates: same kernels, same summation order of the gradients, only the interleaving on the device differs."""
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.criteria.bbox_cx_loss import BoxCXLoss
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.data.images_dataset import SyntheticDataset
+    from spi_amd.configs import hyperparameters, paths_config, global_config
+    import tempfile
+    W, W19 = olo.make_vgg16_weights(seed=0), olo.make_vgg19_head_weights(seed=1)
+    data = SyntheticDataset(1)[0]
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in data.items()}
+    w_pivot = torch.randn(1, 14, 512, generator=torch.Generator().manual_seed(6)).to(DEV)
+    tmp = tempfile.mkdtemp()
+    saved = {k: getattr(paths_config, k) for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir')}
+    hp_saved = (hyperparameters.first_inv_type, hyperparameters.G_1_type, hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda,
+                hyperparameters.pt_depth_lambda, hyperparameters.LPIPS_value_threshold, global_config.concurrent_branches)
+    res = []
+    try:
+        for k in saved:
+            setattr(paths_config, k, f'{tmp}/{k}/')
+        hyperparameters.first_inv_type, hyperparameters.G_1_type = 'mir', 'RotBbox'
+        hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda = 0.1, 0.05, 1.0
+        hyperparameters.LPIPS_value_threshold = -1.0
+        for flag in (False, True):
+            global_config.concurrent_branches = flag
+            coach = RotBboxCoach(None, False, G=_narrow(), lpips_loss=LPIPS(weights=W), box_cx_loss=BoxCXLoss(weights=W19))
+            ctx = coach.prepare_image(data)
+            torch.manual_seed(123)                               # DeviceRNG draws from torch's device generator: same draws in both runs
+            losses = [coach.train_step(i, ctx, w_pivot)[1] for i in range(5)]
+            torch.cuda.synchronize()
+            res.append(([{k: float(v.detach()) for k, v in l.items()} for l in losses], {k: v.detach().clone() for k, v in coach.G.state_dict().items()}))
+    finally:
+        for k, v in saved.items():
+            setattr(paths_config, k, v)
+        (hyperparameters.first_inv_type, hyperparameters.G_1_type, hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda,
+         hyperparameters.pt_depth_lambda, hyperparameters.LPIPS_value_threshold, global_config.concurrent_branches) = hp_saved
+    (la, pa), (lb, pb) = res
+    assert set(la[0]) >= {'rot', 'mirror_rot', 'depth'} and set(la[4]) >= {'rot', 'mirror_rot', 'depth'}
+    for a, b in zip(la, lb):
+        for k in a:
+            assert abs(a[k] - b[k]) <= 1e-4 * abs(a[k]) + 1e-9, (k, a[k], b[k])
+    for k in ('backbone.synthesis.b64.conv1.weight', 'superresolution.block1.conv1.weight', 'decoder.net.2.weight'):
+        assert_close(pa[k], pb[k], 1e-3, 'parameters after 5 steps: ' + k)
