@@ -189,9 +189,9 @@ def test_synthesis_sr_region_equals_full_inside_region():
     g_full = torch.autograd.grad((full * mask).square().sum(), params, allow_unused=True)
     part = G.synthesis(w, c, noise_mode='const', render_noise=noise, sr_region_fn=region)['image']
     assert seen['keys'] == {'image_raw', 'image_depth'}
-    assert_close(part * mask, full * mask, 1e-5, 'image inside the region')        # (split-K layers are not run-to-run bit-stable)
+    assert_close(part * mask, full * mask, 5e-5, 'image inside the region')        # (split-K layers are not run-to-run bit-stable)
     assert float(((part - full).abs() > 1e-3).float().mean()) > 0.3                # most of the image was NOT computed
     g_part = torch.autograd.grad((part * mask).square().sum(), params, allow_unused=True)
     for a, b in zip(g_part, g_full):
         if b is not None:
-            assert_close(a, b, 1e-5, 'gradient through the region forward')
+            assert_close(a, b, 2e-4, 'gradient through the region forward')    # atomics order (wgrad splits, scatter) varies run to run
