@@ -227,6 +227,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow)
         print(json.dumps(out), flush=True)
+    sdist.shutdown()                                             # ranks leave together (rank 0 is still timing its roofline lines)
 
 
 if __name__ == '__main__':

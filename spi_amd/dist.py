@@ -45,3 +45,11 @@ def reduce_stats(values, device=None, op='sum'):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 'sum' else dist.ReduceOp.MAX)
     return t.cpu().tolist()
+
+
+def shutdown():
+    """Barrier + destroy the process group (no-op in a single-process run)."""
+    import torch.distributed as td
+    if td.is_available() and td.is_initialized():
+        td.barrier()
+        td.destroy_process_group()
