@@ -11,6 +11,7 @@ stage-2 part a whole number of 4-iteration super-cycles so the every-4th-step br
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -144,7 +145,8 @@ def main():
     G = TriPlaneGenerator(**ffhq512_kwargs(narrow=args.narrow, depth_resolution=args.depth, depth_resolution_importance=args.depth))
     G = G.eval().requires_grad_(False).to(dev)
     G.neural_rendering_resolution = 128
-    coach = RotBboxCoach(None, False, G=G)
+    with contextlib.redirect_stdout(sys.stderr):                 # the coach announces its name like the reference does; stdout carries the JSON line only
+        coach = RotBboxCoach(None, False, G=G)
     d = SyntheticDataset(world)[rank]                            # one independent image per rank
     data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in d.items()}
     ctx = coach.prepare_image(data)
