@@ -208,7 +208,7 @@ def main():
         if os.path.exists(pmc) and march_rays:
             traffic = json.load(open(pmc)).get('hbm_bytes_per_16384_rays') / 16384.0 * (sum(march_rays) / len(march_rays))
         out = {
-            'metric': 'SPI inversion iters/sec (512^2, 96+96 ray samples)', 'value': world * args.steps / dt, 'unit': 'iters/s',
+            'metric': f'SPI inversion iters/sec (512^2, {args.depth}+{args.depth} ray samples)', 'value': world * args.steps / dt, 'unit': 'iters/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
             'stage1_host_enqueue_ms_per_step': marks.get('stage1_host_ms_per_step'),
             'stages': {'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
@@ -217,8 +217,9 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32+f16sr' if args.sr_fp16 else 'f32', 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
             'random-init weights of the ffhqrebalanced512-128 architecture)',
-            'config': {'workload': 'configs[1]: 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
-                                   f'{args.depth}+{args.depth} samples', 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
+            'config': {'workload': ('configs[4]' if (args.depth == 128 and args.sr_fp16) else 'configs[1]') +
+                                   ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
+                                   f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow)},
             'roofline': {'kernel': 'raymarch_fwd_kernel<3> (final composite, S=%d, C=32)' % S, 'bound': 'hbm', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
