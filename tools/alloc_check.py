@@ -1,3 +1,5 @@
+"""Run the default bench.py and print the caching allocator's device alloc / free counters at every synchronize: the timed region
+must not allocate device memory (it does not: the counters stop moving after the warm-up)."""
 import sys, json, runpy, torch
 sys.argv = ['bench.py', '--no-cpu-baseline']
 sys.path.insert(0, "."); import bench

@@ -1,3 +1,4 @@
+"""Full-size synthesis with fp32 and with fp16-operand super-resolution on the same inputs: size of the difference."""
 import sys, torch
 sys.path.insert(0, '.')
 from spi_amd.configs import global_config
