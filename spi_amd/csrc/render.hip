@@ -1324,6 +1324,27 @@ __global__ void __launch_bounds__(256) merge_sort_kernel(const float* __restrict
     float* d = s_d[wave];
     for (int k = lane; k < S; k += 64) d[k] = (k < Sc) ? coarse[r * Sc + k] : fine[r * Sf + (k - Sc)];
     __builtin_amdgcn_wave_barrier();
+    // The renderer hands over two ascending runs (stratified coarse samples, importance samples emitted in order): then the stable
+    // rank of an element is its index in its own run plus a binary search in the other one (coarse before fine on ties) -- 7 probes
+    // instead of S comparisons.  Anything else (NaNs, unsorted runs) takes the generic O(S^2) rank sort below.
+    bool asc = true;
+    for (int k = lane; k < S; k += 64) asc = asc && (k + 1 >= S || k + 1 == Sc || d[k] <= d[k + 1]);
+    if (__all(asc)) {
+        for (int k = lane; k < S; k += 64) {
+            const float v = d[k];
+            const bool is_c = k < Sc;
+            int lo = is_c ? Sc : 0, hi = is_c ? S : Sc;                 // search the OTHER run
+            while (lo < hi) {                                            // coarse element: #fine < v;  fine element: #coarse <= v
+                const int mid = (lo + hi) >> 1;
+                const float o = d[mid];
+                if (is_c ? (o < v) : (o <= v)) lo = mid + 1; else hi = mid;
+            }
+            const int rank = is_c ? k + (lo - Sc) : (k - Sc) + lo;
+            sorted[r * S + rank] = v;
+            perm[r * S + rank] = k;
+        }
+        return;
+    }
     for (int k = lane; k < S; k += 64) {
         const float v = d[k];
         int rank = 0;

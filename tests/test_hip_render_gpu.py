@@ -121,6 +121,18 @@ def test_merge_sort_matches_torch_sort():
     ref, idx = torch.sort(torch.cat([dc, df], 1), dim=1)
     assert torch.equal(out, ref)
     assert torch.equal(perm.long(), idx)
+    # the renderer's case: two ascending runs (binary-search ranks), with ties inside and across the runs, ragged sizes;
+    # a stable sort of the concatenation puts equal coarse samples first
+    for sc2, sf2 in ((96, 96), (48, 20), (7, 129)):
+        dc = torch.sort((torch.rand(r, sc2, generator=gen) * 40).round() / 40, dim=1)[0].to(DEV)
+        df = torch.sort((torch.rand(r, sf2, generator=gen) * 40).round() / 40, dim=1)[0].to(DEV)
+        df[5] = dc[5, :1]                                                     # a whole run of ties
+        out = torch.empty(r, sc2 + sf2, device=DEV)
+        perm = torch.empty(r, sc2 + sf2, device=DEV, dtype=torch.int32)
+        hip.call('spi_merge_sort_depths', hip.ptr(dc), hip.ptr(df), r, sc2, sf2, hip.ptr(out), hip.ptr(perm), hip.stream())
+        ref, idx = torch.sort(torch.cat([dc, df], 1), dim=1, stable=True)
+        assert torch.equal(out, ref)
+        assert torch.equal(perm.long(), idx)
 
 
 def test_full_render_golden_fwd_bwd(golden):
