@@ -82,20 +82,30 @@ def lib():
     return _lib
 
 
+_PTR_DTYPES = (torch.float32, torch.int32, torch.int64)
+
+
 def ptr(t):
-    """Device pointer of a contiguous fp32 / int32 GPU tensor (None -> NULL)."""
+    """Device pointer of a contiguous fp32 / int32 GPU tensor (None -> NULL).  (On the launch path ~250 times per step: the checks are
+    ordered so that the good case costs three attribute reads.)"""
     if t is None:
         return None
+    if t.is_cuda and t.is_contiguous() and t.dtype in _PTR_DTYPES:
+        return t.data_ptr()
     if not t.is_cuda:
         raise RuntimeError('spi_amd kernels need GPU tensors (no CPU fallback); got a %s tensor' % t.device.type)
     if not t.is_contiguous():
         raise RuntimeError('spi_amd kernels need contiguous tensors')
-    if t.dtype not in (torch.float32, torch.int32, torch.int64):
-        raise RuntimeError(f'unsupported dtype {t.dtype}')
-    return t.data_ptr()
+    raise RuntimeError(f'unsupported dtype {t.dtype}')
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
 def stream():
+    """Raw hipStream_t of torch's current stream on the current device."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -104,5 +114,13 @@ def check(rc, name):
         raise RuntimeError(f'{name} failed ({rc}): {lib().spi_last_error().decode()}')
 
 
+_fns = {}
+
+
 def call(name, *args):
-    check(getattr(lib(), name)(*args), name)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    rc = fn(*args)
+    if rc != 0:
+        check(rc, name)
