@@ -130,11 +130,30 @@ class BoxCXLoss(torch.nn.Module):
         if plan is not None and tuple(x.shape[-2:]) != (256, 256):
             plan = None                                      # the plan is built for the 256^2 working resolution
         boxes = get_landmark_bbox(lm)[:3] if plan is None else [None] * 3
+        # The three boxes (eyes, nose, mouth) go through the VGG head and the contextual loss as ONE batch [3N, ...] instead of three
+        # passes of a few hundred tiny launches each; every reduction of the reference (feature mean over the batch of a box, min /
+        # sum / max over positions, mean over the batch) keeps its own group.
+        n = x.shape[0]
+        cx_in, cy_in = [], []
         for bi, box in enumerate(boxes):
             pl = plan[bi] if plan is not None else roi_plan(box.float(), x.shape[-2], x.shape[-1], x.device)
-            fx = self.vgg_model(roi_align(x, box, plan=pl))
-            fy = self.vgg_model(roi_align(y, box, plan=pl))
-            cx = compute_cx(compute_relative_distance(compute_cosine_distance(fx, fy)), self.band_width)
-            cx = torch.mean(torch.max(cx, dim=1)[0], dim=1)
-            loss = loss + torch.mean(-torch.log(cx + 1e-5))
+            cx_in.append(roi_align(x, box, plan=pl))
+            cy_in.append(roi_align(y, box, plan=pl))
+        nb = len(cx_in)
+        if y.requires_grad:
+            f = self.vgg_model(torch.cat(cx_in + cy_in))
+            fx, fy = f[:nb * n], f[nb * n:]
+        else:
+            fx = self.vgg_model(torch.cat(cx_in))
+            with torch.no_grad():
+                fy = self.vgg_model(torch.cat(cy_in))
+        c, fh, fw = fx.shape[1:]
+        fx5, fy5 = fx.reshape(nb, n, c, fh, fw), fy.reshape(nb, n, c, fh, fw)
+        y_mu = fy5.mean(dim=(1, 3, 4), keepdim=True)                               # per box: mean over its batch and positions (:93)
+        xn = F.normalize(fx5 - y_mu, p=2, dim=2).reshape(nb * n, c, fh * fw)
+        yn = F.normalize(fy5 - y_mu, p=2, dim=2).reshape(nb * n, c, fh * fw)
+        dist = 1 - torch.bmm(xn.transpose(1, 2), yn)
+        cx = compute_cx(compute_relative_distance(dist), self.band_width)
+        cx = torch.mean(torch.max(cx, dim=1)[0], dim=1)                             # [nb * n]
+        loss = (-torch.log(cx + 1e-5)).reshape(nb, n).mean(dim=1).sum()
         return loss * 0.1
