@@ -5,6 +5,7 @@ TEST INFRASTRUCTURE -- see oracle/__init__.py.  Also the `cpu_baseline` leg of b
 Reference lines followed (relative to /root/reference/spi):
   w statistics / schedules / stage-1 loop   training/projectors/mirror_projector.py:34-140
   W+ projector                              training/projectors/w_plus_projector.py:10-113
+  W projector ("sg")                        training/projectors/w_projector.py:9-113
   stage-2 SPI loop                          training/coaches/rot_bbox_cx_coach.py:52-157
   PTI loop                                  training/coaches/pti_coach.py:62-82
   optimiser / seeds                         training/coaches/base_coach.py:28-33,53-60,133-135
@@ -103,8 +104,52 @@ def project_w_plus(P, target, c, lpips_fn, opts, *, mirror, num_steps, w_avg_sam
                 P[k] -= P[k].mean()
                 P[k] *= P[k].square().mean().rsqrt()
         if log is not None:
-            log.append(dict(dist=float(dist), reg=float(reg), loss=float(loss), w=w_opt.detach().clone()))
+            log.append(dict(dist=float(dist.detach()), reg=float(reg.detach()), loss=float(loss.detach()), w=w_opt.detach().clone(),
+                            grad_w=w_opt.grad.detach().clone()))
     return w_opt
+
+
+def project_w(P, target, c, vgg16_fn, opts, *, num_steps, w_avg_samples=600, nrr=128, draws=None, first_inv_lr=5e-3,
+              log=None):
+    """w_projector.project (`first_inv_type='sg'`): ONE w [1,1,512] broadcast to the 14 layers (:77), distance = squared
+    difference of the feature vectors of an injected extractor on 256^2 area-downsampled 0..255 images (:48-51,81-87).
+    Returns w_opt.repeat([1,14,1])."""
+    draws = draws or Draws()
+    P = {k: v.detach().clone().float() for k, v in P.items()}
+    w_avg, w_std = w_stats(P, c, w_avg_samples)
+    nk = noise_keys(P)
+
+    def prep(img):
+        img = (img + 1) * (255 / 2)
+        if img.shape[2] > 256:
+            img = F.interpolate(img, size=(256, 256), mode='area')
+        return img
+    target_features = vgg16_fn(prep(target), resize_images=False, return_lpips=True)
+    w_opt = torch.tensor(w_avg, dtype=torch.float32, requires_grad=True)
+    opt = torch.optim.Adam([w_opt] + [P[k] for k in nk], betas=(0.9, 0.999), lr=first_inv_lr)
+    for k in nk:
+        P[k] = draws.randn(*P[k].shape).requires_grad_(True)
+    opt.param_groups[0]['params'][1:] = [P[k] for k in nk]
+    for step in range(num_steps):
+        lr, w_noise_scale = stage1_schedule(step, num_steps, w_std)
+        for gp in opt.param_groups:
+            gp['lr'] = lr
+        ws = (w_opt + draws.randn(*w_opt.shape) * w_noise_scale).repeat([1, 14, 1])
+        img = _synth(P, ws, c, opts, nrr, draws)['image']
+        dist = (target_features - vgg16_fn(prep(img), resize_images=False, return_lpips=True)).square().sum()
+        reg = lo.noise_regulariser([P[k] for k in nk])
+        loss = dist + reg * 1e5
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            for k in nk:
+                P[k] -= P[k].mean()
+                P[k] *= P[k].square().mean().rsqrt()
+        if log is not None:
+            log.append(dict(dist=float(dist.detach()), reg=float(reg.detach()), loss=float(loss.detach()), w=w_opt.detach().clone(),
+                            grad_w=w_opt.grad.detach().clone()))
+    return w_opt.detach().repeat([1, 14, 1])
 
 
 # ---- stage 2 -----------------------------------------------------------------------------------

@@ -67,6 +67,21 @@ def lpips(W, x, y):
     return loss / n
 
 
+def sg_vgg_features(W, img, resize_images=False, return_lpips=True):
+    """Stand-in for NVIDIA's TorchScript `vgg16.pt` (spi/configs/paths_config.py:5, loaded by load_utils.py:47-50 and called
+    as `vgg16(img_0..255, resize_images=False, return_lpips=True)` by w_projector.py:51,86).  The blob is NOT under
+    /root/reference and cannot be fetched ("parity unpinned" at this edge); restated from its published contract: images
+    in [0, 255] -> [-1, 1] -> LPIPS z-score -> the five VGG16 taps, unit-normalised over channels, scaled by
+    sqrt(lin / (H W)) and flattened, so that the squared L2 distance of two feature vectors IS the LPIPS distance."""
+    assert not resize_images and return_lpips
+    feats = vgg16_features(W, img / 127.5 - 1)
+    out = []
+    for f, lin in zip(feats, W['lins']):
+        hw = f.shape[2] * f.shape[3]
+        out.append((f * torch.sqrt(lin / hw)).flatten(1))
+    return torch.cat(out, dim=1)
+
+
 def l2_loss(a, b):
     return F.mse_loss(a, b)
 

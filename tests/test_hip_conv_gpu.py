@@ -30,12 +30,22 @@ CASES = [  # N, I, O, H, k, pad, transposed, flip, per_sample
     (1, 40, 130, 33, 3, 1, False, False, True), (2, 130, 40, 17, 3, 0, True, False, True), (1, 128, 3, 40, 1, 0, False, False, True),
     (1, 64, 64, 4, 3, 1, False, False, True), (3, 32, 96, 16, 1, 0, False, False, True), (1, 70, 200, 64, 3, 1, False, False, True),
 ]
+# the real layer shapes of the ffhqrebalanced512-128 generator (the instances bench.py times): 512-channel split-K layer,
+# stride-2 transposed 256 -> 128 at 256^2, the 128 -> 128 conv at 512^2, an N = 4 batch sharing one weight set (rot / depth branches),
+# the 512 -> 512 transposed conv at 16^2, torgb 128 -> 96 at 256^2, the VGG16 3 -> 64 stem at 256^2
+FULL_CASES = [
+    (1, 512, 512, 16, 3, 1, False, True, True), (1, 256, 128, 256, 3, 0, True, False, True), (1, 128, 128, 512, 3, 1, False, True, True),
+    (4, 128, 128, 256, 3, 1, False, True, False), (1, 512, 512, 16, 3, 0, True, False, True), (1, 128, 96, 256, 1, 0, False, False, True),
+    (2, 3, 64, 256, 3, 1, False, False, False), (2, 512, 512, 4, 3, 1, False, True, True),
+]
 
 
-@pytest.mark.parametrize('case', CASES)
+@pytest.mark.parametrize('case', CASES + FULL_CASES)
 def test_conv_fwd_dgrad_wgrad_vs_oracle(case):
     from spi_amd.torch_utils.ops import conv2d_mfma
     N, I, O, H, k, pad, tr, flip, per = case
+    big = case in FULL_CASES                        # K up to 4608 terms, weight gradients reduce over up to 1 M pixels: fp32 summation order shows
+    torch.set_num_threads(min(__import__('os').cpu_count() or 1, 32))
     gen = torch.Generator().manual_seed(hash(case) % 1000)
     x = torch.randn(N, I, H, H + 1, generator=gen, requires_grad=True)          # non-square on purpose
     w = (torch.randn(*((N,) if per else ()), O, I, k, k, generator=gen) / (I * k * k) ** 0.5).requires_grad_(True)
@@ -45,10 +55,10 @@ def test_conv_fwd_dgrad_wgrad_vs_oracle(case):
     xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
     y = conv2d_mfma.conv2d(xg, wg, padding=pad, transposed=tr, flip=flip)
     assert y.shape == ref.shape
-    assert_close(y, ref, 3e-6, 'conv fwd')
+    assert_close(y, ref, 1e-5 if big else 3e-6, 'conv fwd')
     hx, hw = torch.autograd.grad(y, [xg, wg], dy.to(DEV))
-    assert_close(hx, gx, 3e-6, 'conv dgrad')
-    assert_close(hw, gw, 2e-5, 'conv wgrad')
+    assert_close(hx, gx, 1e-5 if big else 3e-6, 'conv dgrad')
+    assert_close(hw, gw, 1e-4 if big else 2e-5, 'conv wgrad')
 
 
 def test_conv_fused_epilogue_vs_oracle():

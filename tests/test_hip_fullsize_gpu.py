@@ -1,0 +1,127 @@
+"""Full-width, full-resolution parity: the instances bench.py times, against the oracle on the box's host cores.
+
+ffhqrebalanced512-128 architecture (channel_max = 512), 128^2 rays, 96+96 (and 128+128) samples per ray, 512^2 image:
+the 512-channel split-K layers, the 128 -> 128 @ 512^2 tiles, the 16 384-ray tiled decoder backward.  The oracle
+(oracle/renderer_ref.synthesis, pinned bit-exact against the imported reference by tests/golden/make_golden.py)
+runs the same seeded weights and the same replayed renderer draws (xi, u) on the CPU.
+
+Bars (BASELINE.json north_star): <= 1e-3 relative on RGB / depth, <= 1e-2 on loss values; gradients <= 2e-3.
+Reference: eg3d/training/triplane.py:53-89.
+"""
+import os
+import pytest
+import torch
+
+from conftest import assert_close, rel_err
+from synth_weights import load_manifest, synth_state_dict
+from oracle import renderer_ref as orr
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+GRAD_NAMES = [
+    'backbone.synthesis.b16.conv1.weight',            # 512 -> 512 at 16^2: split-K igemm / wgrad
+    'backbone.synthesis.b32.conv0.weight',            # 512 -> 512 stride-2 transposed, 4 parity classes
+    'backbone.synthesis.b256.conv0.weight',           # 256 -> 128 transposed at 256^2
+    'backbone.synthesis.b256.torgb.weight',           # 1x1, 128 -> 96 (the planes)
+    'superresolution.block0.conv0.weight',            # 32 -> 256 transposed at 256^2
+    'superresolution.block1.conv1.weight',            # 128 -> 128 at 512^2 (largest conv of the loop)
+    'superresolution.block1.torgb.weight',
+    'superresolution.block1.conv0.affine.weight',     # style affine behind the modulation adjoint
+    'decoder.net.0.weight', 'decoder.net.2.weight', 'decoder.net.2.bias',
+    'backbone.synthesis.b128.conv1.noise_strength',
+    'backbone.synthesis.b64.conv0.bias',
+]
+
+
+def _setup(depth, seed=0):
+    from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+    from spi_amd.utils import camera_utils as cu
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    P = synth_state_dict(load_manifest('full'))
+    G = TriPlaneGenerator(**ffhq512_kwargs(depth_resolution=depth, depth_resolution_importance=depth)).eval()
+    G.load_state_dict(P)
+    G = G.to(DEV)
+    G.neural_rendering_resolution = 128
+    gen = torch.Generator().manual_seed(seed)
+    ws = torch.randn(1, 14, 512, generator=gen)
+    c = cu.cal_canonical_c(0.4, 0.1)
+    m = 128 * 128
+    xi, u = torch.rand(1, m, depth, 1, generator=gen), torch.rand(m, depth, generator=gen)
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=depth, depth_resolution_importance=depth)
+    return P, G, ws, c, xi, u, opts, gen
+
+
+def test_synthesis_full_width_96_fwd_bwd_vs_oracle():
+    """BASELINE configs[1] instance: forward outputs, a loss value, gradients wrt W+ and 13 full-width tensors."""
+    P, G, ws, c, xi, u, opts, gen = _setup(96)
+    P = {k: v.clone() for k, v in P.items()}
+    for k in GRAD_NAMES:
+        P[k].requires_grad_(True)
+    wr = ws.clone().requires_grad_(True)
+    ref = orr.synthesis(P, wr, c, opts, neural_rendering_resolution=128, xi=xi, u=u)
+    d_img = torch.randn(ref['image'].shape, generator=gen)
+    d_raw = torch.randn(ref['image_raw'].shape, generator=gen)
+    d_dep = torch.randn(ref['image_depth'].shape, generator=gen)
+
+    def loss_of(o, dev):
+        return ((o['image'] * d_img.to(dev)).mean() + (o['image'] ** 2).mean() * 0.1 + (o['image_raw'] * d_raw.to(dev)).mean()
+                + (o['image_depth'] * d_dep.to(dev)).mean())
+    loss = loss_of(ref, 'cpu')
+    gref = torch.autograd.grad(loss, [wr] + [P[k] for k in GRAD_NAMES])
+
+    wg = ws.to(DEV).requires_grad_(True)
+    params = dict(G.named_parameters())
+    out = G.synthesis(wg, c.to(DEV), noise_mode='const', render_noise=(xi, u))
+    for k in ('image', 'image_raw', 'image_depth'):
+        assert out[k].shape == ref[k].shape
+        assert_close(out[k], ref[k], 1e-3, 'full-width ' + k)
+    # what the kernels actually reach (an order below the bar)
+    assert rel_err(out['image_depth'], ref['image_depth']) < 1e-4
+    lossg = loss_of(out, DEV)
+    assert abs(lossg.item() - loss.item()) <= 1e-2 * abs(loss.item()) + 1e-6
+    ggpu = torch.autograd.grad(lossg, [wg] + [params[k] for k in GRAD_NAMES])
+    for a, b, nm in zip(ggpu, gref, ['ws'] + GRAD_NAMES):
+        assert a.shape == b.shape
+        assert_close(a, b, 2e-3, 'full-width grad ' + nm)
+
+
+def test_synthesis_full_width_128_fwd_vs_oracle():
+    """BASELINE configs[4] sample counts (128 + 128, S = 256 in the final march): forward + gradient wrt W+ of a depth / raw-image loss."""
+    P, G, ws, c, xi, u, opts, gen = _setup(128, seed=3)
+    wr = ws.clone().requires_grad_(True)
+    ref = orr.synthesis(P, wr, c, opts, neural_rendering_resolution=128, xi=xi, u=u)
+    d_raw = torch.randn(ref['image_raw'].shape, generator=gen)
+    loss = (ref['image_raw'] * d_raw).mean() + ref['image_depth'].square().mean()
+    gref, = torch.autograd.grad(loss, wr)
+    wg = ws.to(DEV).requires_grad_(True)
+    out = G.synthesis(wg, c.to(DEV), noise_mode='const', render_noise=(xi, u))
+    for k in ('image', 'image_raw', 'image_depth'):
+        assert_close(out[k], ref[k], 1e-3, 'full-width 128+128 ' + k)
+    lossg = (out['image_raw'] * d_raw.to(DEV)).mean() + out['image_depth'].square().mean()
+    assert abs(lossg.item() - loss.item()) <= 1e-2 * abs(loss.item()) + 1e-6
+    gg, = torch.autograd.grad(lossg, wg)
+    assert_close(gg, gref, 2e-3, 'full-width 128+128 grad ws')
+
+
+def test_synthesis_full_width_batch2_shared_w_vs_oracle():
+    """Stage-1 'mir' call pattern at full size: one W+, two cameras (view + mirrored view); the oracle gets the
+    reference's ws.repeat(2,1,1) (mirror_projector.py:95-99)."""
+    from spi_amd.utils import camera_utils as cu
+    P, G, ws, c, _, _, opts, gen = _setup(96, seed=5)
+    cam = torch.cat([c, cu.cal_mirror_c(c)], 0)
+    m = 128 * 128
+    xi, u = torch.rand(2, m, 96, 1, generator=gen), torch.rand(2 * m, 96, generator=gen)
+    wr = ws.clone().requires_grad_(True)
+    ref = orr.synthesis(P, wr.repeat(2, 1, 1), cam, opts, neural_rendering_resolution=128, xi=xi, u=u)
+    d_img = torch.randn(ref['image'].shape, generator=gen)
+    loss = (ref['image'] * d_img).mean()
+    gref, = torch.autograd.grad(loss, wr)
+    wg = ws.to(DEV).requires_grad_(True)
+    out = G.synthesis(wg, cam.to(DEV), noise_mode='const', render_noise=(xi, u))
+    for k in ('image', 'image_raw', 'image_depth'):
+        assert_close(out[k], ref[k], 1e-3, 'full-width N=2 ' + k)
+    lossg = (out['image'] * d_img.to(DEV)).mean()
+    assert abs(lossg.item() - loss.item()) <= 1e-2 * abs(loss.item()) + 1e-6
+    gg, = torch.autograd.grad(lossg, wg)
+    assert_close(gg, gref, 2e-3, 'full-width N=2 grad ws')
