@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the SPI inversion hot path on MI355X (contract: see the task description / DESIGN.md).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: launched through torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK / WORLD_SIZE
+in the environment) or from a bare shell -- `python bench.py --gpus N` then spawns its own N ranks (one per GPU, RCCL) and relays
+rank 0's JSON line.
 
 Workload (BASELINE.json configs[1]): 1 image per GPU, first_inv_type=mir (500 steps) + G_1_type=RotBbox (1000 steps),
 EG3D ffhqrebalanced512-128 architecture at 512^2 with 96 coarse + 96 fine samples per ray, fp32, synthetic inputs
@@ -36,6 +40,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--depth', type=int, default=96, help='coarse = fine samples per ray')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline', choices=('sample', 'full'), default='sample',
+                    help="sample (default, ~30 s): 1 warm-up + 1 timed stage-1 'mir' step + 1 timed plain stage-2 iteration of the oracle; "
+                         'full (~4 min): + one whole 4-iteration stage-2 super-cycle with the rot / mirror-rot / depth branches and a thread-scaling line')
+    ap.add_argument('--dense', action='store_true', help='NOT the benchmark configuration: switch off the data-driven skipping of exactly-zero gradients / '
+                                                         'unneeded SR tiles in the masked pseudo-view branches (dense bound of the same step)')
     ap.add_argument('--sr-fp16', action='store_true', help='NOT the benchmark configuration: fp16 MFMA in the super-resolution blocks '
                                                            '(BASELINE config 5); the JSON line then says dtype f32+f16sr')
     ap.add_argument('--narrow', action='store_true', help='debug: reduced-width generator (NOT the benchmark configuration)')
@@ -49,32 +58,76 @@ def split_steps(k):
     return k - k2, k2
 
 
-def cpu_baseline(depth, narrow):
-    """Oracle (CPU restatement of the reference, oracle/loops_ref.py) timed on this box's host cores:
-    ONE stage-2 main-branch iteration (G.synthesis fwd+bwd, L2 + LPIPS, Adam over all G parameters)."""
+def cpu_baseline(depth, narrow, mode='sample', k1=8, k2=16):
+    """Oracle (CPU restatement of the reference, oracle/loops_ref.py -- pinned bit-exact against the imported reference) timed on this
+    box's host cores on the same synthetic inputs as the GPU run, per stage:
+      stage 1  one `mir` projector step (view + mirrored view, N = 2 synthesis fwd+bwd, 2 LPIPS, noise regulariser, Adam over w+ / noise maps)
+      stage 2  `RotBbox` iterations: plain (main view: synthesis fwd+bwd, L2 + LPIPS, Adam over all G parameters) and, with mode='full', one
+               whole 4-iteration super-cycle including the rot / mirror-rot / depth branches of every 4th iteration.
+    One untimed warm-up iteration first (thread pool, allocator, first-touch)."""
     from oracle import loops_ref as olp, losses_ref as olo, renderer_ref as orr
     from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
     from spi_amd.data.images_dataset import SyntheticDataset
-    cores = min(os.cpu_count() or 1, 32)        # torch's CPU kernels stop scaling (and thrash) far below the box's 256 hardware threads
+    ncpu = os.cpu_count() or 1
+    cores = min(ncpu, 32)        # torch's CPU kernels stop scaling far below the box's hardware threads (scaling line under mode='full')
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     G = TriPlaneGenerator(**ffhq512_kwargs(narrow=narrow))
     P = {k: v.detach().clone() for k, v in G.state_dict().items()}
     pnames = [k for k, _ in G.named_parameters()]
     del G
-    st = olp.Stage2State(P, pnames)
-    W = olo.make_vgg16_weights(seed=0)
+    W, W19 = olo.make_vgg16_weights(seed=0), olo.make_vgg19_head_weights(seed=1)
+    lp = lambda a, b: olo.lpips(W, a, b)
+    bx = lambda a, b, l: olo.box_cx_loss(W19, a, b, l)
     d = SyntheticDataset(1)[0]
-    data = dict(img=d['img'][None], c=torch.as_tensor(d['c']).reshape(1, 25))
+    mask = d['mask'].reshape(1, 1, 512, 512)
+    data = dict(img=d['img'][None], c=torch.as_tensor(d['c']).reshape(1, 25), lm=d['lm'].reshape(1, 68, 2),
+                face_mask=olp.face_mask_from_parsing(mask).float())
     opts = dict(orr.DEFAULT_RENDERING, depth_resolution=depth, depth_resolution_importance=depth)
     w = torch.randn(1, 14, 512) * 0.5
-    t0 = time.perf_counter()
-    olp.stage2_iteration(st, 1, data, w, opts, lambda a, b: olo.lpips(W, a, b), None, pti_only=True)
-    dt = time.perf_counter() - t0
-    return dict(value=1.0 / dt, unit='iters/s', cores=cores, kind='port',
-                sample=f'1 stage-2 main-branch iteration (1 synthesis fwd+bwd at 512^2 / {depth}+{depth} samples, L2+LPIPS, Adam over '
-                       f'all G parameters; the every-4th-step rot / mirror-rot / depth branches are NOT in the sample), {dt:.1f} s, '
-                       f'torch {torch.__version__} CPU fp32, {cores} threads of {os.cpu_count()}')
+    hp = dict(olp.HP, LPIPS_value_threshold=-1.0)
+
+    def timed(fn):
+        t0 = time.perf_counter()
+        fn()
+        return time.perf_counter() - t0
+
+    st = olp.Stage2State(P, pnames)
+    t_warm = timed(lambda: olp.stage2_iteration(st, 1, data, w, opts, lp, bx, hp=hp))                       # untimed warm-up
+    # stage 1: steps 1.. of a 500-step schedule (step 0 has lr = 0); the loop function runs whole projections, so time 2 steps and 1 step
+    t_s1_2 = timed(lambda: olp.project_w_plus(P, data['img'], data['c'], lp, opts, mirror=True, num_steps=2, w_avg_samples=16))
+    t_s1_1 = timed(lambda: olp.project_w_plus(P, data['img'], data['c'], lp, opts, mirror=True, num_steps=1, w_avg_samples=16))
+    t_s1 = max(t_s1_2 - t_s1_1, 1e-9)                                                                          # one step without the set-up
+    t_plain = timed(lambda: olp.stage2_iteration(st, 1, data, w, opts, lp, bx, hp=hp))
+    res = dict(unit='iters/s', cores=cores, kind='port', host_threads_available=ncpu,
+               stage1_mir_iters_per_s=1.0 / t_s1, stage2_plain_iters_per_s=1.0 / t_plain,
+               seconds=dict(warmup=t_warm, stage1_step=t_s1, stage2_plain_iteration=t_plain))
+    if mode == 'full':
+        t_branch = timed(lambda: olp.stage2_iteration(st, 0, data, w, opts, lp, bx, hp=hp))                   # i % 4 == 0: all three branches
+        t_cycle = t_branch + 3 * t_plain
+        res['seconds'].update(stage2_branch_iteration=t_branch, stage2_super_cycle=t_cycle)
+        res['stage2_rotbbox_iters_per_s'] = 4.0 / t_cycle
+        res['value'] = (k1 + k2) / (k1 * t_s1 + k2 * t_cycle / 4.0)
+        scal = {}
+        for th in (8, 16, 32, 64, 128, ncpu):
+            if th <= ncpu and th not in scal:
+                torch.set_num_threads(th)
+                scal[th] = timed(lambda: olp.stage2_iteration(st, 1, data, w, opts, lp, bx, hp=hp))
+        torch.set_num_threads(cores)
+        res['thread_scaling_s_per_plain_iteration'] = scal
+        res['sample'] = (f"full protocol: 1 warm-up, 1 'mir' step ({t_s1:.1f} s), one 4-iteration RotBbox super-cycle ({t_cycle:.1f} s: branch iteration "
+                         f'{t_branch:.1f} s + 3 x plain {t_plain:.1f} s); value = the same {k1}:{k2} stage mix as the GPU line')
+    else:
+        # without the branch iteration the stage-2 rate is an UPPER bound for the CPU (the branches only add work): say so
+        res['value'] = (k1 + k2) / (k1 * t_s1 + k2 * t_plain)
+        res['sample'] = (f"1 warm-up + 1 timed 'mir' step ({t_s1:.1f} s) + 1 timed PLAIN RotBbox iteration ({t_plain:.1f} s); the every-4th-iteration "
+                         f'rot / mirror-rot / depth branches are not in this sample (value = {k1}:{k2} mix of the two, an upper bound for the CPU); '
+                         'full protocol: `bench.py --cpu-baseline full`, kept under profiles/')
+        full = os.path.join(ROOT, 'profiles', 'cpu_baseline_full.json')
+        if os.path.exists(full):
+            res['full_protocol_recorded'] = json.load(open(full))
+    res['sample'] += f'; 512^2, {depth}+{depth} samples, torch {torch.__version__} CPU fp32, {cores} threads of {ncpu}'
+    return res
 
 
 def conv_roofline(dev, f16):
@@ -111,11 +164,47 @@ def conv_roofline(dev, f16):
             'note': 'achieved = slowest of the three passes; wgrad includes its memset of dw'}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` from a bare shell: spawn one rank per GPU (the reference's analogue: one `--dataset_block i/N` process per
+    GPU, images_dataset.py:149-158), relay their output, and never let a dead rank hang the others: the first non-zero exit kills the rest."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate() if rc else p.wait()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+    return rc or max((p.returncode or 0) for p in procs)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     from spi_amd import dist as sdist
     rank, world, local = sdist.init_from_env()
-    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local)
@@ -133,6 +222,7 @@ def main():
 
     global_config.device = str(dev)
     global_config.enable_fp16_blocks = bool(args.sr_fp16)
+    global_config.exploit_sparsity = not args.dense
     tmp = tempfile.mkdtemp(prefix='spi_bench_')
     for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
         setattr(paths_config, k, f'{tmp}/{k}/')
@@ -146,7 +236,7 @@ def main():
     G = G.eval().requires_grad_(False).to(dev)
     G.neural_rendering_resolution = 128
     with contextlib.redirect_stdout(sys.stderr):                 # the coach announces its name like the reference does; stdout carries the JSON line only
-        coach = RotBboxCoach(None, False, G=G)
+        coach = RotBboxCoach(None, False, G=G, synthetic=True)
     d = SyntheticDataset(world)[rank]                            # one independent image per rank
     data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in d.items()}
     ctx = coach.prepare_image(data)
@@ -188,12 +278,24 @@ def main():
             for e in sorted(ka, key=lambda e: -e.count)[:45]:
                 print(f'{e.count:7d}  dev {e.device_time_total / 1e3:9.2f} ms  cpu {e.cpu_time_total / 1e3:9.2f} ms  {e.key[:90]}', file=sys.stderr)
     else:
-        run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
-    t_enq = time.perf_counter() - t0                             # host time to enqueue the K steps (== dt when host-bound)
-    torch.cuda.synchronize(); sdist.barrier()
+        ok = 1.0
+        try:
+            run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
+        except Exception:                                        # a failing rank still reaches the reduce below: it cannot hang the others
+            import traceback
+            traceback.print_exc()
+            ok = 0.0
+    torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0                           # this rank's own K steps
+    sdist.barrier()
     dt = time.perf_counter() - t0
     events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
     dt = sdist.reduce_stats([dt], device=dev, op='max')[0]
+    slots = [0.0] * (2 * world)                                  # one small all-reduce carries every rank's own time and done-flag
+    slots[rank], slots[world + rank] = dt_rank, ok if not os.environ.get('SPI_TORCH_PROFILE') else 1.0
+    slots = sdist.reduce_stats(slots, device=dev)
+    rank_s, rank_ok = slots[:world], slots[world:]
+    n_ok = int(sum(rank_ok))
     march_ms = [a.elapsed_time(b) for a, b, _ in events]
     march_rays = [r for _, _, r in events]
 
@@ -208,9 +310,12 @@ def main():
         if os.path.exists(pmc) and march_rays:
             traffic = json.load(open(pmc)).get('hbm_bytes_per_16384_rays') / 16384.0 * (sum(march_rays) / len(march_rays))
         out = {
-            'metric': f'SPI inversion iters/sec (512^2, {args.depth}+{args.depth} ray samples)', 'value': world * args.steps / dt, 'unit': 'iters/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3, 'host_enqueue_ms_per_step': t_enq / args.steps * 1e3,
+            'metric': f'SPI inversion iters/sec (512^2, {args.depth}+{args.depth} ray samples)', 'value': n_ok * args.steps / dt, 'unit': 'iters/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
             'stage1_host_enqueue_ms_per_step': marks.get('stage1_host_ms_per_step'),
+            'ranks': {'launched': world, 'completed': n_ok, 'backend': 'rccl (torch.distributed nccl)' if world > 1 else 'none (single process)',
+                      'collectives': 'barrier + 2 all-reduces of <= %d fp64 (timing / done-flags); no data-path collective' % (2 * world),
+                      'per_rank_iters_per_s': [args.steps / t if t > 0 else None for t in rank_s]},
             'stages': {'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
                        'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
                        'note': 'rank 0; stage 2 amortises the every-4th-iteration rot / mirror-rot / depth branches over whole super-cycles'},
@@ -220,7 +325,9 @@ def main():
             'config': {'workload': ('configs[4]' if (args.depth == 128 and args.sr_fp16) else 'configs[1]') +
                                    ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
-                       'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow)},
+                       'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
+                       'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else
+                                   'data-driven skipping of exactly-zero gradients and unneeded SR tiles in the masked pseudo-view branches (result-identical)'},
             'roofline': {'kernel': 'raymarch_fwd_kernel<3> (final composite, S=%d, C=32)' % S, 'bound': 'hbm', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'launches': len(march_ms), 'avg_launch_us': (sum(march_ms) / max(len(march_ms), 1)) * 1e3,
@@ -228,9 +335,11 @@ def main():
         }
         out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16))
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow)
+            out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, k1, k2)
         print(json.dumps(out), flush=True)
     sdist.shutdown()                                             # ranks leave together (rank 0 is still timing its roofline lines)
+    if n_ok != world:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -191,11 +191,15 @@ def mapping(P, z, c, prefix='backbone.mapping.', num_layers=2, num_ws=14, lr_mul
     return x.unsqueeze(1).repeat(1, num_ws, 1)
 
 
-def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gain=1.0):
+def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gain=1.0, noise_rng=None):
     styles = fully_connected(w, P[pfx + 'affine.weight'], P[pfx + 'affine.bias'])
     noise = None
     if noise_mode == 'const':
         noise = P[pfx + 'noise_const'] * P[pfx + 'noise_strength']
+    elif noise_mode == 'random':                     # networks_stylegan2.py:317-318: a fresh [N,1,res,res] draw per layer and call
+        res = x.shape[-1] * up
+        draw = noise_rng.randn(x.shape[0], 1, res, res) if noise_rng is not None else torch.randn(x.shape[0], 1, res, res)
+        noise = draw * P[pfx + 'noise_strength']
     f = P[pfx + 'resample_filter']
     x = modulated_conv2d(x, P[pfx + 'weight'], styles, noise=noise, up=up, padding=1, f=f,
                          flip_weight=(up == 1))
@@ -211,15 +215,15 @@ def torgb_layer(P, pfx, x, w, conv_clamp=None):
     return bias_act(x, P[pfx + 'bias'], clamp=conv_clamp)
 
 
-def synthesis_block(P, pfx, x, img, ws, first=False, noise_mode='const', conv_clamp=None):
+def synthesis_block(P, pfx, x, img, ws, first=False, noise_mode='const', conv_clamp=None, noise_rng=None):
     """ws: [N, num_conv+1, 512] (conv0?, conv1, torgb)."""
     wi = 0
     if first:
         x = P[pfx + 'const'].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
     else:
-        x = synthesis_layer(P, pfx + 'conv0.', x, ws[:, wi], up=2, noise_mode=noise_mode, conv_clamp=conv_clamp)
+        x = synthesis_layer(P, pfx + 'conv0.', x, ws[:, wi], up=2, noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng)
         wi += 1
-    x = synthesis_layer(P, pfx + 'conv1.', x, ws[:, wi], noise_mode=noise_mode, conv_clamp=conv_clamp)
+    x = synthesis_layer(P, pfx + 'conv1.', x, ws[:, wi], noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng)
     wi += 1
     if img is not None:
         img = upsample2d(img, P[pfx + 'resample_filter'])
@@ -229,7 +233,7 @@ def synthesis_block(P, pfx, x, img, ws, first=False, noise_mode='const', conv_cl
 
 
 def backbone_synthesis(P, ws, resolutions=(4, 8, 16, 32, 64, 128, 256), noise_mode='const',
-                       prefix='backbone.synthesis.'):
+                       prefix='backbone.synthesis.', noise_rng=None):
     ws = ws.float()
     x = img = None
     wi = 0
@@ -237,7 +241,7 @@ def backbone_synthesis(P, ws, resolutions=(4, 8, 16, 32, 64, 128, 256), noise_mo
         first = (res == resolutions[0])
         nconv = 1 if first else 2
         x, img = synthesis_block(P, f'{prefix}b{res}.', x, img, ws[:, wi:wi + nconv + 1], first=first,
-                                 noise_mode=noise_mode)
+                                 noise_mode=noise_mode, noise_rng=noise_rng)
         wi += nconv
     return img
 

@@ -11,6 +11,10 @@ pivotal_training_steps = 0
 model_snapshot_interval = 400
 run_name = ''
 
+# perceptual-loss weights: False = read the pretrained files named in paths_config and fail if one is missing (what a real run
+# needs); True = seeded stand-ins (offline benchmark / tests; set by `--synthetic`).  See criteria/weights.py.
+synthetic_weights = False
+
 # fp16 MFMA in the generator blocks that the checkpoint marks `use_fp16` (the super-resolution blocks: sr_num_fp16_res = 4).
 # Off by default: fp32 everywhere reproduces the reference's CPU path, the parity target.  `--sr_fp16` / BASELINE config 5.
 enable_fp16_blocks = False
@@ -19,3 +23,7 @@ enable_fp16_blocks = False
 # Measured neutral on one MI355X (169.5 vs 169.3 ms per super-cycle: the big kernels of every chain fill the chip on their own
 # and the host enqueues the chains one after the other anyway), so it stays off.
 concurrent_branches = False
+
+# data-driven skipping of exactly-zero gradients / unneeded super-resolution tiles in the masked pseudo-view branches.
+# Results are equal either way (tested); False = dense bound: every ray, gradient segment and SR tile is processed (`bench.py --dense`).
+exploit_sparsity = True

@@ -1,7 +1,9 @@
 """Checkpoint and output locations (mirror of spi/configs/paths_config.py)."""
 EG3D_PATH = 'checkpoints/ffhqrebalanced512-128.pkl'
 IDLOSS_PATH = 'checkpoints/model_ir_se50.pth'
-LPIPS_PATH = ''
+LPIPS_PATH = 'checkpoints/lpips_vgg_v0.1.pth'      # richzhang/PerceptualSimilarity lpips/weights/v0.1/vgg.pth ('' in the reference: it downloads the file)
+VGG16_PATH = 'checkpoints/vgg16-397923af.pth'      # torchvision vgg16 state_dict (the reference: torchvision.models.vgg16(True))
+VGG19_PATH = 'checkpoints/vgg19-dcbb9e9c.pth'      # torchvision vgg19 state_dict (the reference: torchvision vgg19(pretrained=True))
 BISENET_PATH = 'checkpoints/bisenet.pth'
 VGG_PATH = 'checkpoints/vgg16.pt'
 

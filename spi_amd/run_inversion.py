@@ -49,6 +49,7 @@ def parse_args(argv=None):
     parser.add_argument('--sr_fp16', action='store_true', help='fp16 MFMA in the super-resolution blocks (BASELINE config 5); default fp32')
     args = parser.parse_args(argv)
     global_config.enable_fp16_blocks = bool(args.sr_fp16)
+    global_config.synthetic_weights = args.synthetic > 0          # seeded perceptual-loss weights only in synthetic mode (criteria/weights.py)
 
     for k in ('use_encoder', 'use_G_avg', 'first_inv_type', 'first_inv_steps', 'G_1_step', 'G_1_type', 'G_2_step',
               'load_embedding_coach_name', 'use_adapt_yaw_range', 'description', 'pt_rot_lambda', 'pt_mirror_rot_lambda',
@@ -114,7 +115,7 @@ def run(argv=None):
     stats = coach.train()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    iters = sum(s['iters'] for s in stats) + len(stats) * hyperparameters.first_inv_steps
+    iters = sum(s['iters'] + s.get('stage1_iters', 0) for s in stats)       # stage-1 steps count only when calc_inversions actually ran
     tot = sdist.reduce_stats([iters, len(stats)], device=global_config.device)
     tmax = sdist.reduce_stats([dt], device=global_config.device, op='max')[0]
     if rank == 0:

@@ -6,7 +6,10 @@ result-identical to the reference:
   * the generator is read from disk ONCE; ``restart_training`` restores G from the frozen ``original_G`` that
     already sits in HBM instead of unpickling both copies again per image (base_coach.py:53-60);
   * one fused Adam launch per step (training/optim.py);
-  * ``use_wandb`` only gates disk logging (it never touched wandb in the reference either).
+  * ``use_wandb`` only gates disk logging (it never touched wandb in the reference either): target / w_inv / G1_inv images and
+    orbit videos under ``experiments_output_dir/<image>/``, the L2 / LPIPS / ID table in ``metric_log.txt`` (:80-87, :141-198);
+  * the perceptual-loss weights are read from the files named in ``paths_config`` and a missing file raises
+    (criteria/weights.py); seeded stand-ins only with ``synthetic=True`` / ``--synthetic``.
 """
 import abc
 import os
@@ -15,6 +18,7 @@ import torch
 
 from ...configs import global_config, paths_config, hyperparameters
 from ...criteria.lpips.lpips import LPIPS
+from ...criteria import weights as pretrained
 from ...utils import load_utils
 from ...utils.camera_utils import cal_mirror_c
 from ..optim import Adam
@@ -34,7 +38,7 @@ def fix_seed():
 
 
 class BaseCoach:
-    def __init__(self, data_loader, use_wandb, G=None, lpips_loss=None, vgg16=None, rng=None):
+    def __init__(self, data_loader, use_wandb, G=None, lpips_loss=None, vgg16=None, rng=None, synthetic=None):
         self.use_wandb = use_wandb
         self.data_loader = data_loader
         self.w_pivots = {}
@@ -43,8 +47,11 @@ class BaseCoach:
         self.coach_name = 'Base_coach'
         self.device = torch.device(global_config.device)
         self.rng = rng
-        self.lpips_loss = (lpips_loss if lpips_loss is not None else LPIPS(net_type='vgg')).to(self.device).eval()
-        self.vgg16 = vgg16
+        self.synthetic = pretrained.want_synthetic(synthetic)
+        if lpips_loss is None:
+            lpips_loss = LPIPS(net_type='vgg', weights=pretrained.lpips_vgg16_weights(self.synthetic))
+        self.lpips_loss = lpips_loss.to(self.device).eval()
+        self.vgg16 = vgg16                                           # 'sg' feature extractor; built on first use (_sg_vgg16)
         self.original_G = (G if G is not None else load_utils.load_eg3d(device=self.device)).to(self.device)
         self.original_G.eval().requires_grad_(False)
         self.G = None
@@ -94,7 +101,52 @@ class BaseCoach:
         if w_pivot is None:
             w_pivot = self.calc_inversions(image_name, image, camera, fg_mask)
         torch.save(w_pivot.detach().cpu(), f'{embedding_dir}/{image_name}.pt')
-        return w_pivot.to(self.device)
+        w_pivot = w_pivot.to(self.device)
+        if self.use_wandb:                                           # (:80-87)
+            camera_m = cal_mirror_c(camera)
+            w_inv = self.log_image_from_w(w_pivot, camera, self.G, f'{image_name}_w_inv')
+            w_inv_m = self.log_image_from_w(w_pivot, camera_m, self.G, f'{image_name}_w_inv_m')
+            if getattr(hyperparameters, 'log_video', True):
+                self.log_video(w_pivot, self.G, os.path.join(paths_config.experiments_output_dir, f'{image_name}_w_inv.mp4'))
+            self.cal_metric(w_inv, image, 'w_inv', fake_m=w_inv_m)
+        return w_pivot
+
+    def log_image_from_w(self, w, c, G, name):
+        """spi/utils/log_utils.py:7-15: synthesise, write <experiments_output_dir>/<name>.jpg, return the image tensor."""
+        from PIL import Image
+        if len(w.size()) <= 2:
+            w = w.unsqueeze(0)
+        with torch.no_grad():
+            img_tensor = G.synthesis(w, c, noise_mode='const')['image']
+            img = (img_tensor[0].permute(1, 2, 0) * 127.5 + 128).clamp(0, 255).to(torch.uint8).cpu().numpy()
+        Image.fromarray(img).save(os.path.join(paths_config.experiments_output_dir, name + '.jpg'))
+        return img_tensor
+
+    def log_target(self, image, name):
+        """log_utils.log_image (:45-54) for a [-1,1] RGB tensor."""
+        from PIL import Image
+        t = image.detach().float().cpu()
+        t = t[0] if t.ndim == 4 else t
+        arr = ((t.permute(1, 2, 0).numpy() + 1) / 2).clip(0, 1) * 255
+        Image.fromarray(arr.astype('uint8')).save(os.path.join(paths_config.experiments_output_dir, name + '.jpg'))
+
+    def finish_image(self, image_name, image, camera, w_pivot):
+        """End-of-image logging of the G_1 stage (rot_bbox_cx_coach.py:160-164, pti_coach.py:88-94)."""
+        if self.use_wandb and hyperparameters.G_1_step > 0:
+            camera_m = cal_mirror_c(camera=camera)
+            g1 = self.log_image_from_w(w_pivot, camera, self.G, f'{image_name}_G1_inv')
+            g1_m = self.log_image_from_w(w_pivot, camera_m, self.G, f'{image_name}_G1_inv_m')
+            if getattr(hyperparameters, 'log_video', True):
+                self.log_video(w_pivot, self.G, path=os.path.join(paths_config.experiments_output_dir, f'{image_name}_G1_inv.mp4'))
+            self.cal_metric(g1, image, 'G1_inv', fake_m=g1_m)
+
+    def _sg_vgg16(self):
+        """The `sg` extractor (base_coach.py:51 loads NVIDIA's TorchScript vgg16.pt, which cannot run on the HIP kernels and does not
+        exist offline): its contract -- squared feature distance == LPIPS-VGG -- rebuilt on the LPIPS weights (criteria/sg_vgg.py)."""
+        if self.vgg16 is None:
+            from ...criteria.sg_vgg import SgVgg16
+            self.vgg16 = SgVgg16(weights=pretrained.lpips_vgg16_weights(self.synthetic)).to(self.device).eval()
+        return self.vgg16
 
     def load_inversions(self, embedding_dir, image_name):
         if image_name in self.w_pivots:
@@ -113,9 +165,7 @@ class BaseCoach:
         common = dict(device=self.device, w_avg_samples=600, num_steps=hyperparameters.first_inv_steps, verbose=self.use_wandb,
                       w_name=image_name, initial_w=None, rng=self.rng)
         if kind == 'sg':
-            if self.vgg16 is None:
-                raise RuntimeError("first_inv_type='sg' needs the NVIDIA vgg16 feature extractor (paths_config.VGG_PATH); none was given")
-            return w_projector.project(self.G, image, camera, vgg16=self.vgg16, **common)
+            return w_projector.project(self.G, image, camera, self._sg_vgg16(), **common)
         if kind == 'sgw+':
             return w_plus_projector.project(self.G, image, camera, lpips_func=self.lpips_loss, **common)
         return mirror_projector.project(self.G, image, camera, lpips_func=self.lpips_loss, fg_mask=fg_mask, **common)
@@ -128,7 +178,7 @@ class BaseCoach:
         """L2 / LPIPS / ID of a synthesised view (and of the mirrored view against the flipped photo), base_coach.py:141-152."""
         if getattr(self, 'metric', None) is None:
             from ...utils.metric_utils import Metric
-            self.metric = Metric(lpips_loss=self.lpips_loss)
+            self.metric = Metric(lpips_loss=self.lpips_loss, device=self.device)
         d = self.metric_dic.setdefault(name, {'l2': [], 'lpips': [], 'id': [], 'l2_m': [], 'lpips_m': [], 'id_m': []})
         for key, (a, b) in (('', (gt, fake)), ('_m', (torch.flip(gt, dims=[3]), fake_m))):
             if b is None:

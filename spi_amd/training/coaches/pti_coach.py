@@ -56,18 +56,29 @@ class SingleIDCoach(BaseCoach):
             fg_mask = 1 - (mask.reshape(1, 1, *mask.shape[-2:]) == 0).float()
             paths_config.experiments_output_dir = os.path.join(output_dir, image_name)
             os.makedirs(paths_config.experiments_output_dir, exist_ok=True)
+            if self.use_wandb:                                   # (:52-53)
+                self.log_target(image, 'target_image')
             self.restart_training()
+            embedding_loaded = hyperparameters.load_embedding_coach_name is not None and os.path.isfile(
+                f"{paths_config.embedding_base_dir}/{hyperparameters.load_embedding_coach_name}/{image_name}.pt")
             w_pivot = self.get_inversion(image_name, image, camera, fg_mask=fg_mask)
             feats = self.lpips_loss.features(image)
             iters = 0
+            log_images_counter = 0
             for i in range(hyperparameters.G_1_step):
                 stop, losses = self.train_step(image, camera, w_pivot, feats)
                 iters += 1
                 if stop:
                     break
+                if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:81-82)
+                    self.log_image_from_w(w_pivot, camera, self.G, f'{image_name}_G1_inv_{log_images_counter}')
                 global_config.training_step += 1
+                log_images_counter += 1
             self.image_counter += 1
-            stats.append(dict(name=image_name, iters=iters))
+            self.finish_image(image_name, image, camera, w_pivot)
+            stats.append(dict(name=image_name, iters=iters, stage1_iters=0 if embedding_loaded else hyperparameters.first_inv_steps))
             self.post_process(w_pivot, camera, self.G, image_name)
         paths_config.experiments_output_dir = output_dir
+        if self.use_wandb:                                        # (:98-99)
+            self.log_metric()
         return stats

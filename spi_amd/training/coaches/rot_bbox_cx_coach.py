@@ -32,7 +32,10 @@ class RotBboxCoach(BaseCoach):
         super().__init__(data_loader, use_wandb, **kw)
         self.coach_name = 'RotBboxCoach'
         self.build_name()
-        self.box_cx_loss = (box_cx_loss if box_cx_loss is not None else BoxCXLoss()).to(self.device).eval()
+        if box_cx_loss is None:
+            from ...criteria import weights as pretrained
+            box_cx_loss = BoxCXLoss(weights=pretrained.vgg19_head_weights(self.synthetic))
+        self.box_cx_loss = box_cx_loss.to(self.device).eval()
         self.rot_bs = 4
 
     def prepare_image(self, data):
@@ -106,7 +109,7 @@ class RotBboxCoach(BaseCoach):
         d_planes = []
 
         def branch_backward(branch_loss, sparse):
-            with sparse_gradients(sparse):                          # sparse: d(image) is exactly zero outside the warp mask
+            with sparse_gradients(sparse and global_config.exploit_sparsity):    # sparse: d(image) is exactly zero outside the warp mask
                 g = torch.autograd.grad(branch_loss, [leaf] + params, allow_unused=True)
             d_planes.append(g[0])
             pending.append(g[1:])
@@ -139,7 +142,7 @@ class RotBboxCoach(BaseCoach):
                     warp['img'], warp['mask'] = rotate(target_camera=cams, target_depth=out['image_depth'], src_image=ctx['image'].repeat(rot_bs, 1, 1, 1),
                                                        src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
                                                        src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
-                    return warp['mask']
+                    return warp['mask'] if global_config.exploit_sparsity else None
                 gs = self._synth(G, ws, cams, rng, sr_region_fn=region, use_cached_backbone=True)
                 losses['rot'] = self.lpips_loss(gs['image'] * warp['mask'], warp['img']) * hp.pt_rot_lambda * rot_bs
                 branch_backward(losses['rot'], True)
@@ -154,7 +157,7 @@ class RotBboxCoach(BaseCoach):
                                                        src_camera=ctx['camera_m'].repeat(rot_bs, 1),
                                                        src_depth=torch.flip(depth_main, dims=[3]).repeat(rot_bs, 1, 1, 1),
                                                        src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
-                    return warp['mask']
+                    return warp['mask'] if global_config.exploit_sparsity else None
                 gm = self._synth(G, ws, cams_m, rng, sr_region_fn=region, use_cached_backbone=True)
                 flip_warp, flip_mask = torch.flip(warp['img'], dims=[3]), torch.flip(warp['mask'], dims=[3])
                 losses['mirror_rot'] = self.box_cx_loss(torch.flip(gm['image'], dims=[3]) * flip_mask, flip_warp,
@@ -223,17 +226,30 @@ class RotBboxCoach(BaseCoach):
             ctx = self.prepare_image(data)
             paths_config.experiments_output_dir = os.path.join(output_dir, image_name)
             os.makedirs(paths_config.experiments_output_dir, exist_ok=True)
+            if self.use_wandb:                                   # (:45-47)
+                self.log_target(ctx['image'], 'target_image')
+                self.log_target(ctx['image_m'], 'mirror_image')
             self.restart_training()
+            embedding_loaded = hyperparameters.load_embedding_coach_name is not None and os.path.isfile(
+                f"{paths_config.embedding_base_dir}/{hyperparameters.load_embedding_coach_name}/{image_name}.pt")
             w_pivot = self.get_inversion(image_name, ctx['image'], ctx['camera'], fg_mask=ctx['fg_mask'])
             iters = 0
+            log_images_counter = 0
             for i in range(hyperparameters.G_1_step):
                 stop, losses = self.train_step(i, ctx, w_pivot)
                 iters += 1
                 if stop:
                     break
+                if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:153-154)
+                    self.log_image_from_w(w_pivot, ctx['camera'], self.G, f'{image_name}_G1_inv_{log_images_counter}')
                 global_config.training_step += 1
+                log_images_counter += 1
             self.image_counter += 1
-            stats.append(dict(name=image_name, iters=iters, **{k: float(v) for k, v in losses.items()}) if iters else dict(name=image_name, iters=0))
+            self.finish_image(image_name, ctx['image'], ctx['camera'], w_pivot)
+            st = dict(name=image_name, iters=iters, stage1_iters=0 if embedding_loaded else hyperparameters.first_inv_steps)
+            stats.append(dict(st, **{k: float(v) for k, v in losses.items()}) if iters else st)
             self.post_process(w_pivot, ctx['camera'], self.G, image_name)
         paths_config.experiments_output_dir = output_dir
+        if self.use_wandb:                                        # (:170-171)
+            self.log_metric()
         return stats

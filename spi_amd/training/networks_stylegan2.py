@@ -279,12 +279,14 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, fp16=False):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, fp16=False, noise_rng=None):
+        """noise_rng (extension): draw source with ``randn(*shape)`` for noise_mode='random' (tests replay recorded draws)."""
         assert noise_mode in ['random', 'const', 'none']
         styles = self.affine(w)
         noise = strength = None
         if self.use_noise and noise_mode == 'random':
-            noise = torch.randn([self.resolution, self.resolution], device=x.device)
+            shape = [1, 1, self.resolution, self.resolution]                           # the reference's draw shape (:317) at N = 1
+            noise = (noise_rng.randn(*shape) if noise_rng is not None else torch.randn(shape, device=x.device)).reshape(shape[2:])
             if x.shape[0] != 1:
                 raise NotImplementedError("noise_mode='random' with batch > 1 is not on the SPI path")
             strength = self.noise_strength

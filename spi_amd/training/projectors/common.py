@@ -146,5 +146,5 @@ def run_projection(G, cameras, dist_fn, *, w_mode, initial_w, num_steps, w_avg_s
     for step in range(num_steps):
         out = proj.step(step)
         if log is not None:
-            log.append(dict(out, w=proj.w_opt.detach().clone()))
+            log.append(dict(out, w=proj.w_opt.detach().clone(), grad_w=proj.w_opt.grad.detach().clone()))
     return proj.w_opt

@@ -7,12 +7,16 @@ offline, so the extractor is a constructor argument ("parity unpinned" at that e
 """
 import torch
 import torch.nn.functional as F
+from ...configs import global_config
 from .common import run_projection
 
 
-def project(G, target, camera, *, vgg16, initial_w=None, num_steps=1000, w_avg_samples=10000, initial_learning_rate=0.01,
+def project(G, target, camera, vgg16, *, num_steps=1000, w_avg_samples=10000, initial_learning_rate=0.01,
             initial_noise_factor=0.05, lr_rampdown_length=0.25, lr_rampup_length=0.05, noise_ramp_length=0.75,
-            regularize_noise_weight=1e5, verbose=False, device, w_name='', rng=None, log=None):
+            regularize_noise_weight=1e5, verbose=False, device, use_wandb=False, initial_w=None, image_log_step=global_config.log_snapshot,
+            w_name='', rng=None, log=None):
+    """Signature of w_projector.py:9-29 (``vgg16`` positional; ``use_wandb`` / ``image_log_step`` accepted, they only gate logging
+    there) plus the two test hooks ``rng`` (draw source) and ``log`` (per-step losses)."""
     assert target.shape[1:] == (G.img_channels, G.img_resolution, G.img_resolution)
 
     def prep(img):

@@ -192,7 +192,8 @@ class _Render(torch.autograd.Function):
         d_sig = torch.empty_like(sig_all)
         # rays with an exactly-zero incoming gradient (SPI's masked pseudo-view losses: 65-90 % of those views) are flagged by
         # the march backward and skipped by the decoder backward; their rows of d_col / d_sig stay unwritten
-        active = torch.empty(r, device=dev, dtype=torch.int32)
+        from ...configs import global_config
+        active = torch.empty(r, device=dev, dtype=torch.int32) if global_config.exploit_sparsity else None
         hip.call('spi_raymarch_bwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), hip.ptr(d_rgb),
                  hip.ptr(dd), None, r, s, s, 32, white_back, hip.ptr(d_col), hip.ptr(d_sig), hip.ptr(active), hip.stream())
         want_w = any(ctx.needs_input_grad[1:5])

@@ -42,7 +42,25 @@ def _reconstruct_stub(meta):
     return PersistentStub(meta)
 
 
-_SAFE_PREFIXES = ('torch', 'numpy', 'collections', '_codecs')
+# EXACT (module, name) pairs a network pickle may reference: tensor / storage rebuilders, containers, numpy scalars and arrays,
+# the plain torch.nn containers EG3D's persistent classes hold (OSGDecoder.net is a Sequential with a Softplus).  Anything else
+# -- in particular dotted names such as ('torch', 'os.system'), which pickle protocol 4 resolves attribute by attribute --
+# is refused.
+_TORCH_DTYPES = ('float32', 'float64', 'float16', 'bfloat16', 'int64', 'int32', 'int16', 'int8', 'uint8', 'bool')
+_STORAGES = ('FloatStorage', 'DoubleStorage', 'HalfStorage', 'BFloat16Storage', 'LongStorage', 'IntStorage', 'ShortStorage',
+             'CharStorage', 'ByteStorage', 'BoolStorage', 'UntypedStorage')
+_ALLOWED = frozenset(
+    [('collections', 'OrderedDict'), ('_codecs', 'encode'),
+     ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_parameter'), ('torch._utils', '_rebuild_parameter_with_state'),
+     ('torch._utils', '_rebuild_tensor'), ('torch.storage', '_load_from_bytes'), ('torch', 'Size'), ('torch', 'device'),
+     ('torch.nn.parameter', 'Parameter'), ('torch._tensor', '_rebuild_from_type_v2'), ('torch', 'Tensor'),
+     ('torch.nn.modules.container', 'Sequential'), ('torch.nn.modules.container', 'ModuleList'),
+     ('torch.nn.modules.container', 'ModuleDict'), ('torch.nn.modules.activation', 'Softplus'),
+     ('numpy', 'ndarray'), ('numpy', 'dtype'),
+     ('numpy.core.multiarray', '_reconstruct'), ('numpy.core.multiarray', 'scalar'),
+     ('numpy._core.multiarray', '_reconstruct'), ('numpy._core.multiarray', 'scalar')]
+    + [('torch', n) for n in _TORCH_DTYPES + _STORAGES])
+_BUILTINS = frozenset(('dict', 'list', 'tuple', 'set', 'frozenset', 'int', 'float', 'bool', 'str', 'bytes', 'slice', 'complex'))
 
 
 class _RestrictedUnpickler(pickle.Unpickler):
@@ -51,10 +69,7 @@ class _RestrictedUnpickler(pickle.Unpickler):
             return _reconstruct_stub
         if module in ('dnnlib.util', 'dnnlib') and name == 'EasyDict':
             return EasyDict
-        if module == 'builtins' and name in ('dict', 'list', 'tuple', 'set', 'frozenset', 'int', 'float', 'bool', 'str', 'bytes',
-                                             'slice', 'complex', 'getattr'):
-            return super().find_class(module, name)
-        if module.split('.')[0] in _SAFE_PREFIXES:
+        if '.' not in name and ((module == 'builtins' and name in _BUILTINS) or (module, name) in _ALLOWED):
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f'refusing to import {module}.{name} from a network pickle')
 

@@ -17,7 +17,10 @@ from ..configs import paths_config
 
 class Metric:
     def __init__(self, lpips_loss=None, id_fn=None, device='cuda'):
-        self.lpips_loss = lpips_loss if lpips_loss is not None else LPIPS(net_type='vgg').to(device).eval()
+        if lpips_loss is None:
+            from ..criteria import weights as pretrained
+            lpips_loss = LPIPS(net_type='vgg', weights=pretrained.lpips_vgg16_weights()).to(device).eval()
+        self.lpips_loss = lpips_loss
         if id_fn is None and os.path.isfile(paths_config.IDLOSS_PATH):
             from ..criteria.id_loss import IDLoss
             id_fn = IDLoss(paths_config.IDLOSS_PATH).to(device).eval().calculate_similarity

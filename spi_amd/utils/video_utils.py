@@ -22,22 +22,25 @@ from . import camera_utils as cu
 def orbit_cameras(num_frames, yaw_range=0.7, pitch_range=0.4, lookat=(0.0, 0.0, 0.2), radius=2.7, device='cpu'):
     """[F,25] cameras of the reference's orbit (video_utils.py:155-160).  It writes 3.14, not pi: kept, the path is part of
     what a user sees."""
-    t = torch.arange(num_frames, dtype=torch.float32, device=device).view(-1, 1)
-    h = 3.14 / 2 + yaw_range * torch.sin(2 * 3.14 * t / num_frames)
-    v = 3.14 / 2 - 0.05 + pitch_range * torch.cos(2 * 3.14 * t / num_frames)
+    t = np.arange(num_frames, dtype=np.float64)                                   # the reference evaluates the angles in float64 (np.sin)
+    h = torch.tensor(3.14 / 2 + yaw_range * np.sin(2 * 3.14 * t / num_frames), dtype=torch.float32, device=device).view(-1, 1)
+    v = torch.tensor(3.14 / 2 - 0.05 + pitch_range * np.cos(2 * 3.14 * t / num_frames), dtype=torch.float32, device=device).view(-1, 1)
     ext = cu.look_at_pose(h, v, torch.tensor(lookat, device=device), radius)
     return torch.cat([ext.reshape(-1, 16), cu._intrinsics(num_frames, device)], dim=1)
 
 
 def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0):
-    """Regular N^3 grid of query points, x fastest (video_utils.py:41-70).  -> ([1, N^3, 3], origin, voxel size)"""
-    origin = np.array(voxel_origin, dtype=np.float32) - cube_length / 2
+    """N^3 query points, x fastest (video_utils.py:41-70).  -> ([1, N^3, 3], origin, voxel size).
+    The reference divides the running index as a FLOAT (`(overall_index.float() / N) % N`, :57-58), so the second and third
+    coordinates are fractional grid positions (each row / slab is sheared by up to one voxel); kept, since the exported
+    density grid is defined by these points (pinned by tests/golden/orbit.npz)."""
+    origin = np.array(voxel_origin) - cube_length / 2
     voxel = cube_length / (N - 1)
-    idx = torch.arange(N ** 3, dtype=torch.int64)
+    idx = torch.arange(0, N ** 3, 1, dtype=torch.int64)
     s = torch.zeros(N ** 3, 3)
     s[:, 2] = idx % N
-    s[:, 1] = (idx // N) % N
-    s[:, 0] = (idx // N // N) % N
+    s[:, 1] = (idx.float() / N) % N
+    s[:, 0] = ((idx.float() / N) / N) % N
     s[:, 0] = s[:, 0] * voxel + origin[2]
     s[:, 1] = s[:, 1] * voxel + origin[1]
     s[:, 2] = s[:, 2] * voxel + origin[0]

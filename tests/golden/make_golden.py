@@ -69,11 +69,13 @@ def build_ref_generator(narrow=True, rk=None):
 
 class Recorder:
     """Record torch.rand / rand_like / randn_like draws made by the reference."""
-    def __init__(self):
+    def __init__(self, randn=False):
         self.draws = []
+        self.randn = randn               # also record torch.randn (StyleGAN2 noise_mode='random' draws)
 
     def __enter__(self):
         self._o = (torch.rand, torch.rand_like, torch.randn_like)
+        self._randn = torch.randn
         rec = self
 
         def wrap(fn):
@@ -83,10 +85,13 @@ class Recorder:
                 return out
             return inner
         torch.rand, torch.rand_like, torch.randn_like = [wrap(f) for f in self._o]
+        if self.randn:
+            torch.randn = wrap(self._randn)
         return self
 
     def __exit__(self, *a):
         torch.rand, torch.rand_like, torch.randn_like = self._o
+        torch.randn = self._randn
 
 
 # ------------------------------------------------------------------------------------------------
@@ -446,9 +451,130 @@ def sec_trajectory():
     save('trajectory', target_seed=np.array([31]), c=c, w_mir=w_mir[:, 0], w_mir_final=w[0], w_plus=w_plus[:, 0],
          w_plus_final=w2[0])
 
+def sec_trajectory_sg():
+    """3 steps of the reference's w_projector.project (`first_inv_type=sg`, BASELINE configs[0]/[2]) on the narrow generator with
+    a seeded stand-in for NVIDIA's vgg16.pt (oracle.losses_ref.sg_vgg_features) injected as `vgg16`; w and dL/dw per step."""
+    from spi.configs import global_config
+    global_config.device = 'cpu'
+    import spi.training.projectors.w_projector as wproj
+    wproj.tqdm = lambda x: x
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import camera_utils as cu
+    G = build_ref_generator(True)
+    G.neural_rendering_resolution = 64
+    W = olo.make_vgg16_weights(seed=0)
+    vgg = lambda img, resize_images=False, return_lpips=True: olo.sg_vgg_features(W, img, resize_images, return_lpips)
+    g = torch.Generator().manual_seed(41)
+    target = torch.rand(1, 3, 512, 512, generator=g) * 2 - 1
+    c = cu.cal_canonical_c(-0.3, 0.05)
+    w_log, g_log = [], []
+    orig_step = torch.optim.Adam.step
+
+    def logging_step(self, *a, **k):
+        g_log.append(self.param_groups[0]['params'][0].grad.detach().clone())
+        r = orig_step(self, *a, **k)
+        w_log.append(self.param_groups[0]['params'][0].detach().clone())
+        return r
+    torch.optim.Adam.step = logging_step
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        w = wproj.project(G, target, c, vgg, num_steps=3, w_avg_samples=64, device=torch.device('cpu'), w_name='t')
+    finally:
+        torch.optim.Adam.step = orig_step
+    from oracle import loops_ref as olp
+    P = {k: v for k, v in G.state_dict().items()}
+    torch.manual_seed(0)
+    np.random.seed(0)
+    log = []
+    w2 = olp.project_w(P, target, c, vgg, dict(RK), num_steps=3, w_avg_samples=64, nrr=64, log=log)
+    diff('sg trajectory w', torch.stack(w_log), torch.stack([l['w'] for l in log]))
+    diff('sg trajectory dL/dw', torch.stack(g_log), torch.stack([l['grad_w'] for l in log]))
+    diff('sg final w [1,14,512]', w, w2)
+    save('trajectory_sg', target_seed=np.array([41]), c=c, w_sg=torch.stack(w_log)[:, 0], gw_sg=torch.stack(g_log)[:, 0], w_sg_final=w[0])
+
+
+def sec_tv():
+    """TriPlaneGenerator.sample_mixed (triplane.py:98-102) and cal_tv_loss (spi/criteria/tv_loss.py:9-19) on the
+    narrow generator: densities / colours at explicit coordinates, the TV value and its gradient wrt W+, with the draws recorded."""
+    from spi.criteria.tv_loss import cal_tv_loss
+    G = build_ref_generator(True)
+    g = torch.Generator().manual_seed(51)
+    ws = torch.randn(1, 14, 512, generator=g)
+    coords = torch.rand(1, 3000, 3, generator=g) * 1.2 - 0.6          # some points outside the box (zero-padded gather)
+    with torch.no_grad():
+        sm = G.sample_mixed(coords, torch.randn(1, 3000, 3, generator=g), ws, noise_mode='const')
+    wr = ws.clone().requires_grad_(True)
+    with Recorder(randn=True) as rec:
+        torch.manual_seed(7)
+        tv = cal_tv_loss(wr, G)                                       # NB: backbone noise_mode defaults to 'random' here (tv_loss.py:14)
+    gw, = torch.autograd.grad(tv, wr)
+    # rand coords, randn perturbation, randn directions (unused by the decoder), then one [1,1,res,res] noise draw per synthesis layer
+    assert len(rec.draws) == 3 + 13, [d.shape for d in rec.draws]
+    # pin the oracle's restatement
+    P = {k: v for k, v in G.state_dict().items()}
+    wo = ws.clone().requires_grad_(True)
+
+    class Replay:
+        def __init__(self, d):
+            self.d = list(d)
+
+        def randn(self, *shape):
+            t = self.d.pop(0)
+            assert tuple(t.shape) == tuple(shape)
+            return t
+    planes = osg.backbone_synthesis(P, wo, noise_mode='random', noise_rng=Replay(rec.draws[3:])).reshape(1, 3, 32, 256, 256)
+    init = rec.draws[0] * 2 - 1
+    allc = torch.cat([init, init + rec.draws[1] * 0.004], 1)
+    rgb_o, sig_o = orr.run_model(P, planes, allc, dict(RK))
+    tv_o = F.l1_loss(sig_o[:, :1000], sig_o[:, 1000:])
+    diff('cal_tv_loss', tv, tv_o)
+    diff('cal_tv_loss dL/dws', gw, torch.autograd.grad(tv_o, wo)[0])
+    rgb2, sig2 = orr.run_model(P, osg.backbone_synthesis(P, ws).reshape(1, 3, 32, 256, 256), coords, dict(RK))
+    diff('sample_mixed sigma', sm['sigma'], sig2)
+    diff('sample_mixed rgb', sm['rgb'], rgb2)
+    save('tv', ws=ws, coords=coords, sigma=sm['sigma'], rgb=sm['rgb'], tv=tv, gws=gw,
+         **{f'r{i}': d for i, d in enumerate(rec.draws)})
+
+
+def sec_orbit():
+    """the camera path of spi/utils/video_utils.py:155-160 (that module itself needs imageio / mrcfile and cannot be
+    imported): the reference's own LookAtPoseSampler (eg3d/camera_utils.py) driven with the orbit expressions of those lines, plus the
+    query grid of create_samples (:41-70), restated from the cited lines with the reference's numpy / torch calls."""
+    from camera_utils import LookAtPoseSampler
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import video_utils as vu
+    out = {}
+    for frames in (120, 7):
+        poses = []
+        for frame_idx in range(frames):
+            pose = LookAtPoseSampler.sample(3.14 / 2 + 0.7 * np.sin(2 * 3.14 * frame_idx / frames),
+                                            3.14 / 2 - 0.05 + 0.4 * np.cos(2 * 3.14 * frame_idx / frames),
+                                            torch.tensor([0, 0, 0.2]), radius=2.7, device='cpu')
+            poses.append(pose.reshape(16))
+        intr = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]).reshape(1, 9).repeat(frames, 1)
+        cams = torch.cat([torch.stack(poses), intr], 1)
+        out[f'cams_{frames}'] = cams
+        diff(f'orbit cameras ({frames} frames)', cams, vu.orbit_cameras(frames))
+    N, cube = 6, 1.0
+    origin = np.array([0, 0, 0]) - cube / 2
+    vs = cube / (N - 1)
+    idx = torch.arange(0, N ** 3, 1, out=torch.LongTensor())
+    smp = torch.zeros(N ** 3, 3)
+    smp[:, 2] = idx % N
+    smp[:, 1] = (idx.float() / N) % N
+    smp[:, 0] = ((idx.float() / N) / N) % N
+    smp[:, 0] = (smp[:, 0] * vs) + origin[2]
+    smp[:, 1] = (smp[:, 1] * vs) + origin[1]
+    smp[:, 2] = (smp[:, 2] * vs) + origin[0]
+    out['samples_6'] = smp
+    print('    (create_samples in the reference uses float division: columns 0/1 are fractional positions, kept as data)')
+    save('orbit', **out)
+
 
 SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, synthesis=sec_synthesis,
-                geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory)
+                geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory, trajectory_sg=sec_trajectory_sg,
+                tv=sec_tv, orbit=sec_orbit)
 
 if __name__ == '__main__':
     todo = sys.argv[1:] or list(SECTIONS)

@@ -52,7 +52,7 @@ def test_cli_pti_then_inference_and_metrics(tmp_path, capsys):
     from spi_amd.utils import load_utils
     from spi_amd.data.images_dataset import SyntheticDataset
     G = load_utils.load_eg3d(device='cuda:0', synthetic=True)
-    c = SingleIDCoach(None, False, G=G)
+    c = SingleIDCoach(None, False, G=G, synthetic=True)
     w, cam, Gl = c.load(os.path.join(ck, names[0] + '.pt'))
     d = SyntheticDataset(1)[0]
     gt = d['img'][None].cuda()
@@ -63,6 +63,48 @@ def test_cli_pti_then_inference_and_metrics(tmp_path, capsys):
     c.log_metric()
     txt = open(os.path.join(str(tmp_path), 'metric_log.txt')).read()
     assert 'Mode: final AVG' in txt and 'Lpips M:' in txt and 'ID Sim: nan' in txt
+
+
+def test_cli_sg_pti_with_logging(tmp_path, capsys):
+    """BASELINE configs[0] + configs[2] through the CLI in the reference's DEFAULT logging mode (no --not_use_wandb): `sg` W projector
+    (seeded extractor in --synthetic mode) then PTI; the w_inv / G1_inv images, orbit frames and metric_log.txt the reference writes
+    (base_coach.py:80-87, pti_coach.py:52-53,81-99) must exist, and reloading the stage-1 embedding must not count stage-1 steps."""
+    from spi_amd import run_inversion
+    from spi_amd.configs import hyperparameters as hp
+    out = str(tmp_path) + '/'
+    hp.LPIPS_value_threshold = -1.0
+    common = ['--output_root', out, '--synthetic', '1', '--depth_resolution', '12', '--depth_resolution_importance', '12']
+    run_inversion.run(common + ['--first_inv_type', 'sg', '--first_inv_steps', '3', '--G_1_type', 'pti', '--G_1_step', '2'])
+    stats = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1])
+    assert stats['iterations'] == 5
+    coach = 'PTI_coach_sg_3_pti_2_rot_0_mirrorrot_0_depth_0_tv_0'
+    exp = os.path.join(out, 'experiments' + coach)                # the reference concatenates without a separator (pti_coach.py:36)
+    name = os.listdir(os.path.join(out, 'embedding', coach))[0][:-3]
+    files = set(os.listdir(os.path.join(exp, name)))
+    assert {'target_image.jpg', f'{name}_w_inv.jpg', f'{name}_w_inv_m.jpg', f'{name}_G1_inv.jpg', f'{name}_G1_inv_m.jpg', f'{name}_G1_inv_0.jpg'} <= files
+    assert len(os.listdir(os.path.join(exp, name, f'{name}_w_inv_frames'))) == 120
+    txt = open(os.path.join(exp, 'metric_log.txt')).read()
+    assert f'Coach name: {coach}' in txt and 'Mode: w_inv\n' in txt and 'Mode: G1_inv AVG' in txt and 'ID: 0 L2:' in txt
+    emb = torch.load(os.path.join(out, 'embedding', coach, name + '.pt'), map_location='cpu')
+    assert emb.shape == (1, 14, 512) and torch.equal(emb[:, 0], emb[:, 13])          # W space: one w for all layers
+    # second run re-uses the embedding: only the 2 stage-2 iterations are counted
+    run_inversion.run(common + ['--not_use_wandb', '--first_inv_type', 'sg', '--first_inv_steps', '3', '--G_1_type', 'pti', '--G_1_step', '2',
+                                '--load_embedding_coach_name', coach])
+    stats = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1])
+    assert stats['iterations'] == 2
+
+
+def test_real_run_without_weights_fails_loudly(tmp_path):
+    """Without --synthetic the perceptual-loss weights must come from the files named in paths_config: a missing file is an error,
+    never a silent fall-back to seeded random features (criteria/weights.py)."""
+    from spi_amd.configs import paths_config, global_config
+    from spi_amd.training.coaches.pti_coach import SingleIDCoach
+    from spi_amd.utils import load_utils
+    G = load_utils.load_eg3d(device='cuda:0', synthetic=True)
+    paths_config.VGG16_PATH = str(tmp_path / 'nope.pth')
+    global_config.synthetic_weights = False
+    with pytest.raises(FileNotFoundError):
+        SingleIDCoach(None, False, G=G)
 
 
 @pytest.mark.parametrize('depth,fp16', [(96, False), (128, True)])

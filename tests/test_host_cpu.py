@@ -141,6 +141,80 @@ def test_network_pickle_reader_never_executes_embedded_source():
             return (os.system, ('echo pwned',))
     with pytest.raises(pickle.UnpicklingError):
         load_utils.read_network_pkl(io.BytesIO(pickle.dumps(dict(G_ema=Evil()))))
+    # protocol-4 STACK_GLOBAL resolves dotted names attribute by attribute: ('torch', 'os.getcwd') must not get through an
+    # allow-list keyed on the top-level module (round-1 advisor finding); nor may any torch global outside the exact list
+    for mod, name in (('torch', 'os.getcwd'), ('torch', 'hub.load'), ('torch.serialization', 'load'), ('numpy', 'load'), ('builtins', 'getattr'),
+                      ('builtins', 'eval')):
+        evil = pickle.PROTO + b'\x04' + b'\x8c' + bytes([len(mod)]) + mod.encode() + b'\x8c' + bytes([len(name)]) + name.encode() + b'\x93)R.'
+        with pytest.raises(pickle.UnpicklingError):
+            load_utils._RestrictedUnpickler(io.BytesIO(evil)).load()
+
+
+def test_pretrained_weight_files_are_required_unless_synthetic(tmp_path):
+    """criteria/weights.py: torchvision / LPIPS files named in paths_config are parsed; a missing file raises; seeded stand-ins only
+    when synthetic mode is requested (round-1 advisor finding: a real run must not silently optimise random features)."""
+    from spi_amd.configs import paths_config, global_config
+    from spi_amd.criteria import weights as pw
+    saved = (paths_config.VGG16_PATH, paths_config.VGG19_PATH, paths_config.LPIPS_PATH, global_config.synthetic_weights)
+    try:
+        global_config.synthetic_weights = False
+        paths_config.VGG16_PATH = str(tmp_path / 'vgg16.pth')
+        paths_config.VGG19_PATH = str(tmp_path / 'vgg19.pth')
+        paths_config.LPIPS_PATH = str(tmp_path / 'lpips.pth')
+        with pytest.raises(FileNotFoundError):
+            pw.lpips_vgg16_weights()
+        with pytest.raises(FileNotFoundError):
+            pw.vgg19_head_weights()
+        assert pw.lpips_vgg16_weights(synthetic=True) is None and pw.vgg19_head_weights(synthetic=True) is None
+        g = torch.Generator().manual_seed(0)
+        cfg16 = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]
+        sd, idx, cin = {}, 0, 3
+        for v in cfg16:                                   # torchvision layout: features.<index in the Sequential>.weight / .bias
+            if v == 'M':
+                idx += 1
+                continue
+            sd[f'features.{idx}.weight'], sd[f'features.{idx}.bias'] = torch.randn(v, cin, 3, 3, generator=g), torch.randn(v, generator=g)
+            cin, idx = v, idx + 2
+        sd['classifier.0.weight'] = torch.zeros(8, 8)
+        torch.save(sd, paths_config.VGG16_PATH)
+        lins = {f'lin{i}.model.1.weight': torch.rand(1, c, 1, 1, generator=g) for i, c in enumerate((64, 128, 256, 512, 512))}
+        torch.save(lins, paths_config.LPIPS_PATH)
+        w = pw.lpips_vgg16_weights()
+        assert len(w['convs']) == 13 and torch.equal(w['convs'][2][0], sd['features.5.weight']) and torch.equal(w['convs'][12][1], sd['features.28.bias'])
+        assert [l.shape for l in w['lins']] == [(64,), (128,), (256,), (512,), (512,)] and torch.equal(w['lins'][3], lins['lin3.model.1.weight'].reshape(-1))
+        torch.save({k.replace('lin', '').replace('model.', ''): v for k, v in lins.items()}, paths_config.LPIPS_PATH)    # the reference's renamed keys
+        assert torch.equal(pw.lpips_vgg16_weights()['lins'][4], lins['lin4.model.1.weight'].reshape(-1))
+        sd19 = {'features.0.weight': torch.randn(64, 3, 3, 3), 'features.0.bias': torch.randn(64), 'features.2.weight': torch.randn(64, 64, 3, 3),
+                'features.2.bias': torch.randn(64), 'features.5.weight': torch.randn(128, 64, 3, 3), 'features.5.bias': torch.randn(128),
+                'features.7.weight': torch.randn(128, 128, 3, 3), 'features.7.bias': torch.randn(128)}
+        torch.save(sd19, paths_config.VGG19_PATH)
+        h = pw.vgg19_head_weights()
+        assert len(h) == 3 and torch.equal(h[2][0], sd19['features.5.weight'])
+    finally:
+        paths_config.VGG16_PATH, paths_config.VGG19_PATH, paths_config.LPIPS_PATH, global_config.synthetic_weights = saved
+
+
+def test_orbit_cameras_and_query_grid_vs_reference_golden(golden):
+    """the 120-frame orbit (video_utils.py:155-160, driven through the reference's LookAtPoseSampler when the golden was
+    made) bit for bit, and create_samples' float-division grid (:41-70)."""
+    from spi_amd.utils import video_utils as vu
+    g = golden('orbit')
+    for frames in (120, 7):
+        assert torch.equal(vu.orbit_cameras(frames), g[f'cams_{frames}'])
+    s, origin, voxel = vu.create_samples(N=6, voxel_origin=[0, 0, 0], cube_length=1.0)
+    assert s.shape == (1, 216, 3) and torch.equal(s[0], g['samples_6']) and abs(voxel - 0.2) < 1e-12
+
+
+def test_sg_feature_distance_is_lpips():
+    """The stand-in for vgg16.pt (oracle.losses_ref.sg_vgg_features): squared feature distance == LPIPS on the same weights, which is
+    the published contract of `return_lpips=True` that w_projector.py:87 relies on."""
+    from oracle import losses_ref as olo
+    W = olo.make_vgg16_weights(seed=0)
+    g = torch.Generator().manual_seed(2)
+    a, b = torch.rand(1, 3, 64, 64, generator=g) * 255, torch.rand(1, 3, 64, 64, generator=g) * 255
+    d = (olo.sg_vgg_features(W, a) - olo.sg_vgg_features(W, b)).square().sum()
+    ref = olo.lpips(W, a / 127.5 - 1, b / 127.5 - 1)
+    assert abs(d.item() - ref.item()) <= 1e-5 * abs(ref.item())
 
 
 def test_projector_w_statistics_and_schedule_host_math():
@@ -171,4 +245,6 @@ def test_orbit_cameras_geometry():
     assert abs(float(yaw[0])) < 2e-3 and abs(float(yaw[60])) < 5e-3      # starts and crosses at the frontal view (3.14 != pi)
     s, o, v = create_samples(N=4, cube_length=1.0)
     assert s.shape == (1, 64, 3) and abs(v - 1 / 3) < 1e-6 and torch.allclose(s[0, 0], torch.tensor([-0.5, -0.5, -0.5]))
-    assert torch.allclose(s[0, 1], torch.tensor([-0.5, -0.5, -0.5 + 1 / 3]))   # the LAST coordinate runs fastest (:57-66)
+    # the LAST coordinate runs fastest (:57-66); the other two are FRACTIONAL positions because the reference divides the running
+    # index as a float (`(overall_index.float() / N) % N`): sample 1 sits at (1/16, 1/4, 1) voxels
+    assert torch.allclose(s[0, 1], torch.tensor([-0.5 + (1 / 16) / 3, -0.5 + (1 / 4) / 3, -0.5 + 1 / 3]))

@@ -19,7 +19,7 @@ hp.LPIPS_value_threshold = -1.0
 torch.manual_seed(0)
 G = TriPlaneGenerator(**ffhq512_kwargs(depth_resolution=96, depth_resolution_importance=96)).eval().requires_grad_(False).to(dev)
 G.neural_rendering_resolution = 128
-coach = RotBboxCoach(None, False, G=G)
+coach = RotBboxCoach(None, False, G=G, synthetic=True)
 d = SyntheticDataset(1)[0]
 data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in d.items()}
 ctx = coach.prepare_image(data)

@@ -18,7 +18,7 @@ hp.pt_rot_lambda, hp.pt_mirror_rot_lambda, hp.pt_depth_lambda, hp.LPIPS_value_th
 torch.manual_seed(0)
 G = TriPlaneGenerator(**ffhq512_kwargs(depth_resolution=96, depth_resolution_importance=96)).eval().requires_grad_(False).to(dev)
 G.neural_rendering_resolution = 128
-coach = RotBboxCoach(None, False, G=G)
+coach = RotBboxCoach(None, False, G=G, synthetic=True)
 d = SyntheticDataset(1)[0]
 ctx = coach.prepare_image({k: (v[None] if torch.is_tensor(v) else v) for k, v in d.items()})
 cams, dist_fn = mirror_setup(ctx['image'], ctx['camera'], coach.lpips_loss, dev)
