@@ -48,6 +48,8 @@ def parse():
     ap.add_argument('--sr-fp16', action='store_true', help='NOT the benchmark configuration: fp16 MFMA in the super-resolution blocks '
                                                            '(BASELINE config 5); the JSON line then says dtype f32+f16sr')
     ap.add_argument('--narrow', action='store_true', help='debug: reduced-width generator (NOT the benchmark configuration)')
+    ap.add_argument('--dry-run', action='store_true', help='plumbing self-test without a GPU: launcher, rendezvous (gloo), barrier and the statistics '
+                                                           'all-reduces run as in a real run, the timed steps are replaced by a sleep; prints no metric')
     return ap.parse_args()
 
 
@@ -197,14 +199,48 @@ def launch_ranks(n):
     return rc or max((p.returncode or 0) for p in procs)
 
 
+def reduce_run_stats(sdist, rank, world, t0, dt_rank, ok, dev):
+    """Barrier, then ONE max-reduce of the wall time and ONE sum-reduce carrying every rank's own time and done-flag.
+    -> (max-over-ranks seconds, per-rank seconds, per-rank done-flags)"""
+    sdist.barrier()
+    dt = time.perf_counter() - t0
+    dt = sdist.reduce_stats([dt], device=dev, op='max')[0]
+    slots = [0.0] * (2 * world)
+    slots[rank], slots[world + rank] = dt_rank, ok
+    slots = sdist.reduce_stats(slots, device=dev)
+    return dt, slots[:world], slots[world:]
+
+
+def dry_run(args, sdist, rank, world):
+    """--dry-run: everything around the GPU work (used by the world-size-2 CPU test)."""
+    sdist.barrier()
+    t0 = time.perf_counter()
+    ok = 1.0
+    try:
+        if os.environ.get('SPI_BENCH_FAIL_RANK') == str(rank):
+            raise RuntimeError('injected failure')
+        time.sleep(0.05 * (rank + 1))
+    except Exception:
+        ok = 0.0
+    dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, time.perf_counter() - t0, ok, None)
+    if rank == 0:
+        print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'seconds_max_over_ranks': dt,
+                          'ranks': {'launched': world, 'completed': int(sum(rank_ok)), 'per_rank_seconds': rank_s}}), flush=True)
+    sdist.shutdown()
+    if int(sum(rank_ok)) != world:
+        sys.exit(3)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus))
     from spi_amd import dist as sdist
-    rank, world, local = sdist.init_from_env()
+    rank, world, local = sdist.init_from_env(backend='gloo' if args.dry_run else None)
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.dry_run:
+        return dry_run(args, sdist, rank, world)
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X (the HIP path has no CPU fallback)')
     torch.cuda.set_device(local)
@@ -277,6 +313,7 @@ def main():
             print(f'==== {tag}: by number of calls', file=sys.stderr)
             for e in sorted(ka, key=lambda e: -e.count)[:45]:
                 print(f'{e.count:7d}  dev {e.device_time_total / 1e3:9.2f} ms  cpu {e.cpu_time_total / 1e3:9.2f} ms  {e.key[:90]}', file=sys.stderr)
+        ok = 1.0
     else:
         ok = 1.0
         try:
@@ -287,14 +324,8 @@ def main():
             ok = 0.0
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0                           # this rank's own K steps
-    sdist.barrier()
-    dt = time.perf_counter() - t0
     events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
-    dt = sdist.reduce_stats([dt], device=dev, op='max')[0]
-    slots = [0.0] * (2 * world)                                  # one small all-reduce carries every rank's own time and done-flag
-    slots[rank], slots[world + rank] = dt_rank, ok if not os.environ.get('SPI_TORCH_PROFILE') else 1.0
-    slots = sdist.reduce_stats(slots, device=dev)
-    rank_s, rank_ok = slots[:world], slots[world:]
+    dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, dt_rank, ok, dev)
     n_ok = int(sum(rank_ok))
     march_ms = [a.elapsed_time(b) for a, b, _ in events]
     march_rays = [r for _, _, r in events]

@@ -27,7 +27,7 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 1
+#define SPI_ABI_VERSION 2   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale */
 int         spi_abi_version(void);
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
 
@@ -79,20 +79,23 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
                             int N, int64_t P, int S, int H, int W, float box_warp, int out_S, int out_off,
                             float* d_planes_nhwc, float* dump_act, spi_stream_t stream);
 
-/* Same backward for the render path, tiled for scatter locality: points are visited as 8x8 patches of
- * neighbouring rays (ray m = row * ray_w + col) x 4 consecutive SORTED sample positions; plane-gradient
- * contributions are pre-summed in an LDS window before touching HBM.  Sample (r, k) has depth
+/* Same backward for the render path, tiled for scatter locality: the 64 x S points of every 8x8 patch of
+ * neighbouring rays (ray m = row * ray_w + col) are ordered by DEPTH (uniform depth bins, no sort: each ray's
+ * samples are already ascending) and visited 256 at a time -- thin slabs of the view frustum whose plane-gradient
+ * contributions are pre-summed in a 16x16-texel LDS window per plane before touching HBM.  Sample (r, k) has depth
  * depths_sorted[r, k] and colour/density/gradient row r*S + perm[r, k] (perm may be NULL = identity).
  * The decoder runs on the fp32 matrix cores and its weight gradients are fused in: with dw1 != NULL the call
  * OVERWRITES dw1 [64,32], db1 [64], dw2 [33,64], db2 [33] (gradients wrt the gained weights w1t^T, b1, w2, b2);
  * dw1 == NULL (all four) = decoder frozen.  d_rgb == NULL = the colour gradient is zero (depth-only loss): the colour
- * layer is skipped.  ray_active (optional, int32 [N*M] from spi_raymarch_bwd): rays flagged 0 are skipped, 8x8 patches
- * without any active ray cost nothing.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
+ * layer is skipped.  d_rgb_scale == NULL: d_rgb is the per-sample gradient [N*M*S,32] (row mapping as above).  d_rgb_scale
+ * != NULL (what spi_raymarch_bwd's d_color_scale output is for): d_rgb is PER RAY [N*M,32] and the gradient of sample row i
+ * of ray r is d_rgb[r,:] * d_rgb_scale[i] -- the [N*M*S,32] tensor never exists.  ray_active (optional, int32 [N*M] from
+ * spi_raymarch_bwd): rays flagged 0 are dropped before the tiles are formed.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
  * (weight fragments + per-wave partial sums; contents undefined afterwards).  d_planes_nhwc is accumulated into. */
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d,
                                    const float* depths_sorted, const int32_t* perm, const float* w1t,
                                    const float* b1, const float* w2, const float* b2, const float* d_rgb,
-                                   const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
+                                   const float* d_rgb_scale, const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
                                    float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1,
                                    float* dw2, float* db2, const int32_t* ray_active, spi_stream_t stream);
 int64_t spi_triplane_decode_bwd_sorted_ws(int N, int M, int S, int ray_w);
@@ -119,13 +122,16 @@ int spi_raymarch_fwd(const float* colors, const float* densities, const float* d
 
 /* Backward: d_rgb [R,C] (NULL = 0: only the depth map is differentiated -- colors / d_colors are then not touched
  * and may be NULL), d_depth [R] (NULL = 0), d_weights [R,S-1] (NULL = 0) ->
- * d_colors [R,S,C], d_densities [R,S] written through perm like the forward reads.
+ * d_colors [R,S,C] and / or d_color_scale [R,S], d_densities [R,S], written through perm like the forward reads.
+ * The colour-row gradient is d_rgb[r,:] * (w[r,k-1] + w[r,k]): d_color_scale receives that per-sample scalar alone
+ * (4 B instead of 128 B per sample; spi_triplane_decode_bwd_sorted rebuilds the rows from d_rgb).  Either output may be NULL.
  * ray_active (optional, int32 [R]): set to 0 for rays whose incoming gradient is exactly zero -- their rows of d_colors /
- * d_densities are then NOT written (all zero by definition); pass the same array to spi_triplane_decode_bwd_sorted. */
+ * d_color_scale / d_densities are then NOT written (all zero by definition); pass the same array to
+ * spi_triplane_decode_bwd_sorted. */
 int spi_raymarch_bwd(const float* colors, const float* densities, const float* depths,
                      const int32_t* perm, const float* clamp2, const float* d_rgb, const float* d_depth,
                      const float* d_weights, int64_t R, int S, int S_store, int C, int white_back,
-                     float* d_colors, float* d_densities, int32_t* ray_active, spi_stream_t stream);
+                     float* d_colors, float* d_color_scale, float* d_densities, int32_t* ray_active, spi_stream_t stream);
 
 /* sample_importance + sample_pdf, renderer.py:194-253.  depths [R,S], weights [R,S-1], u [R,Sf]
  * -> fine depths [R,Sf]: in draw order like the reference (sort_out = 0) or ascending per ray (sort_out = 1;

@@ -454,12 +454,103 @@ __global__ void decoder_partial_reduce_kernel(const float* __restrict__ part, in
     else if (e >= PART_DB2) atomicAdd(db2 + e - PART_DB2, v);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Depth-binned point order for the tiled decoder backward.
+//   A tile of decode_bwd_tiled_kernel scatters its 256 points into one 16 x 16-texel LDS window per plane.  Taking the tile
+//   as "8 x 8 rays x 4 consecutive SORTED SAMPLE INDICES" makes the XY footprint compact but not the depth extent: once the
+//   importance samples cluster, the k-th sorted sample of neighbouring rays sits at different depths and 18 % of the
+//   points left the XZ / ZX windows (straight to global atomics).  Here the 64 x S points of a ray patch are ordered by
+//   DEPTH instead: NBIN uniform depth bins over the patch's own range, bin-major, ray-minor, sample order inside a ray (each
+//   ray's samples are already sorted, so a bin is one contiguous run per ray -> rank = prefix over (bin, ray) counts +
+//   offset inside the run: no sort, deterministic).  256 consecutive entries of that order are one tile: a slab of the
+//   view frustum a few texels thick.  Rays whose gradient is exactly zero (ray_active == 0) are dropped here, so the
+//   masked pseudo-view branches only pay for the rays that carry a gradient.
+//   order[patch][pos] = ray-in-patch << 8 | sorted sample index (S <= 256), count[patch] = live points.
+// ------------------------------------------------------------------------------------------------
+constexpr int NBIN = 64;
+
+__device__ __forceinline__ int patch_ray(int patch, int rl, int ray_w, int patch2d) {
+    if (patch2d) {
+        const int pw = ray_w >> 3;
+        const int py = patch / pw, px = patch - py * pw;
+        return ((py << 3) + (rl >> 3)) * ray_w + (px << 3) + (rl & 7);
+    }
+    return patch * 64 + rl;
+}
+
+__global__ void __launch_bounds__(256) bin_points_kernel(const float* __restrict__ depths, const int32_t* __restrict__ ray_active, int M, int S,
+                                                         int ray_w, int patch2d, int patches, uint16_t* __restrict__ order,
+                                                         int32_t* __restrict__ count) {
+    __shared__ int cnt[NBIN * 64];                // live points of (bin, ray); then its exclusive prefix
+    __shared__ int first[NBIN * 64];              // smallest sample index of that run
+    __shared__ float red[2][4];
+    __shared__ int wsum_s[4];
+    __shared__ int8_t live[64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = blockIdx.x / patches, patch = blockIdx.x - n * patches;
+    if (t < 64) {
+        const int m = patch_ray(patch, t, ray_w, patch2d);
+        live[t] = (m < M) && (!ray_active || ray_active[(int64_t)n * M + m] != 0);
+    }
+    for (int i = t; i < NBIN * 64; i += 256) { cnt[i] = 0; first[i] = 0x7fffffff; }
+    __syncthreads();
+    const int total = 64 * S;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int p = t; p < total; p += 256) {
+        const int rl = p / S, k = p - rl * S;
+        if (!live[rl]) continue;
+        const float d = depths[((int64_t)n * M + patch_ray(patch, rl, ray_w, patch2d)) * S + k];
+        lo = fminf(lo, d); hi = fmaxf(hi, d);
+    }
+    lo = wave_min(lo); hi = wave_max(hi);
+    if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
+    __syncthreads();
+    lo = fminf(fminf(red[0][0], red[0][1]), fminf(red[0][2], red[0][3]));
+    hi = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    const float inv = hi > lo ? (float)NBIN / (hi - lo) : 0.f;
+    auto bin_of = [&](float d) { return min(max((int)((d - lo) * inv), 0), NBIN - 1); };
+    for (int p = t; p < total; p += 256) {
+        const int rl = p / S, k = p - rl * S;
+        if (!live[rl]) continue;
+        const float d = depths[((int64_t)n * M + patch_ray(patch, rl, ray_w, patch2d)) * S + k];
+        const int b = bin_of(d);
+        atomicAdd(&cnt[b * 64 + rl], 1);
+        atomicMin(&first[b * 64 + rl], k);
+    }
+    __syncthreads();
+    // exclusive prefix over the NBIN * 64 counts in (bin, ray) order: 16 consecutive entries per thread
+    constexpr int PER = NBIN * 64 / 256;
+    int loc[PER], sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { loc[i] = sum; sum += cnt[t * PER + i]; }
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) wsum_s[wave] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < wave; ++w) base += wsum_s[w];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) cnt[t * PER + i] = base + loc[i];
+    if (t == 255) count[blockIdx.x] = base + sum;
+    __syncthreads();
+    uint16_t* out = order + (int64_t)blockIdx.x * total;
+    for (int p = t; p < total; p += 256) {
+        const int rl = p / S, k = p - rl * S;
+        if (!live[rl]) continue;
+        const float d = depths[((int64_t)n * M + patch_ray(patch, rl, ray_w, patch2d)) * S + k];
+        const int e = bin_of(d) * 64 + rl;
+        out[cnt[e] + k - first[e]] = (uint16_t)((rl << 8) | k);
+    }
+}
+
 struct TiledArgs {
     const float* planes; const float* ray_o; const float* ray_d; const float* depths; const int32_t* perm;
     const int32_t* ray_active;                // optional per-ray flags from spi_raymarch_bwd: 0 = the ray's gradient rows are all zero (and unwritten)
     int N; int M; int S; int H; int W; float scale;
     int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
     int patches; int kchunks; int tiles;
+    const uint16_t* order; const int32_t* count;   // depth-binned point order of every ray patch (bin_points_kernel)
     int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 4 = skip the MLP, 8 = no flush, 16 = skip points that leave the window, 32 = no LDS atomics, 64 = skip the plane gather
 };
 
@@ -468,8 +559,12 @@ struct TiledArgs {
 template <bool WGRAD, bool RGB>
 __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ frag_g, const float* __restrict__ b1_g,
                                                                  const float* __restrict__ b2_g, const float* __restrict__ d_rgb,
+                                                                 const float* __restrict__ d_rgb_scale,
                                                                  const float* __restrict__ d_sigma, float* __restrict__ d_planes,
                                                                  float* __restrict__ part) {
+    // d_rgb_scale == NULL: d_rgb is the materialised per-sample gradient [R*S, 32].  Otherwise the gradient of sample row i of
+    // ray r is d_rgb[r][:] * d_rgb_scale[i] (what the ray marcher's backward produces: a per-ray vector times a per-sample
+    // scalar); the 2 MB per-ray array stays in L2 and the 128 B per point of gradient traffic disappears.
     __shared__ __attribute__((aligned(16))) float feat[DT * FS];   // rows [point][36]: features 0..31 | d_sigma at col 32; phase B overwrites 0..31 with d_feat
     __shared__ __attribute__((aligned(16))) float gbuf[DT * FS];   // phase B: the weight fragments (8320 floats); phase C: the scatter window
     __shared__ float s_x[DT], s_y[DT], s_z[DT];
@@ -494,20 +589,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     const int n = tile / (a.patches * a.kchunks);
     const int rem = tile - n * (a.patches * a.kchunks);
     const int patch = rem / a.kchunks, kc = rem - patch * a.kchunks;
-    // ---- point owned by this thread
-    const int rl = t & 63, kk = t >> 6;
-    int m;
-    if (a.patch2d) {
-        const int pw = a.ray_w >> 3;
-        const int py = patch / pw, px = patch - py * pw;
-        m = ((py << 3) + (rl >> 3)) * a.ray_w + (px << 3) + (rl & 7);
-    } else {
-        m = patch * 64 + rl;
-    }
-    const int k = kc * 4 + kk;
-    bool valid = (m < a.M) && (k < a.S);
-    if (valid && a.ray_active) valid = a.ray_active[(int64_t)n * a.M + m] != 0;
-    if (!__syncthreads_or(valid)) continue;                    // no ray of this patch carries a gradient: nothing to do (block-uniform)
+    // ---- point owned by this thread: entry kc * 256 + t of the patch's depth-binned order
+    const int pidx = n * a.patches + patch;
+    const int live_pts = a.count[pidx];
+    if (kc * DT >= live_pts) continue;                         // past the patch's last live point (block-uniform)
+    const int pos = kc * DT + t;
+    const bool valid = pos < live_pts;
+    const int id = valid ? (int)a.order[(int64_t)pidx * (64 * a.S) + pos] : 0;
+    const int rl = id >> 8, k = id & 255;
+    const int m = patch_ray(patch, rl, a.ray_w, a.patch2d);
     int row = -1;
     float x = 0.f, y = 0.f, z = 0.f;
     if (valid) {
@@ -520,6 +610,10 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     }
     s_x[t] = x; s_y[t] = y; s_z[t] = z; s_row[t] = row;
     feat[t * FS + 32] = valid ? d_sigma[row] : 0.f;
+    if (RGB && d_rgb_scale) {                                  // columns 33 / 34 of the point's LDS row: its ray and its colour-gradient scale
+        feat[t * FS + 33] = __int_as_float(valid ? n * a.M + m : 0);
+        feat[t * FS + 34] = valid ? d_rgb_scale[row] : 0.f;
+    }
     if (!(a.dbg & 4))
         for (int i = t; i < FRAG_TOTAL; i += DT) gbuf[i] = frag_g[i];      // weight fragments -> LDS (L2-resident source, same for every tile)
     __syncthreads();
@@ -566,10 +660,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         // that ends in s_waitcnt vmcnt(0) -- 4 + 16 serialised HBM round trips per 32 points before this was changed)
         float4 dr[4];
         if (RGB) {
-            const float4* drp = reinterpret_cast<const float4*>(d_rgb + (int64_t)max(myrow, 0) * DEC_IN + 4 * hh_);
+            const int64_t grow = d_rgb_scale ? (int64_t)__float_as_int(frow[33]) : (int64_t)max(myrow, 0);
+            const float gsc = d_rgb_scale ? frow[34] : 1.f;
+            const float4* drp = reinterpret_cast<const float4*>(d_rgb + grow * DEC_IN + 4 * hh_);
             const bool keep = myrow >= 0;              // select, not multiply: the clamped row may be an unwritten (inactive-ray) row
 #pragma unroll
-            for (int g = 0; g < 4; ++g) { float4 v = drp[2 * g]; dr[g] = make_float4(keep ? v.x : 0.f, keep ? v.y : 0.f, keep ? v.z : 0.f, keep ? v.w : 0.f); }
+            for (int g = 0; g < 4; ++g) {
+                float4 v = drp[2 * g];
+                dr[g] = make_float4(keep ? v.x * gsc : 0.f, keep ? v.y * gsc : 0.f, keep ? v.z * gsc : 0.f, keep ? v.w * gsc : 0.f);
+            }
         }
         // H1[j][p] = softplus(W1 F + b1)
         f32x16_t H1[2];
@@ -594,8 +693,10 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         if (WGRAD && RGB) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int prow2 = s_row[pbase + rowmap(r, hh_)];
-                const float v = d_rgb[(int64_t)max(prow2, 0) * DEC_IN + q_];
+                const int p2 = pbase + rowmap(r, hh_);
+                const int prow2 = s_row[p2];
+                const int64_t grow2 = d_rgb_scale ? (int64_t)__float_as_int(feat[p2 * FS + 33]) : (int64_t)max(prow2, 0);
+                const float v = d_rgb[grow2 * DEC_IN + q_] * (d_rgb_scale ? feat[p2 * FS + 34] : 1.f);
                 dr2[r] = prow2 >= 0 ? v : 0.f;
             }
         }
@@ -1134,15 +1235,15 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
         const int32_t* __restrict__ perm, const float* __restrict__ clamp2, const float* __restrict__ d_rgb,
         const float* __restrict__ d_depth, const float* __restrict__ d_weights, int64_t R, int S, int S_store, int white_back,
-        float* __restrict__ d_colors, float* __restrict__ d_densities, int32_t* __restrict__ ray_active) {
+        float* __restrict__ d_colors, float* __restrict__ d_color_scale, float* __restrict__ d_densities, int32_t* __restrict__ ray_active) {
     __shared__ MarchLds lds[RM_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
     if (r >= R) return;
     if (ray_active) {
         // A ray whose incoming gradient is exactly zero contributes exactly zero everywhere downstream: it is only flagged
-        // (its d_colors / d_densities rows are NOT written and must not be read -- spi_triplane_decode_bwd_sorted takes the
-        // same flags).  SPI's masked pseudo-view losses leave 65-90 % of the rays of those views in this state.
+        // (its d_colors / d_color_scale / d_densities rows are NOT written and must not be read -- spi_triplane_decode_bwd_sorted
+        // takes the same flags).  SPI's masked pseudo-view losses leave 65-90 % of the rays of those views in this state.
         bool nz = d_rgb && lane < 32 && d_rgb[r * 32 + lane] != 0.f;
         if (d_depth && lane == 32) nz = d_depth[r] != 0.f;
         const bool any = __any(nz) || d_weights != nullptr;
@@ -1150,8 +1251,45 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
         if (!any) return;
     }
     MarchLds& L = lds[wave];
+    // Same memory schedule as the forward: round trip 1 = permutation + depths, round trip 2 = densities AND every colour row of
+    // the ray (NCH*8 float4 per lane) requested together, in flight while the scans run.  (Until round 2 the colour rows were
+    // fetched 4 row groups at a time AFTER the scans: 0.37 ms per 16 384 rays = 0.29 of the HBM roofline.)
+    const int sub = lane & 7, rg = lane >> 3;
+    float4 creg[NCH * 8];
+    const float4 g4 = d_rgb ? *reinterpret_cast<const float4*>(d_rgb + r * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+        int pk[NCH]; float dp[NCH], sg[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = min(c * 64 + lane, S - 1);
+            pk[c] = perm ? perm[r * S + k] : k;
+            dp[c] = depths[r * S + k];
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            if (k < S) { L.row[k] = pk[c]; L.dep[k] = dp[c]; }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) sg[c] = densities[r * S_store + pk[c]];
+        if (d_rgb != nullptr) {
+#pragma unroll
+            for (int it = 0; it < NCH * 8; ++it) {
+                const int k = min(it * 8 + rg, S - 1);
+                const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4));   // last use of the colour rows
+                creg[it] = make_float4(cv.x, cv.y, cv.z, cv.w);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            if (k < S) L.sig[k] = sg[c];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
     float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
-    march_scalars<NCH>(L, densities, depths, perm, r, S, S_store, lane, alpha, trans, delta, smid);
+    march_scan<NCH>(L, S, lane, alpha, trans, delta, smid);
     float wsum = 0.f, dnum = 0.f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -1162,27 +1300,34 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
     }
     wsum = wave_sum(wsum); dnum = wave_sum(dnum);
     __builtin_amdgcn_wave_barrier();
-    // pass 1 over the colour rows: q_k = <d_rgb, c_k>; write d_colors rows = d_rgb * (w_{k-1} + w_k)
-    const int sub = lane & 7, rg = lane >> 3;
-    const float4 g4 = d_rgb ? *reinterpret_cast<const float4*>(d_rgb + r * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // q_k = <d_rgb, c_k>.  The colour-row gradient is d_rgb * (w_{k-1} + w_k): a per-ray vector times a per-sample scalar.
+    // d_color_scale != NULL: only that scalar is written (4 B per sample; the decoder backward rebuilds the row from d_rgb),
+    // which removes the [R,S,32] gradient tensor -- 403 MB written here and read again there per 128^2 x 192 image.
     if (!d_rgb) {                     // only the depth map is differentiated (SPI's depth branch): no colour traffic at all
 #pragma unroll
         for (int c = 0; c < NCH; ++c) if (c * 64 + lane < S) L.q[c * 64 + lane] = 0.f;
-    } else
-#pragma unroll 4
-    for (int k0 = 0; k0 < S; k0 += 8) {
-        const int k = k0 + rg;
-        float part = 0.f;
-        // the load is unconditional (clamped row): guarded loads serialise, one exec-masked region + full wait per row group
-        const int64_t row = r * S_store + L.row[min(k, S - 1)];
-        const f32x4_t c = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(colors + row * 32 + sub * 4));   // last use of the colour rows
-        if (k < S) {
-            part = g4.x * c.x + g4.y * c.y + g4.z * c.z + g4.w * c.w;
-            const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
-            *reinterpret_cast<float4*>(d_colors + row * 32 + sub * 4) = make_float4(g4.x * v, g4.y * v, g4.z * v, g4.w * v);
+    } else {
+#pragma unroll
+        for (int it = 0; it < NCH * 8; ++it) {
+            const int k = it * 8 + rg;
+            float part = g4.x * creg[it].x + g4.y * creg[it].y + g4.z * creg[it].z + g4.w * creg[it].w;
+            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
+            if (k < S) {
+                if (sub == 0) L.q[k] = part;
+                if (d_colors) {
+                    const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
+                    const f32x4_t o = {g4.x * v, g4.y * v, g4.z * v, g4.w * v};
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(d_colors + (r * S_store + L.row[k]) * 32 + sub * 4));
+                }
+            }
         }
-        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-        if (k < S && sub == 0) L.q[k] = part;
+        if (d_color_scale) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int k = c * 64 + lane;
+                if (k < S) d_color_scale[r * S_store + L.row[k]] = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // dL/dw_k
@@ -1443,22 +1588,24 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
 
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d, const float* depths_sorted,
                                    const int32_t* perm, const float* w1t, const float* b1, const float* w2, const float* b2,
-                                   const float* d_rgb, const float* d_sigma, int N, int M, int S, int ray_w, int H, int W,
-                                   float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1, float* dw2,
-                                   float* db2, const int32_t* ray_active, spi_stream_t stream) {
+                                   const float* d_rgb, const float* d_rgb_scale, const float* d_sigma, int N, int M, int S, int ray_w,
+                                   int H, int W, float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1,
+                                   float* dw2, float* db2, const int32_t* ray_active, spi_stream_t stream) {
     SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_sigma && d_planes_nhwc && workspace,
                 "spi_triplane_decode_bwd_sorted: null tensor");
     SPI_REQUIRE(N > 0 && M > 0 && S > 0 && H > 0 && W > 0 && box_warp > 0.f && ray_w > 0, "spi_triplane_decode_bwd_sorted: bad size");
     SPI_REQUIRE((int64_t)N * 3 * H * W * DEC_IN * 4 < ((int64_t)1 << 31), "spi_triplane_decode_bwd_sorted: the planes tensor must be < 2 GiB (one buffer descriptor)");
     const bool wgrad = dw1 != nullptr;
     SPI_REQUIRE(!wgrad || (db1 && dw2 && db2), "spi_triplane_decode_bwd_sorted: the four decoder gradient outputs come together");
+    SPI_REQUIRE(d_rgb || !d_rgb_scale, "spi_triplane_decode_bwd_sorted: d_rgb_scale given without the per-ray d_rgb");
     TiledArgs a;
     a.planes = planes_nhwc; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths_sorted; a.perm = perm; a.ray_active = ray_active;
     a.N = N; a.M = M; a.S = S; a.H = H; a.W = W; a.scale = 2.f / box_warp; a.ray_w = ray_w;
     a.patch2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
     a.patches = a.patch2d ? M / 64 : (M + 63) / 64;
-    a.kchunks = (S + 3) / 4;
+    a.kchunks = (S + 3) / 4;                                   // 64 * S points per patch / 256 per tile
     a.dbg = g_spi_debug;
+    SPI_REQUIRE(S <= 256, "spi_triplane_decode_bwd_sorted: S <= 256 (sample index packed in 8 bits), got %d", S);
     const int64_t tiles = (int64_t)N * a.patches * a.kchunks;
     SPI_REQUIRE(tiles < (int64_t)1 << 31, "spi_triplane_decode_bwd_sorted: too many tiles");
     a.tiles = (int)tiles;
@@ -1466,8 +1613,13 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     hipStream_t st = as_stream(stream);
     float* frag = workspace;
     float* part = workspace + FRAG_TOTAL;
+    int32_t* count = reinterpret_cast<int32_t*>(part + (int64_t)grid * 4 * PART_ROW);
+    uint16_t* order = reinterpret_cast<uint16_t*>(count + (((int64_t)N * a.patches + 3) & ~(int64_t)3));
+    a.order = order; a.count = count;
+    hipLaunchKernelGGL(bin_points_kernel, dim3((unsigned)(N * a.patches)), dim3(256), 0, st, depths_sorted, ray_active, M, S, ray_w, a.patch2d,
+                       a.patches, order, count);
     hipLaunchKernelGGL(decoder_frag_kernel, dim3(9), dim3(1024), 0, st, w1t, w2, frag);
-#define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_sigma, d_planes_nhwc, part)
+#define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, d_sigma, d_planes_nhwc, part)
     if (wgrad) {
         if (d_rgb) SPI_BWD_LAUNCH(true, true); else SPI_BWD_LAUNCH(true, false);
         hipMemsetAsync(dw1, 0, 64 * 32 * sizeof(float), st); hipMemsetAsync(db1, 0, 64 * sizeof(float), st);
@@ -1485,7 +1637,9 @@ int64_t spi_triplane_decode_bwd_sorted_ws(int N, int M, int S, int ray_w) {
     const bool p2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
     const int64_t patches = p2d ? M / 64 : (M + 63) / 64;
     const int64_t tiles = (int64_t)N * patches * ((S + 3) / 4);
-    return FRAG_TOTAL + std::min<int64_t>(tiles, BWD_MAX_GRID) * 4 * PART_ROW;
+    const int64_t counts = ((int64_t)N * patches + 3) & ~(int64_t)3;                 // int32 per patch (kept 16-byte aligned)
+    const int64_t order = ((int64_t)N * patches * 64 * S + 1) / 2;                   // uint16 per point, in floats
+    return FRAG_TOTAL + std::min<int64_t>(tiles, BWD_MAX_GRID) * 4 * PART_ROW + counts + order;
 }
 
 int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, float* dw2, float* db2, spi_stream_t stream) {
@@ -1532,18 +1686,19 @@ int spi_raymarch_fwd(const float* colors, const float* densities, const float* d
 
 int spi_raymarch_bwd(const float* colors, const float* densities, const float* depths, const int32_t* perm,
                      const float* clamp2, const float* d_rgb, const float* d_depth, const float* d_weights, int64_t R,
-                     int S, int S_store, int C, int white_back, float* d_colors, float* d_densities, int32_t* ray_active,
-                     spi_stream_t stream) {
+                     int S, int S_store, int C, int white_back, float* d_colors, float* d_color_scale, float* d_densities,
+                     int32_t* ray_active, spi_stream_t stream) {
     SPI_REQUIRE(S_store >= S, "spi_raymarch_bwd: S_store must be >= S");
     SPI_REQUIRE(densities && depths && d_densities && R > 0 && (d_rgb == nullptr || colors != nullptr), "spi_raymarch_bwd: null tensor");
     SPI_REQUIRE(S >= 2 && S <= MAXS, "spi_raymarch_bwd: need 2 <= S <= %d, got %d", MAXS, S);
     SPI_REQUIRE(C == 32, "spi_raymarch_bwd: only C = 32 feature channels are supported, got %d", C);
     SPI_REQUIRE(d_depth == nullptr || clamp2 != nullptr, "spi_raymarch_bwd: d_depth given without clamp range");
-    SPI_REQUIRE(d_rgb == nullptr || d_colors != nullptr, "spi_raymarch_bwd: d_rgb given without a d_colors output");
+    SPI_REQUIRE(d_rgb == nullptr || d_colors != nullptr || d_color_scale != nullptr,
+                "spi_raymarch_bwd: d_rgb given without a d_colors or d_color_scale output");
     dim3 grid((unsigned)ceil_div64(R, RM_WAVES)), block(64 * RM_WAVES);
     const int nch = (S + 63) / 64;
 #define LAUNCH_BWD(NCH) hipLaunchKernelGGL(raymarch_bwd_kernel<NCH>, grid, block, 0, as_stream(stream), colors, densities, \
-                                          depths, perm, clamp2, d_rgb, d_depth, d_weights, R, S, S_store, white_back, d_colors, d_densities, ray_active)
+                                          depths, perm, clamp2, d_rgb, d_depth, d_weights, R, S, S_store, white_back, d_colors, d_color_scale, d_densities, ray_active)
     switch (nch) { case 1: LAUNCH_BWD(1); break; case 2: LAUNCH_BWD(2); break; case 3: LAUNCH_BWD(3); break; default: LAUNCH_BWD(4); }
 #undef LAUNCH_BWD
     SPI_LAUNCH_CHECK("spi_raymarch_bwd");

@@ -8,8 +8,10 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """-> (rank, world_size, local_rank).  Initialises torch.distributed when WORLD_SIZE > 1."""
+def init_from_env(backend=None, timeout_s=900):
+    """-> (rank, world_size, local_rank).  Initialises torch.distributed when WORLD_SIZE > 1.  ``timeout_s`` bounds every collective:
+    a rank that died cannot hang the survivors' final reduce for longer than that (the launcher kills them earlier)."""
+    import datetime
     world = int(os.environ.get('WORLD_SIZE', 1))
     rank = int(os.environ.get('RANK', 0))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -20,7 +22,7 @@ def init_from_env(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'      # 'nccl' is RCCL on ROCm
         if backend == 'nccl':
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, world, local
 
 

@@ -11,6 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
+ABI_VERSION = 2          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -32,12 +33,12 @@ _SIGS = {
     'spi_nhwc_to_nchw': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     'spi_triplane_decode_fwd': ([c_p] * 9 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_triplane_decode_bwd': ([c_p] * 11 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
-    'spi_triplane_decode_bwd_sorted': ([c_p] * 11 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f] + [c_p] * 8, c_i),
+    'spi_triplane_decode_bwd_sorted': ([c_p] * 12 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f] + [c_p] * 8, c_i),
     'spi_triplane_decode_bwd_sorted_ws': ([c_i, c_i, c_i, c_i], c_l),
     'spi_decoder_wgrad': ([c_p, c_l, c_p, c_p, c_p, c_p, c_p], c_i),
     'spi_minmax': ([c_p, c_l, c_p, c_p], c_i),
     'spi_raymarch_fwd': ([c_p] * 5 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 5, c_i),
-    'spi_raymarch_bwd': ([c_p] * 8 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 4, c_i),
+    'spi_raymarch_bwd': ([c_p] * 8 + [c_l, c_i, c_i, c_i, c_i] + [c_p] * 5, c_i),
     'spi_importance_sample': ([c_p, c_p, c_p, c_l, c_i, c_i, c_p, c_i, c_p], c_i),
     'spi_merge_sort_depths': ([c_p, c_p, c_l, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_style_grad': ([c_p] * 6 + [c_i, c_i, c_i, c_i, c_f, c_p], c_i),
@@ -76,7 +77,7 @@ def lib():
             fn.argtypes = args
             fn.restype = res
         L.spi_last_error.restype = ctypes.c_char_p
-        if L.spi_abi_version() != 1:
+        if L.spi_abi_version() != ABI_VERSION:
             raise RuntimeError('libspi_hip.so ABI version mismatch')
         _lib = L
     return _lib

@@ -48,7 +48,7 @@ class _RayMarch(torch.autograd.Function):
         dd = d_depth.contiguous().float() if d_depth is not None else None
         dw = d_weights.contiguous().float() if d_weights is not None else None
         hip.call('spi_raymarch_bwd', hip.ptr(colors), hip.ptr(densities), hip.ptr(depths), None, hip.ptr(clamp2), hip.ptr(d_rgb),
-                 hip.ptr(dd), hip.ptr(dw), n * m, s, s, c, ctx.white_back, hip.ptr(d_colors), hip.ptr(d_dens), None, hip.stream())
+                 hip.ptr(dd), hip.ptr(dw), n * m, s, s, c, ctx.white_back, hip.ptr(d_colors), None, hip.ptr(d_dens), None, hip.stream())
         return d_colors, d_dens, None, None
 
 

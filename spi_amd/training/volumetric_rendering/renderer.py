@@ -188,14 +188,16 @@ class _Render(torch.autograd.Function):
         # d_rgb None: only the depth map feeds the loss (SPI's depth branch) -> no colour gradient buffers or traffic at all
         d_rgb = d_rgb.contiguous().float() if d_rgb is not None else None
         dd = d_depth.contiguous().float() if d_depth is not None else None
-        d_col = torch.empty_like(rgb_all) if d_rgb is not None else None
+        # the colour-row gradient is d_rgb[ray] * (w_{k-1} + w_k): the marcher writes the per-sample scalar only and the decoder
+        # backward rebuilds the rows from the per-ray d_rgb -- the [N,M,S,32] gradient tensor (403 MB per image) never exists
+        d_cs = torch.empty_like(sig_all) if d_rgb is not None else None
         d_sig = torch.empty_like(sig_all)
         # rays with an exactly-zero incoming gradient (SPI's masked pseudo-view losses: 65-90 % of those views) are flagged by
         # the march backward and skipped by the decoder backward; their rows of d_col / d_sig stay unwritten
         from ...configs import global_config
         active = torch.empty(r, device=dev, dtype=torch.int32) if global_config.exploit_sparsity else None
         hip.call('spi_raymarch_bwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), hip.ptr(d_rgb),
-                 hip.ptr(dd), None, r, s, s, 32, white_back, hip.ptr(d_col), hip.ptr(d_sig), hip.ptr(active), hip.stream())
+                 hip.ptr(dd), None, r, s, s, 32, white_back, None, hip.ptr(d_cs), hip.ptr(d_sig), hip.ptr(active), hip.stream())
         want_w = any(ctx.needs_input_grad[1:5])
         d_planes = torch.zeros_like(planes_nhwc)
         # one pass over all Sc+Sf samples in sorted order, 8x8 ray patches (LDS-aggregated scatter)
@@ -207,7 +209,7 @@ class _Render(torch.autograd.Function):
         if want_w:                               # decoder weight gradients come out of the same kernel (no activation dump)
             gw = (torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev))
         hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes_nhwc), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(d_all), hip.ptr(perm),
-                 hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_col), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
+                 hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), hip.ptr(d_cs), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
                  hip.ptr(d_planes), hip.ptr(ws), *([hip.ptr(g) for g in gw] if want_w else [None] * 4), hip.ptr(active), hip.stream())
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None

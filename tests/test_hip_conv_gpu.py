@@ -29,6 +29,9 @@ CASES = [  # N, I, O, H, k, pad, transposed, flip, per_sample
     (2, 8, 12, 5, 3, 0, True, False, True), (1, 8, 12, 5, 3, 0, True, True, True), (2, 3, 64, 20, 3, 1, False, False, False),
     (1, 40, 130, 33, 3, 1, False, False, True), (2, 130, 40, 17, 3, 0, True, False, True), (1, 128, 3, 40, 1, 0, False, False, True),
     (1, 64, 64, 4, 3, 1, False, False, True), (3, 32, 96, 16, 1, 0, False, False, True), (1, 70, 200, 64, 3, 1, False, False, True),
+    # narrow-generator shapes with a batch of per-sample weights (few channels, many pixels)
+    (2, 32, 16, 64, 3, 0, True, False, True), (2, 8, 8, 256, 3, 1, False, True, True), (2, 16, 8, 128, 3, 0, True, False, True),
+    (2, 16, 16, 128, 3, 1, False, True, True), (3, 8, 96, 256, 1, 0, False, False, True),
 ]
 # the real layer shapes of the ffhqrebalanced512-128 generator (the instances bench.py times): 512-channel split-K layer,
 # stride-2 transposed 256 -> 128 at 256^2, the 128 -> 128 conv at 512^2, an N = 4 batch sharing one weight set (rot / depth branches),

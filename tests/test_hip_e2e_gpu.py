@@ -78,7 +78,7 @@ def test_cli_sg_pti_with_logging(tmp_path, capsys):
     stats = json.loads([l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1])
     assert stats['iterations'] == 5
     coach = 'PTI_coach_sg_3_pti_2_rot_0_mirrorrot_0_depth_0_tv_0'
-    exp = os.path.join(out, 'experiments' + coach)                # the reference concatenates without a separator (pti_coach.py:36)
+    exp = os.path.join(out, 'experiments', coach)                 # experiments_output_dir ('.../experiments/') += coach_name (pti_coach.py:36)
     name = os.listdir(os.path.join(out, 'embedding', coach))[0][:-3]
     files = set(os.listdir(os.path.join(exp, name)))
     assert {'target_image.jpg', f'{name}_w_inv.jpg', f'{name}_w_inv_m.jpg', f'{name}_G1_inv.jpg', f'{name}_G1_inv_m.jpg', f'{name}_G1_inv_0.jpg'} <= files

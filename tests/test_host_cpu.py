@@ -150,6 +150,32 @@ def test_network_pickle_reader_never_executes_embedded_source():
             load_utils._RestrictedUnpickler(io.BytesIO(evil)).load()
 
 
+def test_bench_self_launches_two_ranks_and_survives_a_failing_rank():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun): the launcher spawns two ranks, they rendezvous on 127.0.0.1 (gloo here,
+    RCCL on the GPU box), run the barrier + the two statistics all-reduces of the real run (--dry-run replaces the GPU steps by a sleep)
+    and rank 0 prints one JSON line.  A rank whose steps raise still reaches the reduce (done-flag 0): nobody hangs, exit code 3."""
+    import json
+    import subprocess
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run', '--steps', '4'], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['n_gpus'] == 2 and line['ranks'] == {'launched': 2, 'completed': 2, 'per_rank_seconds': line['ranks']['per_rank_seconds']}
+    assert len(line['ranks']['per_rank_seconds']) == 2 and line['ranks']['per_rank_seconds'][1] > line['ranks']['per_rank_seconds'][0] > 0
+    assert line['seconds_max_over_ranks'] >= line['ranks']['per_rank_seconds'][1]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=dict(env, SPI_BENCH_FAIL_RANK='1'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 3
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert line['ranks']['completed'] == 1
+    # a mismatching torchrun-style environment is an error, not a silent single-rank run
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=dict(env, WORLD_SIZE='1', RANK='0'),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr + r.stdout
+
+
 def test_pretrained_weight_files_are_required_unless_synthetic(tmp_path):
     """criteria/weights.py: torchvision / LPIPS files named in paths_config are parsed; a missing file raises; seeded stand-ins only
     when synthetic mode is requested (round-1 advisor finding: a real run must not silently optimise random features)."""

@@ -37,7 +37,7 @@ with torch.no_grad():
     d_rgb = torch.randn(m, 32, device=dev); d_depth = torch.randn(m, device=dev)
     d_col = torch.zeros_like(rgb_all); d_sig = torch.zeros_like(sig_all); act = torch.empty(m, device=dev, dtype=torch.int32)
     hip.call('spi_raymarch_bwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(cl), hip.ptr(d_rgb), hip.ptr(d_depth), None,
-             m, s, s, 32, 0, hip.ptr(d_col), hip.ptr(d_sig), hip.ptr(act), hip.stream())
+             m, s, s, 32, 0, hip.ptr(d_col), None, hip.ptr(d_sig), hip.ptr(act), hip.stream())
     # sorted order
     idx = perm.long()
     ds = torch.gather(d_sig, 2, idx)[0]                                    # [m, s]
