@@ -29,6 +29,7 @@ typedef void* spi_stream_t;           /* hipStream_t */
 
 #define SPI_ABI_VERSION 2   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale */
 int         spi_abi_version(void);
+int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
 
 /* activation ids: same numbering as bias_act.py:22-32 `cuda_idx` */

@@ -13,6 +13,7 @@ void spi_set_error(const char* fmt, ...) {
 }
 extern "C" const char* spi_last_error(void) { return g_err; }
 extern "C" int spi_abi_version(void) { return SPI_ABI_VERSION; }
+extern "C" int spi_sizeof_conv_desc(void) { return (int)sizeof(spi_conv_desc); }
 
 // ------------------------------------------------------------------------------------------------
 // bias_act: y = clamp(act(x + b) * gain) and its first / second derivatives expressed through the

@@ -27,6 +27,7 @@ class ConvDesc(ctypes.Structure):
 
 _SIGS = {
     'spi_abi_version': ([], c_i),
+    'spi_sizeof_conv_desc': ([], c_i),
     'spi_ray_sampler': ([c_p, c_p, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_coarse_depths': ([c_p, c_l, c_i, c_f, c_f, c_p, c_p], c_i),
     'spi_nchw_to_nhwc': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
@@ -77,8 +78,9 @@ def lib():
             fn.argtypes = args
             fn.restype = res
         L.spi_last_error.restype = ctypes.c_char_p
-        if L.spi_abi_version() != ABI_VERSION:
-            raise RuntimeError('libspi_hip.so ABI version mismatch')
+        if L.spi_abi_version() != ABI_VERSION or L.spi_sizeof_conv_desc() != ctypes.sizeof(ConvDesc):
+            raise RuntimeError('libspi_hip.so ABI mismatch (version %d, spi_conv_desc %d bytes; this binding: version %d, %d bytes): rebuild with '
+                               '`python -m spi_amd.csrc.build`' % (L.spi_abi_version(), L.spi_sizeof_conv_desc(), ABI_VERSION, ctypes.sizeof(ConvDesc)))
         _lib = L
     return _lib
 

@@ -37,6 +37,31 @@ class PersistentStub:
         self.state = meta['state']
 
 
+class InertObject:
+    """What a PLAIN (non-persistent) class of the reference's own namespaces unpickles to -- e.g. training.triplane.OSGDecoder,
+    training.volumetric_rendering.renderer.ImportanceRenderer, ray_sampler.RaySampler, which EG3D pickles by module path.  The
+    reference module is never imported: the object only keeps the state dict pickle hands it (NEWOBJ + BUILD)."""
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):
+        if isinstance(state, dict):
+            self.__dict__.update(state)
+        else:
+            self.__dict__['_pickle_state'] = state
+
+
+_REF_NAMESPACES = ('training.', 'torch_utils.', 'dnnlib.', 'camera_utils', 'legacy')
+_stub_classes = {}
+
+
+def _inert_class(module, name):
+    key = (module, name)
+    if key not in _stub_classes:
+        _stub_classes[key] = type(name, (InertObject,), {'__module__': 'spi_amd.utils.load_utils', '_ref_path': f'{module}.{name}'})
+    return _stub_classes[key]
+
+
 def _reconstruct_stub(meta):
     assert meta.get('type') == 'class'
     return PersistentStub(meta)
@@ -71,6 +96,8 @@ class _RestrictedUnpickler(pickle.Unpickler):
             return EasyDict
         if '.' not in name and ((module == 'builtins' and name in _BUILTINS) or (module, name) in _ALLOWED):
             return super().find_class(module, name)
+        if '.' not in name and name.isidentifier() and (module + '.').startswith(_REF_NAMESPACES):
+            return _inert_class(module, name)             # a class of the reference's code base: inert stand-in, nothing imported
         raise pickle.UnpicklingError(f'refusing to import {module}.{name} from a network pickle')
 
 

@@ -274,3 +274,58 @@ def test_orbit_cameras_geometry():
     # the LAST coordinate runs fastest (:57-66); the other two are FRACTIONAL positions because the reference divides the running
     # index as a float (`(overall_index.float() / N) % N`): sample 1 sits at (1/16, 1/4, 1) voxels
     assert torch.allclose(s[0, 1], torch.tensor([-0.5 + (1 / 16) / 3, -0.5 + (1 / 4) / 3, -0.5 + 1 / 3]))
+
+
+REF = '/root/reference'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='needs the reference tree (build container only; the GPU box has none)')
+def test_real_eg3d_pickle_written_by_the_reference_loads_without_executing_it(tmp_path):
+    """a network pickle in the REAL EG3D format -- written here by the reference's own `persistence` machinery from its
+    own TriPlaneGenerator class (module source embedded, `_reconstruct_persistent_obj` reducers, EasyDict kwargs), exactly what
+    `legacy.load_network_pkl` reads (legacy.py:24-60) -- goes through spi_amd's restricted reader in a subprocess that cannot import the
+    reference: same init kwargs, same 'rendering_kwargs', same state_dict bit for bit, and a module built from it reproduces the state_dict
+    key set of the reference module.  Nothing of the reference is copied into the repo: the pickle lives in tmp_path only."""
+    import subprocess
+    import textwrap
+    from conftest import ROOT
+    pkl = str(tmp_path / 'network-snapshot.pkl')
+    sd_path = str(tmp_path / 'expected_state.pt')
+    writer = textwrap.dedent(f'''
+        import sys, pickle, copy, torch
+        sys.dont_write_bytecode = True
+        sys.path[:0] = [{REF!r} + '/eg3d']
+        import dnnlib
+        from training.triplane import TriPlaneGenerator
+        rk = dnnlib.EasyDict(superresolution_module='training.superresolution.SuperresolutionHybrid8XDC', sr_antialias=True,
+                             superresolution_noise_mode='none', c_gen_conditioning_zero=False, c_scale=1.0, clamp_mode='softplus',
+                             disparity_space_sampling=False, decoder_lr_mul=1.0, box_warp=1, ray_start=2.25, ray_end=3.3, depth_resolution=48,
+                             depth_resolution_importance=48, white_back=False, image_resolution=512, avg_camera_radius=2.7, avg_camera_pivot=[0, 0, 0.2])
+        torch.manual_seed(3)
+        G = TriPlaneGenerator(z_dim=512, c_dim=25, w_dim=512, img_resolution=512, img_channels=3, mapping_kwargs=dnnlib.EasyDict(num_layers=2),
+                              channel_base=2048, channel_max=32, fused_modconv_default='inference_only', num_fp16_res=0, conv_clamp=None,
+                              sr_num_fp16_res=4, sr_kwargs=dnnlib.EasyDict(channel_base=2048, channel_max=32, fused_modconv_default='inference_only'),
+                              rendering_kwargs=rk).eval().requires_grad_(False)
+        G.neural_rendering_resolution = 64
+        with open({pkl!r}, 'wb') as f:                      # the snapshot layout of eg3d/training/training_loop.py
+            pickle.dump(dict(G=copy.deepcopy(G), D=None, G_ema=G, augment_pipe=None, training_set_kwargs=dict(path='x', use_labels=True)), f)
+        torch.save({{k: v.clone() for k, v in G.state_dict().items()}}, {sd_path!r})
+    ''')
+    r = subprocess.run([sys.executable, '-c', writer], capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))
+    assert r.returncode == 0, r.stderr[-3000:]
+    raw = open(pkl, 'rb').read()
+    assert b'_reconstruct_persistent_obj' in raw and b'class TriPlaneGenerator' in raw        # really the persistence format, source embedded
+    from spi_amd.utils import load_utils
+    assert 'training' not in sys.modules and 'dnnlib' not in sys.modules                          # this process never imported the reference
+    with open(pkl, 'rb') as f:
+        args, kwargs, sd, extra = load_utils.read_network_pkl(f)
+    expected = torch.load(sd_path, map_location='cpu', weights_only=True)
+    assert set(sd) == set(expected) and all(torch.equal(sd[k], expected[k]) for k in expected)
+    assert kwargs['channel_max'] == 32 and kwargs['rendering_kwargs']['depth_resolution'] == 48 and extra['neural_rendering_resolution'] == 64
+    assert extra['rendering_kwargs']['avg_camera_pivot'] == [0, 0, 0.2]
+    G = load_utils.build_generator(args, kwargs, sd, 'cpu')
+    assert set(G.state_dict()) == set(expected)
+    from spi_amd.configs import paths_config
+    G2 = load_utils.load_eg3d(device='cpu', network_pkl=pkl)
+    assert G2.neural_rendering_resolution == 128 and not G2.training and G2.rendering_kwargs['ray_end'] == 3.3     # load_utils.py:28-33
+    assert all(torch.equal(v, expected[k]) for k, v in G2.state_dict().items())

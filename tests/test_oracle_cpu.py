@@ -165,6 +165,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert not missing, missing
     assert sorted(hip.EXPORTS) == declared
     assert hip.lib().spi_abi_version() == hip.ABI_VERSION
+    assert int(re.search(r'#define SPI_ABI_VERSION (\d+)', hdr).group(1)) == hip.ABI_VERSION
+
+
+def test_integration_doc_struct_matches_the_header():
+    """INTEGRATION.md section 4 shows the ctypes mirror of spi_conv_desc a maintainer would paste into the reference: its size must be the
+    library's sizeof(spi_conv_desc) and the binding's own (round-1 review: the doc had lost the `dw_zeroed` field)."""
+    import ctypes
+    from spi_amd import hip
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    m = re.search(r'(class spi_conv_desc\(ctypes\.Structure\):.*?\)\]\n)', doc, re.S)
+    assert m, 'struct block not found in INTEGRATION.md'
+    ns = {'ctypes': ctypes}
+    exec(m.group(1), ns)
+    size = hip.lib().spi_sizeof_conv_desc()
+    assert ctypes.sizeof(ns['spi_conv_desc']) == size == ctypes.sizeof(hip.ConvDesc)
+    assert [f[0] for f in ns['spi_conv_desc']._fields_] == [f[0] for f in hip.ConvDesc._fields_]
+    fields_h = re.search(r'typedef struct spi_conv_desc \{(.*?)\} spi_conv_desc;', open(os.path.join(ROOT, 'include', 'spi_hip.h')).read(), re.S).group(1)
+    for name in (f[0] for f in hip.ConvDesc._fields_):
+        assert re.search(r'\b%s\b' % name, fields_h), name
 
 
 def test_product_has_no_cpu_fallback():
