@@ -7,8 +7,9 @@ generator in batches with ONE ``w`` (``TriPlaneGenerator.synthesis`` shares the 
 views), under ``no_grad``.  Only the single-latent 1x1 grid SPI uses is implemented; keyframe interpolation over several
 latents (the reference's scipy ``interp1d`` over seeds) is not.
 Output: ``imageio`` is not a dependency -- frames are written as ``<mp4 stem>_frames/%04d.jpg`` (PIL), plus the mp4 when
-imageio happens to be importable.  ``gen_shapes`` saves the raw 'sigma' grid as ``.npy`` (the reference's marching-cubes
-``.ply`` needs scikit-image / mrcfile).
+imageio happens to be importable.  ``gen_shapes`` exports the density grid of frame 0 like video_utils.py:198-218: the
+iso-surface at level 10 as ``interpolation_shape/0000_shape.ply`` (``output_ply=True`` there; ``shape_format='mrc'`` for the
+other branch), through utils/shape_utils.py, plus the raw grid as ``.npy`` and the camera path as ``_trajectory.npy``.
 """
 import math
 import os
@@ -84,7 +85,7 @@ def sigma_grid(G, w, resolution=128, max_batch=1 << 22):
 
 @torch.no_grad()
 def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_shapes=False, batch=4, device=None,
-                     voxel_resolution=128, save_frames=True, **_unused):
+                     voxel_resolution=128, save_frames=True, shape_format='ply', shape_level=10, **_unused):
     """Orbit video of ONE latent.  Returns the frames as uint8 [F,H,W,3] (numpy)."""
     w = G_kwargs['w']
     if w.ndim == 2:
@@ -113,7 +114,14 @@ def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_
         except ImportError:
             pass
     if gen_shapes:
-        os.makedirs(os.path.join(os.path.dirname(mp4) or '.', 'interpolation_shape'), exist_ok=True)
-        np.save(os.path.join(os.path.dirname(mp4) or '.', 'interpolation_shape', '0000_sigma.npy'), sigma_grid(G, w.to(device), voxel_resolution))
+        from . import shape_utils
+        outdir = os.path.join(os.path.dirname(mp4) or '.', 'interpolation_shape')
+        os.makedirs(outdir, exist_ok=True)
+        sigmas = sigma_grid(G, w.to(device), voxel_resolution)
+        np.save(os.path.join(outdir, '0000_sigma.npy'), sigmas)
+        if shape_format == 'ply':                                                    # video_utils.py:209-214
+            shape_utils.convert_sdf_samples_to_ply(np.transpose(sigmas, (2, 1, 0)), [0, 0, 0], 1, os.path.join(outdir, '0000_shape.ply'), level=shape_level)
+        else:                                                                        # :215-217
+            shape_utils.write_mrc(os.path.join(outdir, '0000_shape.mrc'), sigmas)
         np.save(stem + '_trajectory.npy', cams[:, :16].reshape(-1, 4, 4).cpu().numpy())
     return frames

@@ -160,6 +160,12 @@ def test_orbit_video_and_sigma_grid(tmp_path):
     assert sig.shape == (16, 16, 16) and __import__('numpy').isfinite(sig).all()
     traj = __import__('numpy').load(mp4[:-4] + '_trajectory.npy')
     assert traj.shape == (6, 4, 4)
+    # the iso-surface export of video_utils.py:209-214 (level 10 of the density grid) is a readable .ply
+    from spi_amd.utils import shape_utils
+    pv, pf = shape_utils.read_ply(os.path.join(os.path.dirname(mp4), 'interpolation_shape', '0000_shape.ply'))
+    assert pv.shape[1] == 3 and pf.shape[1] == 3 and (len(pf) == 0 or pf.max() < len(pv))
+    vu.gen_interp_video(G, {'w': w}, mp4=mp4, w_frames=2, batch=2, gen_shapes=True, voxel_resolution=16, shape_format='mrc', save_frames=False)
+    assert shape_utils.read_mrc(os.path.join(os.path.dirname(mp4), 'interpolation_shape', '0000_shape.mrc')).shape == (16, 16, 16)
 
 
 def test_synthesis_sr_region_equals_full_inside_region():

@@ -329,3 +329,45 @@ def test_real_eg3d_pickle_written_by_the_reference_loads_without_executing_it(tm
     G2 = load_utils.load_eg3d(device='cpu', network_pkl=pkl)
     assert G2.neural_rendering_resolution == 128 and not G2.training and G2.rendering_kwargs['ray_end'] == 3.3     # load_utils.py:28-33
     assert all(torch.equal(v, expected[k]) for k, v in G2.state_dict().items())
+
+
+def test_shape_export_iso_surface_ply_and_mrc(tmp_path):
+    """SURVEY 8f-1 shape export (eg3d/shape_utils.py:40-104, video_utils.py:209-217): iso-surface of an analytic sphere -- every vertex on the
+    sphere to a fraction of a voxel, closed 2-manifold (every edge in exactly two triangles, Euler characteristic 2), outward orientation,
+    area within 1 % -- through the .ply writer / reader; .mrc round trip and convert_mrc."""
+    import numpy as np
+    from spi_amd.utils import shape_utils as su
+    n, R = 48, 15.3
+    ax = np.arange(n, dtype=np.float64) - (n - 1) / 2 + 0.21          # off-centre: no grid node exactly on the surface
+    X, Y, Z = np.meshgrid(ax, ax * 1.0 + 0.13, ax - 0.37, indexing='ij')
+    vol = (R - np.sqrt(X * X + Y * Y + Z * Z)).astype(np.float32)      # > 0 inside
+    ply = str(tmp_path / 's.ply')
+    pts, faces = su.convert_sdf_samples_to_ply(vol, [ax[0], ax[0] + 0.13, ax[0] - 0.37], 1.0, ply, level=0.0)
+    v2, f2 = su.read_ply(ply)
+    assert v2.shape == pts.shape and np.allclose(v2, pts, atol=1e-4) and np.array_equal(f2, faces)
+    assert open(ply, 'rb').read(40).startswith(b'ply\nformat binary_little_endian 1.0\n')
+    r = np.linalg.norm(pts, axis=1)
+    assert abs(r - R).max() < 0.05                                      # linear interpolation of a radial field: well inside a voxel
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), axis=1)
+    uniq, cnt = np.unique(e, axis=0, return_counts=True)
+    assert (cnt == 2).all()                                             # closed manifold
+    assert len(pts) - len(uniq) + len(faces) == 2                       # sphere topology
+    p = pts[faces]
+    nrm = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    assert (np.einsum('ij,ij->i', nrm, p.mean(1)) > 0).all()            # normals point from >= level (inside) to < level (outside)
+    area = 0.5 * np.linalg.norm(nrm, axis=1).sum()
+    assert abs(area / (4 * np.pi * R * R) - 1) < 0.01
+    # scale / offset arguments (shape_utils.py:72-76)
+    pts2, _ = su.convert_sdf_samples_to_ply(vol, [0, 0, 0], 0.5, str(tmp_path / 's2.ply'), offset=np.array([1.0, 2.0, 3.0]), scale=2.0, level=0.0)
+    verts0, _ = su.marching_tetrahedra(vol, 0.0, [0.5] * 3)
+    assert np.allclose(pts2, verts0 / 2.0 - np.array([1.0, 2.0, 3.0]))
+    # .mrc: header fields + round trip + convert_mrc == direct extraction of the transposed grid
+    mrc = str(tmp_path / 'v.mrc')
+    su.write_mrc(mrc, vol)
+    raw = open(mrc, 'rb').read()
+    assert len(raw) == 1024 + vol.size * 4 and raw[208:212] == b'MAP ' and np.frombuffer(raw, '<i4', 4, 0).tolist() == [n, n, n, 2]
+    assert np.array_equal(su.read_mrc(mrc), vol)
+    pm, fm = su.convert_mrc(mrc, str(tmp_path / 'm.ply'), isosurface_level=0)
+    vt, ft = su.marching_tetrahedra(np.transpose(vol, (2, 1, 0)), 0.0)
+    assert np.allclose(pm, vt) and np.array_equal(fm, ft)
+    assert su.marching_tetrahedra(np.zeros((4, 4, 4)), level=1.0)[1].shape == (0, 3)      # nothing crosses the level
