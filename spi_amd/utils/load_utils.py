@@ -168,3 +168,15 @@ def load_eg3d(reload_modules=True, device='cuda', network_pkl=None, synthetic=Fa
     G.neural_rendering_resolution = 128
     G.eval()
     return G
+
+
+def load_bisenet(device=None, path=None):
+    """spi/utils/load_utils.py:36-44: BiSeNet(19) with paths_config.BISENET_PATH loaded, eval mode, on the GPU."""
+    from ..third_part.bisenet import BiSeNet
+    from ..configs import global_config
+    path = path or paths_config.BISENET_PATH
+    if not os.path.isfile(path):
+        raise FileNotFoundError(f'{path} not found (paths_config.BISENET_PATH: the face-parsing checkpoint `bisenet.pth`)')
+    net = BiSeNet(19)
+    net.load_state_dict(torch.load(path, map_location='cpu', weights_only=True))
+    return net.to(device or global_config.device).eval()

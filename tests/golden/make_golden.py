@@ -571,10 +571,51 @@ def sec_orbit():
     print('    (create_samples in the reference uses float division: columns 0/1 are fractional positions, kept as data)')
     save('orbit', **out)
 
+def sec_bisenet():
+    """the reference's own BiSeNet (third_part/bisenet) on seeded synthetic weights (no bisenet.pth offline), eval mode.
+    Two import-time obstacles, both outside the arithmetic: `import torchvision` at the top of bisenet.py (never used in the file; the
+    package does not exist here -> an empty placeholder module is registered for the import) and Resnet18.init_weight's download of the
+    ImageNet weights (resnet.py:79-85; no network -> model_zoo.load_url is pointed at an empty dict, every weight is overwritten anyway)."""
+    import types
+    import torch.utils.model_zoo as modelzoo
+    sys.modules.setdefault('torchvision', types.ModuleType('torchvision'))
+    orig = modelzoo.load_url
+    modelzoo.load_url = lambda *a, **k: {}
+    try:
+        from third_part.bisenet.bisenet import BiSeNet
+        net = BiSeNet(19)
+    finally:
+        modelzoo.load_url = orig
+    from oracle import bisenet_ref as obr
+    man = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(HERE, 'manifest_bisenet.json'), 'w') as f:
+        json.dump(man, f, indent=0)
+    sd = obr.synthetic_state_dict(man, seed=0)
+    net.load_state_dict(sd)
+    net.eval()
+    g = torch.Generator().manual_seed(61)
+    # a smooth synthetic "photo" (low-pass noise) in [-1, 1] like extract_mask.py:58-59 feeds it, plus a second, non-square-friendly size
+    img = F.interpolate(torch.rand(1, 3, 24, 24, generator=g), size=(512, 512), mode='bicubic', align_corners=False).clamp(0, 1) * 2 - 1
+    img2 = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(62)) * 2 - 1
+    with torch.no_grad():
+        out, out16, out32 = net(img)
+        o2 = net(img2)[0]
+        ref = obr.bisenet_forward(sd, img)
+        ref2 = obr.bisenet_forward(sd, img2)[0]
+    for tag, a, b in (('out', out, ref[0]), ('out16', out16, ref[1]), ('out32', out32, ref[2]), ('out (2x3x96x160)', o2, ref2)):
+        diff('bisenet ' + tag, a, b)
+    parsing = torch.argmax(out, dim=1, keepdim=True)
+    top2 = out.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    print(f'    classes present: {parsing.unique().tolist()}; pixels with a top-2 margin < 1e-3: {(margin < 1e-3).float().mean().item():.2e}')
+    save('bisenet', seed=np.array([0]), img_seed=np.array([61]), out_sub=out[:, :, ::8, ::8], out16_sub=out16[:, :, ::16, ::16],
+         out32_sub=out32[:, :, ::16, ::16], parsing=parsing.to(torch.uint8), margin_sub=margin[:, ::8, ::8], out2_sub=o2[:, :, ::4, ::4], out2_mean=o2.mean(dim=(2, 3)),
+         out_mean=out.mean(dim=(2, 3)), out_absmax=out.abs().amax())
+
 
 SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, synthesis=sec_synthesis,
                 geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory, trajectory_sg=sec_trajectory_sg,
-                tv=sec_tv, orbit=sec_orbit)
+                tv=sec_tv, orbit=sec_orbit, bisenet=sec_bisenet)
 
 if __name__ == '__main__':
     todo = sys.argv[1:] or list(SECTIONS)

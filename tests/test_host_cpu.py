@@ -371,3 +371,41 @@ def test_shape_export_iso_surface_ply_and_mrc(tmp_path):
     vt, ft = su.marching_tetrahedra(np.transpose(vol, (2, 1, 0)), 0.0)
     assert np.allclose(pm, vt) and np.array_equal(fm, ft)
     assert su.marching_tetrahedra(np.zeros((4, 4, 4)), level=1.0)[1].shape == (0, 3)      # nothing crosses the level
+
+
+def test_preprocess_driver_layout_feeds_the_dataset(tmp_path):
+    """preprocess/run_total.py: photos -> {input, crop, c, lm, mask}/<name>/target.* -- exactly what PTIDataset reads back; the third-party
+    producers (Deep3DFaceRecon camera / crop, face_alignment landmarks) are injected, the mask producer is the BiSeNet path (a CPU stand-in
+    network here: the real one needs the GPU kernels)."""
+    import numpy as np
+    from PIL import Image
+    from spi_amd.preprocess import run_total
+    from spi_amd.data.images_dataset import PTIDataset
+    src = tmp_path / 'images'
+    src.mkdir()
+    rng = np.random.RandomState(0)
+    for nm in ('a', 'b'):
+        Image.fromarray(rng.randint(0, 255, (300, 280, 3), dtype=np.uint8)).save(src / f'{nm}.png')
+    with pytest.raises(RuntimeError):
+        run_total.run(str(src), str(tmp_path / 'ds'), 'png')
+
+    def camera_fn(path, crop_dir, c_dir, mode):
+        Image.open(path).resize((512, 512)).save(os.path.join(crop_dir, f'target.{mode}'))
+        np.save(os.path.join(c_dir, 'target.npy'), np.arange(25, dtype=np.float32))
+
+    def fake_bisenet(x):                       # logits [N,19,H,W]: class = column band
+        n, _, h, w = x.shape
+        lab = (torch.arange(w) * 19 // w).view(1, 1, 1, w).expand(n, 1, h, w)
+        return (torch.zeros(n, 19, h, w).scatter_(1, lab, 1.0),)
+    done = run_total.run(str(src), str(tmp_path / 'ds'), 'png', camera_fn=camera_fn, landmark_fn=lambda im: np.full((68, 2), 7.0),
+                         bisenet=fake_bisenet, device='cpu')
+    assert done == ['a', 'b']
+    root = str(tmp_path / 'ds')
+    ds = PTIDataset(source_root=os.path.join(root, 'crop'), c_root=os.path.join(root, 'c'), w_root=None, mask_root=os.path.join(root, 'mask'),
+                    lm_root=os.path.join(root, 'lm'), target_name='target', mode='png')
+    assert len(ds) == 2
+    d = ds[0]
+    assert d['img'].shape == (3, 512, 512) and d['mask'].shape == (1, 1, 512, 512) and d['mask'].dtype == torch.int64
+    assert d['lm'].shape == (68, 2) and np.asarray(d['c']).shape == (25,) and int(d['mask'].max()) == 18
+    args = run_total.parse_args([])
+    assert (args.input_root, args.output_root, args.mode) == ('./test/images/', './test/dataset/', 'jpg')

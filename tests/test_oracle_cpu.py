@@ -267,3 +267,25 @@ def test_oracle_idloss_against_reference_golden():
         assert_close(irse_ref.backbone_forward(sd, faces), torch.from_numpy(gold['feats']), 1e-5, 'IR-SE50 features')
         assert_close(irse_ref.extract_feats(sd, img_a), torch.from_numpy(gold['feat_a']), 1e-5, 'extract_feats')
         assert abs(float(irse_ref.calculate_similarity(sd, img_a, img_b)) - float(gold['similarity'])) < 1e-5
+
+
+def test_bisenet_oracle_vs_reference_golden_and_module_keys(golden):
+    """the BiSeNet restatement reproduces the reference network's logits (golden/bisenet.npz, made by running
+    third_part/bisenet on the same seeded weights); the product module has exactly the reference's state_dict keys and shapes, so a real
+    `bisenet.pth` loads unchanged."""
+    import json
+    from oracle import bisenet_ref as obr
+    g = golden('bisenet')
+    man = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'manifest_bisenet.json'))).items()}
+    sd = obr.synthetic_state_dict(man, seed=int(g['seed'][0]))
+    img2 = torch.rand(2, 3, 96, 160, generator=torch.Generator().manual_seed(62)) * 2 - 1
+    with torch.no_grad():
+        o2 = obr.bisenet_forward(sd, img2)[0]
+    assert o2.shape == (2, 19, 96, 160)
+    assert torch.equal(o2[:, :, ::4, ::4], g['out2_sub']) or (o2[:, :, ::4, ::4] - g['out2_sub']).abs().max() < 1e-5 * g['out2_sub'].abs().max()
+    from spi_amd.third_part.bisenet import BiSeNet
+    net = BiSeNet(19)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == man
+    net.load_state_dict(sd)                                       # strict: same names
+    with pytest.raises(RuntimeError):
+        net.train()
