@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--sr-fp16', action='store_true', help='NOT the benchmark configuration: fp16 MFMA in the super-resolution blocks '
                                                            '(BASELINE config 5); the JSON line then says dtype f32+f16sr')
     ap.add_argument('--narrow', action='store_true', help='debug: reduced-width generator (NOT the benchmark configuration)')
+    ap.add_argument('--only', choices=('stage1', 'stage2'), default=None, help='profiling aid, NOT the benchmark configuration: all K steps from one stage')
     ap.add_argument('--dry-run', action='store_true', help='plumbing self-test without a GPU: launcher, rendezvous (gloo), barrier and the statistics '
                                                            'all-reduces run as in a real run, the timed steps are replaced by a sleep; prints no metric')
     return ap.parse_args()
@@ -297,8 +298,14 @@ def main():
 
     w1, w2 = split_steps(args.warmup)
     k1, k2 = split_steps(args.steps)
+    if args.only == 'stage1':
+        (w1, w2), (k1, k2) = (args.warmup, 0), (args.steps, 0)
+    elif args.only == 'stage2':
+        (w1, w2), (k1, k2) = (0, (args.warmup + 3) // 4 * 4), (0, (args.steps + 3) // 4 * 4)
+        args.steps = k2
     run(w1, w2, 25, 0)                                           # untimed warm-up (past the 5 % lr ramp-up)
     rmod.MARCH_EVENTS = []                                       # HIP events around every final-march launch in the timed region
+    rmod.MARCH_BWD_EVENTS = []                                   # ... and around every march-backward launch
     sdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     if os.environ.get('SPI_TORCH_PROFILE'):                      # debugging aid: per-op device time / launch counts per stage (stderr)
@@ -325,6 +332,7 @@ def main():
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0                           # this rank's own K steps
     events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
+    bwd_events, rmod.MARCH_BWD_EVENTS = rmod.MARCH_BWD_EVENTS, None
     dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, dt_rank, ok, dev)
     n_ok = int(sum(rank_ok))
     march_ms = [a.elapsed_time(b) for a, b, _ in events]
@@ -357,6 +365,7 @@ def main():
                                    ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
+                       'only_stage': args.only,
                        'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else
                                    'data-driven skipping of exactly-zero gradients and unneeded SR tiles in the masked pseudo-view branches (result-identical)'},
             'roofline': {'kernel': 'raymarch_fwd_kernel<3> (final composite, S=%d, C=32)' % S, 'bound': 'hbm', 'achieved': achieved,
@@ -364,6 +373,20 @@ def main():
                          'launches': len(march_ms), 'avg_launch_us': (sum(march_ms) / max(len(march_ms), 1)) * 1e3,
                          'bytes_per_ray': per_ray, 'rays_per_launch': (sum(march_rays) / max(len(march_rays), 1))},
         }
+        # second HBM line: the march BACKWARD.  Algorithmic bytes per ACTIVE ray: read S*(C+2)*4 (colours, density, depth)
+        # + (C+1)*4 incoming gradients, write S*2*4 (density gradient + colour-gradient scale; the [R,S,C] colour gradient is never
+        # materialised).  Rays whose incoming gradient is exactly zero are only flagged (one 128-B read): counted as 0 bytes.
+        if bwd_events:
+            bwd_ms = [a.elapsed_time(b) for a, b, _, _ in bwd_events]
+            act = [int(f.sum().item()) if f is not None else r for _, _, r, f in bwd_events]
+            per_ray_b = S * 34 * 4 + 33 * 4 + S * 2 * 4
+            ach = sum(act) * per_ray_b / (sum(bwd_ms) / 1e3) / 1e9
+            dense = [(m, a) for m, a, (_, _, r, _) in zip(bwd_ms, act, bwd_events) if a == r]
+            out['roofline_march_bwd'] = {'kernel': 'raymarch_bwd_kernel<%d> (S=%d, C=32)' % ((S + 63) // 64, S), 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS,
+                                         'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'launches': len(bwd_ms), 'avg_launch_us': sum(bwd_ms) / len(bwd_ms) * 1e3,
+                                         'bytes_per_active_ray': per_ray_b, 'active_rays_per_launch': sum(act) / len(act),
+                                         'dense_launches_only': ({'launches': len(dense), 'achieved': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9,
+                                                                  'frac': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9 / HBM_PEAK_GBS} if dense else None)}
         out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16))
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, k1, k2)

@@ -207,6 +207,14 @@ int spi_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
                        int up, int down, int px0, int px1, int py0, int py1, float gain, float slope,
                        float clamp, int flip, int outH, int outW, spi_stream_t stream);
 
+/* filtered_lrelu.cpp:217 `filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns) -> so`: the activation stage alone, IN PLACE on the
+ * upsampled tensor x [NC, xH, xW], with the reference's bit-packed sign tensor (uint8 [NC, sH, sW/4]: 2 bits per element, 1 = negative,
+ * 2 = clamped; sW a multiple of 4 -- the reference rounds it to 16).  mode 0: x = clamp(lrelu(x * gain)); mode 1: the same and WRITE the
+ * signs; mode 2 (gradient pass): x = x * gain * (slope where the sign read at (col + sx, row + sy) says negative, 0 where clamped, 1 outside
+ * the sign tensor).  clamp < 0 = none.  The caller owns both tensors (the reference allocates `so` inside, filtered_lrelu.cpp:246). */
+int spi_filtered_lrelu_act(float* x, uint8_t* signs, int64_t NC, int xH, int xW, int sH, int sW, int sx, int sy,
+                           float gain, float slope, float clamp, int mode, spi_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Dense convolutions on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
  * Replaces conv2d_gradfix.conv2d / conv_transpose2d with groups = batch as modulated_conv2d uses

@@ -838,6 +838,46 @@ __global__ void __launch_bounds__(256) style_grad_kernel(const float* __restrict
     ds[(int64_t)s * I + i] = r;
 }
 
+// ------------------------------------------------------------------------------------------------
+// filtered_lrelu_act_ (filtered_lrelu.cpp:217-296, filtered_lrelu.cu:1109-1215): gain -> leaky ReLU -> clamp IN PLACE on the upsampled
+// tensor, with the reference's bit-packed sign tensor: 2 bits per element (1 = negative, 2 = clamped), 4 elements per byte,
+// uint8 [N*C, sH, sW/4].  mode 0: plain forward; 1: forward + WRITE signs; 2: READ signs at offset (sx, sy) -- the gradient
+// pass, v = v * gain * (slope if negative) * (0 if clamped).  One thread per sign byte (4 consecutive elements of a row).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) filtered_lrelu_act_kernel(float* __restrict__ x, uint8_t* __restrict__ s, int64_t NC, int xH, int xW, int sH,
+                                                                 int sW, int sx, int sy, float gain, float slope, float clamp, int mode) {
+    const int x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int ymax = mode == 1 ? max(sH, xH) : xH;
+    const int wmax = mode == 1 ? max(sW, xW) : xW;
+    if (x4 >= wmax) return;
+    for (int64_t q = blockIdx.z; q < NC; q += gridDim.z)
+        for (int y = blockIdx.y; y < ymax; y += gridDim.y) {
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = x4 + j;
+                if (xx >= xW || y >= xH) continue;
+                float* pv = x + (q * xH + y) * (int64_t)xW + xx;
+                float v = *pv * gain;
+                if (mode == 2) {
+                    const uint32_t ux = (uint32_t)(xx + sx), uy = (uint32_t)(y + sy);
+                    if (ux < (uint32_t)sW && uy < (uint32_t)sH) {
+                        const uint32_t sb = s[(q * sH + uy) * (int64_t)(sW >> 2) + (ux >> 2)] >> ((ux & 3) << 1);
+                        if (sb & 1) v *= slope;
+                        if (sb & 2) v = 0.f;
+                    }
+                } else {
+                    uint32_t sg = 0;
+                    if (v < 0.f) { v *= slope; sg = 1; }
+                    if (fabsf(v) > clamp) { v = fminf(fmaxf(v, -clamp), clamp); sg = 2; }
+                    bits |= sg << (j << 1);
+                }
+                *pv = v;
+            }
+            if (mode == 1 && x4 < sW && y < sH) s[(q * sH + y) * (int64_t)(sW >> 2) + (x4 >> 2)] = (uint8_t)bits;
+        }
+}
+
 extern "C" {
 
 int spi_bias_act(const float* x, const float* b, const float* xref, const float* yref, const float* dy, float* y, int64_t n,
@@ -960,6 +1000,19 @@ int spi_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
     UpfirdnParams p2{N, C, midH, midW, fdH, fdW, 1, 1, down, down, 0, 0, flip, outH, outW, 1.f};
     ActParams a2{0, 0, 0.f, 1.f, -1.f};
     return launch_upfirdn(tmp, fd, y, p2, nullptr, nullptr, nullptr, nullptr, a2, stream);
+}
+
+int spi_filtered_lrelu_act(float* x, uint8_t* signs, int64_t NC, int xH, int xW, int sH, int sW, int sx, int sy, float gain, float slope,
+                           float clamp, int mode, spi_stream_t stream) {
+    SPI_REQUIRE(x && NC > 0 && xH > 0 && xW > 0, "spi_filtered_lrelu_act: bad argument");
+    SPI_REQUIRE(mode >= 0 && mode <= 2, "spi_filtered_lrelu_act: mode must be 0 (plain), 1 (write signs) or 2 (read signs)");
+    SPI_REQUIRE(mode == 0 || (signs && sH > 0 && sW > 0 && (sW & 3) == 0), "spi_filtered_lrelu_act: sign tensor [NC, sH, sW/4] needs sW %% 4 == 0");
+    const int w = mode == 1 ? std::max(sW, xW) : xW, h = mode == 1 ? std::max(sH, xH) : xH;
+    dim3 grid((unsigned)((w + 1023) / 1024), (unsigned)std::min(h, 65535), (unsigned)std::min<int64_t>(NC, 65535));
+    hipLaunchKernelGGL(filtered_lrelu_act_kernel, grid, dim3(256), 0, as_stream(stream), x, signs, NC, xH, xW, sH, sW, sx, sy, gain, slope,
+                       clamp < 0.f ? INFINITY : clamp, mode);
+    SPI_LAUNCH_CHECK("spi_filtered_lrelu_act");
+    return SPI_OK;
 }
 
 int spi_rotate_warp(const float* tgt_cam, const float* src_cam_inv, const float* src_cam, const float* tgt_depth,
@@ -1092,7 +1145,8 @@ int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoe
 
 int spi_noise_reg_fwd(const float* const* bufs, const int32_t* res, int T, int max_res, float* pyramid, float* means,
                       float* loss, spi_stream_t stream) {
-    SPI_REQUIRE(bufs && res && pyramid && means && loss && T > 0 && max_res >= 1 && max_res <= 2048, "spi_noise_reg_fwd: bad argument");
+    // `means` holds 8 levels x 2 sums per buffer (res, res/2, ... down to 8): 8 * 2^7 = 1024 is the largest resolution that fits
+    SPI_REQUIRE(bufs && res && pyramid && means && loss && T > 0 && max_res >= 1 && max_res <= 1024, "spi_noise_reg_fwd: bad argument (max_res <= 1024)");
     hipLaunchKernelGGL(noise_reg_fwd_kernel, dim3((unsigned)T), dim3(1024), 0, as_stream(stream), bufs, res, (int64_t)max_res * max_res / 2,
                        pyramid, means, loss);
     SPI_LAUNCH_CHECK("spi_noise_reg_fwd");
@@ -1101,7 +1155,7 @@ int spi_noise_reg_fwd(const float* const* bufs, const int32_t* res, int T, int m
 
 int spi_noise_reg_bwd(const float* const* bufs, const int32_t* res, int T, int max_res, const float* pyramid, const float* means,
                       const float* gout, float* grads, const int64_t* goff, float* gpyramid, spi_stream_t stream) {
-    SPI_REQUIRE(bufs && res && pyramid && means && gout && grads && goff && gpyramid && T > 0 && max_res >= 1 && max_res <= 2048,
+    SPI_REQUIRE(bufs && res && pyramid && means && gout && grads && goff && gpyramid && T > 0 && max_res >= 1 && max_res <= 1024,
                 "spi_noise_reg_bwd: bad argument");
     hipLaunchKernelGGL(noise_reg_bwd_kernel, dim3((unsigned)T), dim3(1024), 0, as_stream(stream), bufs, res, (int64_t)max_res * max_res / 2,
                        pyramid, means, gout, grads, goff, gpyramid);

@@ -4,10 +4,14 @@ Same surface as the reference's ``filtered_lrelu`` (eg3d/torch_utils/ops/filtere
 The op is on the reference's *import* path only (networks_stylegan3, never instantiated by the
 StyleGAN2 / 8XDC generator).  Without gradients it is the fused two-pass kernel sequence
 ``spi_filtered_lrelu`` (no global device state: the reference's constant-memory filter buffer makes it
-non-reentrant across streams, filtered_lrelu.cu:81-82).  When a gradient is required -- or the filters
-are separable 1-D -- it runs as the reference's own decomposition (filtered_lrelu.py:121-176:
-bias -> upfirdn2d(up) -> bias_act(lrelu, gain, clamp) -> upfirdn2d(down)) on the differentiable HIP ops,
-so the backward is their adjoint kernels.
+non-reentrant across streams, filtered_lrelu.cu:81-82).  When a gradient is required it runs like the
+reference's plugin op (filtered_lrelu.py:180-270, generic variant :229-236): bias -> ``upfirdn2d`` (up) ->
+``filtered_lrelu_act_`` IN PLACE, which also writes the bit-packed SIGN tensor (2 bits per element of the upsampled
+buffer: negative / clamped, ``spi_filtered_lrelu_act``) -> ``upfirdn2d`` (down); only the filters and the signs are
+kept for the backward, which is the same op with up / down swapped, flipped filters, gain * up^2 / down^2, no
+clamp, and the signs READ at the offset the reference computes (:258-262) -- no full-size activation is stored.
+``filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs)`` is exported with the plugin's meaning.
+Separable 1-D filters take the reference's decomposition on the differentiable HIP ops (:121-176).
 """
 import math
 import torch
@@ -15,12 +19,93 @@ from ... import hip
 from .upfirdn2d import _parse_padding
 
 
+def filtered_lrelu_act_(x, si=None, sx=0, sy=0, gain=math.sqrt(2), slope=0.2, clamp=None, write_signs=False):
+    """Plugin entry point `filtered_lrelu_act_` (filtered_lrelu.cpp:217-296): modifies ``x`` [N,C,H,W] in place; returns the sign tensor it
+    wrote (``write_signs``) or an empty uint8 tensor.  ``si``: signs to read (gradient pass) -- exclusive with ``write_signs``."""
+    assert x.ndim == 4 and x.is_contiguous() and x.dtype == torch.float32
+    n, c, h, w = x.shape
+    read = si is not None and si.numel() > 0
+    assert not (read and write_signs)
+    so = torch.empty(0, dtype=torch.uint8, device=x.device)
+    s, mode, sh, sw = None, 0, 0, 0
+    if write_signs:
+        sw = (w + 15) & ~15                                  # width rounded up to a multiple of 16 elements (filtered_lrelu.cpp:89)
+        s = so = torch.empty(n, c, h, sw >> 2, dtype=torch.uint8, device=x.device)
+        mode, sh = 1, h
+    elif read:
+        assert si.dtype == torch.uint8 and si.is_contiguous() and si.ndim == 4 and si.shape[:2] == (n, c)
+        s, mode, sh, sw = si, 2, si.shape[2], si.shape[3] << 2
+    hip.call('spi_filtered_lrelu_act', hip.ptr(x), hip.ptr(s), n * c, h, w, sh, sw, int(sx), int(sy), float(gain), float(slope),
+             float(-1 if clamp is None else clamp), mode, hip.stream())
+    return so
+
+
+_op_cache = {}
+
+
+def _filtered_lrelu_op(up, down, padding, gain, slope, clamp, flip_filter):
+    """autograd.Function factory keyed like the reference's `_filtered_lrelu_cuda` cache (filtered_lrelu.py:160-176)."""
+    from . import upfirdn2d as _uf
+    px0, px1, py0, py1 = padding
+    key = (up, down, px0, px1, py0, py1, gain, slope, clamp, flip_filter)
+    if key in _op_cache:
+        return _op_cache[key]
+
+    class FilteredLReluHip(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, fu, fd, b, si, sx, sy):
+            x = x.contiguous().float()
+            if fu is None:
+                fu = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            if fd is None:
+                fd = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            write_signs = (si is None or si.numel() == 0) and (x.requires_grad or (b is not None and b.requires_grad))
+            y = x + b.reshape(1, -1, 1, 1) if b is not None else x
+            with torch.no_grad():
+                y = _uf.upfirdn2d(y, fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter).contiguous()
+                if y is x:
+                    y = y.clone()                                    # the activation is in place: never on the caller's tensor
+                so = filtered_lrelu_act_(y, si, sx, sy, gain, slope, clamp, write_signs)
+                y = _uf.upfirdn2d(y, fd, down=down, flip_filter=flip_filter)
+            ctx.save_for_backward(fu, fd, si if (si is not None and si.numel()) else so)
+            ctx.x_shape, ctx.y_shape, ctx.s_ofs, ctx.has_b = x.shape, y.shape, (sx, sy), b is not None
+            return y
+
+        @staticmethod
+        @torch.autograd.function.once_differentiable
+        def backward(ctx, dy):
+            fu, fd, si = ctx.saved_tensors
+            _, _, xh, xw = ctx.x_shape
+            _, _, yh, yw = ctx.y_shape
+            sx, sy = ctx.s_ofs
+            dx = db = None
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[3]:
+                pp = [(fu.shape[-1] - 1) + (fd.shape[-1] - 1) - px0, xw * up - yw * down + px0 - (up - 1),
+                      (fu.shape[0] - 1) + (fd.shape[0] - 1) - py0, xh * up - yh * down + py0 - (up - 1)]
+                gg = gain * (up ** 2) / (down ** 2)
+                sx = sx - (fu.shape[-1] - 1) + px0
+                sy = sy - (fu.shape[0] - 1) + py0
+                dx = _filtered_lrelu_op(down, up, tuple(pp), gg, slope, None, not flip_filter).apply(dy.contiguous().float(), fd, fu, None, si, sx, sy)
+            if ctx.has_b and ctx.needs_input_grad[3]:
+                db = dx.sum([0, 2, 3])
+            return dx, None, None, db, None, None, None
+
+    _op_cache[key] = FilteredLReluHip
+    return FilteredLReluHip
+
+
 def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=math.sqrt(2), slope=0.2, clamp=None,
                    flip_filter=False, impl='hip'):
     assert isinstance(x, torch.Tensor) and x.ndim == 4
     need_grad = torch.is_grad_enabled() and (x.requires_grad or (b is not None and b.requires_grad))
     separable = (fu is not None and fu.ndim == 1 and fu.numel() > 1) or (fd is not None and fd.ndim == 1 and fd.numel() > 1)
-    if need_grad or separable:
+    if need_grad and not separable:
+        fu2 = None if fu is None else (fu.float().reshape(1, 1) ** 2 if fu.ndim == 1 else fu.float())
+        fd2 = None if fd is None else (fd.float().reshape(1, 1) ** 2 if fd.ndim == 1 else fd.float())
+        op = _filtered_lrelu_op(int(up), int(down), tuple(_parse_padding(padding)), float(gain), float(slope),
+                                None if clamp is None else float(clamp), bool(flip_filter))
+        return op.apply(x, fu2, fd2, b, None, 0, 0)
+    if separable:
         from . import bias_act as _ba, upfirdn2d as _uf
         y = _ba.bias_act(x, b) if b is not None else x
         y = _uf.upfirdn2d(y, fu, up=up, padding=_parse_padding(padding), gain=up ** 2, flip_filter=flip_filter)

@@ -5,11 +5,19 @@ Semantics of ``torch.optim.Adam(params, lr, betas=(0.9, 0.999), eps=1e-8)`` as b
 MI355X-first: at construction every parameter's storage is moved into ONE contiguous fp32 buffer
 (``p.data`` becomes a view) and so is its gradient; ``zero_grad`` is one memset, ``step`` is one
 kernel (``spi_adam_multi``) streaming 4 flat arrays -- 28 B/parameter, HBM-bound -- instead of
-O(#tensors) launches.  A parameter that receives no gradient sees g = 0, for which the update is
-exactly 0 (m = v = 0): the same end state as torch skipping it.
+O(#tensors) launches.  A parameter that NEVER receives a gradient sees g = 0, for which the update is
+exactly 0 (m = v = 0): the same end state as torch skipping it.  Both SPI loops satisfy "always or never":
+every tensor the main loss reaches gets a gradient on every step (W+ and the 13 noise maps in stage 1; all of
+backbone.synthesis / superresolution / decoder in stage 2) and the mapping network never does.  A parameter that
+received gradients on SOME steps only would differ from torch.optim.Adam(set_to_none=True), which skips it with its
+own step counter while this kernel keeps decaying its moments under the shared step count -- not a case either
+loop produces, and `step()` asserts it in debug runs (SPI_ADAM_CHECK=1).
 """
+import os
 import torch
 from .. import hip
+
+_CHECK = bool(os.environ.get('SPI_ADAM_CHECK'))
 
 
 class Adam:
@@ -61,6 +69,17 @@ class Adam:
                 p.grad = self.flat_g[off:off + n].view(p.shape)
             off += n
         self.step_count += 1
+        if _CHECK:                                       # debug: the always-or-never assumption above
+            off = 0
+            had = getattr(self, '_had_grad', None)
+            now = []
+            for p in self.params:
+                n = p.numel()
+                now.append(bool((self.flat_g[off:off + n] != 0).any()))
+                off += n
+            if had is not None and any(h and not n_ for h, n_ in zip(had, now)):
+                raise AssertionError('a parameter that had a gradient before has none now: flat Adam differs from torch.optim.Adam here')
+            self._had_grad = [h or n_ for h, n_ in zip(had, now)] if had is not None else now
         grp = self.param_groups[0]
         hip.call('spi_adam_multi', hip.ptr(self._table), hip.ptr(self._sizes), 1, self._total, float(grp['lr']), float(grp['betas'][0]),
                  float(grp['betas'][1]), float(grp['eps']), self.step_count, hip.stream())

@@ -27,6 +27,7 @@ from .ray_marcher import MipRayMarcher2, depth_range
 
 DEC_DUMP_ROWS = 193
 MARCH_EVENTS = None      # bench.py: list collecting (start, end, rays) HIP events around every final-march launch
+MARCH_BWD_EVENTS = None  # bench.py: the same around every march-backward launch with a colour gradient: (start, end, rays, active-ray flags)
 
 
 def decoder_tensors(decoder):
@@ -196,8 +197,16 @@ class _Render(torch.autograd.Function):
         # the march backward and skipped by the decoder backward; their rows of d_col / d_sig stay unwritten
         from ...configs import global_config
         active = torch.empty(r, device=dev, dtype=torch.int32) if global_config.exploit_sparsity else None
+        timed = MARCH_BWD_EVENTS is not None and d_rgb is not None
+        if timed:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
         hip.call('spi_raymarch_bwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), hip.ptr(d_rgb),
                  hip.ptr(dd), None, r, s, s, 32, white_back, None, hip.ptr(d_cs), hip.ptr(d_sig), hip.ptr(active), hip.stream())
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            MARCH_BWD_EVENTS.append((e0, e1, r, active))
         want_w = any(ctx.needs_input_grad[1:5])
         d_planes = torch.zeros_like(planes_nhwc)
         # one pass over all Sc+Sf samples in sorted order, 8x8 ray patches (LDS-aggregated scatter)

@@ -144,3 +144,46 @@ def test_upfirdn2d_tiled_ragged_vs_oracle(inh, pad):
         assert_close(a, b, 2e-5, 'tiled fused ' + nm)
     assert_close(upfirdn2d.upfirdn2d(x.detach().to(DEV), f.to(DEV), padding=[pad] * 4, flip_filter=True),
                  osg.upfirdn2d(x.detach(), f, padding=(pad,) * 4, flip_filter=True), 2e-6, 'tiled plain')
+
+
+def test_filtered_lrelu_act_sign_tensor_modes():
+    """`filtered_lrelu_act_` (filtered_lrelu.cpp:217-296, .cu:1109-1215): in-place gain / lrelu / clamp, the bit-packed sign tensor it writes
+    (2 bits per element: 1 = negative, 2 = clamped; 4 per byte; width rounded up to 16 elements) and the gradient pass that reads it at an offset."""
+    from spi_amd.torch_utils.ops.filtered_lrelu import filtered_lrelu_act_
+    gen = torch.Generator().manual_seed(4)
+    n, c, h, w = 2, 3, 9, 37
+    x = torch.randn(n, c, h, w, generator=gen) * 2
+    gain, slope, clamp = 1.3, 0.2, 1.7
+    v = x * gain
+    neg = v < 0
+    v = torch.where(neg, v * slope, v)
+    clamped = v.abs() > clamp
+    ref = v.clamp(-clamp, clamp)
+    code = torch.where(clamped, torch.full_like(x, 2), neg.float()).long()               # clamp overrides sign
+    for write in (False, True):
+        y = x.clone().to(DEV)
+        so = filtered_lrelu_act_(y, None, 0, 0, gain, slope, clamp, write_signs=write)
+        assert_close(y, ref, 1e-6, 'act forward')
+        if not write:
+            assert so.numel() == 0
+            continue
+        sw = (w + 15) & ~15
+        assert so.dtype == torch.uint8 and so.shape == (n, c, h, sw // 4)
+        s = so.cpu().long()
+        unpacked = torch.stack([(s >> (2 * j)) & 3 for j in range(4)], dim=-1).reshape(n, c, h, sw)
+        assert torch.equal(unpacked[..., :w], code) and int(unpacked[..., w:].sum()) == 0
+        # gradient pass: read the signs at an offset (sx, sy); outside the sign tensor the element is just scaled by the gain
+        sx, sy = 3, -2
+        g = torch.randn(n, c, h + 1, w - 5, generator=gen)
+        gd = g.clone().to(DEV).contiguous()
+        filtered_lrelu_act_(gd, so, sx, sy, 0.7, slope, None, write_signs=False)
+        yy, xx = torch.meshgrid(torch.arange(h + 1) + sy, torch.arange(w - 5) + sx, indexing='ij')
+        inside = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < sw)
+        cc = torch.zeros(n, c, h + 1, w - 5, dtype=torch.long)
+        cc[:, :, inside] = unpacked[:, :, yy[inside], xx[inside]]
+        expect = g * 0.7 * torch.where(cc == 1, torch.tensor(slope), torch.tensor(1.0)) * (cc != 2).float()
+        assert_close(gd, expect, 1e-6, 'act gradient pass (read signs)')
+    # no clamp: code 2 never appears
+    y = x.clone().to(DEV)
+    so = filtered_lrelu_act_(y, None, 0, 0, gain, slope, None, write_signs=True)
+    assert int(((so.cpu().long() >> 1) & 0x55).sum()) == 0
