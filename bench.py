@@ -48,6 +48,11 @@ def parse():
     ap.add_argument('--sr-fp16', action='store_true', help='NOT the benchmark configuration: fp16 MFMA in the super-resolution blocks '
                                                            '(BASELINE config 5); the JSON line then says dtype f32+f16sr')
     ap.add_argument('--narrow', action='store_true', help='debug: reduced-width generator (NOT the benchmark configuration)')
+    ap.add_argument('--conv-precision', choices=('f32', 'bf16x6', 'bf16x3'), default='f32',
+                    help='arithmetic of the dense convolutions: f32 = exact fp32 MFMA (default, the benchmark configuration); bf16x6 / bf16x3 = fp32 operands '
+                         'split into 3 / 2 bf16 pieces, 6 / 3 bf16 MFMAs with fp32 accumulation (opt-in; the JSON line then says so in dtype)')
+    ap.add_argument('--alt-conv-precision', choices=('none', 'bf16x6', 'bf16x3'), default='bf16x6',
+                    help='after the timed region, time the same K steps once more with this conv arithmetic and report it as `alt` (never as `value`)')
     ap.add_argument('--only', choices=('stage1', 'stage2'), default=None, help='profiling aid, NOT the benchmark configuration: all K steps from one stage')
     ap.add_argument('--dry-run', action='store_true', help='plumbing self-test without a GPU: launcher, rendezvous (gloo), barrier and the statistics '
                                                            'all-reduces run as in a real run, the timed steps are replaced by a sleep; prints no metric')
@@ -133,7 +138,7 @@ def cpu_baseline(depth, narrow, mode='sample', k1=8, k2=16):
     return res
 
 
-def conv_roofline(dev, f16):
+def conv_roofline(dev, f16, prec=0):
     """Second roofline line: the matrix-core kernels that hold most of the step's GPU time (igemm_kernel / wgrad_kernel).  Times the
     largest convolution of the loop -- superresolution b512.conv1, 128 -> 128, 3x3 at 512^2, one image -- with HIP events on the
     launch stream, outside the timed region: forward, data gradient, weight gradient."""
@@ -145,9 +150,10 @@ def conv_roofline(dev, f16):
     w = torch.randn(n, o, k, k, i, device=dev) * 0.03
     y = torch.empty(n, o, h, h, device=dev)
     dx, dw = torch.empty_like(x), torch.empty_like(w)
-    d = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1, f16=int(f16))
+    d = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1, f16=1 if f16 else prec)
     flop = 2.0 * n * o * i * k * k * h * h
-    peak = 2500.0 if f16 else 157.3                              # dense MFMA peaks (TFLOP/s): fp16 / fp32, MI355X_MICROARCH.md
+    # dense MFMA peaks (TFLOP/s), MI355X_MICROARCH.md: fp16 2500, fp32 157.3; split-bf16 modes: the bf16 peak / number of piece products
+    peak = 2500.0 if f16 else {0: 157.3, 2: 2500.0 / 3, 3: 2500.0 / 6}[prec]
     res = {}
     for name, fn in (('fwd', lambda: hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())),
                      ('dgrad', lambda: hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(y), hip.ptr(w), hip.ptr(dx), hip.stream())),
@@ -260,6 +266,7 @@ def main():
     global_config.device = str(dev)
     global_config.enable_fp16_blocks = bool(args.sr_fp16)
     global_config.exploit_sparsity = not args.dense
+    global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
     tmp = tempfile.mkdtemp(prefix='spi_bench_')
     for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
         setattr(paths_config, k, f'{tmp}/{k}/')
@@ -335,6 +342,25 @@ def main():
     bwd_events, rmod.MARCH_BWD_EVENTS = rmod.MARCH_BWD_EVENTS, None
     dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, dt_rank, ok, dev)
     n_ok = int(sum(rank_ok))
+    alt = None
+    if args.alt_conv_precision != 'none' and args.alt_conv_precision != args.conv_precision and ok and not os.environ.get('SPI_TORCH_PROFILE'):
+        # the same K steps once more with the split-bf16 convolutions (opt-in arithmetic; reported beside the benchmark value, never as it)
+        global_config.conv_precision = {'bf16x6': 3, 'bf16x3': 2}[args.alt_conv_precision]
+        main_marks = dict(marks)
+        run(min(w1, 2), min(w2, 4), 25 + w1 + k1, ((w2 + k2 + 3) // 4) * 4)
+        sdist.barrier(); torch.cuda.synchronize()
+        ta = time.perf_counter()
+        run(k1, k2, 25 + w1 + k1 + 2, ((w2 + k2 + 7) // 4) * 4)
+        torch.cuda.synchronize(); sdist.barrier()
+        dta = sdist.reduce_stats([time.perf_counter() - ta], device=dev, op='max')[0]
+        alt = {'conv_precision': args.alt_conv_precision, 'value': world * args.steps / dta, 'unit': 'iters/s', 'ms_per_step': dta / args.steps * 1e3,
+               'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
+               'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
+               'note': 'same K steps, dense convs with fp32 operands split into bf16 pieces on the bf16 matrix cores (fp32 accumulate); '
+                       'bf16x6 = 3 pieces / 6 products, error ~2^-23 per product, passes the conv parity tests at the exact kernels\' tolerance; '
+                       'NOT the benchmark value'}
+        marks.clear(); marks.update(main_marks)
+        global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
     march_ms = [a.elapsed_time(b) for a, b, _ in events]
     march_rays = [r for _, _, r in events]
 
@@ -359,7 +385,7 @@ def main():
                        'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
                        'note': 'rank 0; stage 2 amortises the every-4th-iteration rot / mirror-rot / depth branches over whole super-cycles'},
             'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32+f16sr' if args.sr_fp16 else 'f32', 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32+f16sr' if args.sr_fp16 else 'f32') + ('' if args.conv_precision == 'f32' else f' (convolutions: fp32 operands split {args.conv_precision}, fp32 accumulate)'), 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
             'random-init weights of the ffhqrebalanced512-128 architecture)',
             'config': {'workload': ('configs[4]' if (args.depth == 128 and args.sr_fp16) else 'configs[1]') +
                                    ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
@@ -387,7 +413,9 @@ def main():
                                          'bytes_per_active_ray': per_ray_b, 'active_rays_per_launch': sum(act) / len(act),
                                          'dense_launches_only': ({'launches': len(dense), 'achieved': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9,
                                                                   'frac': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9 / HBM_PEAK_GBS} if dense else None)}
-        out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16))
+        out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16), global_config.conv_precision)
+        if alt is not None:
+            out['alt'] = alt
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, k1, k2)
         print(json.dumps(out), flush=True)

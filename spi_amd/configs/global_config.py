@@ -24,6 +24,14 @@ enable_fp16_blocks = False
 # and the host enqueues the chains one after the other anyway), so it stays off.
 concurrent_branches = False
 
+# arithmetic of the dense convolutions (spi_conv_desc.compute_f16 of every conv that does not ask for fp16):
+#   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak) -- the default, bit-for-bit fp32 FMA chains
+#   3  fp32 operands split into THREE bf16 pieces, the six significant piece products on the bf16 matrix cores with fp32 accumulation
+#      (error ~2^-23 per product: fp32-level; 2.7x less matrix-pipe time)
+#   2  two pieces, three products (error ~2^-16 per product; 5.3x less matrix-pipe time)
+# `--conv_precision {f32,bf16x6,bf16x3}` / `bench.py --conv-precision`.
+conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[os.environ.get('SPI_CONV_PRECISION', 'f32')]   # env override: run any test / tool in a split mode
+
 # data-driven skipping of exactly-zero gradients / unneeded super-resolution tiles in the masked pseudo-view branches.
 # Results are equal either way (tested); False = dense bound: every ray, gradient segment and SR tile is processed (`bench.py --dense`).
 exploit_sparsity = True

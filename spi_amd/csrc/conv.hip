@@ -81,8 +81,77 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 //   F16 (needs BUF, no SPLITK): operands are rounded to fp16 when they are staged in LDS ([k/4][m][4] halves, one 8-byte
 //   fragment per lane) and multiplied on v_mfma_f32_32x32x8_f16 with fp32 accumulation -- the precision of the reference's
 //   `use_fp16` super-resolution blocks (superresolution.py:271), at 16x the fp32 matrix rate.
+//   PREC 2 / 3 (needs BUF, no SPLITK): "split bf16" -- every fp32 operand is cut into 2 / 3 bf16 pieces when it is staged in LDS
+//   (x = c0 + c1 [+ c2] exactly up to 2^-16 / 2^-24 relative: truncating splits, each residual is exact) and the product is the sum of
+//   the 3 / 6 significant piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: c0*c0 + c0*c1 + c1*c0 [+ c0*c2 + c2*c0 +
+//   c1*c1].  bf16 keeps fp32's exponent range, so no scaling is needed (an fp16 split underflows on small gradients).  The bf16
+//   matrix rate is 16x the fp32 one: 3 / 6 MFMAs of K = 16 replace 8 of K = 2 (64 cycles each) -- 5.3x / 2.7x less matrix-pipe time
+//   at an error of ~2^-16 / ~2^-23 per product.  LDS layout per piece: [k/8][m][8 bf16] = one 16-byte fragment per lane.
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
-template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF, bool AMF = false, bool F16 = false>
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int prec_pieces(int prec) { return prec == 3 ? 3 : 2; }
+constexpr int prec_lds_factor(int prec) { return prec == 3 ? 3 : 2; }          // LDS halves per element / 1  (fp32 = 2 halves)
+
+// x -> up to three bf16 pieces (bit patterns), truncating: x == f(c0) + f(c1) + f(c2) + O(2^-24 |x|)
+template <int NS>
+__device__ __forceinline__ void split_bf16(float x, unsigned short (&c)[3]) {
+    const unsigned b0 = __float_as_uint(x) & 0xffff0000u;
+    c[0] = (unsigned short)(b0 >> 16);
+    const float r1 = x - __uint_as_float(b0);
+    const unsigned b1 = __float_as_uint(r1) & 0xffff0000u;
+    c[1] = (unsigned short)(b1 >> 16);
+    if (NS == 3) {
+        const float r2 = r1 - __uint_as_float(b1);
+        c[2] = (unsigned short)(__float_as_uint(r2) >> 16);
+    } else c[2] = 0;
+}
+
+// Split a run of PER consecutive-k fp32 values (same row) and write each piece as ONE packed LDS store: layout per piece
+// [k/8][row][8 bf16], `k0` (a multiple of PER) is the run's first k.  Pairs are packed with v_perm_b32 (the high halves of two registers).
+template <int NS, int PER>
+__device__ __forceinline__ void store_split_run(float* lds, int LD, int row, int k0, const float (&v)[PER]) {
+    static_assert(PER == 2 || PER == 4 || PER == 8 || PER == 16, "run length");
+    unsigned pk[3][PER / 2];
+#pragma unroll
+    for (int i = 0; i < PER / 2; ++i) {
+        const float x0 = v[2 * i], x1 = v[2 * i + 1];
+        pk[0][i] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        pk[1][i] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        if (NS == 3) {
+            const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+            pk[2][i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+        }
+    }
+    unsigned* base = reinterpret_cast<unsigned*>(lds) + ((((k0 >> 3) * LD + row) << 3) + (k0 & 7)) / 2;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        unsigned* d = base + q * LD * 8;                          // one piece = 2 k-cells x LD rows x 8 halves = LD * 8 dwords
+        if (PER == 2) d[0] = pk[q][0];
+        else if (PER == 4) *reinterpret_cast<uint2*>(d) = make_uint2(pk[q][0], pk[q][1]);
+        else if (PER == 8) *reinterpret_cast<uint4*>(d) = make_uint4(pk[q][0], pk[q][1], pk[q][2], pk[q][3]);
+        else {
+            *reinterpret_cast<uint4*>(d) = make_uint4(pk[q][0], pk[q][1], pk[q][2], pk[q][3]);
+            *reinterpret_cast<uint4*>(d + LD * 4) = make_uint4(pk[q][4 % (PER / 2)], pk[q][5 % (PER / 2)], pk[q][6 % (PER / 2)], pk[q][7 % (PER / 2)]);
+        }
+    }
+}
+
+// accumulate the significant piece products of one K = 16 slab for one 32x32 tile, small terms first
+template <int NS>
+__device__ __forceinline__ f32x16 mfma_split(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x16 acc) {
+    if (NS == 3) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+    return acc;
+}
+
+template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF, bool AMF = false, int PREC = 0>
 __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ wgt, float* __restrict__ out,
                                                             Epilogue ep, int nsplit) {
@@ -94,10 +163,14 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     constexpr int B_KSTEP = NT / BN;          // k rows covered per pass (p fastest)
     static_assert(NT >= BN && NT % BK == 0 && NT % BN == 0 && A_PER >= 1 && B_PER >= 1, "tile/threads mismatch");
     static_assert(!AMF || (BUF && NT % BM == 0), "m-fast A loads need the buffer path");
-    static_assert(!F16 || (BUF && !SPLITK), "fp16 operands: buffer path, no split-K");
+    constexpr bool F16 = (PREC == 1);
+    constexpr bool SPL = (PREC >= 2);
+    constexpr int NS = prec_pieces(PREC);
+    static_assert(PREC == 0 || (BUF && !SPLITK), "fp16 / split-bf16 operands: buffer path, no split-K");
     constexpr int A_KSTEP = AMF ? NT / BM : 0; // AMF: k rows covered per pass (m fastest)
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    constexpr int LDSF = SPL ? prec_lds_factor(PREC) : 2;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA * LDSF / 2];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB * LDSF / 2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -177,8 +250,13 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     }
 
     // ---- per-thread load coordinates
-    const int a_k = AMF ? tid / BM : tid % BK, a_m = AMF ? tid % BM : tid / BK;
-    const int b_p = tid % BN, b_k = tid / BN;
+    // fp32 / fp16: a thread's elements are strided (A: one k, rows A_MSTEP apart -- or with AMF one row, ks A_KSTEP apart; B: one pixel, ks
+    // B_KSTEP apart).  Split-bf16: every thread owns a RUN of consecutive ks of one row / pixel (A_PER resp. B_PER long), so that a piece
+    // of the run is one packed LDS store.
+    constexpr int RA = BK / A_PER;                                   // SPL: k-runs per A row
+    const int a_k = SPL ? (AMF ? (tid / BM) * A_PER : (tid % RA) * A_PER) : (AMF ? tid / BM : tid % BK);
+    const int a_m = SPL ? (AMF ? tid % BM : tid / RA) : (AMF ? tid % BM : tid / BK);
+    const int b_p = tid % BN, b_k = SPL ? (tid / BN) * B_PER : tid / BN;
     const int p = p0 + b_p;
     const bool pv = p < npix;
     const int Y = pv ? p / C.OWp : 0, X = pv ? p - Y * C.OWp : 0;
@@ -207,14 +285,14 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * 4), 0x00020000);
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
-            const int m = m0 + a_m + (AMF ? 0 : j * A_MSTEP);
-            const int k = a_k + (AMF ? j * A_KSTEP : 0);
+            const int m = m0 + a_m + ((AMF || SPL) ? 0 : j * A_MSTEP);
+            const int k = a_k + (SPL ? j : (AMF ? j * A_KSTEP : 0));
             voffA[j] = m < P.Mo ? (unsigned)((m * P.wsm + k * P.wsc) * 4) : OOB;
         }
     }
     // per-slab addressing state (scalars + one vector offset), computed once per slab by slab_setup()
     const int chs4 = __builtin_amdgcn_readfirstlane((int)chs * 4);               // bytes between input channels (scalar)
-    const int kstr4 = __builtin_amdgcn_readfirstlane(B_KSTEP * (int)chs * 4);     // bytes between the channels one thread loads
+    const int kstr4 = __builtin_amdgcn_readfirstlane((SPL ? 1 : B_KSTEP) * (int)chs * 4);     // bytes between the channels one thread loads
     struct SlabAddr { int t, c0; int soffA; unsigned voffB; int soffB; bool okB; int iy, ix; };
     auto slab_setup = [&](int s) {
         SlabAddr q;
@@ -227,8 +305,24 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         q.soffB = __builtin_amdgcn_readfirstlane(q.c0 * chs4);
         return q;
     };
+    // Split-bf16 forward (k = channel is the contiguous axis of tap-major weights, wsc == 1): a thread's run of A_PER consecutive ks is A_PER / 4
+    // 16-byte global loads (rows beyond Mo read row Mo-1 and are zeroed afterwards; Ci % 16 == 0 keeps every k in range).
+    constexpr int AVW = A_PER >= 4 ? 4 : A_PER;                      // floats per vector load
+    const bool a_row_ok = (m0 + a_m) < P.Mo;
+    const float* a_ptr = wb + (int64_t)min(m0 + a_m, P.Mo - 1) * P.wsm + a_k;
     auto load_a = [&](Stage& S, const SlabAddr& q, int j) {
-        if (BUF) {
+        if constexpr (SPL && !AMF) {
+            if (j % AVW == 0) {
+                const float* src = a_ptr + (q.soffA >> 2) + j;
+                if constexpr (AVW == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(src);
+                    S.ra[j] = a_row_ok ? v.x : 0.f; S.ra[j + 1] = a_row_ok ? v.y : 0.f; S.ra[j + 2] = a_row_ok ? v.z : 0.f; S.ra[j + 3] = a_row_ok ? v.w : 0.f;
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(src);
+                    S.ra[j] = a_row_ok ? v.x : 0.f; S.ra[j + 1] = a_row_ok ? v.y : 0.f;
+                }
+            }
+        } else if (BUF) {
             S.ra[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, (int)voffA[j], q.soffA, 0));
         } else {
             const int c = q.c0 + a_k;
@@ -257,14 +351,18 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         for (int j = 0; j < B_PER; ++j) load_b(S, q, j);
     };
     auto store_a = [&](const Stage& S, int buf, int j) {
-        if constexpr (F16) {
+        if constexpr (SPL) {
+            if (j == 0) store_split_run<NS, A_PER>(As[buf], LDA, a_m, a_k, S.ra);
+        } else if constexpr (F16) {
             const int k = AMF ? a_k + j * A_KSTEP : a_k, m = AMF ? a_m : a_m + j * A_MSTEP;
             reinterpret_cast<_Float16*>(As[buf])[((k >> 2) * LDA + m) * 4 + (k & 3)] = (_Float16)S.ra[j];
         } else if (AMF) As[buf][(a_k + j * A_KSTEP) * LDA + a_m] = S.ra[j];
         else As[buf][a_k * LDA + a_m + j * A_MSTEP] = (BUF || ((S.am >> j) & 1u)) ? S.ra[j] : 0.f;
     };
     auto store_b = [&](const Stage& S, int buf, int j) {
-        if constexpr (F16) {
+        if constexpr (SPL) {
+            if (j == 0) store_split_run<NS, B_PER>(Bs[buf], LDB, b_p, b_k, S.rb);
+        } else if constexpr (F16) {
             const int k = b_k + j * B_KSTEP;
             reinterpret_cast<_Float16*>(Bs[buf])[((k >> 2) * LDB + b_p) * 4 + (k & 3)] = (_Float16)S.rb[j];
         } else Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? S.rb[j] : 0.f;
@@ -283,6 +381,41 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     auto step = [&](int s, int buf, Stage& L, const Stage& W) {
         L.am = L.bm = 0;
         const SlabAddr q2 = slab_setup(s + 2);
+        if constexpr (SPL) {
+            // one K = 16 step per slab: all piece fragments of the wave's tiles (16 B each), then per tile NS*(NS+1)/2 MFMAs.  The loads
+            // of slab s+2 are issued behind the first tile row, slab s+1 is split and written to the other LDS buffer behind the last.
+            const bf16x8_t* Ab = reinterpret_cast<const bf16x8_t*>(As[buf]) + fk * LDA + wm * TM * 32 + fr;
+            const bf16x8_t* Bb = reinterpret_cast<const bf16x8_t*>(Bs[buf]) + fk * LDB + wn * TN * 32 + fr;
+            bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i][q] = Ab[q * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j][q] = Bb[q * 2 * LDB + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(af[i], bf[j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < A_PER; ++j) load_a(L, q2, j);
+#pragma unroll
+                    for (int j = 0; j < B_PER; ++j) load_b(L, q2, j);
+                }
+                if (i == TM - 1) {
+#pragma unroll
+                    for (int j = 0; j < A_PER; ++j) store_a(W, buf ^ 1, j);
+#pragma unroll
+                    for (int j = 0; j < B_PER; ++j) store_b(W, buf ^ 1, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            return;
+        }
         constexpr int NK = F16 ? BK / 8 : BK / 2;
         // one body for both operand types: FragT = float (one k per lane half) or 4 halves (k = 4*half .. 4*half+3)
         using FragT = typename std::conditional<F16, half4_t, float>::type;
@@ -395,7 +528,7 @@ __global__ void conv_epilogue_kernel(float* __restrict__ y, int64_t total, int O
 //   range whose dOut segments are flagged into an LDS list and then runs the pipeline over that list only (masked losses: most
 //   slabs multiply by an all-zero A operand).
 constexpr int WG_LISTMAX = 2048;
-template <int WM, int WN, int TM, int TN, bool F16 = false, bool FAST = false, bool SPARSE = false>
+template <int WM, int WN, int TM, int TN, int PREC = 0, bool FAST = false, bool SPARSE = false>
 __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in,
                                                             const float* __restrict__ dout, float* __restrict__ dw,
                                                             int pix_per_block) {
@@ -405,8 +538,12 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     constexpr int A_PER = BM * BK / NT, B_PER = BN * BK / NT;
     constexpr int ROWSTEP = NT / BK;
     constexpr unsigned OOB = 0x40000000u;          // two of them still add up to an out-of-range offset
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+    constexpr bool F16 = (PREC == 1);
+    constexpr bool SPL = (PREC >= 2);
+    constexpr int NS = prec_pieces(PREC);
+    constexpr int LDSF = SPL ? prec_lds_factor(PREC) : 2;
+    __shared__ __attribute__((aligned(16))) float As[2][BK * LDA * LDSF / 2];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB * LDSF / 2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int n = blockIdx.z / P.ncls, ci = blockIdx.z % P.ncls;
@@ -501,11 +638,23 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
         }
     };
     auto store_a = [&](const Stage& S, int buf, int q) {
-        if constexpr (F16) reinterpret_cast<_Float16*>(As[buf])[((l_p >> 2) * LDA + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.ra[q];
+        if constexpr (SPL) {
+            unsigned short c[3];
+            split_bf16<NS>(S.ra[q], c);
+            unsigned short* base = reinterpret_cast<unsigned short*>(As[buf]) + (((l_p >> 3) * LDA + l_r + q * ROWSTEP) << 3) + (l_p & 7);
+#pragma unroll
+            for (int z = 0; z < NS; ++z) base[z * 2 * LDA * 8] = c[z];
+        } else if constexpr (F16) reinterpret_cast<_Float16*>(As[buf])[((l_p >> 2) * LDA + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.ra[q];
         else As[buf][l_p * LDA + l_r + q * ROWSTEP] = S.ra[q];
     };
     auto store_b = [&](const Stage& S, int buf, int q) {
-        if constexpr (F16) reinterpret_cast<_Float16*>(Bs[buf])[((l_p >> 2) * LDB + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.rb[q];
+        if constexpr (SPL) {
+            unsigned short c[3];
+            split_bf16<NS>(S.rb[q], c);
+            unsigned short* base = reinterpret_cast<unsigned short*>(Bs[buf]) + (((l_p >> 3) * LDB + l_r + q * ROWSTEP) << 3) + (l_p & 7);
+#pragma unroll
+            for (int z = 0; z < NS; ++z) base[z * 2 * LDB * 8] = c[z];
+        } else if constexpr (F16) reinterpret_cast<_Float16*>(Bs[buf])[((l_p >> 2) * LDB + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.rb[q];
         else Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = S.rb[q];
     };
 
@@ -571,6 +720,34 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     };
     const int fr = lane & 31, fk = lane >> 5;
     auto step = [&](int s, int buf, Stage& L, const Stage& W) {
+        if constexpr (SPL) {
+            const bf16x8_t* Ab = reinterpret_cast<const bf16x8_t*>(As[buf]) + fk * LDA + wm * TM * 32 + fr;
+            const bf16x8_t* Bb = reinterpret_cast<const bf16x8_t*>(Bs[buf]) + fk * LDB + wn * TN * 32 + fr;
+            bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int z = 0; z < NS; ++z) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[i][z] = Ab[z * 2 * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[j][z] = Bb[z * 2 * LDB + j * 32];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(af[i], bf[j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) load_all(L, slab_pk(s + 2));
+                if (i == TM - 1) {
+#pragma unroll
+                    for (int q = 0; q < A_PER; ++q) store_a(W, buf ^ 1, q);
+#pragma unroll
+                    for (int q = 0; q < B_PER; ++q) store_b(W, buf ^ 1, q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            return;
+        }
         constexpr int NK = F16 ? BK / 8 : BK / 2;
         using FragT = typename std::conditional<F16, half4_t, float>::type;
         const FragT* Ab = reinterpret_cast<const FragT*>(As[buf]) + wm * TM * 32 + fr;
@@ -649,6 +826,7 @@ static int validate(const spi_conv_desc* d, const char* who) {
     SPI_REQUIRE(d->transposed == 0 || d->pad == 0, "%s: transposed mode takes padding 0", who);
     SPI_REQUIRE(d->pad >= 0 && d->pad < d->kh, "%s: bad padding", who);
     SPI_REQUIRE((int64_t)d->I * d->kh * d->kw < 65536 && (int64_t)d->O * d->kh * d->kw < 65536, "%s: channel count too large", who);
+    SPI_REQUIRE(d->compute_f16 >= 0 && d->compute_f16 <= 3, "%s: compute_f16 must be 0 (fp32 MFMA), 1 (fp16), 2 (bf16 x3 split) or 3 (bf16 x6 split)", who);
     return SPI_OK;
 }
 
@@ -729,7 +907,7 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, int nsplit, hipStream_t st, bool f16) {
+static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, int nsplit, hipStream_t st, int prec) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     int maxpix = 0;
     for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
@@ -740,9 +918,11 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
         if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
         else if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
         else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
-    } else if (f16 && buf) {
-        if (P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
-        else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, false, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
+    } else if (prec && buf && (prec == 1 || P.wsm == 1 || P.wsc == 1)) {      // split-bf16 without channels-innermost weights: exact fp32 below
+#define SPI_IG_PREC(PR) do { if (P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true, PR>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); \
+                             else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, false, PR>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); } while (0)
+        if (prec == 1) SPI_IG_PREC(1); else if (prec == 2) SPI_IG_PREC(2); else SPI_IG_PREC(3);
+#undef SPI_IG_PREC
     } else {
         if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
         else if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
@@ -750,7 +930,7 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
     }
 }
 
-static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st, bool f16 = false) {
+static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st, int f16 = 0) {
     int maxpix = 0, maxT = 0;
     for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxT = std::max(maxT, P.cls[c].taps.T); }
     auto blocks = [&](int bm, int bn) { return (int64_t)((maxpix + bn - 1) / bn) * ((P.Mo + bm - 1) / bm) * P.N * P.ncls; };
@@ -765,8 +945,10 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     static const int bm_of[5] = {32, 128, 64, 32, 64}, bn_of[5] = {128, 128, 64, 32, 256};
     const int64_t nb = blocks(bm_of[cfg], bn_of[cfg]);
     int nsplit = 1;
-    const bool f16_ok = f16 && (P.Ci % BK == 0) && (P.in_bs * 4 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31));
-    if (nb < 512 && nslab >= 8 && !f16_ok) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);      // fp16 operands: never split (one precision per call)
+    const bool f16_ok = f16 == 1 && (P.Ci % BK == 0) && (P.in_bs * 4 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31));
+    // fp16 operands: never split (one precision per call).  Split-bf16 requests on grids that need split-K run the exact fp32 kernels
+    // (the 4^2..32^2 layers: a higher precision than asked for, on a small share of the FLOPs).
+    if (nb < 512 && nslab >= 8 && !f16_ok) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);
     if (nsplit > 1) {
         hipError_t e = hipMemsetAsync(out, 0, (size_t)P.N * P.out_bs * sizeof(float), st);
         if (e != hipSuccess) { spi_set_error("conv: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
@@ -798,7 +980,7 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     IGemmParams P; make_forward(d, P);
     if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
     Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
-    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16 != 0); if (rc) return rc;
+    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_fwd");
     return SPI_OK;
 }
@@ -808,7 +990,7 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     SPI_REQUIRE(dy && w && dx, "spi_conv2d_dgrad: null tensor");
     IGemmParams P; make_dgrad(d, P);
     Epilogue ep{nullptr, nullptr, nullptr, 0, 0.f, 1.f, -1.f};
-    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16 != 0); if (rc) return rc;
+    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_dgrad");
     return SPI_OK;
 }
@@ -846,16 +1028,17 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     for (int c = 0; c < P.ncls; ++c) fastw = fastw && P.cls[c].OWp >= BK;
     const bool sparse = d->dy_seg_flags != nullptr && ppb / BK + 1 <= WG_LISTMAX && (maxpix + BK - 1) / BK <= 64 * 256;
     if (sparse) { P.seg_flags = d->dy_seg_flags; P.nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
-#define SPI_WG_LAUNCH(F16F, FASTF, SPF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, F16F, FASTF, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
-    if (BM == 32) {
-#define SPI_WG_SKINNY(F16F, SPF) hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1, F16F, false, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
-        if (sparse) { if (d->compute_f16) SPI_WG_SKINNY(true, true); else SPI_WG_SKINNY(false, true); }
-        else { if (d->compute_f16) SPI_WG_SKINNY(true, false); else SPI_WG_SKINNY(false, false); }
+#define SPI_WG_LAUNCH(PR, FASTF, SPF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, PR, FASTF, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
+#define SPI_WG_SKINNY(PR, SPF) hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1, PR, false, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
+#define SPI_WG_BY_PREC(CALL, ...) do { switch (prec) { case 1: CALL(1, __VA_ARGS__); break; case 2: CALL(2, __VA_ARGS__); break; case 3: CALL(3, __VA_ARGS__); break; \
+                                                         default: CALL(0, __VA_ARGS__); } } while (0)
+    const int prec = d->compute_f16;
+    if (BM == 32) { if (sparse) SPI_WG_BY_PREC(SPI_WG_SKINNY, true); else SPI_WG_BY_PREC(SPI_WG_SKINNY, false); }
+    else if (sparse) SPI_WG_BY_PREC(SPI_WG_LAUNCH, false, true);
+    else if (fastw) SPI_WG_BY_PREC(SPI_WG_LAUNCH, true, false);
+    else SPI_WG_BY_PREC(SPI_WG_LAUNCH, false, false);
+#undef SPI_WG_BY_PREC
 #undef SPI_WG_SKINNY
-    }
-    else if (sparse) { if (d->compute_f16) SPI_WG_LAUNCH(true, false, true); else SPI_WG_LAUNCH(false, false, true); }
-    else if (d->compute_f16) { if (fastw) SPI_WG_LAUNCH(true, true, false); else SPI_WG_LAUNCH(true, false, false); }
-    else { if (fastw) SPI_WG_LAUNCH(false, true, false); else SPI_WG_LAUNCH(false, false, false); }
 #undef SPI_WG_LAUNCH
     SPI_LAUNCH_CHECK("spi_conv2d_wgrad");
     return SPI_OK;

@@ -149,4 +149,11 @@ def conv2d(x, w, bias=None, noise=None, noise_strength=None, padding=0, transpos
         a = float(d_alpha if alpha is None else alpha)
         g = float(d_gain if gain is None else gain)
         c = float(-1 if clamp is None else clamp)
-    return _Conv2d.apply(x, w, bias, noise, noise_strength, int(padding), bool(transposed), bool(flip), act_id, a, g, c, bool(fp16), bool(sparse_grad))
+    return _Conv2d.apply(x, w, bias, noise, noise_strength, int(padding), bool(transposed), bool(flip), act_id, a, g, c, precision(fp16), bool(sparse_grad))
+
+
+def precision(fp16=False):
+    """spi_conv_desc.compute_f16 for a conv: 1 = fp16 operands (the reference's use_fp16 blocks, opt-in), else the run-wide setting
+    ``global_config.conv_precision``: 0 = exact fp32 MFMA, 2 / 3 = fp32 operands split into 2 / 3 bf16 pieces, 3 / 6 bf16 MFMAs."""
+    from ...configs import global_config
+    return 1 if fp16 else int(global_config.conv_precision)

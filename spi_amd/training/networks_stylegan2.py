@@ -178,10 +178,10 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                 assert act_id in (1, 3), 'fused epilogue of the frozen-weight path supports linear / lrelu'
                 a_, g_, c_ = float(d_alpha), float(d_gain if gain is None else gain), float(-1 if clamp is None else clamp)
             return _ModConvFrozen.apply(x, weight, styles, bias, noise, noise_strength, int(padding), False, not flip_weight, act_id, a_, g_, c_,
-                                        bool(demodulate), float(style_gain), bool(fp16), _tap_energy(weight) if demodulate else None)
+                                        bool(demodulate), float(style_gain), conv2d_mfma.precision(fp16), _tap_energy(weight) if demodulate else None)
         assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
         z = _ModConvFrozen.apply(x, weight, styles, None, None, None, 0, True, flip_weight, 0, 0.0, 1.0, -1.0, bool(demodulate),
-                                 float(style_gain), bool(fp16), _tap_energy(weight) if demodulate else None)
+                                 float(style_gain), conv2d_mfma.precision(fp16), _tap_energy(weight) if demodulate else None)
         return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
                                             padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
     w = modulate_weights(weight, styles, demodulate, style_gain)

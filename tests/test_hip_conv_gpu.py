@@ -294,3 +294,42 @@ def test_conv_forward_needed_output_region(n, i, o, h, k, transposed):
             assert_close(gw, hw, 2e-6, 'wgrad through a region forward')
     with conv2d_mfma.needed_output({(oh + 1, ow): flags}):              # other resolutions are untouched
         assert torch.equal(conv2d_mfma.conv2d(x, w, **kw), dense)
+
+
+SPLIT_CASES = [(1, 64, 128, 40, 3, 1, False, True, True), (2, 32, 48, 24, 3, 0, True, False, True), (1, 128, 128, 96, 3, 1, False, True, True),
+               (2, 16, 32, 33, 1, 0, False, False, True), (4, 128, 128, 64, 3, 1, False, True, False), (1, 256, 128, 64, 3, 0, True, False, True),
+               (1, 64, 64, 128, 3, 1, False, False, False)]
+
+
+@pytest.mark.parametrize('prec,tol', [(3, 2e-6), (2, 6e-5)])
+@pytest.mark.parametrize('case', SPLIT_CASES)
+def test_conv_split_bf16_modes_vs_fp32_reference(case, prec, tol):
+    """global_config.conv_precision = 3 / 2: fp32 operands cut into 3 / 2 bf16 pieces while they are staged in LDS, the 6 / 3 significant piece
+    products on the bf16 matrix cores with fp32 accumulation.  Against the plain fp32 convolution (CPU): the 3-piece mode holds the SAME
+    tolerance as the exact-fp32 MFMA kernels (products carry ~2^-23 relative error), the 2-piece mode ~2^-16 per product.
+    All three passes; operands scaled over 12 orders of magnitude (bf16 keeps fp32's exponent range: no underflow on tiny gradients)."""
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    from spi_amd.configs import global_config
+    N, I, O, H, k, pad, tr, flip, per = case
+    gen = torch.Generator().manual_seed(hash(case) % 1000 + prec)
+    for xs, ws, ds in ((1.0, 1.0, 1.0), (1e-6, 30.0, 1e-7)):
+        x = (torch.randn(N, I, H, H + 1, generator=gen) * xs).requires_grad_(True)
+        w = (torch.randn(*((N,) if per else ()), O, I, k, k, generator=gen) * ws / (I * k * k) ** 0.5).requires_grad_(True)
+        ref = _ref_conv(x, w, pad, tr, flip)
+        dy = torch.randn(ref.shape, generator=gen) * ds
+        gx, gw = torch.autograd.grad(ref, [x, w], dy)
+        xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+        old = global_config.conv_precision
+        global_config.conv_precision = prec
+        try:
+            y = conv2d_mfma.conv2d(xg, wg, padding=pad, transposed=tr, flip=flip)
+            hx, hw = torch.autograd.grad(y, [xg, wg], dy.to(DEV))
+            global_config.conv_precision = 0
+            y0 = conv2d_mfma.conv2d(xg, wg, padding=pad, transposed=tr, flip=flip)
+        finally:
+            global_config.conv_precision = old
+        assert_close(y, ref, tol, f'split x{prec} fwd')
+        assert_close(hx, gx, tol, f'split x{prec} dgrad')
+        assert_close(hw, gw, 10 * tol, f'split x{prec} wgrad')
+        if prec == 2 and H >= 40 and not tr:       # (grids that need split-K run the exact fp32 kernels whatever was asked for)
+            assert not torch.equal(y, y0), 'the 2-piece mode must really run different arithmetic'
