@@ -125,3 +125,68 @@ def test_synthesis_full_width_batch2_shared_w_vs_oracle():
     assert abs(lossg.item() - loss.item()) <= 1e-2 * abs(loss.item()) + 1e-6
     gg, = torch.autograd.grad(lossg, wg)
     assert_close(gg, gref, 2e-3, 'full-width N=2 grad ws')
+
+
+@pytest.mark.timeout(3000)
+def test_stage2_full_size_branch_iteration_vs_oracle():
+    """The exact instance bench.py times in stage 2, including its data-driven sparse paths: ONE RotBbox iteration with all three pseudo-view
+    branches (i % 4 == 0: rot, mirror-rot, depth; rot_bbox_cx_coach.py:68-157) at full width, 512^2, 128^2 rays, 96+96 samples, against the
+    oracle's iteration on the host cores (~100 s) with every random draw replayed: the five loss values within 1e-2 (north_star) and the
+    gradients Adam consumes -- the sum of the four backward passes, through zero-gradient ray skipping, sparse dgrad / wgrad and the
+    region-restricted super-resolution forward -- within 2e-3 (observed: 2e-6 .. 3e-5)."""
+    from oracle import losses_ref as olo, loops_ref as olp
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.criteria.bbox_cx_loss import BoxCXLoss
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.data.images_dataset import SyntheticDataset
+    from spi_amd.utils.rng import ReplayRNG
+    from spi_amd.configs import hyperparameters, paths_config
+    import tempfile
+    P, G, _, _, _, _, opts, _ = _setup(96)
+    G = G.requires_grad_(False)
+    W, W19 = olo.make_vgg16_weights(seed=0), olo.make_vgg19_head_weights(seed=1)
+    data = SyntheticDataset(1)[0]
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in data.items()}
+    w_pivot = torch.randn(1, 14, 512, generator=torch.Generator().manual_seed(6)) * 0.7
+    man = load_manifest('full')
+    pnames = [k for k in man if not (k.endswith('noise_const') or k.endswith('resample_filter') or k.endswith('w_avg'))]
+    keys = ('backbone.synthesis.b64.conv1.weight', 'backbone.synthesis.b256.conv0.weight', 'superresolution.block1.conv1.weight',
+            'superresolution.block0.conv1.affine.weight', 'decoder.net.0.weight', 'decoder.net.2.weight', 'backbone.synthesis.b256.torgb.weight',
+            'superresolution.block1.torgb.weight', 'backbone.synthesis.b16.conv1.weight')
+    st = olp.Stage2State(P, pnames)
+    mask = data['mask'].reshape(1, 1, 512, 512)
+    od = dict(img=data['img'], c=torch.as_tensor(data['c']).reshape(1, 25), lm=data['lm'].reshape(1, 68, 2),
+              face_mask=olp.face_mask_from_parsing(mask).float())
+    draws = olp.Draws()
+    torch.manual_seed(0)
+    hp = dict(olp.HP, LPIPS_value_threshold=-1.0)
+    ref = olp.stage2_iteration(st, 0, od, w_pivot, opts, lambda a, b: olo.lpips(W, a, b), lambda a, b, l: olo.box_cx_loss(W19, a, b, l), hp=hp, draws=draws)
+    assert {'l2', 'lpips', 'rot', 'mirror_rot', 'depth'} <= set(ref)
+    ref_grads = {k: st.P[k].grad.detach().clone() for k in keys}
+    tmp = tempfile.mkdtemp()
+    saved = {k: getattr(paths_config, k) for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir')}
+    hp_saved = (hyperparameters.first_inv_type, hyperparameters.G_1_type, hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda,
+                hyperparameters.pt_depth_lambda, hyperparameters.LPIPS_value_threshold)
+    try:
+        for k in saved:
+            setattr(paths_config, k, f'{tmp}/{k}/')
+        hyperparameters.first_inv_type, hyperparameters.G_1_type = 'mir', 'RotBbox'
+        hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda = 0.1, 0.05, 1.0
+        hyperparameters.LPIPS_value_threshold = -1.0
+        coach = RotBboxCoach(None, False, G=G, lpips_loss=LPIPS(weights=W), box_cx_loss=BoxCXLoss(weights=W19))
+        ctx = coach.prepare_image(data)
+        rng = ReplayRNG(draws.log, DEV)
+        got = coach.train_step(0, ctx, w_pivot.to(DEV), rng=rng)[1]
+        assert rng.pos == len(draws.log)
+        for k in ('l2', 'lpips', 'rot', 'mirror_rot', 'depth'):
+            assert abs(got[k].item() - ref[k]) <= 1e-2 * abs(ref[k]) + 1e-7, (k, got[k].item(), ref[k])
+        params = dict(coach.G.named_parameters())
+        errs = {k: rel_err(params[k].grad, ref_grads[k]) for k in keys}
+        print('full-size stage-2 branch iteration: pre-Adam gradient errors', {k: f'{v:.1e}' for k, v in errs.items()})
+        for k in keys:
+            assert errs[k] <= 2e-3, (k, errs[k])               # observed 2e-6 .. 3e-5
+    finally:
+        for k, v in saved.items():
+            setattr(paths_config, k, v)
+        (hyperparameters.first_inv_type, hyperparameters.G_1_type, hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda,
+         hyperparameters.pt_depth_lambda, hyperparameters.LPIPS_value_threshold) = hp_saved
