@@ -230,9 +230,15 @@ typedef struct spi_conv_desc {
     int flip;                 /* 1: spatially flip the kernel (true convolution)                       */
     int w_tap_major;          /* 0: weights [O, I, kh, kw] (PyTorch);  1: [O, kh, kw, I] (channels innermost:  */
                               /*    contiguous slab loads and contiguous weight-gradient writes)        */
-    int compute_f16;          /* 1: operands rounded to fp16, fp16 MFMA with fp32 accumulation (the reference's */
-                              /*    use_fp16 super-resolution blocks); tensors stay fp32 in memory.  Needs      */
-                              /*    I % 16 == 0, otherwise the fp32 kernels run                                 */
+    int compute_f16;          /* arithmetic of the three passes; tensors stay fp32 in memory, accumulation is fp32:     */
+                              /*  0: exact fp32 MFMA (v_mfma_f32_32x32x2_f32)                                            */
+                              /*  1: operands rounded to fp16, fp16 MFMA (the reference's use_fp16 super-resolution     */
+                              /*     blocks)                                                                             */
+                              /*  2 / 3: "split bf16": each fp32 operand is cut into 2 / 3 bf16 pieces when it is staged */
+                              /*     in LDS and the 3 / 6 significant piece products run on v_mfma_f32_32x32x16_bf16     */
+                              /*     (error ~2^-16 / ~2^-23 per product; bf16 keeps the fp32 exponent range)             */
+                              /*  modes 1-3 need whole 16-channel chunks (I % 16 == 0) and a grid that does not need     */
+                              /*  split-K; otherwise the exact fp32 kernels run                                          */
     int64_t w_batch_stride;   /* elements between per-sample weights; 0 = weights shared by the batch  */
     /* fused epilogue of the forward (all optional): y = clamp(act(acc + noise*noise_gain + bias)*gain) */
     const float* bias;        /* [O] */
