@@ -137,6 +137,10 @@ __device__ __forceinline__ void store_split_run(float* lds, int LD, int row, int
     }
 }
 
+// piece products in accumulation order (small terms first): NS = 3: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0); NS = 2: (1,0) (0,1) (0,0)
+template <int NS> __device__ __forceinline__ constexpr int split_pa(int pi) { return NS == 3 ? (pi == 0 ? 2 : pi == 1 ? 0 : pi == 2 ? 1 : pi == 3 ? 1 : 0) : (pi == 0 ? 1 : 0); }
+template <int NS> __device__ __forceinline__ constexpr int split_pb(int pi) { return NS == 3 ? (pi == 0 ? 0 : pi == 1 ? 2 : pi == 2 ? 1 : pi == 3 ? 0 : pi == 4 ? 1 : 0) : (pi == 1 ? 1 : 0); }
+
 // accumulate the significant piece products of one K = 16 slab for one 32x32 tile, small terms first
 template <int NS>
 __device__ __forceinline__ f32x16 mfma_split(const bf16x8_t (&a)[3], const bf16x8_t (&b)[3], f32x16 acc) {
@@ -394,20 +398,28 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j][q] = Bb[q * 2 * LDB + j * 32];
             }
+            // product-major order: consecutive MFMAs go to DIFFERENT accumulators (TM*TN of them between two MFMAs on the same one), so
+            // the dependent-accumulator latency of the matrix pipe is hidden; small products first.
+            constexpr int NP = NS * (NS + 1) / 2;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int pi = 0; pi < NP; ++pi) {
+                const int ca = split_pa<NS>(pi), cb = split_pb<NS>(pi);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(af[i], bf[j], acc[i][j]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca], bf[j][cb], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (i == 0) {
+                if (pi == 0) {
 #pragma unroll
                     for (int j = 0; j < A_PER; ++j) load_a(L, q2, j);
 #pragma unroll
                     for (int j = 0; j < B_PER; ++j) load_b(L, q2, j);
                 }
-                if (i == TM - 1) {
+                if (pi == NP / 2) {
 #pragma unroll
                     for (int j = 0; j < A_PER; ++j) store_a(W, buf ^ 1, j);
+                }
+                if (pi == NP / 2 + 1) {
 #pragma unroll
                     for (int j = 0; j < B_PER; ++j) store_b(W, buf ^ 1, j);
                 }
@@ -731,15 +743,21 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
 #pragma unroll
                 for (int j = 0; j < TN; ++j) bf[j][z] = Bb[z * 2 * LDB + j * 32];
             }
+            constexpr int NP = NS * (NS + 1) / 2;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
+            for (int pi = 0; pi < NP; ++pi) {
+                const int ca = split_pa<NS>(pi), cb = split_pb<NS>(pi);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = mfma_split<NS>(af[i], bf[j], acc[i][j]);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca], bf[j][cb], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (i == 0) load_all(L, slab_pk(s + 2));
-                if (i == TM - 1) {
+                if (pi == 0) load_all(L, slab_pk(s + 2));
+                if (pi == NP / 2) {
 #pragma unroll
                     for (int q = 0; q < A_PER; ++q) store_a(W, buf ^ 1, q);
+                }
+                if (pi == NP / 2 + 1) {
 #pragma unroll
                     for (int q = 0; q < B_PER; ++q) store_b(W, buf ^ 1, q);
                 }
@@ -942,7 +960,10 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     else if (blocks(128, 128) >= 384) cfg = 1;
     else if (P.Mo >= 64 && maxpix >= 64) cfg = 2;
     else cfg = 3;
-    static const int bm_of[5] = {32, 128, 64, 32, 64}, bn_of[5] = {128, 128, 64, 32, 256};
+    // 2-piece split-bf16: the matrix pipe is 5.3x faster, so the per-slab staging work (splitting, LDS stores) weighs more: a 128 x 256
+    // tile halves the A-operand work per MFMA (measured: +10..20 % at 256 channels; the 3-piece mode loses a third with it -- registers)
+    if (f16 == 2 && cfg == 1 && blocks(128, 256) >= 512) cfg = 5;
+    static const int bm_of[6] = {32, 128, 64, 32, 64, 128}, bn_of[6] = {128, 128, 64, 32, 256, 256};
     const int64_t nb = blocks(bm_of[cfg], bn_of[cfg]);
     int nsplit = 1;
     const bool f16_ok = f16 == 1 && (P.Ci % BK == 0) && (P.in_bs * 4 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31));
@@ -958,6 +979,7 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     case 1: launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, nsplit, st, f16); break;
     case 2: launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
     case 4: launch_igemm<1, 4, 2, 2>(P, in, w, out, ep, nsplit, st, f16); break;
+    case 5: launch_igemm<2, 2, 2, 4>(P, in, w, out, ep, nsplit, st, f16); break;
     default: launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
     }
     if (nsplit > 1 && (ep.bias || ep.noise || ep.act)) {
