@@ -61,11 +61,15 @@ class LPIPS(torch.nn.Module):
         with torch.no_grad():
             return [f.detach() for f in self.net(self._resize(y.float()))]
 
-    def forward(self, x, y=None, y_feats=None):
+    def forward(self, x, y=None, y_feats=None, sample_weights=None):
+        """``sample_weights`` (extension, [N] tensor): returns sum_i w_i * d(x_i, y_i) instead of the batch mean -- several single-image
+        LPIPS terms with their own weights (the mirror projector's `lpips(view) + lpips(mirror view) * weight_m`, mirror_projector.py:104)
+        as ONE pass through the VGG (batch 2 fills the matrix cores better than two passes of batch 1)."""
         n = x.shape[0]
         fx = self.net(self._resize(x.float()))
         fy = y_feats if y_feats is not None else self.features(y)
         loss = 0.0
         for i, (a, b) in enumerate(zip(fx, fy)):
-            loss = loss + _LpipsTail.apply(a, b, getattr(self, f'lin{i}')).sum()
-        return loss / n
+            d = _LpipsTail.apply(a, b, getattr(self, f'lin{i}'))
+            loss = loss + ((d * sample_weights).sum() if sample_weights is not None else d.sum())
+        return loss if sample_weights is not None else loss / n

@@ -19,8 +19,15 @@ def mirror_setup(target, c, lpips_func, device):
     cameras = torch.cat([c, camera_m], dim=0).to(device)
     weight_m = cal_camera_weight(camera_m)[0]
     feats, feats_m = (lpips_func.features(target), lpips_func.features(target_m)) if hasattr(lpips_func, 'features') else (None, None)
+    both = sw = None
+    from ...criteria.lpips.lpips import LPIPS
+    if feats is not None and isinstance(lpips_func, LPIPS):
+        both = [torch.cat([a, b], dim=0) for a, b in zip(feats, feats_m)]         # the two fixed targets as one batch
+        sw = torch.stack([torch.ones((), device=device), torch.as_tensor(weight_m, device=device, dtype=torch.float32).reshape(())])
 
     def dist_fn(images):
+        if both is not None:                                 # same value: lpips(view) * 1 + lpips(mirror view) * weight_m, one VGG pass
+            return lpips_func(images, y_feats=both, sample_weights=sw)
         if feats is not None:
             return lpips_func(images[:1], y_feats=feats) + lpips_func(images[1:], y_feats=feats_m) * weight_m
         return lpips_func(images[:1], target) + lpips_func(images[1:], target_m) * weight_m
