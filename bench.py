@@ -344,16 +344,26 @@ def main():
     n_ok = int(sum(rank_ok))
     alt = None
     if args.alt_conv_precision != 'none' and args.alt_conv_precision != args.conv_precision and ok and not os.environ.get('SPI_TORCH_PROFILE'):
-        # the same K steps once more with the split-bf16 convolutions (opt-in arithmetic; reported beside the benchmark value, never as it)
+        # the same K steps once more with the split-bf16 convolutions (opt-in arithmetic; reported beside the benchmark value, never as it).
+        # A failure here must not cost the benchmark line: the collectives below run on every rank either way.
         global_config.conv_precision = {'bf16x6': 3, 'bf16x3': 2}[args.alt_conv_precision]
         main_marks = dict(marks)
-        run(min(w1, 2), min(w2, 4), 25 + w1 + k1, ((w2 + k2 + 3) // 4) * 4)
+        alt_err = None
+        try:
+            run(min(w1, 2), min(w2, 4), 25 + w1 + k1, ((w2 + k2 + 3) // 4) * 4)
+        except Exception as e:                                    # noqa: BLE001
+            alt_err = repr(e)
         sdist.barrier(); torch.cuda.synchronize()
         ta = time.perf_counter()
-        run(k1, k2, 25 + w1 + k1 + 2, ((w2 + k2 + 7) // 4) * 4)
+        try:
+            if alt_err is None:
+                run(k1, k2, 25 + w1 + k1 + 2, ((w2 + k2 + 7) // 4) * 4)
+        except Exception as e:                                    # noqa: BLE001
+            alt_err = repr(e)
         torch.cuda.synchronize(); sdist.barrier()
         dta = sdist.reduce_stats([time.perf_counter() - ta], device=dev, op='max')[0]
-        alt = {'conv_precision': args.alt_conv_precision, 'value': world * args.steps / dta, 'unit': 'iters/s', 'ms_per_step': dta / args.steps * 1e3,
+        bad = sdist.reduce_stats([0.0 if alt_err is None else 1.0], device=dev)[0]
+        alt = {'conv_precision': args.alt_conv_precision, 'error': alt_err or 'failed on another rank'} if bad else {'conv_precision': args.alt_conv_precision, 'value': world * args.steps / dta, 'unit': 'iters/s', 'ms_per_step': dta / args.steps * 1e3,
                'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
                'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
                'note': 'same K steps, dense convs with fp32 operands split into bf16 pieces on the bf16 matrix cores (fp32 accumulate); '
@@ -417,7 +427,10 @@ def main():
         if alt is not None:
             out['alt'] = alt
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, k1, k2)
+            try:
+                out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, k1, k2)
+            except Exception as e:                                # noqa: BLE001  (a host-side failure must not lose the GPU measurement)
+                out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)
     sdist.shutdown()                                             # ranks leave together (rank 0 is still timing its roofline lines)
     if n_ok != world:
