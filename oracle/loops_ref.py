@@ -19,7 +19,7 @@ import torch.nn.functional as F
 from . import renderer_ref as rr
 from . import losses_ref as lo
 from . import stylegan_ref as sg
-from spi_amd.utils import camera_utils as cu      # host-side geometry (pinned against the reference directly)
+from . import camera_ref as cu                     # independent restatement, pinned against the reference's outputs (golden/geometry.npz)
 
 
 class Draws:

@@ -110,6 +110,20 @@ def test_camera_utils_golden(golden):
     assert torch.equal(calculate_face_mask(g['parsing']), g['face_mask'])
 
 
+def test_oracle_camera_restatement_golden(golden):
+    """oracle/camera_ref.py (what the oracle loops use; written independently of the product's camera_utils) against the reference's outputs."""
+    from oracle import camera_ref as ocr
+    g = golden('geometry')
+    cams = g['canon']
+    assert torch.equal(ocr.cal_mirror_c(cams), g['mirror'])
+    assert_close(ocr.cal_camera_weight(cams), g['weight'], 1e-6, 'oracle cal_camera_weight')
+    assert_close(ocr.cal_camera_weight(g['mirror']), g['weight_m'], 1e-6, 'oracle mirror weight')
+    assert_close(ocr.sample_surrounding_camera(cams[1:2], 4, 0.2, 0.1, rand=(g['sur_r0'], g['sur_r1'])), g['sur'], 1e-6, 'oracle surrounding')
+    assert_close(ocr.sample_camera(4, 0.7, 0.4, rand=(g['sc_r0'], g['sc_r1'])), g['sc'], 1e-6, 'oracle sample_camera')
+    src = open(os.path.join(ROOT, 'oracle', 'loops_ref.py')).read() + open(os.path.join(ROOT, 'oracle', 'camera_ref.py')).read()
+    assert 'spi_amd' not in src.replace('spi_amd/utils/camera_utils.py', '')        # the oracle loops no longer import the product
+
+
 def test_oracle_rotate_golden(golden):
     g = golden('geometry')
     rgb, m = olo.rotate(g['sur'][:2], g['rot_tdepth'], g['rot_img'], g['canon'][1:2].repeat(2, 1), g['rot_sdepth'], g['rot_msk'], EPS=5e-2)
