@@ -156,3 +156,85 @@ def test_cli_spi_mir_rotbbox_full_size(tmp_path, capsys, depth, fp16):
         assert first[-1]['l2'] < 0.5 * first[0]['l2'] and seen[-1]['l2'] < 0.5 * seen[0]['l2']
         for a, b in zip(first, seen):
             assert abs(a['l2'] - b['l2']) <= 0.25 * abs(b['l2']), (a['l2'], b['l2'])
+
+
+def test_cli_two_images_restart_between_images(tmp_path, capsys):
+    """Two images in one run (base_coach.py:53-60 `restart_training` per image): each image gets its own checkpoint / embedding / picture,
+    the generator is restored from the frozen original before the second image (its W+ start and its first loss do not depend on the first
+    image's fine-tuning), iterations are summed over images."""
+    from spi_amd import run_inversion
+    from spi_amd.configs import hyperparameters as hp
+    from spi_amd.training.coaches import pti_coach as pc
+    out = str(tmp_path) + '/'
+    hp.LPIPS_value_threshold = -1.0
+    hp.log_video = False
+    first_losses = []
+    orig = pc.SingleIDCoach.train_step
+
+    def spy(self, *a, **k):
+        stop, losses = orig(self, *a, **k)
+        first_losses.append(float(losses['loss']))
+        return stop, losses
+    pc.SingleIDCoach.train_step = spy
+    try:
+        args = ['--output_root', out, '--synthetic', '2', '--not_use_wandb', '--depth_resolution', '12', '--depth_resolution_importance', '12',
+                '--first_inv_type', 'sgw+', '--first_inv_steps', '2', '--G_1_type', 'pti', '--G_1_step', '3']
+        run_inversion.run(args)
+        a = list(first_losses)
+        first_losses.clear()
+        run_inversion.run(args[:3] + ['1'] + args[4:] + ['--output_root', out + 'solo/'])      # image 0 alone
+        b = list(first_losses)
+    finally:
+        pc.SingleIDCoach.train_step = orig
+        del hp.log_video
+    stats = [json.loads(l) for l in capsys.readouterr().out.splitlines() if l.startswith('{')]
+    assert stats[0]['images'] == 2 and stats[0]['iterations'] == 2 * (2 + 3)
+    coach = 'PTI_coach_sgw+_2_pti_3_rot_0_mirrorrot_0_depth_0_tv_0'
+    assert sorted(os.listdir(os.path.join(out, 'checkpoints', coach))) == ['synthetic_00000.pt', 'synthetic_00001.pt']
+    assert sorted(os.listdir(os.path.join(out, 'image', coach))) == ['synthetic_00000.jpg', 'synthetic_00001.jpg']
+    assert len(a) == 6 and len(b) == 3
+    # image 0 behaves the same alone and as the first of two; image 1 starts from the ORIGINAL generator: its first loss is of the size
+    # of image 0's first loss (a generator already fine-tuned on image 0 for 3 steps would not be -- both targets are independent noise)
+    assert all(abs(x - y) <= 1e-3 * abs(y) for x, y in zip(a[:3], b))
+    assert a[0] > a[2] and a[3] > a[5] and abs(a[3] - a[0]) < 0.2 * a[0]
+    ck0 = torch.load(os.path.join(out, 'checkpoints', coach, 'synthetic_00000.pt'), map_location='cpu')
+    ck1 = torch.load(os.path.join(out, 'checkpoints', coach, 'synthetic_00001.pt'), map_location='cpu')
+    k = 'superresolution.block1.conv1.weight'
+    assert not torch.equal(ck0['G'][k], ck1['G'][k]) and not torch.equal(ck0['w'], ck1['w'])
+
+
+def test_coach_reads_pretrained_weight_files(tmp_path):
+    """A run WITHOUT --synthetic: the coaches read torchvision / LPIPS weight files through paths_config (criteria/weights.py) and the losses
+    they build equal the ones built from the same tensors directly."""
+    from oracle import losses_ref as olo
+    from spi_amd.configs import paths_config, global_config, hyperparameters as hp
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.utils import load_utils
+    W, W19 = olo.make_vgg16_weights(seed=3), olo.make_vgg19_head_weights(seed=4)
+    idx16 = [0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28]
+    sd16 = {}
+    for i, (w, b) in zip(idx16, W['convs']):
+        sd16[f'features.{i}.weight'], sd16[f'features.{i}.bias'] = w, b
+    sd19 = {}
+    for i, (w, b) in zip([0, 2, 5], W19):
+        sd19[f'features.{i}.weight'], sd19[f'features.{i}.bias'] = w, b
+    paths_config.VGG16_PATH, paths_config.VGG19_PATH, paths_config.LPIPS_PATH = (str(tmp_path / n) for n in ('v16.pth', 'v19.pth', 'lp.pth'))
+    torch.save(sd16, paths_config.VGG16_PATH); torch.save(sd19, paths_config.VGG19_PATH)
+    torch.save({f'lin{i}.model.1.weight': l for i, l in enumerate(W['lins'])}, paths_config.LPIPS_PATH)
+    global_config.synthetic_weights = False
+    hp.first_inv_type, hp.G_1_type = 'mir', 'RotBbox'
+    for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
+        setattr(paths_config, k, f'{tmp_path}/{k}/')
+    G = load_utils.load_eg3d(device='cuda:0', synthetic=True)
+    coach = RotBboxCoach(None, False, G=G)
+    g = torch.Generator().manual_seed(0)
+    a, b = (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).cuda(), (torch.rand(1, 3, 512, 512, generator=g) * 2 - 1).cuda()
+    ref = LPIPS(weights=W).cuda()(a, b)
+    assert abs(float(coach.lpips_loss(a, b)) - float(ref)) <= 1e-6 * abs(float(ref))
+    with torch.no_grad():
+        cpu = olo.lpips(W, a.cpu(), b.cpu())
+    assert abs(float(ref) - float(cpu)) <= 1e-3 * abs(float(cpu))
+    sg = coach._sg_vgg16()
+    d = (sg((a + 1) * 127.5) - sg((b + 1) * 127.5)).square().sum()
+    assert d.item() > 0 and torch.isfinite(d)
