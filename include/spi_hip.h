@@ -162,11 +162,12 @@ int spi_bias_act(const float* x, const float* b, const float* xref, const float*
  * networks_stylegan2.py:320-329) in ONE pass over dy [N,C,HW]:
  *   dz      = dy * d y/d z                (act in {linear, relu, lrelu}; y = saved output; y = NULL: dz = dy, dz may be NULL)
  *   d_bias[c]   += sum_{n,hw} dz           (NULL to skip; CALLER zeroes)
- *   d_pixsum[hw] += sum_{n,c} dz           (NULL to skip; CALLER zeroes; d_noise = d_pixsum * strength,
- *                                           d_strength = sum(d_pixsum * noise))
+ *   d_pixsum[hw] += sum_{n,c} dz           (NULL to skip; CALLER zeroes; d_noise = d_pixsum * strength)
+ *   d_strength[0] += sum_hw d_pixsum[hw] * noise[hw]   (noise [HW] and d_strength together, NULL to skip; needs d_pixsum; CALLER zeroes)
  * replaces bias_act(grad=1) + two full-tensor torch reductions of the reference's autograd graph. */
-int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, int N, int C,
-                 int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream);
+int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, const float* noise,
+                 float* d_strength, int N, int C, int64_t HW, int act, float alpha, float gain, float clamp,
+                 spi_stream_t stream);
 
 /* out[r] += sum_p a[r,p] * b'[r,p] for r < rows (= N*C), p < HW  (out: CALLER zeroes).  With act != 0, b is a layer
  * OUTPUT y = clamp(act(z + noise*noise_gain + bias)*gain) and b' is the reconstructed conv result z (act in {linear,

@@ -117,7 +117,8 @@ __global__ void bias_act_kernel(const float* __restrict__ x, const float* __rest
 template <int PX>
 __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                        float* __restrict__ dz, float* __restrict__ d_bias,
-                                                       float* __restrict__ d_pixsum, int N, int C, int64_t HW, int cchunk,
+                                                       float* __restrict__ d_pixsum, const float* __restrict__ noise,
+                                                       float* __restrict__ d_strength, int N, int C, int64_t HW, int cchunk,
                                                        ActParams ap) {
     __shared__ float bpart[512][4];                        // per-channel wave partials of this block (host keeps cchunk <= 512)
     const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
@@ -126,44 +127,67 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
     float pix[PX];
 #pragma unroll
     for (int j = 0; j < PX; ++j) pix[j] = 0.f;
-    for (int c = c_beg; c < c_end; ++c) {
-        float bsum = 0.f;
-        for (int n = 0; n < N; ++n) {
-            const int64_t off = ((int64_t)n * C + c) * HW + p0;
-            float g[PX], yy[PX];
+    // (n, c) pairs of the chunk are walked UN at a time with all 2*UN loads issued before the first use: with the per-pixel sums
+    // wanted the grid is small (every channel split costs one same-address atomic per pixel), so the memory-level parallelism has to
+    // come from inside the thread -- one pair at a time ran at 2.9 TB/s on the 512^2 layers.
+    constexpr int UN = 4;
+    const int npair = (c_end - c_beg) * N;
+    float bsum = 0.f;
+    int cur_c = c_beg;
+    for (int q0 = 0; q0 < npair; q0 += UN) {
+        float g[UN][PX], yy[UN][PX];
+        int64_t off[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int q = min(q0 + u, npair - 1);
+            const int c = c_beg + q / N, n = q - (q / N) * N;
+            off[u] = ((int64_t)n * C + c) * HW + p0;
             if (ok) {
                 if (PX == 4) {
-                    const f32x4_t g4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dy + off));      // dy and y are read once
-                    g[0] = g4.x; g[1] = g4.y; g[2] = g4.z; g[3] = g4.w;
-                    if (y) { const f32x4_t y4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(y + off)); yy[0] = y4.x; yy[1] = y4.y; yy[2] = y4.z; yy[3] = y4.w; }
-                } else { g[0] = dy[off]; if (y) yy[0] = y[off]; }
+                    const f32x4_t g4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dy + off[u]));      // dy and y are read once
+                    g[u][0] = g4.x; g[u][1] = g4.y; g[u][2] = g4.z; g[u][3] = g4.w;
+                    if (y) { const f32x4_t y4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(y + off[u])); yy[u][0] = y4.x; yy[u][1] = y4.y; yy[u][2] = y4.z; yy[u][3] = y4.w; }
+                } else { g[u][0] = dy[off[u]]; if (y) yy[u][0] = y[off[u]]; }
             } else {
 #pragma unroll
-                for (int j = 0; j < PX; ++j) g[j] = 0.f;
+                for (int j = 0; j < PX; ++j) g[u][j] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int q = q0 + u;
+            if (q >= npair) break;
+            const int c = c_beg + q / N;
+            if (c != cur_c) {                                  // channel finished: its wave partial goes to LDS
+                if (d_bias) {
+                    const float bs = wave_sum(bsum);
+                    if ((threadIdx.x & 63) == 0) bpart[cur_c - c_beg][threadIdx.x >> 6] = bs;
+                }
+                bsum = 0.f; cur_c = c;
             }
             if (y && ok) {
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    const float pre = yy[j] / ap.gain;                         // activation output before the gain (as bias_act grad=1)
-                    float v = g[j];
+                    const float pre = yy[u][j] / ap.gain;                      // activation output before the gain (as bias_act grad=1)
+                    float v = g[u][j];
                     if (ap.act == SPI_ACT_RELU) v = pre > 0.f ? v : 0.f;
                     else if (ap.act == SPI_ACT_LRELU) v = pre > 0.f ? v : v * ap.alpha;
                     v *= ap.gain;
-                    if (ap.clamp >= 0.f) v = (yy[j] > -ap.clamp && yy[j] < ap.clamp) ? v : 0.f;
-                    g[j] = v;
+                    if (ap.clamp >= 0.f) v = (yy[u][j] > -ap.clamp && yy[u][j] < ap.clamp) ? v : 0.f;
+                    g[u][j] = v;
                 }
                 if (dz) {
-                    if (PX == 4) *reinterpret_cast<float4*>(dz + off) = make_float4(g[0], g[1], g[2], g[3]);
-                    else dz[off] = g[0];
+                    if (PX == 4) *reinterpret_cast<float4*>(dz + off[u]) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
+                    else dz[off[u]] = g[u][0];
                 }
             }
 #pragma unroll
-            for (int j = 0; j < PX; ++j) { pix[j] += g[j]; bsum += g[j]; }
+            for (int j = 0; j < PX; ++j) { pix[j] += g[u][j]; bsum += g[u][j]; }
         }
-        if (d_bias) {
-            bsum = wave_sum(bsum);
-            if ((threadIdx.x & 63) == 0) bpart[c - c_beg][threadIdx.x >> 6] = bsum;
-        }
+    }
+    if (d_bias && npair > 0) {
+        const float bs = wave_sum(bsum);
+        if ((threadIdx.x & 63) == 0) bpart[cur_c - c_beg][threadIdx.x >> 6] = bs;
     }
     if (d_bias) {                                          // one global atomic per channel per block, issued by different lanes
         __syncthreads();
@@ -178,6 +202,18 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
             if (gridDim.y == 1) d_pixsum[p0 + j] = pix[j];
             else atomicAdd(d_pixsum + p0 + j, pix[j]);
         }
+    }
+    if (d_strength) {                                      // sum_p pixsum[p] * noise[p] is linear in the blocks' partial pixel sums: one atomic per block
+        float sn = 0.f;
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) sn = fmaf(pix[j], noise[p0 + j], sn);
+        }
+        sn = wave_sum(sn);
+        __shared__ float spart[4];
+        if ((threadIdx.x & 63) == 0) spart[threadIdx.x >> 6] = sn;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(d_strength, (spart[0] + spart[1]) + (spart[2] + spart[3]));
     }
 }
 
@@ -919,21 +955,24 @@ static int launch_upfirdn(const float* x, const float* f, float* y, const Upfird
     return SPI_OK;
 }
 
-int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, int N, int C, int64_t HW,
-                 int act, float alpha, float gain, float clamp, spi_stream_t stream) {
+int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
+                 int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream) {
     SPI_REQUIRE(dy && N > 0 && C > 0 && HW > 0, "spi_tail_bwd: bad argument");
+    SPI_REQUIRE(!d_strength || (noise && d_pixsum), "spi_tail_bwd: d_strength needs noise and d_pixsum");
     SPI_REQUIRE(!y || (act >= SPI_ACT_LINEAR && act <= SPI_ACT_LRELU && gain != 0.f), "spi_tail_bwd: activation must be linear / relu / lrelu");
     SPI_REQUIRE(y || !dz, "spi_tail_bwd: dz without a saved output (dz == dy)");
     ActParams ap{act, 1, alpha, gain, clamp};
     const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz)) % 16 == 0);
     const int64_t per_block = vec ? 1024 : 256;
     const unsigned gx = (unsigned)ceil_div64(HW, per_block);
-    // channel splits: enough blocks to spread the work, but every split adds one same-address atomic per pixel to d_pixsum
-    int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, (d_pixsum ? 128 : 1024) / gx));
+    // channel splits: enough blocks (~1024) to fill 256 CUs.  With the per-pixel sums every split adds ONE atomic per pixel address (HW * splits
+    // atomics in all, each address touched `splits` times over the whole kernel: no hot spot) -- capped at 16.  (Until round 2 the cap was
+    // 128 / gx, i.e. 128-256 blocks on the 256^2 / 512^2 layers: 1.3-2.8 TB/s against 4.1-5.6 without the sums.)
+    int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? 16 : 1024)));
     const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
     splits = (C + cchunk - 1) / cchunk;
-    if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);
-    else hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, N, C, HW, cchunk, ap);
+    if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
+    else hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
     SPI_LAUNCH_CHECK("spi_tail_bwd");
     return SPI_OK;
 }

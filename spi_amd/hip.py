@@ -53,7 +53,7 @@ _SIGS = {
     'spi_conv2d_wgrad': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
     'spi_rotate_warp': ([c_p] * 7 + [c_i, c_i, c_i, c_f, c_p, c_p, c_p], c_i),
     'spi_chan_dot': ([c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_i, c_f, c_f, c_p], c_i),
-    'spi_tail_bwd': ([c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_p], c_i),
+    'spi_tail_bwd': ([c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_modulate_fwd': ([c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p], c_i),
     'spi_modulate_bwd': ([c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p], c_i),
     'spi_noise_reg_fwd': ([c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p], c_i),

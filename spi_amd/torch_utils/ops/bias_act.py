@@ -37,7 +37,7 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
 def tail_zero_elems(dy, noise, need_noise, need_strength, need_bias):
     """floats of zeroed scratch tail_backward needs for this call (its caller may provide them as ``zero_buf``)"""
     want_pix = noise is not None and (need_noise or need_strength)
-    return (dy.shape[1] if need_bias else 0) + (dy[0, 0].numel() if want_pix else 0)
+    return (dy.shape[1] if need_bias else 0) + (dy[0, 0].numel() if want_pix else 0) + (1 if (noise is not None and need_strength) else 0)
 
 
 def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise, need_strength, need_bias, zero_buf=None):
@@ -51,19 +51,22 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
     if y is None and not want_pix and not need_bias:
         return dy, None, None, None
     dz = torch.empty_like(dy) if y is not None else None
+    want_s = want_pix and need_strength
     if zero_buf is None:
-        zero_buf = torch.zeros((c if need_bias else 0) + (hw if want_pix else 0), device=dy.device, dtype=torch.float32)
+        zero_buf = torch.zeros((c if need_bias else 0) + (hw if want_pix else 0) + (1 if want_s else 0), device=dy.device, dtype=torch.float32)
     nb = c if need_bias else 0
     d_bias = zero_buf[:nb] if need_bias else None
     pix = zero_buf[nb:nb + hw].view(dy.shape[2:]) if want_pix else None
-    hip.call('spi_tail_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), n, c, hw, act_id, alpha, gain, clamp,
-             hip.stream())
+    ds = zero_buf[nb + hw:nb + hw + 1] if want_s else None             # sum_hw pixsum * noise comes out of the same launch
+    nzc = noise.contiguous().float() if want_s else None
+    hip.call('spi_tail_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), hip.ptr(nzc), hip.ptr(ds), n, c, hw, act_id, alpha,
+             gain, clamp, hip.stream())
     d_noise = d_strength = None
     if want_pix:
         if need_noise:
             d_noise = pix * strength if strength is not None else pix
         if need_strength:
-            d_strength = (pix * noise).sum().reshape(())
+            d_strength = ds.reshape(())
     return (dz if dz is not None else dy), d_noise, d_strength, d_bias
 
 
