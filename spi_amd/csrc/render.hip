@@ -559,9 +559,12 @@ struct TiledArgs {
 template <bool WGRAD, bool RGB>
 __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ frag_g, const float* __restrict__ b1_g,
                                                                  const float* __restrict__ b2_g, const float* __restrict__ d_rgb,
-                                                                 const float* __restrict__ d_rgb_scale,
+                                                                 const float* __restrict__ d_rgb_scale, const float* __restrict__ colors,
                                                                  const float* __restrict__ d_sigma, float* __restrict__ d_planes,
                                                                  float* __restrict__ part) {
+    // colors != NULL: the forward's colour rows [R*S, 32] (= sigmoid(y) * 1.002 - 0.001).  The sigmoid the colour layer's derivative needs is
+    // read back from them instead of recomputing the layer's pre-activations: 32 of the 130 MFMAs per 32 points disappear (64 of 292 with
+    // weight gradients) for one 128-byte row per point.
     // d_rgb_scale == NULL: d_rgb is the materialised per-sample gradient [R*S, 32].  Otherwise the gradient of sample row i of
     // ray r is d_rgb[r][:] * d_rgb_scale[i] (what the ray marcher's backward produces: a per-ray vector times a per-sample
     // scalar); the 2 MB per-ray array stays in L2 and the 128 B per point of gradient traffic disappears.
@@ -700,7 +703,19 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 dr2[r] = prow2 >= 0 ? v : 0.f;
             }
         }
-        if (RGB) {
+        if (RGB && colors) {
+            // sigmoid from the saved colour rows: (c + 0.001) / 1.002, in both orientations (the same addressing as the gradient rows)
+            const float4* crp = reinterpret_cast<const float4*>(colors + (int64_t)max(myrow, 0) * DEC_IN + 4 * hh_);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 c4 = crp[2 * g];
+                Y1[4 * g] = c4.x; Y1[4 * g + 1] = c4.y; Y1[4 * g + 2] = c4.z; Y1[4 * g + 3] = c4.w;
+            }
+            if (WGRAD) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y2[r] = colors[(int64_t)max(s_row[pbase + rowmap(r, hh_)], 0) * DEC_IN + q_];
+            }
+        } else if (RGB) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Y1[r] = b2[1 + rowmap(r, hh_)]; Y2[r] = b2[1 + q_]; }
 #pragma unroll
@@ -713,14 +728,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
             }
         }
         // dY = d_rgb * d(sigmoid * 1.002 - 0.001)
+        const bool saved = colors != nullptr;
 #pragma unroll
         for (int r = 0; RGB && r < 16; ++r) {
-            const float sg = sigmoid_fast(Y1[r]);
+            const float sg = saved ? (Y1[r] + 0.001f) * (1.f / 1.002f) : sigmoid_fast(Y1[r]);
             const float4 d4 = dr[r >> 2];
             const float dv1 = (r & 3) == 0 ? d4.x : ((r & 3) == 1 ? d4.y : ((r & 3) == 2 ? d4.z : d4.w));      // channel rowmap(r,hh_) = (r&3) + 8(r>>2) + 4hh
             Y1[r] = dv1 * 1.002f * sg * (1.f - sg);
             if (WGRAD) {
-                const float sg2 = sigmoid_fast(Y2[r]);
+                const float sg2 = saved ? (Y2[r] + 0.001f) * (1.f / 1.002f) : sigmoid_fast(Y2[r]);
                 Y2[r] = dr2[r] * 1.002f * sg2 * (1.f - sg2);
             }
         }
@@ -1588,7 +1604,7 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
 
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d, const float* depths_sorted,
                                    const int32_t* perm, const float* w1t, const float* b1, const float* w2, const float* b2,
-                                   const float* d_rgb, const float* d_rgb_scale, const float* d_sigma, int N, int M, int S, int ray_w,
+                                   const float* d_rgb, const float* d_rgb_scale, const float* colors, const float* d_sigma, int N, int M, int S, int ray_w,
                                    int H, int W, float box_warp, float* d_planes_nhwc, float* workspace, float* dw1, float* db1,
                                    float* dw2, float* db2, const int32_t* ray_active, spi_stream_t stream) {
     SPI_REQUIRE(planes_nhwc && ray_o && ray_d && depths_sorted && w1t && b1 && w2 && b2 && d_sigma && d_planes_nhwc && workspace,
@@ -1619,7 +1635,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     hipLaunchKernelGGL(bin_points_kernel, dim3((unsigned)(N * a.patches)), dim3(256), 0, st, depths_sorted, ray_active, M, S, ray_w, a.patch2d,
                        a.patches, order, count);
     hipLaunchKernelGGL(decoder_frag_kernel, dim3(9), dim3(1024), 0, st, w1t, w2, frag);
-#define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, d_sigma, d_planes_nhwc, part)
+#define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, colors, d_sigma, d_planes_nhwc, part)
     if (wgrad) {
         if (d_rgb) SPI_BWD_LAUNCH(true, true); else SPI_BWD_LAUNCH(true, false);
         hipMemsetAsync(dw1, 0, 64 * 32 * sizeof(float), st); hipMemsetAsync(db1, 0, 64 * sizeof(float), st);

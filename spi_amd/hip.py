@@ -34,7 +34,7 @@ _SIGS = {
     'spi_nhwc_to_nchw': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     'spi_triplane_decode_fwd': ([c_p] * 9 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_triplane_decode_bwd': ([c_p] * 11 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
-    'spi_triplane_decode_bwd_sorted': ([c_p] * 12 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f] + [c_p] * 8, c_i),
+    'spi_triplane_decode_bwd_sorted': ([c_p] * 13 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f] + [c_p] * 8, c_i),
     'spi_triplane_decode_bwd_sorted_ws': ([c_i, c_i, c_i, c_i], c_l),
     'spi_decoder_wgrad': ([c_p, c_l, c_p, c_p, c_p, c_p, c_p], c_i),
     'spi_minmax': ([c_p, c_l, c_p, c_p], c_i),

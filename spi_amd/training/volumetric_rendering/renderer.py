@@ -218,7 +218,7 @@ class _Render(torch.autograd.Function):
         if want_w:                               # decoder weight gradients come out of the same kernel (no activation dump)
             gw = (torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev))
         hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes_nhwc), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(d_all), hip.ptr(perm),
-                 hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), hip.ptr(d_cs), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
+                 hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), hip.ptr(d_cs), hip.ptr(rgb_all if d_rgb is not None else None), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
                  hip.ptr(d_planes), hip.ptr(ws), *([hip.ptr(g) for g in gw] if want_w else [None] * 4), hip.ptr(active), hip.stream())
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None

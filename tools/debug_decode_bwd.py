@@ -33,7 +33,7 @@ for wgrad in (False, True):
     ws = torch.empty(hip.lib().spi_triplane_decode_bwd_sorted_ws(N, M, S, res), device=dev)
     gw = [torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev)]
     hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(depths), None, hip.ptr(w1t), hip.ptr(b1),
-             hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), None, hip.ptr(d_sig), N, M, S, res, H, H, 1.0, hip.ptr(dp), hip.ptr(ws),
+             hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), None, None, hip.ptr(d_sig), N, M, S, res, H, H, 1.0, hip.ptr(dp), hip.ptr(ws),
              *([hip.ptr(g) for g in gw] if wgrad else [None] * 4), None, hip.stream())
     torch.cuda.synchronize()
     e = (dp - dp_ref).abs()
