@@ -27,7 +27,8 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 2   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale */
+#define SPI_ABI_VERSION 3   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+                             * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -260,10 +261,18 @@ typedef struct spi_conv_desc {
     const int32_t* out_seg_flags;
     int dw_zeroed;            /* spi_conv2d_wgrad only: 1 = the caller already zeroed dw (saves the memset launch when dw is a slice of
                                * a buffer that was cleared together with other small gradients) */
+    /* optional scratch memory (device, 16-byte aligned).  With at least spi_conv2d_workspace_bytes(d, pass) bytes the 3x3 / stride-1 /
+     * pad-1 forward and data-gradient passes of large layers run as Winograd F(2x2, 3x3) -- fp32 operands, fp32 accumulation, 2.25x fewer
+     * MFMAs; the result differs from the direct sum by a few fp32 roundings (what cuDNN runs for the reference's fp32 3x3 convs).
+     * NULL / too small: the implicit-GEMM kernels run.  The workspace holds the transformed weights of THIS call only. */
+    void* workspace;
+    int64_t workspace_bytes;
 } spi_conv_desc;
 /* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
  * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).
  * output size: stride-1: H + 2*pad - kh + 1;  transposed: 2*H + kh - 2  (= 2H+1 for 3x3).          */
+/* bytes of workspace with which pass (0 forward, 1 dgrad, 2 wgrad) takes its Winograd path; 0 = the pass has none for this shape */
+int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass);
 int spi_conv2d_fwd  (const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream);
 int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, float* dx, spi_stream_t stream);
 /* dw has the layout/batching of w; with shared weights the batch is summed. */

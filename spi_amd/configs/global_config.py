@@ -35,3 +35,7 @@ conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[os.environ.get('SPI_CONV_P
 # data-driven skipping of exactly-zero gradients / unneeded super-resolution tiles in the masked pseudo-view branches.
 # Results are equal either way (tested); False = dense bound: every ray, gradient segment and SR tile is processed (`bench.py --dense`).
 exploit_sparsity = True
+
+# Winograd F(2x2, 3x3) for the 3x3 / stride-1 forward and data-gradient passes of the large layers (winograd.hip): fp32 operands and
+# accumulation, 2.25x fewer MFMAs; results differ from the direct sums by a few fp32 roundings.  Off = implicit GEMM everywhere.
+conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'

@@ -9,7 +9,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ['elementwise.hip', 'render.hip', 'conv.hip']
+SOURCES = ['elementwise.hip', 'render.hip', 'conv.hip', 'winograd.hip']
+# winograd.hip keeps its 256 accumulators per lane in AGPRs (the other 256 registers hold operands and the loaders' state)
+NO_VGPR_FORM = {'winograd.hip'}
 LIB = os.path.join(HERE, 'libspi_hip.so')
 STAMP = os.path.join(HERE, '.build_stamp')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wno-comment',
@@ -37,7 +39,8 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(HERE, src.replace('.hip', '.o'))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ['-c', os.path.join(HERE, src), '-o', obj]
+        flags = [f for f in FLAGS if not (src in NO_VGPR_FORM and f in ('-mllvm', '-amdgpu-mfma-vgpr-form=1'))]
+        cmd = [hipcc] + flags + ['-c', os.path.join(HERE, src), '-o', obj]
         if verbose:
             print('[spi_amd build]', ' '.join(cmd), flush=True)
         procs.append(subprocess.Popen(cmd))

@@ -23,6 +23,27 @@ void spi_set_error(const char* fmt, ...);
         }                                                                               \
     } while (0)
 
+// fused forward epilogue of the convolutions: y = clamp(act(acc + noise * noise_gain + bias) * gain)
+struct Epilogue { const float* bias; const float* noise; const float* noise_gain; int act; float alpha, gain, clamp; };
+typedef Epilogue WinoEpilogue;
+
+// Winograd F(2x2, 3x3) problem (winograd.hip): stride 1, pad 1, output H x W
+struct WinoParams {
+    int N, nw;                    // batch; number of weight sets (N with per-sample weights, else 1)
+    int Mo, Ci, H, W;
+    int bx, by;                   // 16 x 16-pixel blocks per row / column
+    int ocp;                      // Mo rounded up to 64 (rows of the transformed weights)
+    int64_t in_bs, out_bs, wbs, u_bs;
+    int wsm, wsc, widx[9];        // weight addressing: w[n*wbs + m*wsm + c*wsc + widx[(dy+1)*3 + (dx+1)]]
+    const int32_t* seg_flags;     // dgrad: zero-segment map of the gradient operand (or NULL)
+    const int32_t* out_flags;     // forward: needed-output map (or NULL)
+    int nseg;
+    int64_t u_bs_of() const { return (int64_t)16 * Ci * ocp; }      // floats of one transformed weight set
+};
+int64_t spi_wino_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));
+int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const Epilogue& ep, void* workspace, hipStream_t st)
+    __attribute__((visibility("hidden")));
+
 static inline hipStream_t as_stream(spi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -53,8 +53,6 @@ __device__ __forceinline__ void split_k(int k, int T, unsigned magic, int& c, in
     else { c = (int)__umulhi((unsigned)k, magic); t = k - c * T; }
 }
 
-struct Epilogue { const float* bias; const float* noise; const float* noise_gain; int act; float alpha, gain, clamp; };
-
 __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
     switch (e.act) {
     case SPI_ACT_LINEAR: break;
@@ -990,7 +988,32 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     return SPI_OK;
 }
 
+// Winograd eligibility of a forward / dgrad problem: 3x3, stride 1, pad 1, exact fp32, whole 8-channel slabs, and enough 16 x 16 x 64
+// blocks to fill the 256 CUs once (smaller layers keep the implicit GEMM, whose split-K fills the chip).
+static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
+    if (d->transposed || d->kh != 3 || d->pad != 1 || d->compute_f16 != 0 || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
+    if (P.Ci % 8 != 0 || P.in_bs * 4 >= (1ll << 31) || P.IH != P.OH || P.IW != P.OW) return false;
+    Wp.N = P.N; Wp.nw = d->w_batch_stride ? P.N : 1; Wp.Mo = P.Mo; Wp.Ci = P.Ci; Wp.H = P.OH; Wp.W = P.OW;
+    Wp.bx = (P.OW + 15) / 16; Wp.by = (P.OH + 15) / 16; Wp.ocp = (P.Mo + 63) / 64 * 64;
+    Wp.in_bs = P.in_bs; Wp.out_bs = P.out_bs; Wp.wbs = P.wbs; Wp.u_bs = 0; Wp.wsm = P.wsm; Wp.wsc = P.wsc;
+    const TapSet& T = P.cls[0].taps;
+    for (int t = 0; t < 9; ++t) {
+        if (T.dy[t] < -1 || T.dy[t] > 1 || T.dx[t] < -1 || T.dx[t] > 1) return false;
+        Wp.widx[(T.dy[t] + 1) * 3 + (T.dx[t] + 1)] = T.widx[t];
+    }
+    Wp.seg_flags = P.seg_flags; Wp.out_flags = P.out_flags; Wp.nseg = P.seg_flags ? P.nseg : P.out_nseg;
+    const int64_t blocks = (int64_t)Wp.bx * Wp.by * (Wp.ocp / 64) * P.N;
+    return blocks >= 256 && P.Mo >= 48;
+}
+
 extern "C" {
+
+int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass) {
+    if (validate(d, "spi_conv2d_workspace_bytes") || pass < 0 || pass > 1) return 0;
+    IGemmParams P; WinoParams Wp;
+    if (pass == 0) make_forward(d, P); else make_dgrad(d, P);
+    return make_wino(d, P, Wp) ? spi_wino_workspace_bytes(Wp) : 0;
+}
 
 int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream) {
     int rc = validate(d, "spi_conv2d_fwd"); if (rc) return rc;
@@ -1002,6 +1025,13 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     IGemmParams P; make_forward(d, P);
     if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
     Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
+    WinoParams Wp;
+    if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
+        SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
+        rc = spi_wino_launch(Wp, x, w, y, ep, d->workspace, as_stream(stream)); if (rc) return rc;
+        SPI_LAUNCH_CHECK("spi_conv2d_fwd (winograd)");
+        return SPI_OK;
+    }
     rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_fwd");
     return SPI_OK;
@@ -1012,6 +1042,13 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     SPI_REQUIRE(dy && w && dx, "spi_conv2d_dgrad: null tensor");
     IGemmParams P; make_dgrad(d, P);
     Epilogue ep{nullptr, nullptr, nullptr, 0, 0.f, 1.f, -1.f};
+    WinoParams Wp;
+    if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
+        SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_dgrad: workspace must be 16-byte aligned");
+        rc = spi_wino_launch(Wp, dy, w, dx, ep, d->workspace, as_stream(stream)); if (rc) return rc;
+        SPI_LAUNCH_CHECK("spi_conv2d_dgrad (winograd)");
+        return SPI_OK;
+    }
     rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_dgrad");
     return SPI_OK;

@@ -1,0 +1,292 @@
+// Winograd F(2x2, 3x3) convolutions on the gfx950 matrix cores, fp32 throughout.
+//
+// The 3x3 / stride-1 / pad-1 convolutions of the generator's 128^2 .. 512^2 layers (and their data gradients, which are
+// convolutions of the same shape with flipped, transposed weights) carry two thirds of the step's FLOPs.  Minimal filtering
+// (Lavin & Gray) computes a 2x2 output tile from a 4x4 input patch with 16 multiplications per (in, out) channel pair
+// instead of 36:
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A           g: 3x3 taps, d: 4x4 patch, Y: 2x2 outputs
+//
+// so the channel reduction becomes 16 independent GEMMs  M_f[oc, tile] = sum_c U_f[oc, c] V_f[c, tile]  (f = the 16
+// "frequencies"), 2.25x fewer MFMAs than the implicit GEMM of conv.hip, still v_mfma_f32_32x32x2_f32 with fp32 operands and
+// fp32 accumulation (the transforms add and halve only: the result differs from the direct sum by a few fp32 roundings --
+// this is the algorithm cuDNN picks for the reference's fp32 3x3 convolutions).
+//
+// One block = 8 x 8 tiles (16 x 16 output pixels) x 64 output channels x all 16 frequencies = 65536 accumulators
+// = 256 per lane (AGPRs; one wave per SIMD).  Per slab of 8 input channels:
+//   * U (transformed weights, produced once per call by wino_weight_kernel in exactly the LDS image) goes global -> LDS
+//     directly (global_load_lds_dwordx4, no registers in between);
+//   * every thread loads the 4x4 patches of one tile for two channels with raw buffer loads (out-of-image -> 0 in
+//     hardware, the slab's channel offset is scalar), transforms them (32 adds per patch) and writes V to LDS;
+//   * every wave runs 64 MFMAs (16 frequencies x 4 k-steps) on its 32 oc x 32 tile quadrant, operands read as one
+//     16-byte LDS fragment per (frequency, operand) = 4 k-steps.
+// The loads of slab s+2 and the transform + LDS writes of slab s+1 are interleaved with the MFMAs of slab s.
+// The output transform (A^T M A), noise / bias / activation epilogue and the 2x2 stores run on the accumulators in registers.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WKC = 8;                 // input channels per slab
+constexpr int WOC = 64;                // output channels per block
+constexpr int WSLAB = 16 * 2 * 64 * 4; // floats of one operand slab in LDS: [f 16][h 2][row 64][j 4], channel k = 2j + h
+
+// ---- weights: U[n][slab][f][h][ocp][j] = (G g G^T)[f] of channel c = slab*8 + 2j + h, output channel oc (zero rows up to ocp)
+__global__ void __launch_bounds__(256) wino_weight_kernel(WinoParams P, const float* __restrict__ w, float* __restrict__ U) {
+    const int64_t total = (int64_t)P.nw * (P.Ci / WKC) * 2 * P.ocp;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        const int oc = (int)(g % P.ocp);
+        int64_t r = g / P.ocp;
+        const int h = (int)(r & 1); r >>= 1;
+        const int slab = (int)(r % (P.Ci / WKC));
+        const int n = (int)(r / (P.Ci / WKC));
+        float u[4][16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float gk[3][3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gk[t / 3][t % 3] = 0.f;
+            if (oc < P.Mo) {
+                const float* wp = w + (int64_t)n * P.wbs + (int64_t)oc * P.wsm + (int64_t)(slab * WKC + 2 * j + h) * P.wsc;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) gk[t / 3][t % 3] = wp[P.widx[t]];       // widx[(dy+1)*3 + (dx+1)]
+            }
+            float t4[4][3];                                                          // G g
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                t4[0][s] = gk[0][s];
+                t4[1][s] = 0.5f * (gk[0][s] + gk[1][s] + gk[2][s]);
+                t4[2][s] = 0.5f * (gk[0][s] - gk[1][s] + gk[2][s]);
+                t4[3][s] = gk[2][s];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {                                            // (G g) G^T
+                u[j][a * 4 + 0] = t4[a][0];
+                u[j][a * 4 + 1] = 0.5f * (t4[a][0] + t4[a][1] + t4[a][2]);
+                u[j][a * 4 + 2] = 0.5f * (t4[a][0] - t4[a][1] + t4[a][2]);
+                u[j][a * 4 + 3] = t4[a][2];
+            }
+        }
+        float4* dst = reinterpret_cast<float4*>(U + (int64_t)n * P.u_bs) + ((int64_t)(slab * 16) * 2 + h) * P.ocp + oc;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) dst[(int64_t)f * 2 * P.ocp] = make_float4(u[0][f], u[1][f], u[2][f], u[3][f]);
+    }
+}
+
+__device__ __forceinline__ float wino_act(const WinoEpilogue& e, float v) {
+    if (e.act == SPI_ACT_RELU) v = fmaxf(v, 0.f);
+    else if (e.act == SPI_ACT_LRELU) v = v > 0.f ? v : v * e.alpha;
+    v *= e.gain;
+    if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
+    return v;
+}
+
+__global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const float* __restrict__ in, const float* __restrict__ U,
+                                                           float* __restrict__ out, WinoEpilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // Us[2][WSLAB] | Vs[2][WSLAB] = 128 KB
+    float* Us = lds;
+    float* Vs = lds + 2 * WSLAB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l32 = lane & 31;
+    const int ocw = wave >> 1, tw = wave & 1;                         // MFMA quadrant: 32 output channels x 32 tiles
+    const int n = blockIdx.z, oc0 = blockIdx.y * WOC;
+    const int bxi = blockIdx.x % P.bx, byi = blockIdx.x / P.bx;
+    const int oy0 = byi * 16, ox0 = bxi * 16;
+    const int64_t HW = (int64_t)P.H * P.W;
+    float* ob = out + (int64_t)n * P.out_bs;
+
+    // ---- needed-output map (forward) / zero-segment map of the gradient operand (dgrad): nothing flagged in the block's
+    //      output rows resp. receptive field -> the result is exactly zero: write it and leave.
+    if (P.out_flags || P.seg_flags) {
+        const int32_t* fl = (P.out_flags ? P.out_flags : P.seg_flags) + (int64_t)n * P.nseg;
+        const int halo = P.out_flags ? 0 : 1;
+        const int ylo = max(oy0 - halo, 0), yhi = min(oy0 + 15 + halo, P.H - 1);
+        const int xlo = max(ox0 - halo, 0), xhi = min(ox0 + 15 + halo, P.W - 1);
+        int any = 0;
+        const int rows = yhi - ylo + 1;
+        for (int e = tid; e < rows * 4; e += 256) {                  // <= 4 segments per row (18 pixels span at most 3)
+            const int iy = ylo + (e >> 2);
+            const int sg = ((iy * P.W + xlo) >> 4) + (e & 3);
+            if (sg <= ((iy * P.W + xhi) >> 4)) any |= fl[sg];
+        }
+        if (!__syncthreads_or(any)) {
+            for (int e = tid; e < WOC * 256; e += 256) {
+                const int m = oc0 + (e >> 8), yy = oy0 + ((e >> 4) & 15), xx = ox0 + (e & 15);
+                if (m < P.Mo && yy < P.H && xx < P.W) ob[(int64_t)m * HW + (int64_t)yy * P.W + xx] = 0.f;
+            }
+            return;
+        }
+    }
+
+    // ---- loader coordinates: tile = lane (8 x 8 tiles), channels k = 2*(jb + q) + hch, q = 0, 1
+    const int hch = wave & 1, jb = (wave >> 1) * 2;
+    const int ty = lane >> 3, tx = lane & 7;
+    unsigned voff[16];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int iy = oy0 + 2 * ty - 1 + r, ix = ox0 + 2 * tx - 1 + c;
+            voff[r * 4 + c] = (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? (unsigned)((iy * P.W + ix) * 4) : BUF_OOB;
+        }
+    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(in + (int64_t)n * P.in_bs, P.in_bs * 4);
+    const int chs4 = __builtin_amdgcn_readfirstlane((int)HW * 4);
+    const int nslab = P.Ci / WKC;
+
+    float d[2][16];
+    // patches of slab s, channel q, rows r0 .. r0+1 of the 4x4 patch
+    auto load_patch = [&](int s, int q, int r0) {
+        s = min(s, nslab - 1);
+        const int soff = __builtin_amdgcn_readfirstlane((s * WKC + 2 * (jb + q) + hch) * chs4);
+#pragma unroll
+        for (int e = r0 * 4; e < r0 * 4 + 8; ++e) d[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, (int)voff[e], soff, 0));
+    };
+    // U segment i of slab s: global -> LDS directly (global_load_lds_dwordx4: lane l lands at M0 + 16 l), no registers in between.
+    // Inline assembly on purpose: through the builtin hipcc treats every later LDS access as a possible alias of the transfer and puts
+    // s_waitcnt vmcnt(0) in front of it -- twelve full memory latencies per slab.  The waits are placed by hand instead (end of slab).
+    unsigned uvoff[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) uvoff[i] = (unsigned)((((int64_t)(i * 4 + wave) * P.ocp + oc0 + lane) * 16));
+    const char* Ubase = reinterpret_cast<const char*>(U + (int64_t)n * P.u_bs);
+    const unsigned lds_us = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Us;
+    auto copy_u = [&](int buf, int s, int i) {
+        s = min(s, nslab - 1);
+        const char* src = Ubase + (int64_t)s * 32 * P.ocp * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_us + (unsigned)((buf * WSLAB + (((i * 4 + wave) * 64) << 2)) * 4));
+        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(uvoff[i]), "s"(src) : "memory", "m0");
+    };
+    // B^T d B of both channels' patches, row group a (4 of the 16 frequencies), written as one 8-byte store per frequency
+    auto transform_store = [&](float* Vb, int a) {
+        float v[2][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float t[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                t[c] = a == 0 ? d[q][0 + c] - d[q][8 + c] : a == 1 ? d[q][4 + c] + d[q][8 + c] : a == 2 ? d[q][8 + c] - d[q][4 + c] : d[q][4 + c] - d[q][12 + c];
+            }
+            v[q][0] = t[0] - t[2]; v[q][1] = t[1] + t[2]; v[q][2] = t[2] - t[1]; v[q][3] = t[1] - t[3];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+            *reinterpret_cast<float2*>(Vb + ((((a * 4 + b) * 2 + hch) * 64 + lane) << 2) + jb) = make_float2(v[0][b], v[1][b]);
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // prologue: slab 0 -> LDS[0], slab 1 in flight
+#pragma unroll
+    for (int i = 0; i < 8; ++i) copy_u(0, 0, i);
+    load_patch(0, 0, 0); load_patch(0, 0, 2); load_patch(0, 1, 0); load_patch(0, 1, 2);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) transform_store(Vs, a);
+    load_patch(1, 0, 0); load_patch(1, 0, 2); load_patch(1, 1, 0); load_patch(1, 1, 2);
+    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                 // the eight U transfers are older than the 32 patch loads of slab 1
+    __syncthreads();
+
+    const int aoff = ((h * 64 + ocw * 32 + l32) << 2), boff = ((h * 64 + tw * 32 + l32) << 2);
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        const float* Ub = Us + buf * WSLAB + aoff;
+        const float* Vb = Vs + buf * WSLAB + boff;
+        float* Vw = Vs + (buf ^ 1) * WSLAB;
+        float4 af[2], bf[2];
+        af[0] = *reinterpret_cast<const float4*>(Ub);
+        bf[0] = *reinterpret_cast<const float4*>(Vb);
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            if (f + 1 < 16) {
+                af[(f + 1) & 1] = *reinterpret_cast<const float4*>(Ub + (f + 1) * 512);
+                bf[(f + 1) & 1] = *reinterpret_cast<const float4*>(Vb + (f + 1) * 512);
+            }
+            const float4 a4 = af[f & 1], b4 = bf[f & 1];
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // side work in the shadow of the matrix pipe: slab s+1 (in registers since the last iteration) -> the other LDS buffer,
+            // then the loads of slab s+2
+            if (f < 4) { copy_u(buf ^ 1, s + 1, 2 * f); copy_u(buf ^ 1, s + 1, 2 * f + 1); }
+            else if (f >= 8 && f < 12) transform_store(Vw, f - 8);
+            else if (f >= 12) load_patch(s + 2, (f - 12) >> 1, ((f - 12) & 1) * 2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");             // U of slab s+1 has landed (the patch loads of s+2 are younger)
+        __syncthreads();
+    }
+
+    // ---- output transform A^T M A + epilogue; C/D layout: col = lane & 31 (tile), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int tile = tw * 32 + l32;
+    const int oy = oy0 + 2 * (tile >> 3), ox = ox0 + 2 * (tile & 7);
+    if (oy >= P.H || ox >= P.W) return;
+    const bool y1 = oy + 1 < P.H, x1 = ox + 1 < P.W;
+    const int64_t pix = (int64_t)oy * P.W + ox;
+    float nz[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (ep.noise) {
+        const float ng = ep.noise_gain ? ep.noise_gain[0] : 1.f;
+        nz[0][0] = ep.noise[pix] * ng;
+        if (x1) nz[0][1] = ep.noise[pix + 1] * ng;
+        if (y1) { nz[1][0] = ep.noise[pix + P.W] * ng; if (x1) nz[1][1] = ep.noise[pix + P.W + 1] * ng; }
+    }
+    const bool vec = x1 && ((P.W & 1) == 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = oc0 + ocw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m >= P.Mo) continue;
+        float s0[4], s1[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            s0[a] = acc[a * 4 + 0][r] + acc[a * 4 + 1][r] + acc[a * 4 + 2][r];
+            s1[a] = acc[a * 4 + 1][r] - acc[a * 4 + 2][r] - acc[a * 4 + 3][r];
+        }
+        float y[2][2];
+        y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s1[0] + s1[1] + s1[2];
+        y[1][0] = s0[1] - s0[2] - s0[3]; y[1][1] = s1[1] - s1[2] - s1[3];
+        const float bv = ep.bias ? ep.bias[m] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                float v = y[a][b] + nz[a][b] + bv;
+                if (ep.act) v = wino_act(ep, v);
+                y[a][b] = v;
+            }
+        float* dst = ob + (int64_t)m * HW + pix;
+        if (vec) {
+            *reinterpret_cast<float2*>(dst) = make_float2(y[0][0], y[0][1]);
+            if (y1) *reinterpret_cast<float2*>(dst + P.W) = make_float2(y[1][0], y[1][1]);
+        } else {
+            dst[0] = y[0][0];
+            if (x1) dst[1] = y[0][1];
+            if (y1) { dst[P.W] = y[1][0]; if (x1) dst[P.W + 1] = y[1][1]; }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+int64_t spi_wino_workspace_bytes(const WinoParams& P) { return (int64_t)P.nw * P.u_bs_of() * 4; }
+
+int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const WinoEpilogue& ep, void* workspace, hipStream_t st) {
+    float* U = static_cast<float*>(workspace);
+    P.u_bs = P.nw > 1 ? P.u_bs_of() : 0;
+    {
+        const int64_t total = (int64_t)P.nw * (P.Ci / WKC) * 2 * P.ocp;
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+        WinoParams Pw = P; Pw.u_bs = P.u_bs_of();
+        hipLaunchKernelGGL(wino_weight_kernel, dim3(grid), dim3(256), 0, st, Pw, w, U);
+    }
+    static bool attr_set = false;
+    constexpr size_t lds_bytes = 4 * WSLAB * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { spi_set_error("winograd conv: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(P.bx * P.by), (unsigned)(P.ocp / WOC), (unsigned)P.N);
+    hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), lds_bytes, st, P, in, U, out, ep);
+    return SPI_OK;
+}

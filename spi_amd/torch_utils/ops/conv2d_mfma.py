@@ -70,6 +70,20 @@ def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, n
                         act, alpha, gain, clamp, hip.ptr(dy_flags), hip.ptr(out_flags), int(dw_zeroed))
 
 
+def _workspace(d, pass_id, device):
+    """Scratch memory with which `pass_id` (0 forward, 1 dgrad) of the conv `d` takes its Winograd path (None: it has none, or
+    ``global_config.conv_winograd`` is off).  Comes from torch's caching allocator: no device allocation after warm-up."""
+    from ...configs import global_config
+    if not global_config.conv_winograd or d.kh != 3 or d.transposed or d.compute_f16:
+        return None
+    nbytes = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), pass_id)
+    if nbytes <= 0:
+        return None
+    ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+    return ws
+
+
 def out_size(h, k, pad, transposed):
     return 2 * h + k - 2 if transposed else h + 2 * pad - k + 1
 
@@ -94,6 +108,7 @@ class _Conv2d(torch.autograd.Function):
         if of is not None:
             assert of.dtype == torch.int32 and tuple(of.shape) == (n, (oh * ow + 15) // 16), 'needed_output: flags must be int32 [N, ceil(OH*OW/16)]'
         d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16, out_flags=of)
+        ws = _workspace(d, 0, x.device)                 # noqa: F841  (keeps the scratch tensor alive until the launch is enqueued)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
         ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)
@@ -121,6 +136,7 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
+            ws = _workspace(d, 1, x.device)             # noqa: F841
             hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w), hip.ptr(dx), hip.stream())
         if ctx.needs_input_grad[1]:
             dw = zbuf[n_tail:].view(w.shape)

@@ -53,7 +53,10 @@ def timeit(fn, reps):
 def main():
     dev = 'cuda'
     print(f'{"layer":34s} {"GF":>7s} | {"fwd ms":>8s} {"TF/s":>6s} | {"dgrad ms":>8s} {"TF/s":>6s} | {"wgrad ms":>8s} {"TF/s":>6s}')
+    only = os.environ.get('SPI_BENCH_ONLY')
     for name, N, I, O, H, k, tr, per in SHAPES:
+        if only and only not in name:
+            continue
         x = torch.randn(N, I, H, H, device=dev)
         w = torch.randn(*((N,) if per else ()), O, I, k, k, device=dev) * 0.05
         pad = k // 2 if not tr else 0
@@ -63,10 +66,15 @@ def main():
         wbs = O * I * k * k if per else 0
         d = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
         s = hip.stream()
+        wino = os.environ.get('SPI_BENCH_WINO', '1') != '0'
+        dg = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
+        wsf = cm._workspace(d, 0, x.device) if wino else None
+        wsg = cm._workspace(dg, 1, x.device) if wino else None
+        name = name + (' [W]' if wsf is not None else '')
         flops = 2.0 * N * O * I * k * k * (H * H if tr else oh * oh)
         reps = 3 if flops > 2e10 else 10
         f = timeit(lambda: hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), s), reps)
-        g = timeit(lambda: hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(y), hip.ptr(w), hip.ptr(dx), s), reps)
+        g = timeit(lambda: hip.call('spi_conv2d_dgrad', ctypes.byref(dg), hip.ptr(y), hip.ptr(w), hip.ptr(dx), s), reps)
         h = timeit(lambda: hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(y), hip.ptr(dw), s), reps) if per else float('nan')
         tf = lambda ms: flops / ms / 1e9
         print(f'{name:34s} {flops / 1e9:7.1f} | {f:8.3f} {tf(f):6.1f} | {g:8.3f} {tf(g):6.1f} | {h:8.3f} {tf(h):6.1f}', flush=True)
