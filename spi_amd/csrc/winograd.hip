@@ -14,13 +14,13 @@
 //
 // One block = 8 x 8 tiles (16 x 16 output pixels) x 64 output channels x all 16 frequencies = 65536 accumulators
 // = 256 per lane (AGPRs; one wave per SIMD).  Per slab of 8 input channels:
-//   * U (transformed weights, produced once per call by wino_weight_kernel in exactly the LDS image) goes global -> LDS
-//     directly (global_load_lds_dwordx4, no registers in between);
-//   * every thread loads the 4x4 patches of one tile for two channels with raw buffer loads (out-of-image -> 0 in
-//     hardware, the slab's channel offset is scalar), transforms them (32 adds per patch) and writes V to LDS;
+//   * U (transformed weights, produced once per call by wino_weight_kernel in exactly the LDS image) and the slab's raw
+//     8 x 18 x 18 input window go global -> LDS directly (global_load_lds_dwordx4 / buffer_load_dword ... lds: no registers
+//     in between, out-of-image pixels arrive as 0), one slab resp. two slabs ahead;
+//   * every thread reads the 4x4 patches of one tile for two channels from the raw window, transforms them (32 adds per
+//     patch) and writes V to LDS -- in the shadow of the MFMAs of the previous slab;
 //   * every wave runs 64 MFMAs (16 frequencies x 4 k-steps) on its 32 oc x 32 tile quadrant, operands read as one
 //     16-byte LDS fragment per (frequency, operand) = 4 k-steps.
-// The loads of slab s+2 and the transform + LDS writes of slab s+1 are interleaved with the MFMAs of slab s.
 // The output transform (A^T M A), noise / bias / activation epilogue and the 2x2 stores run on the accumulators in registers.
 #include "common.hpp"
 
@@ -29,6 +29,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int WKC = 8;                 // input channels per slab
 constexpr int WOC = 64;                // output channels per block
 constexpr int WSLAB = 16 * 2 * 64 * 4; // floats of one operand slab in LDS: [f 16][h 2][row 64][j 4], channel k = 2j + h
+constexpr int WRAW = 41 * 64;          // floats of one raw input window in LDS: [8 channels][18][18] = 2592, rounded up to whole wave transfers
 
 // ---- weights: U[n][slab][f][h][ocp][j] = (G g G^T)[f] of channel c = slab*8 + 2j + h, output channel oc (zero rows up to ocp)
 __global__ void __launch_bounds__(256) wino_weight_kernel(WinoParams P, const float* __restrict__ w, float* __restrict__ U) {
@@ -82,7 +83,7 @@ __device__ __forceinline__ float wino_act(const WinoEpilogue& e, float v) {
 
 __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const float* __restrict__ in, const float* __restrict__ U,
                                                            float* __restrict__ out, WinoEpilogue ep) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];       // Us[2][WSLAB] | Vs[2][WSLAB] = 128 KB
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // Us[2][WSLAB] | Vs[2][WSLAB] | Rs[2][WRAW] = 148.5 KB
     float* Us = lds;
     float* Vs = lds + 2 * WSLAB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -117,59 +118,72 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         }
     }
 
-    // ---- loader coordinates: tile = lane (8 x 8 tiles), channels k = 2*(jb + q) + hch, q = 0, 1
-    const int hch = wave & 1, jb = (wave >> 1) * 2;
-    const int ty = lane >> 3, tx = lane & 7;
-    unsigned voff[16];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int iy = oy0 + 2 * ty - 1 + r, ix = ox0 + 2 * tx - 1 + c;
-            voff[r * 4 + c] = (iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? (unsigned)((iy * P.W + ix) * 4) : BUF_OOB;
-        }
+    // ---- data movement: no global load of the main loop goes through registers.
+    //  * raw input: the slab's 8 x 18 x 18 window (16 x 16 pixels + halo) lands in LDS slot by slot (buffer_load_dword ... lds: lane l of
+    //    a wave writes LDS[M0 + 4 l] from its OWN global address, out-of-image offsets return 0): 41 wave-instructions per slab,
+    //    per-lane offsets fixed for the whole kernel, the slab's channel base is the scalar offset;
+    //  * U: eight 16-byte transfers per thread (global_load_lds_dwordx4).
+    // Inline assembly on purpose: through the builtins hipcc treats every later LDS access as a possible alias of a transfer in flight
+    // and waits vmcnt(0) in front of it.  Here every transfer of an iteration is issued at its top and awaited once, before its barrier.
     const __amdgpu_buffer_rsrc_t rsI = make_rsrc(in + (int64_t)n * P.in_bs, P.in_bs * 4);
     const int chs4 = __builtin_amdgcn_readfirstlane((int)HW * 4);
     const int nslab = P.Ci / WKC;
-
-    float d[2][16];
-    // patches of slab s, channel q, rows r0 .. r0+1 of the 4x4 patch
-    auto load_patch = [&](int s, int q, int r0) {
-        s = min(s, nslab - 1);
-        const int soff = __builtin_amdgcn_readfirstlane((s * WKC + 2 * (jb + q) + hch) * chs4);
+    unsigned voffR[11];
 #pragma unroll
-        for (int e = r0 * 4; e < r0 * 4 + 8; ++e) d[q][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsI, (int)voff[e], soff, 0));
-    };
-    // U segment i of slab s: global -> LDS directly (global_load_lds_dwordx4: lane l lands at M0 + 16 l), no registers in between.
-    // Inline assembly on purpose: through the builtin hipcc treats every later LDS access as a possible alias of the transfer and puts
-    // s_waitcnt vmcnt(0) in front of it -- twelve full memory latencies per slab.  The waits are placed by hand instead (end of slab).
+    for (int i = 0; i < 11; ++i) {
+        const int slot = (i * 4 + wave) * 64 + lane;
+        const int ch = slot / 324, rem = slot - ch * 324, r = rem / 18, c = rem - r * 18;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+        voffR[i] = (slot < WKC * 324 && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? (unsigned)(ch * chs4 + (iy * P.W + ix) * 4) : BUF_OOB;
+    }
     unsigned uvoff[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) uvoff[i] = (unsigned)((((int64_t)(i * 4 + wave) * P.ocp + oc0 + lane) * 16));
     const char* Ubase = reinterpret_cast<const char*>(U + (int64_t)n * P.u_bs);
-    const unsigned lds_us = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Us;
-    auto copy_u = [&](int buf, int s, int i) {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    auto copy_u = [&](int buf, int s, int i) {                        // segment i (0..7) of U[s]
         s = min(s, nslab - 1);
         const char* src = Ubase + (int64_t)s * 32 * P.ocp * 16;
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_us + (unsigned)((buf * WSLAB + (((i * 4 + wave) * 64) << 2)) * 4));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * WSLAB + (((i * 4 + wave) * 64) << 2)) * 4));
         asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(uvoff[i]), "s"(src) : "memory", "m0");
     };
-    // B^T d B of both channels' patches, row group a (4 of the 16 frequencies), written as one 8-byte store per frequency
-    auto transform_store = [&](float* Vb, int a) {
-        float v[2][4];
+    auto copy_raw = [&](int rbuf, int s, int i) {                     // wave transfer i (0..10) of the raw window of slab s
+        s = min(s, nslab - 1);
+        const int soff = __builtin_amdgcn_readfirstlane(s * WKC * chs4);
+        if (i < 10 || wave == 0) {                                   // 41 wave transfers: the last round is wave 0's alone
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((4 * WSLAB + rbuf * WRAW + (i * 4 + wave) * 64) * 4));
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(dst), "v"(voffR[i]), "s"(rsI), "s"(soff) : "memory", "m0");
+        }
+    };
+
+    // ---- transform: tile = lane (8 x 8 tiles), channels k = 2*(jb + q) + hch, q = 0, 1: 4x4 patches from the raw window (8-byte reads)
+    const int hch = wave & 1, jb = (wave >> 1) * 2;
+    const int ty = lane >> 3, tx = lane & 7;
+    float d[2][16];
+    auto read_patch_row = [&](const float* Rb, int r) {               // row r of both channels' patches
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            float t[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                t[c] = a == 0 ? d[q][0 + c] - d[q][8 + c] : a == 1 ? d[q][4 + c] + d[q][8 + c] : a == 2 ? d[q][8 + c] - d[q][4 + c] : d[q][4 + c] - d[q][12 + c];
-            }
-            v[q][0] = t[0] - t[2]; v[q][1] = t[1] + t[2]; v[q][2] = t[2] - t[1]; v[q][3] = t[1] - t[3];
+            const float* pr = Rb + (2 * (jb + q) + hch) * 324 + (2 * ty + r) * 18 + 2 * tx;
+            const float2 lo = *reinterpret_cast<const float2*>(pr), hi = *reinterpret_cast<const float2*>(pr + 2);
+            d[q][r * 4 + 0] = lo.x; d[q][r * 4 + 1] = lo.y; d[q][r * 4 + 2] = hi.x; d[q][r * 4 + 3] = hi.y;
         }
+    };
+    // B^T d B: row group a (4 of the 16 frequencies) of channel q's patch ...
+    float vt[2][4];
+    auto transform_rows = [&](int a, int q) {
+        float t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            t[c] = a == 0 ? d[q][0 + c] - d[q][8 + c] : a == 1 ? d[q][4 + c] + d[q][8 + c] : a == 2 ? d[q][8 + c] - d[q][4 + c] : d[q][4 + c] - d[q][12 + c];
+        vt[q][0] = t[0] - t[2]; vt[q][1] = t[1] + t[2]; vt[q][2] = t[2] - t[1]; vt[q][3] = t[1] - t[3];
+    };
+    // ... and the two channels of a frequency written as one 8-byte store
+    auto store_rows = [&](float* Vb, int a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-            *reinterpret_cast<float2*>(Vb + ((((a * 4 + b) * 2 + hch) * 64 + lane) << 2) + jb) = make_float2(v[0][b], v[1][b]);
+            *reinterpret_cast<float2*>(Vb + ((((a * 4 + b) * 2 + hch) * 64 + lane) << 2) + jb) = make_float2(vt[0][b], vt[1][b]);
     };
+    auto transform_store = [&](float* Vb, int a) { transform_rows(a, 0); transform_rows(a, 1); store_rows(Vb, a); };
 
     f32x16 acc[16];
 #pragma unroll
@@ -177,14 +191,16 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-    // prologue: slab 0 -> LDS[0], slab 1 in flight
+    float* Rs = lds + 4 * WSLAB;
+    // prologue: U[0], raw[0], raw[1] -> LDS; V[0] from raw[0]
 #pragma unroll
-    for (int i = 0; i < 8; ++i) copy_u(0, 0, i);
-    load_patch(0, 0, 0); load_patch(0, 0, 2); load_patch(0, 1, 0); load_patch(0, 1, 2);
+    for (int i = 0; i < 11; ++i) { if (i < 8) copy_u(0, 0, i); copy_raw(0, 0, i); copy_raw(1, 1, i); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) read_patch_row(Rs, r);
 #pragma unroll
     for (int a = 0; a < 4; ++a) transform_store(Vs, a);
-    load_patch(1, 0, 0); load_patch(1, 0, 2); load_patch(1, 1, 0); load_patch(1, 1, 2);
-    asm volatile("s_waitcnt vmcnt(32)" ::: "memory");                 // the eight U transfers are older than the 32 patch loads of slab 1
     __syncthreads();
 
     const int aoff = ((h * 64 + ocw * 32 + l32) << 2), boff = ((h * 64 + tw * 32 + l32) << 2);
@@ -193,29 +209,43 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         const float* Ub = Us + buf * WSLAB + aoff;
         const float* Vb = Vs + buf * WSLAB + boff;
         float* Vw = Vs + (buf ^ 1) * WSLAB;
-        float4 af[2], bf[2];
-        af[0] = *reinterpret_cast<const float4*>(Ub);
-        bf[0] = *reinterpret_cast<const float4*>(Vb);
+        // 4 frequencies per group, k-step outermost: consecutive MFMAs go to different accumulators.  Behind EVERY MFMA one micro-slot of
+        // side work is issued (64 per slab; an MFMA occupies the pipe for 64 cycles after a 4-cycle issue, so a handful of
+        // instructions per slot run in its shadow, while a clump of 20 behind four MFMAs would leave the pipe idle):
+        //   * the next group's operand fragments (first 8 slots of a group),
+        //   * this iteration's transfers: raw[s+2] -> the raw buffer slab s lived in (11), U[s+1] -> the other U buffer (8),
+        //   * raw[s+1] -> V[s+1]: patch rows (4 slots), then per row group of the transform: channel 0, channel 1, the stores.
+        const float* Rn = Rs + (buf ^ 1) * WRAW;
+        float4 af[2][4], bf[2][4];
 #pragma unroll
-        for (int f = 0; f < 16; ++f) {
-            if (f + 1 < 16) {
-                af[(f + 1) & 1] = *reinterpret_cast<const float4*>(Ub + (f + 1) * 512);
-                bf[(f + 1) & 1] = *reinterpret_cast<const float4*>(Vb + (f + 1) * 512);
-            }
-            const float4 a4 = af[f & 1], b4 = bf[f & 1];
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[f], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+            af[0][i] = *reinterpret_cast<const float4*>(Ub + i * 512);
+            bf[0][i] = *reinterpret_cast<const float4*>(Vb + i * 512);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = g * 16 + j * 4 + i, t = m & 15;
+            acc[g * 4 + i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][j], bf[g & 1][i][j], acc[g * 4 + i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            // side work in the shadow of the matrix pipe: slab s+1 (in registers since the last iteration) -> the other LDS buffer,
-            // then the loads of slab s+2
-            if (f < 4) { copy_u(buf ^ 1, s + 1, 2 * f); copy_u(buf ^ 1, s + 1, 2 * f + 1); }
-            else if (f >= 8 && f < 12) transform_store(Vw, f - 8);
-            else if (f >= 12) load_patch(s + 2, (f - 12) >> 1, ((f - 12) & 1) * 2);
+            if (g + 1 < 4 && t < 8) {
+                if (t < 4) af[(g + 1) & 1][t] = *reinterpret_cast<const float4*>(Ub + ((g + 1) * 4 + t) * 512);
+                else bf[(g + 1) & 1][t - 4] = *reinterpret_cast<const float4*>(Vb + ((g + 1) * 4 + t - 4) * 512);
+            }
+            if ((m & 3) == 1 && (m >> 2) < 11) copy_raw(buf, s + 2, m >> 2);
+            if ((m & 3) == 3 && (m >> 2) < 8) copy_u(buf ^ 1, s + 1, m >> 2);
+            if ((m & 3) == 2 && (m >> 2) < 4) read_patch_row(Rn, m >> 2);
+            if (m >= 24 && m < 40) {
+                const int a = (m - 24) >> 2, ph = (m - 24) & 3;
+                if (ph < 2) transform_rows(a, ph);
+                else if (ph == 2) store_rows(Vw, a);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");             // U of slab s+1 has landed (the patch loads of s+2 are younger)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this iteration's transfers have landed
         __syncthreads();
     }
 
@@ -280,7 +310,7 @@ int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, c
         hipLaunchKernelGGL(wino_weight_kernel, dim3(grid), dim3(256), 0, st, Pw, w, U);
     }
     static bool attr_set = false;
-    constexpr size_t lds_bytes = 4 * WSLAB * sizeof(float);
+    constexpr size_t lds_bytes = (4 * WSLAB + 2 * WRAW) * sizeof(float);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { spi_set_error("winograd conv: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e)); return SPI_ERR_LAUNCH; }

@@ -8,4 +8,4 @@ for c in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_I
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmcc_$i -o pmc -- python tools/pmc_conv.py > gpurun_out/pmc_conv/pass$i.log 2>&1 < /dev/null
   echo "pass $i rc=$?"
 done
-PMC_NAME_LEN=70 python tools/pmc_summarize.py /tmp/pmcc_1 /tmp/pmcc_2 /tmp/pmcc_3 | grep -E "igemm|wgrad" | tee gpurun_out/pmc_conv/summary${SPI_BENCH_F16:-0}.txt
+PMC_NAME_LEN=70 python tools/pmc_summarize.py /tmp/pmcc_1 /tmp/pmcc_2 /tmp/pmcc_3 | grep -E "igemm|wgrad|wino" | tee gpurun_out/pmc_conv/summary${SPI_BENCH_F16:-0}.txt
