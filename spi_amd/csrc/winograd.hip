@@ -262,6 +262,41 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         if (x1) nz[0][1] = ep.noise[pix + 1] * ng;
         if (y1) { nz[1][0] = ep.noise[pix + P.W] * ng; if (x1) nz[1][1] = ep.noise[pix + P.W + 1] * ng; }
     }
+    // interior blocks (all 64 channels, all 16 x 16 pixels, even row length): no per-element tests, branch-free activation
+    //   lrelu / relu / linear = max(v, 0) + slope * min(v, 0) (one rounding, as v * alpha); clamp with +-FLT_MAX when there is none
+    if (oc0 + WOC <= P.Mo && oy0 + 16 <= P.H && ox0 + 16 <= P.W && (P.W & 1) == 0) {
+        const bool has_epi = ep.act != 0 || ep.bias || ep.noise;
+        const float slope = ep.act == SPI_ACT_LRELU ? ep.alpha : ep.act == SPI_ACT_RELU ? 0.f : 1.f;
+        const float cl = ep.clamp >= 0.f ? ep.clamp : 3.402823466e38f;
+        float* dst0 = ob + (int64_t)(oc0 + ocw * 32 + 4 * h) * HW + pix;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int mo = (r & 3) + 8 * (r >> 2);
+            float s0[4], s1[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                s0[a] = acc[a * 4 + 0][r] + acc[a * 4 + 1][r] + acc[a * 4 + 2][r];
+                s1[a] = acc[a * 4 + 1][r] - acc[a * 4 + 2][r] - acc[a * 4 + 3][r];
+            }
+            float y[2][2];
+            y[0][0] = s0[0] + s0[1] + s0[2]; y[0][1] = s1[0] + s1[1] + s1[2];
+            y[1][0] = s0[1] - s0[2] - s0[3]; y[1][1] = s1[1] - s1[2] - s1[3];
+            if (has_epi) {
+                const float bv = ep.bias ? ep.bias[oc0 + ocw * 32 + 4 * h + mo] : 0.f;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float v = y[a][b] + nz[a][b] + bv;
+                        v = (fmaxf(v, 0.f) + slope * fminf(v, 0.f)) * ep.gain;
+                        y[a][b] = fminf(fmaxf(v, -cl), cl);
+                    }
+            }
+            float* dst = dst0 + (int64_t)mo * HW;
+            *reinterpret_cast<float2*>(dst) = make_float2(y[0][0], y[0][1]);
+            *reinterpret_cast<float2*>(dst + P.W) = make_float2(y[1][0], y[1][1]);
+        }
+    } else {
     const bool vec = x1 && ((P.W & 1) == 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -294,6 +329,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
             if (x1) dst[1] = y[0][1];
             if (y1) { dst[P.W] = y[1][0]; if (x1) dst[P.W + 1] = y[1][1]; }
         }
+    }
     }
 }
 

@@ -236,7 +236,7 @@ def test_seg_flags_vs_torch():
 @pytest.mark.parametrize('kind', ['box', 'blobs', 'pixel', 'dense', 'empty'])
 @pytest.mark.parametrize('n,i,o,h,k,transposed,fp16', [(2, 32, 48, 128, 3, False, False), (1, 128, 3, 130, 1, False, False),
                                                       (2, 32, 128, 64, 3, True, False), (1, 128, 128, 128, 3, False, True),
-                                                      (1, 16, 16, 131, 3, False, False)])
+                                                      (1, 16, 16, 131, 3, False, False), (1, 64, 64, 256, 3, False, False)])   # last: Winograd dgrad
 def test_conv_backward_sparse_gradient_equals_dense(kind, n, i, o, h, k, transposed, fp16):
     """`with sparse_gradients()`: dgrad / wgrad skip the all-zero 16-pixel segments of dy -> same gradients as the dense kernels
     (up to the order of the fp32 sums), and exact zeros where the dense result is exactly zero."""
@@ -264,7 +264,8 @@ def test_conv_backward_sparse_gradient_equals_dense(kind, n, i, o, h, k, transpo
         assert_close(sparse[2], dense[2], 1e-6, 'bias gradient')
 
 
-@pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 128, 3, False), (1, 128, 3, 130, 1, False), (2, 32, 128, 64, 3, True), (1, 16, 16, 131, 3, False)])
+@pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 128, 3, False), (1, 128, 3, 130, 1, False), (2, 32, 128, 64, 3, True), (1, 16, 16, 131, 3, False),
+                                                  (1, 32, 64, 256, 3, False)])                                    # last: Winograd forward
 def test_conv_forward_needed_output_region(n, i, o, h, k, transposed):
     """`with needed_output({(OH, OW): flags})`: output tiles without a flagged segment may be skipped (zeros); every flagged pixel is
     bit-identical to the dense forward, and the backward still works on the region."""
@@ -282,7 +283,7 @@ def test_conv_forward_needed_output_region(n, i, o, h, k, transposed):
         with conv2d_mfma.needed_output({(oh, ow): flags}):
             y = conv2d_mfma.conv2d(x, w, **kw)
         assert torch.equal(y * m, dense * m), kind
-        big = k == 3 and not transposed and h == 128                    # small problems run split-K: dense, flags ignored
+        big = k == 3 and not transposed and h in (128, 256)             # small problems run split-K: dense, flags ignored
         if kind == 'empty' and big:
             assert float(y.detach().abs().max()) == 0
         if kind == 'box':
@@ -294,6 +295,84 @@ def test_conv_forward_needed_output_region(n, i, o, h, k, transposed):
             assert_close(gw, hw, 2e-6, 'wgrad through a region forward')
     with conv2d_mfma.needed_output({(oh + 1, ow): flags}):              # other resolutions are untouched
         assert torch.equal(conv2d_mfma.conv2d(x, w, **kw), dense)
+
+
+WINO_CASES = [  # N, I, O, H, W, flip, per_sample, epilogue
+    (1, 16, 64, 256, 256, True, True, True),        # interior fast path (even sizes, whole channel chunks) with the fused epilogue
+    (2, 24, 96, 250, 246, True, True, False),       # ragged edges, 96 channels = one and a half chunks, per-sample weights
+    (1, 64, 48, 272, 301, False, False, True),      # odd row length (scalar stores), shared weights, 48 of 64 channel rows
+    (4, 8, 64, 128, 128, True, False, False),       # batch sharing one weight set
+]
+
+
+@pytest.mark.parametrize('case', WINO_CASES)
+def test_conv_winograd_vs_oracle_and_implicit_gemm(case):
+    """The Winograd F(2x2, 3x3) path (winograd.hip) of the forward and data-gradient passes against the CPU oracle, and against the
+    implicit-GEMM kernels on the same inputs.  fp32 throughout: tolerance 1e-5 of the tensor's max (direct kernels: 3e-6 .. 1e-5); the
+    two HIP paths agree to 6e-6."""
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.configs import global_config
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    N, I, O, H, W, flip, per, epi = case
+    torch.set_num_threads(min(__import__('os').cpu_count() or 1, 32))
+    gen = torch.Generator().manual_seed(N * 100 + O)
+    x = torch.randn(N, I, H, W, generator=gen, requires_grad=True)
+    w = (torch.randn(*((N,) if per else ()), O, I, 3, 3, generator=gen) / (I * 9) ** 0.5).requires_grad_(True)
+    b = torch.randn(O, generator=gen) if epi else None
+    nz = torch.randn(H, W, generator=gen) if epi else None
+    st = torch.tensor(0.3) if epi else None
+    ref = _ref_conv(x, w, 1, False, flip)
+    if epi:
+        ref = osg.bias_act(ref + nz * st, b, act='lrelu', gain=1.3, clamp=2.0)
+    dy = torch.randn(ref.shape, generator=gen)
+    gx, = torch.autograd.grad(ref, [x], dy)
+    kw = dict(padding=1, flip=flip)
+    if epi:
+        kw.update(bias=b.to(DEV), noise=nz.to(DEV), noise_strength=st.to(DEV), act='lrelu', gain=1.3, clamp=2.0)
+    # the shape must actually take the Winograd path (both passes)
+    d = conv2d_mfma._desc(N, I, O, H, W, 3, 1, False, flip, O * I * 9 if per else 0, tap_major=1)
+    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 0) == (N if per else 1) * 16 * I * ((O + 63) // 64 * 64) * 4
+    assert (hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 1) > 0) == (I >= 48)
+    outs = {}
+    for wino in (True, False):
+        old = global_config.conv_winograd
+        global_config.conv_winograd = wino
+        try:
+            xg, wg = x.detach().to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+            y = conv2d_mfma.conv2d(xg, wg, **kw)
+            hx, hw = torch.autograd.grad(y, [xg, wg], dy.to(DEV))
+        finally:
+            global_config.conv_winograd = old
+        outs[wino] = (y.detach(), hx, hw)
+    assert_close(outs[True][0], ref, 1e-5, 'winograd fwd')
+    assert_close(outs[True][0], outs[False][0], 6e-6, 'winograd vs implicit GEMM fwd')
+    if not epi:
+        assert_close(outs[True][1], gx, 1e-5, 'winograd dgrad')
+        assert_close(outs[True][1], outs[False][1], 6e-6, 'winograd vs implicit GEMM dgrad')
+        assert_close(outs[True][2], outs[False][2], 1e-5, 'wgrad behind either forward')
+    else:
+        # behind lrelu + clamp a pre-activation within 1e-6 of the kink or of the clamp bound may land on the other side of it in another
+        # summation order: its gradient flips between slope values (a few of the 4 M pre-activations), and each flip reaches the 9 x I
+        # gradient entries under its taps
+        for got, want, what in ((outs[True][1], gx, 'dgrad vs oracle'), (outs[True][1], outs[False][1], 'dgrad vs implicit GEMM')):
+            diff = (got.cpu() - want.cpu()).abs() / want.cpu().abs().max()
+            assert float((diff > 1e-5).float().mean()) < 5e-3 and float(diff.median()) < 1e-6, what
+
+
+def test_conv_winograd_is_not_offered_where_it_does_not_apply():
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    for args, kw in [((1, 64, 64, 256, 256, 1, 0, False, False, 0), {}),                  # 1x1
+                     ((1, 64, 64, 128, 128, 3, 0, True, False, 0), {}),                   # stride-2 transposed
+                     ((1, 512, 512, 16, 16, 3, 1, False, False, 0), {}),                  # too few blocks: split-K implicit GEMM fills the chip
+                     ((1, 12, 64, 256, 256, 3, 1, False, False, 0), {}),                  # no whole 8-channel slabs
+                     ((1, 64, 64, 256, 256, 3, 1, False, False, 0), dict(f16=3))]:        # split-bf16 arithmetic requested
+        d = conv2d_mfma._desc(*args, tap_major=1, **kw)
+        assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 0) == 0, args
+    d = conv2d_mfma._desc(1, 64, 64, 256, 256, 3, 1, False, False, 0, tap_major=1)
+    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0                  # no Winograd weight-gradient pass (yet)
 
 
 SPLIT_CASES = [(1, 64, 128, 40, 3, 1, False, True, True), (2, 32, 48, 24, 3, 0, True, False, True), (1, 128, 128, 96, 3, 1, False, True, True),
