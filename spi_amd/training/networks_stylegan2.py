@@ -85,7 +85,7 @@ class _ModConvFrozen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16, ww=None):
         import ctypes
-        from ..torch_utils.ops.conv2d_mfma import _desc, out_size
+        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace, out_size
         x = x.contiguous().float()
         weight = weight.detach().contiguous().float()
         st = styles.detach().contiguous().float()
@@ -105,6 +105,7 @@ class _ModConvFrozen(torch.autograd.Function):
         nz = noise.detach().contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
         d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16)
+        ws = _workspace(d, 0, x.device)                 # noqa: F841  (Winograd scratch, alive until the launch is enqueued)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w2), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0 or bb is not None or nz is not None)
         ctx.save_for_backward(x, weight, st, w2, dcoef, y, bb, nz, ng, ww)
@@ -115,7 +116,7 @@ class _ModConvFrozen(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         import ctypes
-        from ..torch_utils.ops.conv2d_mfma import _desc
+        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace
         x, weight, st, w2, dcoef, y, bb, nz, ng, ww = ctx.saved_tensors
         pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, demodulate, sgain, f16 = ctx.cfg
         o, i, kh, kw = weight.shape
@@ -129,6 +130,7 @@ class _ModConvFrozen(torch.autograd.Function):
                                                                  zero_buf=zb)
         d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, tap_major=1, f16=f16)
         dx = torch.empty_like(x)
+        ws = _workspace(d, 1, x.device)                 # noqa: F841
         hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w2), hip.ptr(dx), hip.stream())
         a = zb[n_tail:n_tail + n * i]
         hip.call('spi_chan_dot', hip.ptr(x), hip.ptr(dx), hip.ptr(a), n * i, i, h * wd, None, None, None, 0, 0.0, 1.0, hip.stream())
