@@ -43,6 +43,7 @@ def parse():
     ap.add_argument('--cpu-baseline', choices=('sample', 'full'), default='sample',
                     help="sample (default, ~30 s): 1 warm-up + 1 timed stage-1 'mir' step + 1 timed plain stage-2 iteration of the oracle; "
                          'full (~4 min): + one whole 4-iteration stage-2 super-cycle with the rot / mirror-rot / depth branches and a thread-scaling line')
+    ap.add_argument('--no-winograd', action='store_true', help='3x3 convolutions on the implicit-GEMM kernels only (global_config.conv_winograd = False)')
     ap.add_argument('--dense', action='store_true', help='NOT the benchmark configuration: switch off the data-driven skipping of exactly-zero gradients / '
                                                          'unneeded SR tiles in the masked pseudo-view branches (dense bound of the same step)')
     ap.add_argument('--sr-fp16', action='store_true', help='NOT the benchmark configuration: fp16 MFMA in the super-resolution blocks '
@@ -168,9 +169,32 @@ def conv_roofline(dev, f16, prec=0):
         avg = sum(ms) / len(ms)
         res[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12}
     worst = min(v['achieved'] for v in res.values())
-    return {'kernel': 'igemm_kernel / wgrad_kernel on SR b512.conv1 (128->128, 3x3, 512^2, N=1)', 'bound': 'mfma', 'achieved': worst, 'peak': peak,
-            'unit': 'TFLOP/s', 'frac': worst / peak, 'flop_per_launch': flop, 'passes': res,
-            'note': 'achieved = slowest of the three passes; wgrad includes its memset of dw'}
+    out = {'kernel': 'igemm_kernel / wgrad_kernel on SR b512.conv1 (128->128, 3x3, 512^2, N=1)', 'bound': 'mfma', 'achieved': worst, 'peak': peak,
+           'unit': 'TFLOP/s', 'frac': worst / peak, 'flop_per_launch': flop, 'passes': res,
+           'note': 'achieved = slowest of the three passes; wgrad includes its memset of dw'}
+    # the same layer on the Winograd F(2x2, 3x3) path the loop actually takes for forward / dgrad of the >= 128^2 3x3 layers (exact fp32
+    # mode only): `achieved` counts the direct convolution's FLOPs (the algorithmic work), `executed` the MFMA FLOPs issued (/ 2.25)
+    from spi_amd.configs import global_config
+    if global_config.conv_winograd and not f16 and prec == 0:
+        wres = {}
+        for name, pid, fn in (('fwd', 0, lambda dd: hip.call('spi_conv2d_fwd', ctypes.byref(dd), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())),
+                              ('dgrad', 1, lambda dd: hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(y), hip.ptr(w), hip.ptr(dx), hip.stream()))):
+            dd = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1)
+            ws = cm._workspace(dd, pid, x.device)
+            if ws is None:
+                continue
+            for _ in range(3):
+                fn(dd)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a, b in ev:
+                a.record(); fn(dd); b.record()
+            torch.cuda.synchronize()
+            avg = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            wres[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12, 'executed': flop / 2.25 / (avg * 1e-3) / 1e12,
+                          'frac_executed': flop / 2.25 / (avg * 1e-3) / 1e12 / peak}
+        out['winograd'] = {'kernel': 'wino_weight_kernel + wino_conv_kernel, same layer', 'passes': wres,
+                           'note': 'fp32 operands and accumulation; 16 MFMA multiplications per 2x2 output tile and channel pair instead of 36'}
+    return out
 
 
 def launch_ranks(n):
@@ -266,6 +290,8 @@ def main():
     global_config.device = str(dev)
     global_config.enable_fp16_blocks = bool(args.sr_fp16)
     global_config.exploit_sparsity = not args.dense
+    if args.no_winograd:
+        global_config.conv_winograd = False
     global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
     tmp = tempfile.mkdtemp(prefix='spi_bench_')
     for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
@@ -402,6 +428,8 @@ def main():
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only,
+                       'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
+                                   if global_config.conv_winograd and global_config.conv_precision == 0 else 'implicit GEMM'),
                        'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else
                                    'data-driven skipping of exactly-zero gradients and unneeded SR tiles in the masked pseudo-view branches (result-identical)'},
             'roofline': {'kernel': 'raymarch_fwd_kernel<3> (final composite, S=%d, C=32)' % S, 'bound': 'hbm', 'achieved': achieved,
