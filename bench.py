@@ -427,7 +427,7 @@ def main():
                                    ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
-                       'only_stage': args.only,
+                       'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
                        'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
                                    if global_config.conv_winograd and global_config.conv_precision == 0 else 'implicit GEMM'),
                        'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else
@@ -435,7 +435,9 @@ def main():
             'roofline': {'kernel': 'raymarch_fwd_kernel<3> (final composite, S=%d, C=32)' % S, 'bound': 'hbm', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'launches': len(march_ms), 'avg_launch_us': (sum(march_ms) / max(len(march_ms), 1)) * 1e3,
-                         'bytes_per_ray': per_ray, 'rays_per_launch': (sum(march_rays) / max(len(march_rays), 1))},
+                         'bytes_per_ray': per_ray, 'rays_per_launch': (sum(march_rays) / max(len(march_rays), 1)),
+                         'note': ('HIP events around every eagerly enqueued launch of the timed region; stage-1 steps replayed from the captured HIP graph '
+                                  'carry no events' if global_config.stage1_hip_graph else 'HIP events around every launch of the timed region')},
         }
         # second HBM line: the march BACKWARD.  Algorithmic bytes per ACTIVE ray: read S*(C+2)*4 (colours, density, depth)
         # + (C+1)*4 incoming gradients, write S*2*4 (density gradient + colour-gradient scale; the [R,S,C] colour gradient is never

@@ -331,6 +331,11 @@ int spi_lpips_layer_bwd(const float* fx, const float* fy, const float* lin, cons
  *   step is the 1-based step count used for bias correction. */
 int spi_adam_multi(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, float lr, float beta1,
                    float beta2, float eps, int step, spi_stream_t stream);
+/* The same launch with its step-dependent scalars in DEVICE memory: hyper = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} (3 floats).
+ * A stage-1 step captured in a HIP graph replays this launch unchanged; the host refreshes `hyper` (one 12-byte copy) before
+ * each replay. */
+int spi_adam_multi_dev(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, const float* hyper,
+                       float beta1, float beta2, float eps, spi_stream_t stream);
 
 #ifdef __cplusplus
 }

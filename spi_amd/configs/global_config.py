@@ -39,3 +39,7 @@ exploit_sparsity = True
 # Winograd F(2x2, 3x3) for the 3x3 / stride-1 forward and data-gradient passes of the large layers (winograd.hip): fp32 operands and
 # accumulation, 2.25x fewer MFMAs; results differ from the direct sums by a few fp32 roundings.  Off = implicit GEMM everywhere.
 conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
+
+# stage 1: capture the projector step in a HIP graph after an eager warm-up step and replay it (projectors/common.py).  The step is
+# GPU-bound either way; the graph takes the ~10 ms of host enqueue work per step off the CPU.  Off: every step is enqueued eagerly.
+stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'

@@ -64,6 +64,7 @@ _SIGS = {
     'spi_lpips_layer_fwd': ([c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
     'spi_lpips_layer_bwd': ([c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
     'spi_adam_multi': ([c_p, c_p, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p], c_i),
+    'spi_adam_multi_dev': ([c_p, c_p, c_i, c_l, c_p, c_f, c_f, c_f, c_p], c_i),
 }
 EXPORTS = sorted(list(_SIGS) + ['spi_last_error'])
 

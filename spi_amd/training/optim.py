@@ -58,8 +58,26 @@ class Adam:
         self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.flat_g.zero_()
         self.step_count = 0
 
+    def hyper_values(self, step_count=None):
+        """(lr, 1 - beta1^t, sqrt(1 - beta2^t)) exactly as spi_adam_multi forms them on the host (fp32 powf / sqrtf), for `step(hyper=...)`."""
+        import ctypes
+        import ctypes.util
+        libm = getattr(Adam, '_libm', None)
+        if libm is None:
+            libm = Adam._libm = ctypes.CDLL(ctypes.util.find_library('m') or 'libm.so.6')
+            libm.powf.restype, libm.powf.argtypes = ctypes.c_float, [ctypes.c_float, ctypes.c_float]
+            libm.sqrtf.restype, libm.sqrtf.argtypes = ctypes.c_float, [ctypes.c_float]
+        grp = self.param_groups[0]
+        t = float(self.step_count + 1 if step_count is None else step_count)
+        f32 = lambda v: ctypes.c_float(v).value
+        bc1 = f32(1.0 - libm.powf(grp['betas'][0], t))
+        bc2 = libm.sqrtf(f32(1.0 - libm.powf(grp['betas'][1], t)))
+        return f32(grp['lr']), bc1, bc2
+
     @torch.no_grad()
-    def step(self):
+    def step(self, hyper=None):
+        """hyper: optional DEVICE tensor [lr, 1 - beta1^t, sqrt(1 - beta2^t)] (see `hyper_values`): the launch then carries no step-dependent
+        host scalar and can be replayed from a captured HIP graph."""
         off = 0
         for p in self.params:               # gradients that autograd placed elsewhere are folded back in
             n = p.numel()
@@ -81,5 +99,9 @@ class Adam:
                 raise AssertionError('a parameter that had a gradient before has none now: flat Adam differs from torch.optim.Adam here')
             self._had_grad = [h or n_ for h, n_ in zip(had, now)] if had is not None else now
         grp = self.param_groups[0]
+        if hyper is not None:
+            hip.call('spi_adam_multi_dev', hip.ptr(self._table), hip.ptr(self._sizes), 1, self._total, hip.ptr(hyper), float(grp['betas'][0]),
+                     float(grp['betas'][1]), float(grp['eps']), hip.stream())
+            return
         hip.call('spi_adam_multi', hip.ptr(self._table), hip.ptr(self._sizes), 1, self._total, float(grp['lr']), float(grp['betas'][0]),
                  float(grp['betas'][1]), float(grp['eps']), self.step_count, hip.stream())

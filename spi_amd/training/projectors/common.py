@@ -116,10 +116,80 @@ class Projection:
         self.optimizer = Adam([self.w_opt] + list(self.noise_bufs.values()), betas=(0.9, 0.999), lr=hyperparameters.first_inv_lr)
         self.noise_reg = NoiseRegulariser(self.noise_bufs.values())          # after Adam: it moves the parameters into its flat buffer
 
-    def step(self, step):
-        G, rng, w_opt = self.G, self.rng, self.w_opt
+    # ---- HIP-graph replay -------------------------------------------------------------------------------------------------------
+    # A stage-1 step is ~600 launches with no data-dependent host decision: after one eager warm-up step the second is CAPTURED
+    # (torch.cuda.graph: forward, backward, Adam, re-normalisation) and every later step is one graph launch.  What changes from step
+    # to step lives in device memory: `_hyper` = [lr, 1 - beta1^t, sqrt(1 - beta2^t), w_noise_scale], refreshed by one 16-byte copy
+    # before each replay; the random draws are torch's graph-safe philox streams.  Same kernels in the same order as the eager step.
+    # Only with the device generator (ReplayRNG draws come from a host list) and only on the GPU; a failed capture falls back to eager
+    # steps and says so once.
+    GRAPH_WARMUP = 1                                             # eager steps before the capture (lazy initialisations, allocator warm-up)
+    HYPER_RING = 32                                              # pinned slots for the per-step scalars = how far the host may run ahead
+
+    def _graph_ok(self):
+        from ...configs import global_config
+        return (global_config.stage1_hip_graph and isinstance(self.rng, DeviceRNG) and self.w_opt.is_cuda and not getattr(self, '_graph_failed', False))
+
+    def _set_hyper(self, step):
         lr, w_noise_scale = stage1_schedule(step, self.num_steps, self.w_std, **self.sched)
         self.optimizer.param_groups[0]['lr'] = lr
+        lr32, bc1, bc2 = self.optimizer.hyper_values()
+        if not hasattr(self, '_hyper'):
+            self._hyper = torch.zeros(4, device=self.w_opt.device, dtype=torch.float32)
+            self._hyper_ring = torch.zeros(self.HYPER_RING, 4, dtype=torch.float32).pin_memory()
+            self._hyper_events = [None] * self.HYPER_RING
+            self._hyper_pos = 0
+        # the host runs ahead of the GPU: each step's values get their own pinned slot, reused only after its copy has executed
+        k = self._hyper_pos % self.HYPER_RING
+        self._hyper_pos += 1
+        if self._hyper_events[k] is not None:
+            self._hyper_events[k].synchronize()
+        slot = self._hyper_ring[k]
+        slot[0], slot[1], slot[2], slot[3] = lr32, bc1, bc2, w_noise_scale
+        self._hyper.copy_(slot, non_blocking=True)
+        ev = self._hyper_events[k] or torch.cuda.Event()
+        ev.record()
+        self._hyper_events[k] = ev
+
+    def _graph_step(self, step):
+        if getattr(self, '_graph', None) is not None:
+            self._set_hyper(step)
+            self.optimizer.step_count += 1
+            self._graph.replay()
+            return {k: v.clone() for k, v in self._graph_out.items()}      # the graph's outputs are overwritten by the next replay
+        self._n_eager = getattr(self, '_n_eager', 0) + 1
+        if self._n_eager <= self.GRAPH_WARMUP:
+            return self._body(step, device_hyper=True)
+        self._set_hyper(step)
+        try:
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                out = self._body(step, device_hyper=True, hyper_is_set=True)
+        except Exception as e:                                   # noqa: BLE001  (capture is an optimisation: the eager step is always valid)
+            import sys
+            self._graph_failed = True
+            torch.cuda.synchronize()
+            print(f'[spi_amd] stage-1 HIP-graph capture failed ({type(e).__name__}: {e}); continuing with eager steps', file=sys.stderr)
+            return self._body(step, device_hyper=False)
+        self._graph, self._graph_out = g, out
+        g.replay()                                               # capture records, it does not execute: run the captured step once
+        return {k: v.clone() for k, v in out.items()}
+
+    def step(self, step):
+        if self._graph_ok():
+            return self._graph_step(step)
+        return self._body(step, device_hyper=False)
+
+    def _body(self, step, device_hyper, hyper_is_set=False):
+        G, rng, w_opt = self.G, self.rng, self.w_opt
+        if device_hyper:
+            if not hyper_is_set:
+                self._set_hyper(step)
+            w_noise_scale = self._hyper[3]
+        else:
+            lr, w_noise_scale = stage1_schedule(step, self.num_steps, self.w_std, **self.sched)
+            self.optimizer.param_groups[0]['lr'] = lr
         ws = w_opt + rng.randn(*w_opt.shape) * w_noise_scale
         if self.w_mode == 'w':
             ws = ws.repeat([1, self.num_ws, 1])
@@ -133,7 +203,7 @@ class Projection:
         loss = dist + reg_loss * self.reg_weight
         self.optimizer.zero_grad()
         loss.backward()
-        self.optimizer.step()
+        self.optimizer.step(hyper=self._hyper[:3] if device_hyper else None)
         self.noise_reg.renorm()
         return dict(dist=dist.detach(), reg=reg_loss.detach(), loss=loss.detach())
 

@@ -152,12 +152,13 @@ class _Render(torch.autograd.Function):
         rgb = torch.empty(n, m, 32, device=dev, dtype=torch.float32) if not depth_only else None
         depth = torch.empty(n, m, 1, device=dev, dtype=torch.float32)
         wsum = torch.empty(n, m, 1, device=dev, dtype=torch.float32)
-        if MARCH_EVENTS is not None and not depth_only:
+        timed_fwd = MARCH_EVENTS is not None and not depth_only and not torch.cuda.is_current_stream_capturing()   # (a captured step cannot hold timing events)
+        if timed_fwd:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()
         hip.call('spi_raymarch_fwd', hip.ptr(rgb_all), hip.ptr(sig_all), hip.ptr(d_all), hip.ptr(perm), hip.ptr(clamp2), r, s, s, 32,
                  white_back, hip.ptr(rgb), hip.ptr(depth), None, hip.ptr(wsum), hip.stream())
-        if MARCH_EVENTS is not None and not depth_only:
+        if timed_fwd:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             MARCH_EVENTS.append((e0, e1, r))
@@ -197,7 +198,7 @@ class _Render(torch.autograd.Function):
         # the march backward and skipped by the decoder backward; their rows of d_col / d_sig stay unwritten
         from ...configs import global_config
         active = torch.empty(r, device=dev, dtype=torch.int32) if global_config.exploit_sparsity else None
-        timed = MARCH_BWD_EVENTS is not None and d_rgb is not None
+        timed = MARCH_BWD_EVENTS is not None and d_rgb is not None and not torch.cuda.is_current_stream_capturing()
         if timed:
             e0 = torch.cuda.Event(enable_timing=True)
             e0.record()

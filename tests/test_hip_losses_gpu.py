@@ -148,6 +148,63 @@ def test_stage1_mirror_trajectory_vs_oracle():
     assert w.shape == (1, 14, 512)
 
 
+def test_stage1_hip_graph_replay_equals_eager_steps():
+    """The captured stage-1 step (projectors/common.py: one eager warm-up step, capture, replay) walks the same trajectory as eager
+    steps: same kernels in the same order, the step-dependent scalars (lr, Adam bias corrections, W-noise scale) read from device memory.
+    Draws come from fixed device tensors (a DeviceRNG whose values repeat every step) so both runs see identical randomness."""
+    from spi_amd.configs import global_config
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.training.projectors.common import Projection
+    from spi_amd.training.projectors.mirror_projector import mirror_setup
+    from spi_amd.utils.rng import DeviceRNG
+    from spi_amd.utils import camera_utils as cu
+
+    class FixedDraws(DeviceRNG):                                 # capturable: no generator state, the same tensors at every step
+        def __init__(self, device):
+            super().__init__(device)
+            self.cache, self.gen = {}, torch.Generator().manual_seed(5)
+
+        def _get(self, kind, shape):
+            key = (kind, tuple(shape))
+            if key not in self.cache:
+                fn = torch.rand if kind == 'u' else torch.randn
+                self.cache[key] = fn(*shape, generator=self.gen).to(self.device)
+            return self.cache[key]
+
+        def rand(self, *shape):
+            return self._get('u', shape)
+
+        def randn(self, *shape):
+            return self._get('n', shape)
+
+    W = olo.make_vgg16_weights(seed=0)
+    gen = torch.Generator().manual_seed(32)
+    target = (torch.rand(1, 3, 512, 512, generator=gen) * 2 - 1).to(DEV)
+    c = cu.cal_canonical_c(0.4, 0.0).to(DEV)
+    lp = LPIPS(weights=W).to(DEV)
+    runs = {}
+    old = global_config.stage1_hip_graph
+    try:
+        for graph in (False, True):
+            global_config.stage1_hip_graph = graph
+            cameras, dist_fn = mirror_setup(target, c, lp, torch.device(DEV))
+            proj = Projection(_narrow(), cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=40, w_avg_samples=64, device=torch.device(DEV),
+                              rng=FixedDraws(DEV))
+            for buf in proj.noise_bufs.values():                 # the constructor re-initialised them from the cache: same in both runs
+                assert buf.requires_grad
+            outs = [proj.step(i) for i in range(7)]
+            assert (getattr(proj, '_graph', None) is not None) == graph, 'graph capture did not happen' if graph else 'unexpected graph'
+            assert proj.optimizer.step_count == 7
+            runs[graph] = (proj.w_opt.detach().clone(), [o['loss'].item() for o in outs], [b.detach().clone() for b in proj.noise_bufs.values()])
+    finally:
+        global_config.stage1_hip_graph = old
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert abs(a - b) <= 1e-5 * abs(b), (runs[True][1], runs[False][1])
+    assert_close(runs[True][0], runs[False][0], 1e-5, 'w+ after 7 steps, graph vs eager')
+    for a, b in zip(runs[True][2], runs[False][2]):
+        assert_close(a, b, 1e-4, 'noise maps after 7 steps, graph vs eager')
+
+
 @pytest.mark.timeout(2400)
 def test_stage2_rotbbox_iteration_vs_oracle():
     """One full stage-2 iteration (i = 0: main + rot + mirror-rot + depth branches) and one plain iteration."""
