@@ -43,3 +43,9 @@ conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
 # stage 1: capture the projector step in a HIP graph after an eager warm-up step and replay it (projectors/common.py).  The step is
 # GPU-bound either way; the graph takes the ~10 ms of host enqueue work per step off the CPU.  Off: every step is enqueued eagerly.
 stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'
+
+# stage 2: the same for the RotBbox iteration (rot_bbox_cx_coach.py): one graph for the plain iteration, one for the iteration with the
+# rot / mirror-rot / depth branches; the early-stop test and the Adam launch stay on the host.  OPT-IN (SPI_STAGE2_GRAPH=1): correct
+# at reduced size (test_stage2_hip_graph_replay_equals_eager_iterations) and for the plain iteration at full size, but the replayed
+# branch iteration faults inside torch's min-reduction backward at full size on ROCm 7.0 / torch 2.10 -- eager by default.
+stage2_hip_graph = os.environ.get('SPI_STAGE2_GRAPH', '0') == '1'

@@ -81,9 +81,11 @@ def roi_align(x, boxes, output_size=80, plan=None):
             j += 1
         img = x[i:j + 1]
         xf, yf = pl['xf'], pl['yf']
-        top, bot = img[:, :, pl['yl'], :], img[:, :, pl['yh'], :]
-        val = ((top[..., pl['xl']] * (1 - xf) + top[..., pl['xh']] * xf) * (1 - yf).view(1, 1, -1, 1)
-               + (bot[..., pl['xl']] * (1 - xf) + bot[..., pl['xh']] * xf) * yf.view(1, 1, -1, 1))
+        # index_select, not img[:, :, idx]: the backward of advanced indexing is a sort-based index_put_, which faulted when the iteration
+        # was replayed from a captured HIP graph; index_select's backward is an atomic index_add_
+        top, bot = img.index_select(2, pl['yl']), img.index_select(2, pl['yh'])
+        val = ((top.index_select(3, pl['xl']) * (1 - xf) + top.index_select(3, pl['xh']) * xf) * (1 - yf).view(1, 1, -1, 1)
+               + (bot.index_select(3, pl['xl']) * (1 - xf) + bot.index_select(3, pl['xh']) * xf) * yf.view(1, 1, -1, 1))
         val = val * pl['yv'].view(1, 1, -1, 1) * pl['xv'].view(1, 1, 1, -1)
         res.append(val.reshape(j + 1 - i, c, out, pl['gh'], out, pl['gw']).mean(dim=(3, 5)))
         i = j + 1

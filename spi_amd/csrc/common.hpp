@@ -44,6 +44,11 @@ int64_t spi_wino_workspace_bytes(const WinoParams& P) __attribute__((visibility(
 int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const Epilogue& ep, void* workspace, hipStream_t st)
     __attribute__((visibility("hidden")));
 
+// Zero `n_floats` floats on `st` with a kernel.  Not hipMemsetAsync: as a node of a captured HIP graph a memset whose byte count is not a
+// multiple of 16 (the decoder's 33-float bias gradient) leaves garbage behind on replays (ROCm 7.0; tools/ubench/graph_memset.py),
+// and the loops replay their steps from graphs.
+int spi_zero_async(float* p, int64_t n_floats, hipStream_t st) __attribute__((visibility("hidden")));
+
 static inline hipStream_t as_stream(spi_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }

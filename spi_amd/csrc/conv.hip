@@ -969,8 +969,7 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     // (the 4^2..32^2 layers: a higher precision than asked for, on a small share of the FLOPs).
     if (nb < 512 && nslab >= 8 && !f16_ok) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);
     if (nsplit > 1) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)P.N * P.out_bs * sizeof(float), st);
-        if (e != hipSuccess) { spi_set_error("conv: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+        spi_zero_async(out, (int64_t)P.N * P.out_bs, st);
     }
     switch (cfg) {
     case 0: launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
@@ -1064,8 +1063,7 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     const int64_t wsz = (int64_t)d->O * d->I * d->kh * d->kw;
     const int64_t nw = (d->w_batch_stride == 0) ? 1 : d->N;
     if (!d->dw_zeroed) {
-        hipError_t e = hipMemsetAsync(dw, 0, (size_t)(nw * wsz) * sizeof(float), as_stream(stream));
-        if (e != hipSuccess) { spi_set_error("spi_conv2d_wgrad: memset failed: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+        spi_zero_async(dw, nw * wsz, as_stream(stream));
     }
     // tile 128 x 128; split the pixel reduction so the grid has ~>= 1024 blocks
     // (a 32-row tile for layers with <= 32 output channels -- the 3-channel torgb layers: a 128-row tile spends 97 % of its MFMAs on

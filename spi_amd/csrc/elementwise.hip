@@ -13,6 +13,21 @@ void spi_set_error(const char* fmt, ...) {
 }
 extern "C" const char* spi_last_error(void) { return g_err; }
 extern "C" int spi_abi_version(void) { return SPI_ABI_VERSION; }
+
+__global__ void __launch_bounds__(256) zero_kernel(float* __restrict__ p, int64_t n) {
+    const int64_t n4 = n >> 2;
+    const bool aligned = (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (aligned ? n4 : 0); i += (int64_t)gridDim.x * 256)
+        reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (aligned ? n4 * 4 : 0) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0.f;
+}
+
+int spi_zero_async(float* p, int64_t n_floats, hipStream_t st) {
+    if (n_floats <= 0) return SPI_OK;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(n_floats, 1024), 4096);
+    hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, st, p, n_floats);
+    return SPI_OK;
+}
 extern "C" int spi_sizeof_conv_desc(void) { return (int)sizeof(spi_conv_desc); }
 
 // ------------------------------------------------------------------------------------------------

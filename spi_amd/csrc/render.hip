@@ -1638,8 +1638,8 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
 #define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, colors, d_sigma, d_planes_nhwc, part)
     if (wgrad) {
         if (d_rgb) SPI_BWD_LAUNCH(true, true); else SPI_BWD_LAUNCH(true, false);
-        hipMemsetAsync(dw1, 0, 64 * 32 * sizeof(float), st); hipMemsetAsync(db1, 0, 64 * sizeof(float), st);
-        hipMemsetAsync(dw2, 0, 33 * 64 * sizeof(float), st); hipMemsetAsync(db2, 0, 33 * sizeof(float), st);
+        spi_zero_async(dw1, 64 * 32, st); spi_zero_async(db1, 64, st);
+        spi_zero_async(dw2, 33 * 64, st); spi_zero_async(db2, 33, st);
         hipLaunchKernelGGL(decoder_partial_reduce_kernel, dim3((PART_DB2 + 33 + 255) / 256, 32), dim3(256), 0, st, part, (int)grid * 4, dw1, db1, dw2, db2);
     } else {
         if (d_rgb) SPI_BWD_LAUNCH(false, true); else SPI_BWD_LAUNCH(false, false);
@@ -1662,8 +1662,8 @@ int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, f
     SPI_REQUIRE(dump && dw1 && db1 && dw2 && db2 && cols > 0, "spi_decoder_wgrad: bad argument");
     SPI_REQUIRE(cols % 4 == 0 && ((uintptr_t)dump & 15) == 0, "spi_decoder_wgrad: dump must be 16-byte aligned with cols %% 4 == 0");
     hipStream_t st = as_stream(stream);
-    hipMemsetAsync(dw1, 0, 64 * 32 * sizeof(float), st); hipMemsetAsync(db1, 0, 64 * sizeof(float), st);
-    hipMemsetAsync(dw2, 0, 33 * 64 * sizeof(float), st); hipMemsetAsync(db2, 0, 33 * sizeof(float), st);
+    spi_zero_async(dw1, 64 * 32, st); spi_zero_async(db1, 64, st);
+    spi_zero_async(dw2, 33 * 64, st); spi_zero_async(db2, 33, st);
     int64_t chunk = (cols + 1023) / 1024;                    // ~1024 blocks
     chunk = std::max<int64_t>(256, ((chunk + WG_BK - 1) / WG_BK) * WG_BK);
     const unsigned grid = (unsigned)ceil_div64(cols, chunk);

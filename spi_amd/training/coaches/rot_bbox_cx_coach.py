@@ -48,6 +48,9 @@ class RotBboxCoach(BaseCoach):
         ctx = dict(image=image, camera=camera, image_m=torch.flip(image, dims=[3]), camera_m=cal_mirror_c(camera=camera),
                    fg_mask=1 - (mask == 0).float(), face_mask=calculate_face_mask(mask).float(), lm=data['lm'].to(dev).float().reshape(1, 68, 2))
         ctx['face_mask_m'] = torch.flip(ctx['face_mask'], dims=[3])
+        # inverse source extrinsics of the two warps (rotate): constant per image, and torch.inverse cannot run inside a HIP-graph capture
+        for k in ('camera', 'camera_m'):
+            ctx[k + '_inv'] = torch.inverse(ctx[k].repeat(self.rot_bs, 1)[:, :16].reshape(-1, 4, 4)).reshape(-1, 16).contiguous()
         ctx['weight_m'] = float(cal_camera_weight(camera)[0])
         ctx['yaw_range'] = float(cal_camera_gauss_weight(camera)[0]) if hyperparameters.use_adapt_yaw_range else 0.2
         ctx['target_feats'] = self.lpips_loss.features(image)
@@ -75,10 +78,74 @@ class RotBboxCoach(BaseCoach):
         noise = (rng.rand(n, m, int(rk['depth_resolution']), 1), rng.rand(n * m, max(int(rk['depth_resolution_importance']), 1)))
         return G.synthesis(ws, cams, noise_mode='const', render_noise=noise, **kw)
 
+    # ---- HIP-graph replay (MI355X-first; the eager iteration below is the definition) --------------------------------------------
+    # An iteration is ~1000 launches (every 4th: ~3500) whose sequence depends on nothing the GPU computes -- the data-driven skipping
+    # happens inside the kernels -- so after one eager iteration of its kind (plain / with the pseudo-view branches) the next one is
+    # CAPTURED (forward, losses, every backward, gradient folding) and later ones are a single graph launch.  The early-stop test
+    # stays on the host, where the reference has it, BEFORE the optimiser step: the graph leaves `lpips <= threshold` in a device
+    # byte, the host reads it after the replay and only then launches Adam (one eager launch, host scalars).  Graphs are keyed to
+    # the image's tensors, the pivot and the generator / optimiser instances and dropped when any of them changes.
+    GRAPH_WARMUP = int(os.environ.get('SPI_GRAPH_WARMUP', '1'))          # eager iterations of a kind before its capture
+
+    def _graph_ok(self, rng):
+        return (global_config.stage2_hip_graph and isinstance(rng, DeviceRNG) and torch.device(self.device).type == 'cuda'
+                and not global_config.concurrent_branches and not getattr(self, '_graph_failed', False))
+
+    def _graph_train_step(self, i, ctx, w_pivot, rng):
+        key = (id(ctx), w_pivot.data_ptr(), id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold))    # (the threshold is baked in)
+        if getattr(self, '_g2_key', None) != key:
+            self._g2_key, self._g2 = key, {}
+        st = self._g2.setdefault('branch' if i % self.rot_bs == 0 else 'plain', dict(eager=0, graph=None))
+        if st['graph'] is None:
+            if st['eager'] < self.GRAPH_WARMUP:                  # the first iterations of a kind run eagerly (lazy initialisations, allocator
+                st['eager'] += 1                                 # warm-up, the frozen generator's tri-plane cache of the depth branch)
+                return self._eager_train_step(i, ctx, w_pivot, rng)
+            flag = torch.zeros(1, device=self.device, dtype=torch.uint8)
+            try:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    _, losses = self._forward_backward(i, ctx, w_pivot, rng, flag_buf=flag)
+            except Exception as e:                               # noqa: BLE001  (capture is an optimisation: the eager iteration is always valid)
+                import sys
+                self._graph_failed = True
+                torch.cuda.synchronize()
+                print(f'[spi_amd] stage-2 HIP-graph capture failed ({type(e).__name__}: {e}); continuing with eager iterations', file=sys.stderr)
+                import traceback
+                print(''.join(traceback.format_tb(e.__traceback__)[-6:]), file=sys.stderr)
+                return self._eager_train_step(i, ctx, w_pivot, rng)
+            st.update(graph=g, losses=losses, flag=flag, flag_host=torch.zeros(1, dtype=torch.uint8).pin_memory(), event=torch.cuda.Event())
+        st['graph'].replay()
+        st['flag_host'].copy_(st['flag'], non_blocking=True)
+        st['event'].record()
+        st['event'].synchronize()                                # the loop's one host read (:148), here after the whole iteration
+        losses = {k: v.clone() for k, v in st['losses'].items()}  # the graph's outputs are overwritten by the next replay
+        if bool(st['flag_host'][0]):
+            return True, losses
+        self.optimizer.step()
+        return False, losses
+
     def train_step(self, i, ctx, w_pivot, rng=None):
         """One iteration of the stage-2 loop.  Returns (stop, losses dict of 0-dim device tensors)."""
-        hp = hyperparameters
         rng = rng or self.rng or DeviceRNG(self.device)
+        if self._graph_ok(rng):
+            return self._graph_train_step(i, ctx, w_pivot, rng)
+        return self._eager_train_step(i, ctx, w_pivot, rng)
+
+    def _eager_train_step(self, i, ctx, w_pivot, rng):
+        stop_flag, losses = self._forward_backward(i, ctx, w_pivot, rng, flag_buf=None)
+        # the loop's one host read (:148).  The flag was copied to pinned memory right after the main forward, so the
+        # wait ends when the GPU has passed THAT point (not the whole iteration): the backward passes keep the GPU busy
+        # while the host enqueues the optimiser step and the next forward.
+        if stop_flag is not None and stop_flag():
+            return True, losses
+        self.optimizer.step()
+        return False, losses
+
+    def _forward_backward(self, i, ctx, w_pivot, rng, flag_buf):
+        """Everything of an iteration up to the early-stop test: forward passes, losses, backward passes, gradients folded into .grad.
+        flag_buf None: returns (callable waiting for `lpips <= threshold` on the host, losses); else the flag goes into that device byte."""
+        hp = hyperparameters
         G, rot_bs = self.G, self.rot_bs
         ws = w_pivot.detach()
         self.optimizer.zero_grad()
@@ -101,7 +168,12 @@ class RotBboxCoach(BaseCoach):
         if hp.pt_lpips_lambda > 0:
             losses['lpips'] = torch.squeeze(self.lpips_loss(gen['image'], y_feats=ctx['target_feats']))
             loss = loss + losses['lpips'] * hp.pt_lpips_lambda
-        stop_flag = self._async_flag(losses['lpips'] <= hp.LPIPS_value_threshold) if 'lpips' in losses else None
+        stop_flag = None
+        if 'lpips' in losses:
+            if flag_buf is None:
+                stop_flag = self._async_flag(losses['lpips'] <= hp.LPIPS_value_threshold)
+            else:
+                flag_buf.copy_((losses['lpips'].detach() <= hp.LPIPS_value_threshold).reshape(1).to(torch.uint8))
         # The reference calls backward() once per loss (:69,85,105,131): every parameter's .grad is read-modify-written once per
         # call (~150 tiny add_ launches each).  Here each call returns its gradients as fresh tensors (autograd.grad) and they are
         # folded into .grad in the reference's order with one multi-tensor add per call: the same sums.
@@ -141,7 +213,7 @@ class RotBboxCoach(BaseCoach):
                     # loss looks at image * warp_mask, and the SR convs skip the tiles no visible pixel depends on (triplane.synthesis)
                     warp['img'], warp['mask'] = rotate(target_camera=cams, target_depth=out['image_depth'], src_image=ctx['image'].repeat(rot_bs, 1, 1, 1),
                                                        src_camera=ctx['camera'].repeat(rot_bs, 1), src_depth=depth_main.repeat(rot_bs, 1, 1, 1),
-                                                       src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
+                                                       src_mask=ctx['face_mask'].repeat(rot_bs, 1, 1, 1), EPS=5e-2, src_cam2world_inv=ctx['camera_inv'])
                     return warp['mask'] if global_config.exploit_sparsity else None
                 gs = self._synth(G, ws, cams, rng, sr_region_fn=region, use_cached_backbone=True)
                 losses['rot'] = self.lpips_loss(gs['image'] * warp['mask'], warp['img']) * hp.pt_rot_lambda * rot_bs
@@ -156,7 +228,7 @@ class RotBboxCoach(BaseCoach):
                     warp['img'], warp['mask'] = rotate(target_camera=cams_m, target_depth=out['image_depth'], src_image=ctx['image_m'].repeat(rot_bs, 1, 1, 1),
                                                        src_camera=ctx['camera_m'].repeat(rot_bs, 1),
                                                        src_depth=torch.flip(depth_main, dims=[3]).repeat(rot_bs, 1, 1, 1),
-                                                       src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2)
+                                                       src_mask=ctx['face_mask_m'].repeat(rot_bs, 1, 1, 1), EPS=5e-2, src_cam2world_inv=ctx['camera_m_inv'])
                     return warp['mask'] if global_config.exploit_sparsity else None
                 gm = self._synth(G, ws, cams_m, rng, sr_region_fn=region, use_cached_backbone=True)
                 flip_warp, flip_mask = torch.flip(warp['img'], dims=[3]), torch.flip(warp['mask'], dims=[3])
@@ -207,13 +279,9 @@ class RotBboxCoach(BaseCoach):
             for p, g in have:
                 if p.grad is None:
                     p.grad = g
-        # the loop's one host read (:148).  The flag was copied to pinned memory right after the main forward, so the
-        # wait ends when the GPU has passed THAT point (not the whole iteration): the backward passes keep the GPU busy
-        # while the host enqueues the optimiser step and the next forward.
-        if stop_flag is not None and stop_flag():
-            return True, losses
-        self.optimizer.step()
-        return False, losses
+        # detached: a caller that keeps the dict must not keep the iteration's autograd graph alive with it (with the previous iteration's
+        # graph still referenced, ending a HIP-graph capture of the next one crashed inside the runtime)
+        return stop_flag, {k: v.detach() for k, v in losses.items()}
 
     def train(self):
         paths_config.experiments_output_dir += f'{self.coach_name}'

@@ -171,6 +171,8 @@ class Projection:
             self._graph_failed = True
             torch.cuda.synchronize()
             print(f'[spi_amd] stage-1 HIP-graph capture failed ({type(e).__name__}: {e}); continuing with eager steps', file=sys.stderr)
+            import traceback
+            print(''.join(traceback.format_tb(e.__traceback__)[-6:]), file=sys.stderr)
             return self._body(step, device_hyper=False)
         self._graph, self._graph_out = g, out
         g.replay()                                               # capture records, it does not execute: run the captured step once

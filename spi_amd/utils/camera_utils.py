@@ -31,7 +31,7 @@ def _normalize(v):
 
 def create_cam2world_matrix(forward, origin):
     forward = _normalize(forward)
-    up = torch.tensor([0.0, 1.0, 0.0], dtype=torch.float32, device=origin.device).expand_as(forward)
+    up = _const([0.0, 1.0, 0.0], origin.device).expand_as(forward)
     right = -_normalize(torch.cross(up, forward, dim=-1))
     up = _normalize(torch.cross(forward, right, dim=-1))
     b = forward.shape[0]
@@ -40,6 +40,19 @@ def create_cam2world_matrix(forward, origin):
     trans = torch.eye(4, device=origin.device).unsqueeze(0).repeat(b, 1, 1)
     trans[:, :3, 3] = origin
     return trans @ rot
+
+
+_CONSTS = {}
+
+
+def _const(values, device):
+    """Small constant tensor on `device`, uploaded once (a host -> device copy cannot be part of a captured HIP graph, and the samplers run
+    inside the stage-2 iteration)."""
+    key = (tuple(map(tuple, values)) if isinstance(values[0], (list, tuple)) else tuple(values), str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, dtype=torch.float32, device=device)
+    return t
 
 
 def look_at_pose(h, v, lookat, radius):
@@ -54,7 +67,7 @@ def look_at_pose(h, v, lookat, radius):
 
 
 def _intrinsics(batch_size, device):
-    return torch.tensor([[FOCAL, 0, 0.5], [0, FOCAL, 0.5], [0, 0, 1]], device=device).view(1, 9).repeat(batch_size, 1)
+    return _const([[FOCAL, 0, 0.5], [0, FOCAL, 0.5], [0, 0, 1]], device).view(1, 9).repeat(batch_size, 1)
 
 
 def sample_camera(batch_size=1, yaw_range=0.35, pitch_range=0.25, device='cpu', rand=None):
@@ -64,13 +77,13 @@ def sample_camera(batch_size=1, yaw_range=0.35, pitch_range=0.25, device='cpu', 
         rv = torch.rand((batch_size, 1), device=device)
     else:
         rh, rv = rand
-    lookat = torch.tensor(LOOKAT, device=device)
+    lookat = _const(LOOKAT, device)
     ext = look_at_pose(rh * yaw_range + math.pi / 2, rv * pitch_range + (math.pi / 2 + PITCH_BIAS), lookat, RADIUS)
     return torch.cat([ext.reshape(-1, 16), _intrinsics(batch_size, device)], dim=1)
 
 
 def cal_canonical_c(yaw_angle=0, pitch_angle=0, batch_size=1, device='cpu'):
-    lookat = torch.tensor(LOOKAT, device=device)
+    lookat = _const(LOOKAT, device)
     h = torch.full((batch_size, 1), math.pi / 2 + yaw_angle, device=device)
     v = torch.full((batch_size, 1), math.pi / 2 + PITCH_BIAS + pitch_angle, device=device)
     ext = look_at_pose(h, v, lookat, RADIUS)

@@ -9,14 +9,17 @@ from .. import hip
 
 
 @torch.no_grad()
-def rotate(target_camera, target_depth, src_image, src_camera, src_depth, src_mask=None, EPS=5e-2):
+def rotate(target_camera, target_depth, src_image, src_camera, src_depth, src_mask=None, EPS=5e-2, src_cam2world_inv=None):
+    """src_cam2world_inv [n,16]: optional precomputed inverse of the source extrinsics (constant per image in SPI's loop; `torch.inverse`
+    synchronises with the host and cannot be part of a captured HIP graph)."""
     n = src_image.shape[0]
     res = src_image.shape[-1]
     dres = target_depth.shape[-1]
     dev = src_image.device
     tgt = target_camera.reshape(n, 25).float().contiguous()
     src = src_camera.reshape(n, 25).float().contiguous()
-    src_inv = torch.inverse(src[:, :16].reshape(n, 4, 4)).reshape(n, 16).contiguous()
+    src_inv = (torch.inverse(src[:, :16].reshape(n, 4, 4)).reshape(n, 16) if src_cam2world_inv is None
+               else src_cam2world_inv.reshape(n, 16).float()).contiguous()
     td = target_depth.reshape(n, dres, dres).float().contiguous()
     sd = src_depth.reshape(n, dres, dres).float().contiguous()
     img = src_image.float().contiguous()

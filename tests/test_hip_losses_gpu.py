@@ -265,6 +265,77 @@ def test_stage2_rotbbox_iteration_vs_oracle():
         assert rel_err(sd[k].cpu() - st.P0[k], st.P[k].detach() - st.P0[k]) < 5e-2, k
 
 
+@pytest.mark.timeout(1500)
+def test_stage2_hip_graph_replay_equals_eager_iterations():
+    """The two captured stage-2 iterations (plain; with the rot / mirror-rot / depth branches; opt-in, global_config.stage2_hip_graph)
+    against eager iterations: 10 iterations (eager 0, 1; captures at 2 and 4; replays) with draws that repeat every iteration, same losses and same parameters at the end."""
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.criteria.bbox_cx_loss import BoxCXLoss
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.data.images_dataset import SyntheticDataset
+    from spi_amd.utils.rng import DeviceRNG
+    from spi_amd.configs import hyperparameters, paths_config, global_config
+    import tempfile
+
+    class FixedDraws(DeviceRNG):
+        def __init__(self, device):
+            super().__init__(device)
+            self.cache, self.gen = {}, torch.Generator().manual_seed(9)
+
+        def rand(self, *shape):
+            if shape not in self.cache:
+                self.cache[shape] = torch.rand(*shape, generator=self.gen).to(self.device)
+            return self.cache[shape]
+
+    W, W19 = olo.make_vgg16_weights(seed=0), olo.make_vgg19_head_weights(seed=1)
+    data = SyntheticDataset(1)[0]
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in data.items()}
+    w_pivot = torch.randn(1, 14, 512, generator=torch.Generator().manual_seed(6)).to(DEV)
+    tmp = tempfile.mkdtemp()
+    for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
+        setattr(paths_config, k, f'{tmp}/{k}/')
+    hyperparameters.first_inv_type, hyperparameters.G_1_type = 'mir', 'RotBbox'
+    hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda = 0.1, 0.05, 1.0
+    old, old_thr = global_config.stage2_hip_graph, hyperparameters.LPIPS_value_threshold
+    runs = {}
+    try:
+        hyperparameters.LPIPS_value_threshold = -1.0
+        for graph in (False, True):
+            global_config.stage2_hip_graph = graph
+            coach = RotBboxCoach(None, False, G=_narrow(), lpips_loss=LPIPS(weights=W), box_cx_loss=BoxCXLoss(weights=W19))
+            ctx = coach.prepare_image(data)
+            rng = FixedDraws(DEV)
+            hist = []
+            for i in range(10):
+                stop, losses = coach.train_step(i, ctx, w_pivot, rng=rng)
+                assert not stop
+                hist.append({k: float(v) for k, v in losses.items()})
+            kinds = getattr(coach, '_g2', {})
+            assert (all(kinds.get(k, {}).get('graph') is not None for k in ('plain', 'branch'))) == graph, kinds.keys()
+            runs[graph] = (hist, {k: v.detach().clone() for k, v in coach.G.state_dict().items()})
+        # the threshold is baked into a captured iteration, so it is part of the graphs' key: a new value drops them, the next iteration
+        # runs eagerly and stops BEFORE the optimiser step, like the reference
+        hyperparameters.LPIPS_value_threshold = 1e9
+        before = {k: v.detach().clone() for k, v in coach.G.state_dict().items()}
+        stop, _ = coach.train_step(11, ctx, w_pivot, rng=rng)
+        assert stop and not coach._g2 .get('plain', {}).get('graph') and all(torch.equal(v, before[k]) for k, v in coach.G.state_dict().items())
+        # and a replayed iteration stops too: two eager-free kinds later the plain graph exists again with the new threshold baked in
+        assert coach.train_step(13, ctx, w_pivot, rng=rng)[0] and coach.train_step(14, ctx, w_pivot, rng=rng)[0]
+        assert coach._g2['plain']['graph'] is not None and all(torch.equal(v, before[k]) for k, v in coach.G.state_dict().items())
+    finally:
+        global_config.stage2_hip_graph, hyperparameters.LPIPS_value_threshold = old, old_thr
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-4 * abs(b[k]) + 1e-9, (k, a[k], b[k])
+    moved = 0
+    for k, v in runs[False][1].items():
+        if v.dtype.is_floating_point and 'noise_const' not in k:
+            assert_close(runs[True][1][k], v, 2e-3, f'{k} after 10 iterations, graph vs eager')
+            moved += 1
+    assert moved > 50
+
+
 def test_noise_regulariser_fused_vs_reference_expression():
     """spi_noise_reg_fwd/bwd + spi_noise_renorm against the reference's expression (mirror_projector.py:106-116,127-131)."""
     import torch.nn.functional as F
