@@ -313,6 +313,14 @@ def main():
     cameras, dist_fn = mirror_setup(ctx['image'], ctx['camera'], coach.lpips_loss, dev)
     proj = Projection(coach.G, cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=500, w_avg_samples=600, device=dev)
     w_pivot = proj.w_opt.detach().clone()
+    # set-up, not warm-up: the projector replays its step from a HIP graph that it captures on its second call (one eager step first); a
+    # real run pays for that once in 500 steps, so it is built here and neither the W warm-up steps nor the K timed steps contain it
+    graph_build_steps = 0
+    if global_config.stage1_hip_graph:
+        while getattr(proj, '_graph', None) is None and not getattr(proj, '_graph_failed', False) and graph_build_steps < 3:
+            proj.step(graph_build_steps)
+            graph_build_steps += 1
+        torch.cuda.synchronize()
 
     marks = {}
 
@@ -428,6 +436,7 @@ def main():
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
+                       'stage1_graph_build_steps_before_warmup': graph_build_steps, 'stage2_hip_graph': bool(global_config.stage2_hip_graph),
                        'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
                                    if global_config.conv_winograd and global_config.conv_precision == 0 else 'implicit GEMM'),
                        'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else

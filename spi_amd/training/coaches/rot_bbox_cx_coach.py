@@ -88,8 +88,10 @@ class RotBboxCoach(BaseCoach):
     GRAPH_WARMUP = int(os.environ.get('SPI_GRAPH_WARMUP', '1'))          # eager iterations of a kind before its capture
 
     def _graph_ok(self, rng):
+        import torch.distributed as tdist
         return (global_config.stage2_hip_graph and isinstance(rng, DeviceRNG) and torch.device(self.device).type == 'cuda'
-                and not global_config.concurrent_branches and not getattr(self, '_graph_failed', False))
+                and not global_config.concurrent_branches and not getattr(self, '_graph_failed', False)
+                and not (tdist.is_available() and tdist.is_initialized()))
 
     def _graph_train_step(self, i, ctx, w_pivot, rng):
         key = (id(ctx), w_pivot.data_ptr(), id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold))    # (the threshold is baked in)

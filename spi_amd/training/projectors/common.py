@@ -128,7 +128,11 @@ class Projection:
 
     def _graph_ok(self):
         from ...configs import global_config
-        return (global_config.stage1_hip_graph and isinstance(self.rng, DeviceRNG) and self.w_opt.is_cuda and not getattr(self, '_graph_failed', False))
+        import torch.distributed as tdist
+        # (not beside an initialised process group: RCCL's watchdog thread issues HIP calls of its own, which a capture in global mode does not
+        #  tolerate; the step is GPU-bound, so the multi-GPU runs lose nothing by enqueueing eagerly)
+        return (global_config.stage1_hip_graph and isinstance(self.rng, DeviceRNG) and self.w_opt.is_cuda and not getattr(self, '_graph_failed', False)
+                and not (tdist.is_available() and tdist.is_initialized()))
 
     def _set_hyper(self, step):
         lr, w_noise_scale = stage1_schedule(step, self.num_steps, self.w_std, **self.sched)
