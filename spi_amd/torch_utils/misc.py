@@ -1,0 +1,52 @@
+"""Tracing helpers of the reference's ``torch_utils/misc.py`` that the hot path uses.
+
+``profiled_function`` (misc.py:102-107 wraps a function in ``torch.autograd.profiler.record_function``) marks the same two functions as
+the reference does -- ``normalize_2nd_moment`` and ``modulated_conv2d`` (networks_stylegan2.py:27,33) -- and ``trace_range`` marks the
+phases of one synthesis (backbone / renderer / super-resolution) and of the two loops (losses, optimiser).  On MI355X the ranges are
+rocTX ranges (``torch.cuda.nvtx`` is rocTX on ROCm): ``rocprofv3 --marker-trace --kernel-trace`` shows them beside the kernels.
+They cost a Python call each, so they are OFF unless ``SPI_TRACE=1`` (or ``enable_tracing(True)``): the default run has no marker
+overhead and a captured HIP graph contains none.
+"""
+import contextlib
+import functools
+import os
+
+import torch
+
+_enabled = [os.environ.get('SPI_TRACE', '0') == '1']
+
+
+def enable_tracing(on=True):
+    _enabled[0] = bool(on)
+
+
+def tracing_enabled():
+    return _enabled[0]
+
+
+@contextlib.contextmanager
+def trace_range(name):
+    """rocTX range + autograd-profiler range around a phase; a no-op context when tracing is off."""
+    if not _enabled[0]:
+        yield
+        return
+    use_roctx = torch.cuda.is_available()
+    if use_roctx:
+        torch.cuda.nvtx.range_push(name)
+    try:
+        with torch.autograd.profiler.record_function(name):
+            yield
+    finally:
+        if use_roctx:
+            torch.cuda.nvtx.range_pop()
+
+
+def profiled_function(fn):
+    """Same contract as the reference's decorator (the range carries the function's name); free when tracing is off."""
+    @functools.wraps(fn)
+    def decorator(*args, **kwargs):
+        if not _enabled[0]:
+            return fn(*args, **kwargs)
+        with trace_range(fn.__name__):
+            return fn(*args, **kwargs)
+    return decorator

@@ -24,6 +24,7 @@ from ...utils.mask_utils import calculate_face_mask
 from ...utils.camera_utils import cal_mirror_c, cal_camera_weight, sample_surrounding_camera, sample_camera, cal_camera_gauss_weight
 from ...utils.rng import DeviceRNG
 from ...torch_utils.ops.conv2d_mfma import sparse_gradients
+from ...torch_utils.misc import trace_range
 from .base_coach import BaseCoach
 
 
@@ -183,7 +184,7 @@ class RotBboxCoach(BaseCoach):
         d_planes = []
 
         def branch_backward(branch_loss, sparse):
-            with sparse_gradients(sparse and global_config.exploit_sparsity):    # sparse: d(image) is exactly zero outside the warp mask
+            with sparse_gradients(sparse and global_config.exploit_sparsity), trace_range('stage2/backward'):    # sparse: d(image) is exactly zero outside the warp mask
                 g = torch.autograd.grad(branch_loss, [leaf] + params, allow_unused=True)
             d_planes.append(g[0])
             pending.append(g[1:])
@@ -252,13 +253,13 @@ class RotBboxCoach(BaseCoach):
                 branch_backward(losses['depth'], False)
 
             if hp.pt_rot_lambda > 0:
-                with on_stream(0):
+                with on_stream(0), trace_range('stage2/rot_branch'):
                     rot_branch()
             if hp.pt_mirror_rot_lambda > 0 and ctx['weight_m'] > 0:
-                with on_stream(1):
+                with on_stream(1), trace_range('stage2/mirror_rot_branch'):
                     mirror_branch()
             if hp.pt_depth_lambda > 0:
-                with on_stream(2):
+                with on_stream(2), trace_range('stage2/depth_branch'):
                     depth_branch()
             if side:
                 for st in side:
@@ -271,7 +272,8 @@ class RotBboxCoach(BaseCoach):
         dpl = d_planes[0]
         for g in d_planes[1:]:
             dpl = dpl + g
-        pending.append(torch.autograd.grad(planes, bb_params, grad_outputs=dpl, allow_unused=True))
+        with trace_range('stage2/backbone_backward'):
+            pending.append(torch.autograd.grad(planes, bb_params, grad_outputs=dpl, allow_unused=True))
         for grads in pending:
             plist = bb_params if grads is pending[-1] else params
             have = [(p, g) for p, g in zip(plist, grads) if g is not None]

@@ -21,8 +21,10 @@ import torch
 from .. import hip
 from ..configs import global_config
 from ..torch_utils.ops import bias_act, upfirdn2d, conv2d_mfma
+from ..torch_utils import misc
 
 
+@misc.profiled_function
 def normalize_2nd_moment(x, dim=1, eps=1e-8):
     return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
 
@@ -151,6 +153,7 @@ class _ModConvFrozen(torch.autograd.Function):
                 None, None, None, None, None, None, None, None, None, None, None)
 
 
+@misc.profiled_function
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                      flip_weight=True, fused_modconv=True, noise_strength=None, bias=None, act=None, gain=None, clamp=None,
                      style_gain=1.0, fp16=False):

@@ -19,6 +19,7 @@ from ... import hip
 from ...configs import hyperparameters
 from ...utils.rng import DeviceRNG
 from ..optim import Adam
+from ...torch_utils.misc import trace_range
 from .schedule import stage1_schedule
 
 
@@ -204,13 +205,16 @@ class Projection:
         rk = G.rendering_kwargs
         noise = (rng.rand(batch, m, int(rk['depth_resolution']), 1), rng.rand(batch * m, max(int(rk['depth_resolution_importance']), 1)))
         images = G.synthesis(ws, self.cameras, noise_mode='const', render_noise=noise)['image']
-        dist = self.dist_fn(images)
-        reg_loss = self.noise_reg()
-        loss = dist + reg_loss * self.reg_weight
+        with trace_range('stage1/losses'):
+            dist = self.dist_fn(images)
+            reg_loss = self.noise_reg()
+            loss = dist + reg_loss * self.reg_weight
         self.optimizer.zero_grad()
-        loss.backward()
-        self.optimizer.step(hyper=self._hyper[:3] if device_hyper else None)
-        self.noise_reg.renorm()
+        with trace_range('stage1/backward'):
+            loss.backward()
+        with trace_range('stage1/optimizer'):
+            self.optimizer.step(hyper=self._hyper[:3] if device_hyper else None)
+            self.noise_reg.renorm()
         return dict(dist=dist.detach(), reg=reg_loss.detach(), loss=loss.detach())
 
 

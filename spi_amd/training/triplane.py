@@ -11,6 +11,7 @@ Extras that do not exist in the reference (all optional, result-identical):
     (the depth-regularisation branch, rot_bbox_cx_coach.py:136-138).
 """
 import torch
+from ..torch_utils import misc
 from .networks_stylegan2 import Generator as StyleGAN2Backbone, FullyConnectedLayer
 from .superresolution import SR_REGISTRY
 from .volumetric_rendering.renderer import ImportanceRenderer
@@ -86,7 +87,8 @@ class TriPlaneGenerator(torch.nn.Module):
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
         else:
-            planes = self._planes(ws, update_emas=update_emas, **synthesis_kwargs)
+            with misc.trace_range('synthesis/backbone'):
+                planes = self._planes(ws, update_emas=update_emas, **synthesis_kwargs)
         if cache_backbone:
             self._last_planes = planes
         if planes.shape[0] == 1 and n > 1:
@@ -94,7 +96,8 @@ class TriPlaneGenerator(torch.nn.Module):
             # rot_bbox_cx_coach.py:92): the tri-planes do not depend on the camera, so the backbone runs ONCE and the views
             # share its output; autograd sums the per-view plane gradients before the single backbone backward pass.
             planes = planes.expand(n, -1, -1, -1, -1)
-        feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs, noise=render_noise, depth_only=depth_only)
+        with misc.trace_range('synthesis/renderer'):
+            feat, depth, _ = self.renderer(planes, self.decoder, ray_o, ray_d, self.rendering_kwargs, noise=render_noise, depth_only=depth_only)
         r = self.neural_rendering_resolution
         if depth_only:
             return {'image_depth': depth.permute(0, 2, 1).reshape(n, 1, r, r)}
@@ -107,12 +110,13 @@ class TriPlaneGenerator(torch.nn.Module):
             region = sr_region_fn(out) if sr_region_fn is not None else None
             if region is not None and hasattr(self.superresolution, 'needed_output_maps'):
                 from ..torch_utils.ops import conv2d_mfma
-                with conv2d_mfma.needed_output(self.superresolution.needed_output_maps(region)):
+                with conv2d_mfma.needed_output(self.superresolution.needed_output_maps(region)), misc.trace_range('synthesis/superresolution'):
                     out['image'] = self.superresolution(rgb_image, feature_image, ws,
                                                         noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **sr_kwargs)
             else:
-                out['image'] = self.superresolution(rgb_image, feature_image, ws,
-                                                    noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **sr_kwargs)
+                with misc.trace_range('synthesis/superresolution'):
+                    out['image'] = self.superresolution(rgb_image, feature_image, ws,
+                                                        noise_mode=self.rendering_kwargs['superresolution_noise_mode'], **sr_kwargs)
         return out
 
     def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):

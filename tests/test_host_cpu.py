@@ -409,3 +409,34 @@ def test_preprocess_driver_layout_feeds_the_dataset(tmp_path):
     assert d['lm'].shape == (68, 2) and np.asarray(d['c']).shape == (25,) and int(d['mask'].max()) == 18
     args = run_total.parse_args([])
     assert (args.input_root, args.output_root, args.mode) == ('./test/images/', './test/dataset/', 'jpg')
+
+
+def test_tracing_helpers_mirror_the_reference_decorator():
+    """torch_utils/misc.py: `profiled_function` keeps the wrapped function's name and result (reference misc.py:102-107) and marks the two
+    functions the reference marks; ranges are free when tracing is off and nest when it is on (CPU: autograd-profiler ranges only)."""
+    import torch
+    from spi_amd.torch_utils import misc
+    from spi_amd.training import networks_stylegan2 as sg
+
+    @misc.profiled_function
+    def twice(x, k=2):
+        return x * k
+    assert twice.__name__ == 'twice' and twice(3, k=4) == 12
+    assert sg.modulated_conv2d.__name__ == 'modulated_conv2d' and sg.normalize_2nd_moment.__name__ == 'normalize_2nd_moment'
+    old = misc.tracing_enabled()
+    try:
+        misc.enable_tracing(True)
+        with torch.autograd.profiler.profile() as prof:
+            with misc.trace_range('outer'):
+                y = sg.normalize_2nd_moment(torch.ones(2, 8))
+                assert twice(5) == 10
+        names = {e.name for e in prof.function_events}
+        assert {'outer', 'normalize_2nd_moment', 'twice'} <= names
+        assert torch.allclose(y, torch.ones(2, 8), atol=1e-6)
+        misc.enable_tracing(False)
+        with torch.autograd.profiler.profile() as prof:
+            with misc.trace_range('silent'):
+                twice(1)
+        assert 'silent' not in {e.name for e in prof.function_events}
+    finally:
+        misc.enable_tracing(old)
