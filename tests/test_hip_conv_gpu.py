@@ -360,6 +360,48 @@ def test_conv_winograd_vs_oracle_and_implicit_gemm(case):
             assert float((diff > 1e-5).float().mean()) < 5e-3 and float(diff.median()) < 1e-6, what
 
 
+def test_conv_winograd_random_shapes_vs_implicit_gemm():
+    """24 seeded random problems that take the Winograd path (ragged image sizes, 8 .. 128 input channels, output channels that are not a
+    multiple of the 64-channel chunk, shared / per-sample weights, flipped taps, fused epilogues): forward and data gradient equal the
+    implicit-GEMM kernels' to 1e-5 of the tensor's maximum (median for gradients behind an activation, see the kink-flip note above)."""
+    import ctypes
+    import random
+    from spi_amd import hip
+    from spi_amd.configs import global_config
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    rnd = random.Random(3)
+    done = 0
+    old = global_config.conv_winograd
+    try:
+        while done < 24:
+            N, I, O = rnd.choice([1, 1, 2, 3]), rnd.choice([8, 16, 24, 40, 64, 72, 128]), rnd.choice([48, 64, 80, 100, 128, 130, 192])
+            H, W = rnd.randint(40, 300), rnd.randint(40, 300)
+            flip, per, epi = rnd.random() < 0.5, rnd.random() < 0.6, rnd.random() < 0.5
+            d = conv2d_mfma._desc(N, I, O, H, W, 3, 1, False, flip, O * I * 9 if per else 0, tap_major=1)
+            if hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 0) == 0:
+                continue
+            done += 1
+            g = torch.Generator().manual_seed(done)
+            x = torch.randn(N, I, H, W, generator=g).to(DEV).requires_grad_(True)
+            w = (torch.randn(*((N,) if per else ()), O, I, 3, 3, generator=g) / (I * 9) ** 0.5).to(DEV).requires_grad_(True)
+            kw = dict(padding=1, flip=flip)
+            if epi:
+                kw.update(bias=torch.randn(O, generator=g).to(DEV), noise=torch.randn(H, W, generator=g).to(DEV), noise_strength=torch.tensor(0.3, device=DEV),
+                          act=rnd.choice(['lrelu', 'linear', 'relu']), gain=1.3, clamp=rnd.choice([None, 2.0]))
+            dy = torch.randn(N, O, H, W, generator=g).to(DEV)
+            outs = []
+            for wino in (True, False):
+                global_config.conv_winograd = wino
+                y = conv2d_mfma.conv2d(x, w, **kw)
+                outs.append((y.detach(), torch.autograd.grad(y, [x], dy)[0]))
+            what = f'case {done}: {(N, I, O, H, W, flip, per, epi)}'
+            assert_close(outs[0][0], outs[1][0], 1e-5, what + ' fwd')
+            diff = (outs[0][1] - outs[1][1]).abs() / outs[1][1].abs().max()
+            assert float(diff.median() if epi else diff.max()) < 1e-5, what + ' dgrad'
+    finally:
+        global_config.conv_winograd = old
+
+
 def test_conv_winograd_is_not_offered_where_it_does_not_apply():
     import ctypes
     from spi_amd import hip
