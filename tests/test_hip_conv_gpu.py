@@ -360,6 +360,25 @@ def test_conv_winograd_vs_oracle_and_implicit_gemm(case):
             assert float((diff > 1e-5).float().mean()) < 5e-3 and float(diff.median()) < 1e-6, what
 
 
+def test_conv_wgrad_zeroes_a_dirty_buffer_itself():
+    """spi_conv2d_wgrad with dw_zeroed = 0 clears dw with the library's own kernel (spi_zero_async; not hipMemsetAsync, whose captured
+    form misbehaves for odd byte counts on ROCm 7.0): a dirty, odd-sized (135-float) buffer ends up holding exactly the gradient."""
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(12)
+    N, I, O, H = 2, 5, 3, 20
+    x = torch.randn(N, I, H, H, generator=gen)
+    dy = torch.randn(N, O, H, H, generator=gen)
+    w = torch.randn(O, I, 3, 3, generator=gen, requires_grad=True)
+    ref, = torch.autograd.grad(F.conv2d(x, w, padding=1), [w], dy)
+    d = conv2d_mfma._desc(N, I, O, H, H, 3, 1, False, False, 0, tap_major=1, dw_zeroed=0)
+    dw = torch.full((O, 3, 3, I), 7.5, device=DEV)                       # tap-major layout, dirty
+    xg, dyg = x.to(DEV), dy.to(DEV)
+    hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(xg), hip.ptr(dyg), hip.ptr(dw), hip.stream())
+    assert_close(dw.permute(0, 3, 1, 2), ref, 2e-5, 'wgrad into a dirty buffer')
+
+
 def test_conv_winograd_random_shapes_vs_implicit_gemm():
     """24 seeded random problems that take the Winograd path (ragged image sizes, 8 .. 128 input channels, output channels that are not a
     multiple of the 64-channel chunk, shared / per-sample weights, flipped taps, fused epilogues): forward and data gradient equal the
