@@ -384,7 +384,7 @@ def main():
         main_marks = dict(marks)
         alt_err = None
         try:
-            run(min(w1, 2), min(w2, 4), 25 + w1 + k1, ((w2 + k2 + 3) // 4) * 4)
+            run(2 if k1 else 0, min(w2, 4), 25 + w1 + k1, ((w2 + k2 + 3) // 4) * 4)      # (2 stage-1 steps: the projector re-captures its graph for this arithmetic)
         except Exception as e:                                    # noqa: BLE001
             alt_err = repr(e)
         sdist.barrier(); torch.cuda.synchronize()

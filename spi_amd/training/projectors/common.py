@@ -157,6 +157,12 @@ class Projection:
         self._hyper_events[k] = ev
 
     def _graph_step(self, step):
+        from ...configs import global_config
+        # the captured launches bake in the arithmetic of the run: another setting drops the graph (one eager step, then a new capture)
+        key = (global_config.conv_precision, global_config.conv_winograd, global_config.enable_fp16_blocks, global_config.exploit_sparsity)
+        if getattr(self, '_graph_key', key) != key:
+            self._graph, self._n_eager = None, 0
+        self._graph_key = key
         if getattr(self, '_graph', None) is not None:
             self._set_hyper(step)
             self.optimizer.step_count += 1
