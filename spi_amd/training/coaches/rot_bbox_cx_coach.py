@@ -95,7 +95,8 @@ class RotBboxCoach(BaseCoach):
                 and not (tdist.is_available() and tdist.is_initialized()))
 
     def _graph_train_step(self, i, ctx, w_pivot, rng):
-        key = (id(ctx), w_pivot.data_ptr(), id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold))    # (the threshold is baked in)
+        key = (id(ctx), w_pivot.data_ptr(), id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold),    # (the threshold is baked in,
+               global_config.conv_precision, global_config.conv_winograd, global_config.enable_fp16_blocks, global_config.exploit_sparsity)   # and so is the arithmetic)
         if getattr(self, '_g2_key', None) != key:
             self._g2_key, self._g2 = key, {}
         st = self._g2.setdefault('branch' if i % self.rot_bs == 0 else 'plain', dict(eager=0, graph=None))
