@@ -175,7 +175,7 @@ def conv_roofline(dev, f16, prec=0):
     # the same layer on the Winograd F(2x2, 3x3) path the loop actually takes for forward / dgrad of the >= 128^2 3x3 layers (exact fp32
     # mode only): `achieved` counts the direct convolution's FLOPs (the algorithmic work), `executed` the MFMA FLOPs issued (/ 2.25)
     from spi_amd.configs import global_config
-    if global_config.conv_winograd and not f16 and prec == 0:
+    if global_config.conv_winograd and not f16 and prec in (0, 3):
         wres = {}
         for name, pid, fn in (('fwd', 0, lambda dd: hip.call('spi_conv2d_fwd', ctypes.byref(dd), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())),
                               ('dgrad', 1, lambda dd: hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(y), hip.ptr(w), hip.ptr(dx), hip.stream()))):
@@ -400,7 +400,7 @@ def main():
         alt = {'conv_precision': args.alt_conv_precision, 'error': alt_err or 'failed on another rank'} if bad else {'conv_precision': args.alt_conv_precision, 'value': world * args.steps / dta, 'unit': 'iters/s', 'ms_per_step': dta / args.steps * 1e3,
                'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
                'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
-               'note': 'same K steps, dense convs with fp32 operands split into bf16 pieces on the bf16 matrix cores (fp32 accumulate); '
+               'note': 'same K steps, dense convs with fp32 operands split into bf16 pieces on the bf16 matrix cores (fp32 accumulate; bf16x6: the large 3x3 forward / dgrad passes stay on the fp32 Winograd kernel, which is at least as precise and faster there); '
                        'bf16x6 = 3 pieces / 6 products, error ~2^-23 per product, passes the conv parity tests at the exact kernels\' tolerance; '
                        'NOT the benchmark value'}
         marks.clear(); marks.update(main_marks)
@@ -438,7 +438,7 @@ def main():
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
                        'stage1_graph_build_steps_before_warmup': graph_build_steps, 'stage2_hip_graph': bool(global_config.stage2_hip_graph),
                        'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
-                                   if global_config.conv_winograd and global_config.conv_precision == 0 else 'implicit GEMM'),
+                                   if global_config.conv_winograd and global_config.conv_precision in (0, 3) else 'implicit GEMM'),
                        'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else
                                    'data-driven skipping of exactly-zero gradients and unneeded SR tiles in the masked pseudo-view branches (result-identical)'},
             'roofline': {'kernel': 'raymarch_fwd_kernel<3> (final composite, S=%d, C=32)' % S, 'bound': 'hbm', 'achieved': achieved,

@@ -264,7 +264,8 @@ typedef struct spi_conv_desc {
     /* optional scratch memory (device, 16-byte aligned).  With at least spi_conv2d_workspace_bytes(d, pass) bytes the 3x3 / stride-1 /
      * pad-1 forward and data-gradient passes of large layers run as Winograd F(2x2, 3x3) -- fp32 operands, fp32 accumulation, 2.25x fewer
      * MFMAs; the result differs from the direct sum by a few fp32 roundings (what cuDNN runs for the reference's fp32 3x3 convs).
-     * NULL / too small: the implicit-GEMM kernels run.  The workspace holds the transformed weights of THIS call only. */
+     * NULL / too small: the implicit-GEMM kernels run.  The workspace holds the transformed weights of THIS call only.  Offered for
+     * compute_f16 = 0 and 3 (the 6-product split asks for fp32-equivalent products, which fp32 Winograd delivers faster on these layers). */
     void* workspace;
     int64_t workspace_bytes;
 } spi_conv_desc;

@@ -990,7 +990,9 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
 // Winograd eligibility of a forward / dgrad problem: 3x3, stride 1, pad 1, exact fp32, whole 8-channel slabs, and enough 16 x 16 x 64
 // blocks to fill the 256 CUs once (smaller layers keep the implicit GEMM, whose split-K fills the chip).
 static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
-    if (d->transposed || d->kh != 3 || d->pad != 1 || d->compute_f16 != 0 || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
+    // (compute_f16 = 3, the 6-product bf16 split, asks for fp32-equivalent products: the fp32 Winograd path is at least that precise and faster
+    //  than the split implicit GEMM on these layers, so it serves that mode too; modes 1 and 2 trade precision for speed and keep their kernels)
+    if (d->transposed || d->kh != 3 || d->pad != 1 || (d->compute_f16 != 0 && d->compute_f16 != 3) || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
     if (P.Ci % 8 != 0 || P.in_bs * 4 >= (1ll << 31) || P.IH != P.OH || P.IW != P.OW) return false;
     Wp.N = P.N; Wp.nw = d->w_batch_stride ? P.N : 1; Wp.Mo = P.Mo; Wp.Ci = P.Ci; Wp.H = P.OH; Wp.W = P.OW;
     Wp.bx = (P.OW + 15) / 16; Wp.by = (P.OH + 15) / 16; Wp.ocp = (P.Mo + 63) / 64 * 64;

@@ -74,7 +74,7 @@ def _workspace(d, pass_id, device):
     """Scratch memory with which `pass_id` (0 forward, 1 dgrad) of the conv `d` takes its Winograd path (None: it has none, or
     ``global_config.conv_winograd`` is off).  Comes from torch's caching allocator: no device allocation after warm-up."""
     from ...configs import global_config
-    if not global_config.conv_winograd or d.kh != 3 or d.transposed or d.compute_f16:
+    if not global_config.conv_winograd or d.kh != 3 or d.transposed or d.compute_f16 not in (0, 3):
         return None
     nbytes = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), pass_id)
     if nbytes <= 0:

@@ -429,7 +429,8 @@ def test_conv_winograd_is_not_offered_where_it_does_not_apply():
                      ((1, 64, 64, 128, 128, 3, 0, True, False, 0), {}),                   # stride-2 transposed
                      ((1, 512, 512, 16, 16, 3, 1, False, False, 0), {}),                  # too few blocks: split-K implicit GEMM fills the chip
                      ((1, 12, 64, 256, 256, 3, 1, False, False, 0), {}),                  # no whole 8-channel slabs
-                     ((1, 64, 64, 256, 256, 3, 1, False, False, 0), dict(f16=3))]:        # split-bf16 arithmetic requested
+                     ((1, 64, 64, 256, 256, 3, 1, False, False, 0), dict(f16=2)),         # 3-product bf16 split requested: its own (faster) kernels
+                     ((1, 64, 64, 256, 256, 3, 1, False, False, 0), dict(f16=1))]:        # fp16 operands requested
         d = conv2d_mfma._desc(*args, tap_major=1, **kw)
         assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 0) == 0, args
     d = conv2d_mfma._desc(1, 64, 64, 256, 256, 3, 1, False, False, 0, tap_major=1)
