@@ -1,5 +1,5 @@
 """Soak run of the real CLI at the benchmark size (full-width generator, 512^2, 96+96): 120 stage-1 steps (replayed from the HIP graph) +\n120 RotBbox iterations incl. checkpoint / embedding / image output; prints the run statistics line."""
-import json, sys, time, io, contextlib
+import json, os, sys, time, io, contextlib
 sys.path.insert(0, '.')
 from spi_amd import run_inversion
 from spi_amd.configs import hyperparameters as hp
@@ -7,7 +7,8 @@ hp.LPIPS_value_threshold = -1.0
 t0 = time.time()
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
-    run_inversion.run(['--output_root', '/tmp/soak_out/', '--synthetic', '1', '--not_use_wandb', '--first_inv_type', 'mir', '--first_inv_steps', '120',
-                       '--G_1_type', 'RotBbox', '--G_1_step', '120', '--depth_resolution', '96', '--depth_resolution_importance', '96'])
+    run_inversion.run(['--output_root', '/tmp/soak_out/', '--synthetic', '1', '--not_use_wandb', '--first_inv_type', 'mir', '--first_inv_steps', os.environ.get('STEPS1', '120'),
+                       '--G_1_type', 'RotBbox', '--G_1_step', os.environ.get('STEPS2', '120'), '--depth_resolution', '96', '--depth_resolution_importance', '96',
+                       '--pt_rot_lambda', '0.1', '--pt_mirror_rot_lambda', '0.05', '--pt_depth_lambda', '1.0'])      # the README's RotBbox command (BASELINE configs[1])
 line = [l for l in buf.getvalue().splitlines() if l.startswith('{')][-1]
 print('wall', round(time.time() - t0, 1), 's', line[:600])
