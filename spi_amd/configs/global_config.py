@@ -25,9 +25,13 @@ enable_fp16_blocks = False
 concurrent_branches = False
 
 # arithmetic of the dense convolutions (spi_conv_desc.compute_f16 of every conv that does not ask for fp16):
-#   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak) -- the default, bit-for-bit fp32 FMA chains
+#   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak) -- the default.  Bit-for-bit fp32 FMA chains ONLY together with
+#      conv_winograd = False (SPI_CONV_WINOGRAD=0): with the Winograd default below, the forward / dgrad passes of the large 3x3 layers
+#      are fp32 minimal filtering, which rounds differently from the direct sums (a few fp32 ulps; tested to 1e-5 of the tensor maximum)
 #   3  fp32 operands split into THREE bf16 pieces, the six significant piece products on the bf16 matrix cores with fp32 accumulation
-#      (error ~2^-23 per product: fp32-level; 2.7x less matrix-pipe time)
+#      (error ~2^-23 per product: fp32-level; 2.7x less matrix-pipe time).  With conv_winograd on, the large 3x3 forward / dgrad passes
+#      of this mode are served by the fp32 Winograd kernel (at least as precise, and faster there); SPI_CONV_WINOGRAD=0 forces the split
+#      kernels everywhere
 #   2  two pieces, three products (error ~2^-16 per product; 5.3x less matrix-pipe time)
 # `--conv_precision {f32,bf16x6,bf16x3}` / `bench.py --conv-precision`.
 conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[os.environ.get('SPI_CONV_PRECISION', 'f32')]   # env override: run any test / tool in a split mode

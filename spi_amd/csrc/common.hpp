@@ -61,6 +61,17 @@ __device__ __forceinline__ float softplus_f(float x) {          // torch Softplu
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
 
+// The conv epilogues' activation (linear / relu / lrelu), gain and clamp -- ONE definition for the implicit GEMM, the Winograd border
+// blocks and the Winograd interior fast path.  Written with selects so that NaN and +-inf behave like torch's relu / leaky_relu /
+// clamp on the reference's CPU path (NaN propagates; fmaxf / fminf would turn it into 0 or +-clamp and hide a diverging run).
+__device__ __forceinline__ float conv_act_gain_clamp(int act, float alpha, float gain, float clamp, float v) {
+    if (act == SPI_ACT_RELU) v = v < 0.f ? 0.f : v;
+    else if (act == SPI_ACT_LRELU) v = v > 0.f ? v : v * alpha;
+    v *= gain;
+    if (clamp >= 0.f) v = v > clamp ? clamp : (v < -clamp ? -clamp : v);
+    return v;
+}
+
 // Hardware-transcendental versions (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each) for the decoder
 // MLP, where 96 activations per point would otherwise cost more issue slots than the 4160 FMAs.
 // Absolute error <= ~2e-7 on outputs that are O(1); parity tests bound the end-to-end effect.

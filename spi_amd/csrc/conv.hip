@@ -54,15 +54,7 @@ __device__ __forceinline__ void split_k(int k, int T, unsigned magic, int& c, in
 }
 
 __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
-    switch (e.act) {
-    case SPI_ACT_LINEAR: break;
-    case SPI_ACT_RELU: v = fmaxf(v, 0.f); break;
-    case SPI_ACT_LRELU: v = v > 0.f ? v : v * e.alpha; break;
-    default: break;
-    }
-    v *= e.gain;
-    if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
-    return v;
+    return conv_act_gain_clamp(e.act, e.alpha, e.gain, e.clamp, v);
 }
 
 // -------------------------------------------------------------------------------------------------

@@ -74,11 +74,7 @@ __global__ void __launch_bounds__(256) wino_weight_kernel(WinoParams P, const fl
 }
 
 __device__ __forceinline__ float wino_act(const WinoEpilogue& e, float v) {
-    if (e.act == SPI_ACT_RELU) v = fmaxf(v, 0.f);
-    else if (e.act == SPI_ACT_LRELU) v = v > 0.f ? v : v * e.alpha;
-    v *= e.gain;
-    if (e.clamp >= 0.f) v = fminf(fmaxf(v, -e.clamp), e.clamp);
-    return v;
+    return conv_act_gain_clamp(e.act, e.alpha, e.gain, e.clamp, v);
 }
 
 __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const float* __restrict__ in, const float* __restrict__ U,
@@ -262,12 +258,11 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         if (x1) nz[0][1] = ep.noise[pix + 1] * ng;
         if (y1) { nz[1][0] = ep.noise[pix + P.W] * ng; if (x1) nz[1][1] = ep.noise[pix + P.W + 1] * ng; }
     }
-    // interior blocks (all 64 channels, all 16 x 16 pixels, even row length): no per-element tests, branch-free activation
-    //   lrelu / relu / linear = max(v, 0) + slope * min(v, 0) (one rounding, as v * alpha); clamp with +-FLT_MAX when there is none
+    // interior blocks (all 64 channels, all 16 x 16 pixels, even row length): no per-element bounds tests.  The activation is the same
+    //   conv_act_gain_clamp as the border blocks and the implicit GEMM: NaN and +-inf propagate identically in every block of a layer,
+    //   so a diverging run shows up in the loss wherever the bad value sits.
     if (oc0 + WOC <= P.Mo && oy0 + 16 <= P.H && ox0 + 16 <= P.W && (P.W & 1) == 0) {
         const bool has_epi = ep.act != 0 || ep.bias || ep.noise;
-        const float slope = ep.act == SPI_ACT_LRELU ? ep.alpha : ep.act == SPI_ACT_RELU ? 0.f : 1.f;
-        const float cl = ep.clamp >= 0.f ? ep.clamp : 3.402823466e38f;
         float* dst0 = ob + (int64_t)(oc0 + ocw * 32 + 4 * h) * HW + pix;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -288,8 +283,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         float v = y[a][b] + nz[a][b] + bv;
-                        v = (fmaxf(v, 0.f) + slope * fminf(v, 0.f)) * ep.gain;
-                        y[a][b] = fminf(fmaxf(v, -cl), cl);
+                        y[a][b] = conv_act_gain_clamp(ep.act, ep.alpha, ep.gain, ep.clamp, v);      // block-uniform branches
                     }
             }
             float* dst = dst0 + (int64_t)mo * HW;
@@ -345,12 +339,13 @@ int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, c
         WinoParams Pw = P; Pw.u_bs = P.u_bs_of();
         hipLaunchKernelGGL(wino_weight_kernel, dim3(grid), dim3(256), 0, st, Pw, w, U);
     }
-    static bool attr_set = false;
+    // The dynamic-LDS limit is a per-DEVICE function attribute: set it on every launch (a host-side table update, legal during stream
+    // capture) instead of caching "done" in a process-wide flag, which was wrong for a process that touches a second GPU and racy
+    // between threads.
     constexpr size_t lds_bytes = (4 * WSLAB + 2 * WRAW) * sizeof(float);
-    if (!attr_set) {
+    {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { spi_set_error("winograd conv: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
-        attr_set = true;
     }
     dim3 grid((unsigned)(P.bx * P.by), (unsigned)(P.ocp / WOC), (unsigned)P.N);
     hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), lds_bytes, st, P, in, U, out, ep);

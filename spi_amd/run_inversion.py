@@ -46,12 +46,14 @@ def parse_args(argv=None):
     parser.add_argument('--network_pkl', type=str, default=None)
     parser.add_argument('--depth_resolution', type=int, default=None)
     parser.add_argument('--depth_resolution_importance', type=int, default=None)
-    parser.add_argument('--conv_precision', choices=('f32', 'bf16x6', 'bf16x3'), default='f32',
-                        help='dense-conv arithmetic: exact fp32 MFMA (default) or fp32 operands split into 3 / 2 bf16 pieces on the bf16 matrix cores')
+    parser.add_argument('--conv_precision', choices=('f32', 'bf16x6', 'bf16x3'), default=None,
+                        help='dense-conv arithmetic: exact fp32 MFMA (f32) or fp32 operands split into 3 / 2 bf16 pieces on the bf16 matrix cores; '
+                             'not given = keep global_config.conv_precision (f32 unless SPI_CONV_PRECISION says otherwise)')
     parser.add_argument('--sr_fp16', action='store_true', help='fp16 MFMA in the super-resolution blocks (BASELINE config 5); default fp32')
     args = parser.parse_args(argv)
     global_config.enable_fp16_blocks = bool(args.sr_fp16)
-    global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
+    if args.conv_precision is not None:                           # only an explicit flag overrides the SPI_CONV_PRECISION environment default
+        global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
     global_config.synthetic_weights = args.synthetic > 0          # seeded perceptual-loss weights only in synthetic mode (criteria/weights.py)
 
     for k in ('use_encoder', 'use_G_avg', 'first_inv_type', 'first_inv_steps', 'G_1_step', 'G_1_type', 'G_2_step',

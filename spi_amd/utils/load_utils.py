@@ -67,6 +67,14 @@ def _reconstruct_stub(meta):
     return PersistentStub(meta)
 
 
+def _load_storage_from_bytes(b):
+    """Stand-in for torch.storage._load_from_bytes, which a tensor's storage reduces to (`torch.save` of the storage in the legacy
+    format, nested inside the network pickle).  The real function is `torch.load(BytesIO(b), weights_only=False)` -- a full,
+    unrestricted unpickle of the nested blob, through which a crafted pickle could call anything.  Here the nested blob goes through
+    torch's own weights-only unpickler (tensors / storages / plain containers only; anything else raises UnpicklingError)."""
+    return torch.load(io.BytesIO(b), map_location='cpu', weights_only=True)
+
+
 # EXACT (module, name) pairs a network pickle may reference: tensor / storage rebuilders, containers, numpy scalars and arrays,
 # the plain torch.nn containers EG3D's persistent classes hold (OSGDecoder.net is a Sequential with a Softplus).  Anything else
 # -- in particular dotted names such as ('torch', 'os.system'), which pickle protocol 4 resolves attribute by attribute --
@@ -94,6 +102,8 @@ class _RestrictedUnpickler(pickle.Unpickler):
             return _reconstruct_stub
         if module in ('dnnlib.util', 'dnnlib') and name == 'EasyDict':
             return EasyDict
+        if module == 'torch.storage' and name == '_load_from_bytes':
+            return _load_storage_from_bytes               # never the real one: see the shim's docstring
         if '.' not in name and ((module == 'builtins' and name in _BUILTINS) or (module, name) in _ALLOWED):
             return super().find_class(module, name)
         if '.' not in name and name.isidentifier() and (module + '.').startswith(_REF_NAMESPACES):

@@ -25,6 +25,22 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _restore_config_modules():
+    """The reference keeps its run configuration in module globals (configs/global_config.py, hyperparameters.py, paths_config.py) and
+    run_inversion.parse_args writes into them; so do several tests.  Snapshot the three modules before every test and put them back
+    afterwards, so the suite does not depend on the order the tests run in (round-2 advisor finding)."""
+    from spi_amd.configs import global_config, hyperparameters, paths_config
+    mods = (global_config, hyperparameters, paths_config)
+    saved = [{k: v for k, v in vars(m).items() if not k.startswith('__')} for m in mods]
+    yield
+    for m, old in zip(mods, saved):
+        for k in [k for k in vars(m) if not k.startswith('__') and k not in old]:
+            delattr(m, k)
+        for k, v in old.items():
+            setattr(m, k, v)
+
+
 class Golden:
     def __init__(self, name):
         self.z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)

@@ -148,6 +148,25 @@ def test_network_pickle_reader_never_executes_embedded_source():
         evil = pickle.PROTO + b'\x04' + b'\x8c' + bytes([len(mod)]) + mod.encode() + b'\x8c' + bytes([len(name)]) + name.encode() + b'\x93)R.'
         with pytest.raises(pickle.UnpicklingError):
             load_utils._RestrictedUnpickler(io.BytesIO(evil)).load()
+    # round-2 advisor finding: a storage reduces to torch.storage._load_from_bytes(<nested torch.save blob>), and the real function
+    # is an UNRESTRICTED torch.load of that blob.  A nested payload whose __reduce__ calls something must be refused ...
+    marker = 'SPI_NESTED_PAYLOAD_RAN'
+    os.environ.pop(marker, None)
+
+    class Nested:
+        def __reduce__(self):
+            return (os.putenv, (marker, '1'))
+    inner = io.BytesIO()
+    torch.save(Nested(), inner, _use_new_zipfile_serialization=False)
+    mod, name = 'torch.storage', '_load_from_bytes'
+    outer = (pickle.PROTO + b'\x04' + b'\x8c' + bytes([len(mod)]) + mod.encode() + b'\x8c' + bytes([len(name)]) + name.encode() + b'\x93' +
+             pickle.dumps(inner.getvalue(), protocol=4)[2:-1] + b'\x85R.')
+    with pytest.raises(pickle.UnpicklingError):
+        load_utils._RestrictedUnpickler(io.BytesIO(outer)).load()
+    # ... while an honest legacy storage blob (what every tensor of a real EG3D pickle carries) still loads
+    st = torch.arange(6, dtype=torch.float32)
+    back = load_utils._RestrictedUnpickler(io.BytesIO(pickle.dumps(dict(t=st), protocol=4))).load()['t']
+    assert torch.equal(back, st)
 
 
 def test_bench_self_launches_two_ranks_and_survives_a_failing_rank():
