@@ -10,8 +10,11 @@ rank 0's JSON line.
 Workload (BASELINE.json configs[1]): 1 image per GPU, first_inv_type=mir (500 steps) + G_1_type=RotBbox (1000 steps),
 EG3D ffhqrebalanced512-128 architecture at 512^2 with 96 coarse + 96 fine samples per ray, fp32, synthetic inputs
 and seeded random-init weights (no checkpoint / dataset exists offline).  A "step" is one iteration of the hot path;
-the K timed steps keep the configuration's 1:2 mix of stage-1 ('mir') and stage-2 ('RotBbox') iterations, with the
-stage-2 part a whole number of 4-iteration super-cycles so the every-4th-step branches are amortised exactly.
+the K timed steps are split between stage-1 ('mir') and stage-2 ('RotBbox') iterations as close to the configuration's 1:2 as K allows,
+with the stage-2 part a whole number of 4-iteration super-cycles so the every-4th-step branches are amortised exactly.  `value` does
+NOT depend on how K happened to split: it is the rate of the configuration's exact 500:1000 mix computed from the two per-stage rates
+measured inside the timed region (max over ranks per stage), value = 3 / (1 / r_stage1 + 2 / r_stage2); `ms_per_step` = 1000 / value per
+GPU, and the raw K-step wall time is reported beside it (`timed_region`).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -54,6 +57,7 @@ def parse():
                          'split into 3 / 2 bf16 pieces, 6 / 3 bf16 MFMAs with fp32 accumulation (opt-in; the JSON line then says so in dtype)')
     ap.add_argument('--alt-conv-precision', choices=('none', 'bf16x6', 'bf16x3'), default='bf16x6',
                     help='after the timed region, time the same K steps once more with this conv arithmetic and report it as `alt` (never as `value`)')
+    ap.add_argument('--no-dense-leg', action='store_true', help='skip the extra `dense` measurement (stage 2 once more without the data-driven skipping)')
     ap.add_argument('--only', choices=('stage1', 'stage2'), default=None, help='profiling aid, NOT the benchmark configuration: all K steps from one stage')
     ap.add_argument('--dry-run', action='store_true', help='plumbing self-test without a GPU: launcher, rendezvous (gloo), barrier and the statistics '
                                                            'all-reduces run as in a real run, the timed steps are replaced by a sleep; prints no metric')
@@ -125,16 +129,18 @@ def cpu_baseline(depth, narrow, mode='sample', k1=8, k2=16):
         torch.set_num_threads(cores)
         res['thread_scaling_s_per_plain_iteration'] = scal
         res['sample'] = (f"full protocol: 1 warm-up, 1 'mir' step ({t_s1:.1f} s), one 4-iteration RotBbox super-cycle ({t_cycle:.1f} s: branch iteration "
-                         f'{t_branch:.1f} s + 3 x plain {t_plain:.1f} s); value = the same {k1}:{k2} stage mix as the GPU line')
+                         f'{t_branch:.1f} s + 3 x plain {t_plain:.1f} s); value = the same {k1}:{k2} stage mix as the `value` of the GPU line')
     else:
         # without the branch iteration the stage-2 rate is an UPPER bound for the CPU (the branches only add work): say so
         res['value'] = (k1 + k2) / (k1 * t_s1 + k2 * t_plain)
         res['sample'] = (f"1 warm-up + 1 timed 'mir' step ({t_s1:.1f} s) + 1 timed PLAIN RotBbox iteration ({t_plain:.1f} s); the every-4th-iteration "
-                         f'rot / mirror-rot / depth branches are not in this sample (value = {k1}:{k2} mix of the two, an upper bound for the CPU); '
+                         f'rot / mirror-rot / depth branches are not in this sample (value = the {k1}:{k2} mix of the two like the GPU line, an upper bound for the CPU); '
                          'full protocol: `bench.py --cpu-baseline full`, kept under profiles/')
         full = os.path.join(ROOT, 'profiles', 'cpu_baseline_full.json')
         if os.path.exists(full):
-            res['full_protocol_recorded'] = json.load(open(full))
+            rec = json.load(open(full))
+            rec.pop('gpu_value_same_run_iters_per_s', None)       # (a GPU number of the day the file was recorded; the line above it is the live one)
+            res['full_protocol_recorded'] = rec
     res['sample'] += f'; 512^2, {depth}+{depth} samples, torch {torch.__version__} CPU fp32, {cores} threads of {ncpu}'
     return res
 
@@ -242,6 +248,29 @@ def reduce_run_stats(sdist, rank, world, t0, dt_rank, ok, dev):
     return dt, slots[:world], slots[world:]
 
 
+def device_identity(local):
+    """(device index, PCI domain, bus, device) of this rank's GPU as floats for the statistics all-reduce; zeros without a GPU."""
+    if not torch.cuda.is_available():
+        return [float(local), 0.0, 0.0, 0.0]
+    p = torch.cuda.get_device_properties(local)
+    return [float(local), float(getattr(p, 'pci_domain_id', 0)), float(getattr(p, 'pci_bus_id', -1)), float(getattr(p, 'pci_device_id', -1))]
+
+
+def gather_rank_devices(sdist, rank, world, local, dev):
+    """One sum-reduce in which every rank fills its own 4 slots -> per-rank device records (same collective kind as the timing reduce)."""
+    slots = [0.0] * (4 * world)
+    slots[4 * rank:4 * rank + 4] = device_identity(local)
+    slots = sdist.reduce_stats(slots, device=dev)
+    return [{'rank': r, 'device_index': int(slots[4 * r]), 'pci': '%04x:%02x:%02x' % tuple(int(v) for v in slots[4 * r + 1:4 * r + 4])} for r in range(world)]
+
+
+def process_group_info(world):
+    import torch.distributed as td
+    if world > 1 and td.is_available() and td.is_initialized():
+        return {'world_size': td.get_world_size(), 'backend': td.get_backend()}
+    return {'world_size': 1, 'backend': None}
+
+
 def dry_run(args, sdist, rank, world):
     """--dry-run: everything around the GPU work (used by the world-size-2 CPU test)."""
     sdist.barrier()
@@ -254,9 +283,14 @@ def dry_run(args, sdist, rank, world):
     except Exception:
         ok = 0.0
     dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, time.perf_counter() - t0, ok, None)
+    devices = gather_rank_devices(sdist, rank, world, int(os.environ.get('LOCAL_RANK', rank)), None)
+    from spi_amd.configs import global_config
+    from spi_amd.training.projectors.common import graph_policy, capture_mode
     if rank == 0:
         print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'seconds_max_over_ranks': dt,
-                          'ranks': {'launched': world, 'completed': int(sum(rank_ok)), 'per_rank_seconds': rank_s}}), flush=True)
+                          'ranks': {'launched': world, 'completed': int(sum(rank_ok)), 'per_rank_seconds': rank_s, 'devices': devices,
+                                    'process_group': process_group_info(world)},
+                          'stage1_hip_graph_policy': graph_policy(global_config.stage1_hip_graph), 'graph_capture_mode': capture_mode()}), flush=True)
     sdist.shutdown()
     if int(sum(rank_ok)) != world:
         sys.exit(3)
@@ -330,12 +364,14 @@ def main():
             proj.step(s1_base + i)
         marks['stage1_host_ms_per_step'] = (time.perf_counter() - ta) / max(n1, 1) * 1e3    # stage 1 never syncs: pure host enqueue cost
         torch.cuda.synchronize()                                 # one sync between the stages: SURVEY 8d asks for both rates separately
-        marks['stage1_ms_per_step'] = (time.perf_counter() - ta) / max(n1, 1) * 1e3
+        marks['stage1_s'] = time.perf_counter() - ta
+        marks['stage1_ms_per_step'] = marks['stage1_s'] / max(n1, 1) * 1e3
         tb = time.perf_counter()
         for i in range(n2):
             coach.train_step(s2_base + i, ctx, w_pivot)
         torch.cuda.synchronize()
-        marks['stage2_ms_per_step'] = (time.perf_counter() - tb) / max(n2, 1) * 1e3
+        marks['stage2_s'] = time.perf_counter() - tb
+        marks['stage2_ms_per_step'] = marks['stage2_s'] / max(n2, 1) * 1e3
 
     w1, w2 = split_steps(args.warmup)
     k1, k2 = split_steps(args.steps)
@@ -347,6 +383,8 @@ def main():
     run(w1, w2, 25, 0)                                           # untimed warm-up (past the 5 % lr ramp-up)
     rmod.MARCH_EVENTS = []                                       # HIP events around every final-march launch in the timed region
     rmod.MARCH_BWD_EVENTS = []                                   # ... and around every march-backward launch
+    rmod.DECODE_FWD_EVENTS = []                                  # ... every tri-plane gather + decoder forward launch
+    rmod.DECODE_BWD_EVENTS = []                                  # ... every tiled decoder-backward call
     sdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     if os.environ.get('SPI_TORCH_PROFILE'):                      # debugging aid: per-op device time / launch counts per stage (stderr)
@@ -374,8 +412,22 @@ def main():
     dt_rank = time.perf_counter() - t0                           # this rank's own K steps
     events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
     bwd_events, rmod.MARCH_BWD_EVENTS = rmod.MARCH_BWD_EVENTS, None
+    dfwd_events, rmod.DECODE_FWD_EVENTS = rmod.DECODE_FWD_EVENTS, None
+    dbwd_events, rmod.DECODE_BWD_EVENTS = rmod.DECODE_BWD_EVENTS, None
     dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, dt_rank, ok, dev)
     n_ok = int(sum(rank_ok))
+    rank_devices = gather_rank_devices(sdist, rank, world, local, dev)
+    graph_ranks = int(sdist.reduce_stats([1.0 if getattr(proj, '_graph', None) is not None else 0.0], device=dev)[0])
+    # per-stage wall time, max over ranks: the two rates `value` is computed from
+    st_s = sdist.reduce_stats([marks.get('stage1_s', 0.0), marks.get('stage2_s', 0.0)], device=dev, op='max')
+
+    def mix_value(t1, t2):
+        """whole-job iters/s of the configuration's exact 500:1000 stage mix from the measured per-stage times (n_ok ranks, one image each)"""
+        if k1 and k2:
+            return n_ok * 3.0 / (t1 / k1 + 2.0 * t2 / k2)
+        return n_ok * (k1 + k2) / max(t1 + t2, 1e-12)
+    value = mix_value(st_s[0], st_s[1])
+    main_stage_s = list(st_s)
     alt = None
     if args.alt_conv_precision != 'none' and args.alt_conv_precision != args.conv_precision and ok and not os.environ.get('SPI_TORCH_PROFILE'):
         # the same K steps once more with the split-bf16 convolutions (opt-in arithmetic; reported beside the benchmark value, never as it).
@@ -397,7 +449,9 @@ def main():
         torch.cuda.synchronize(); sdist.barrier()
         dta = sdist.reduce_stats([time.perf_counter() - ta], device=dev, op='max')[0]
         bad = sdist.reduce_stats([0.0 if alt_err is None else 1.0], device=dev)[0]
-        alt = {'conv_precision': args.alt_conv_precision, 'error': alt_err or 'failed on another rank'} if bad else {'conv_precision': args.alt_conv_precision, 'value': world * args.steps / dta, 'unit': 'iters/s', 'ms_per_step': dta / args.steps * 1e3,
+        alt_s = sdist.reduce_stats([marks.get('stage1_s', 0.0), marks.get('stage2_s', 0.0)], device=dev, op='max')
+        alt = {'conv_precision': args.alt_conv_precision, 'error': alt_err or 'failed on another rank'} if bad else {'conv_precision': args.alt_conv_precision, 'value': mix_value(alt_s[0], alt_s[1]), 'unit': 'iters/s', 'ms_per_step': 1e3 * world / mix_value(alt_s[0], alt_s[1]),
+               'timed_region_s': dta,
                'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
                'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
                'note': 'same K steps, dense convs with fp32 operands split into bf16 pieces on the bf16 matrix cores (fp32 accumulate; bf16x6: the large 3x3 forward / dgrad passes stay on the fp32 Winograd kernel, which is at least as precise and faster there); '
@@ -405,6 +459,30 @@ def main():
                        'NOT the benchmark value'}
         marks.clear(); marks.update(main_marks)
         global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
+    dense = None
+    if not args.dense and not args.no_dense_leg and ok and k2 and not os.environ.get('SPI_TORCH_PROFILE'):
+        # the dense bound of the same step: the stage-2 iterations once more with the data-driven skipping of exactly-zero gradients /
+        # unneeded SR tiles switched off (stage 1 has no masked branch: its rate is the main run's).  Reported beside `value`, never as it.
+        global_config.exploit_sparsity = False
+        main_marks = dict(marks)
+        dense_err = None
+        base2 = ((w2 + 2 * k2 + 15) // 4) * 4
+        try:
+            run(0, 4, 0, base2)                                   # one untimed super-cycle (allocator / workspace shapes of the dense branches)
+            sdist.barrier(); torch.cuda.synchronize()
+            run(0, k2, 0, base2 + 4)
+        except Exception as e:                                    # noqa: BLE001
+            dense_err = repr(e)
+        torch.cuda.synchronize(); sdist.barrier()
+        d_s = sdist.reduce_stats([marks.get('stage2_s', 0.0)], device=dev, op='max')[0]
+        bad = sdist.reduce_stats([0.0 if dense_err is None else 1.0], device=dev)[0]
+        dense = {'error': dense_err or 'failed on another rank'} if bad else {
+            'value': mix_value(main_stage_s[0], d_s), 'unit': 'iters/s', 'stage2_rotbbox_iters_per_s_per_gpu': k2 / d_s,
+            'stage1_mir_iters_per_s_per_gpu': (k1 / main_stage_s[0]) if k1 else None,
+            'note': 'dense bound: every ray, gradient segment and SR tile of the masked rot / mirror-rot branches processed (global_config.exploit_sparsity '
+                    '= False); same results (tested); stage 1 has no masked branch, its time is the main run\'s; NOT the benchmark value'}
+        marks.clear(); marks.update(main_marks)
+        global_config.exploit_sparsity = True
     march_ms = [a.elapsed_time(b) for a, b, _ in events]
     march_rays = [r for _, _, r in events]
 
@@ -419,12 +497,17 @@ def main():
         if os.path.exists(pmc) and march_rays:
             traffic = json.load(open(pmc)).get('hbm_bytes_per_16384_rays') / 16384.0 * (sum(march_rays) / len(march_rays))
         out = {
-            'metric': f'SPI inversion iters/sec (512^2, {args.depth}+{args.depth} ray samples)', 'value': n_ok * args.steps / dt, 'unit': 'iters/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': dt / args.steps * 1e3,
+            'metric': f'SPI inversion iters/sec (512^2, {args.depth}+{args.depth} ray samples)', 'value': value, 'unit': 'iters/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * max(n_ok, 1) / value,
+            'value_definition': 'exact 500:1000 (1:2) mix of the two per-stage rates measured in the timed region, max over ranks per stage: '
+                                'n_gpus * 3 / (1/r_stage1 + 2/r_stage2); independent of how K splits into stages',
+            'timed_region': {'steps': args.steps, 'seconds_max_over_ranks': dt, 'raw_iters_per_s_at_this_k_split': n_ok * args.steps / dt,
+                             'stage1_seconds_max_over_ranks': main_stage_s[0], 'stage2_seconds_max_over_ranks': main_stage_s[1]},
             'stage1_host_enqueue_ms_per_step': marks.get('stage1_host_ms_per_step'),
             'ranks': {'launched': world, 'completed': n_ok, 'backend': 'rccl (torch.distributed nccl)' if world > 1 else 'none (single process)',
                       'collectives': 'barrier + 2 all-reduces of <= %d fp64 (timing / done-flags); no data-path collective' % (2 * world),
-                      'per_rank_iters_per_s': [args.steps / t if t > 0 else None for t in rank_s]},
+                      'per_rank_iters_per_s': [args.steps / t if t > 0 else None for t in rank_s], 'devices': rank_devices,
+                      'process_group': process_group_info(world), 'ranks_replaying_stage1_graph': graph_ranks},
             'stages': {'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
                        'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
                        'note': 'rank 0; stage 2 amortises the every-4th-iteration rot / mirror-rot / depth branches over whole super-cycles'},
@@ -433,7 +516,7 @@ def main():
             'random-init weights of the ffhqrebalanced512-128 architecture)',
             'config': {'workload': ('configs[4]' if (args.depth == 128 and args.sr_fp16) else 'configs[1]') +
                                    ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
-                                   f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'stage1_mir': k1, 'stage2_rotbbox': k2},
+                                   f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'value_mix': 'stage1:stage2 = 1:2 exact (500:1000), computed from the per-stage rates' if (k1 and k2) else 'single stage', 'timed_steps': {'stage1_mir': k1, 'stage2_rotbbox': k2}},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
                        'stage1_graph_build_steps_before_warmup': graph_build_steps, 'stage2_hip_graph': bool(global_config.stage2_hip_graph),
@@ -462,12 +545,47 @@ def main():
                                          'bytes_per_active_ray': per_ray_b, 'active_rays_per_launch': sum(act) / len(act),
                                          'dense_launches_only': ({'launches': len(dense), 'achieved': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9,
                                                                   'frac': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9 / HBM_PEAK_GBS} if dense else None)}
+        # the fused gather + decoder forward is bound by cache-level gather bandwidth + VALU, not by HBM: report the effective gather
+        # rate (12 corner rows x 128 B per point, served by L1 / L2 / MALL) against the L2 figure of MI355X_MICROARCH.md and the decoder's
+        # vector FLOP rate against the fp32 vector peak.
+        if dfwd_events:
+            ms = [a.elapsed_time(b) for a, b, _ in dfwd_events]
+            pts = [p for _, _, p in dfwd_events]
+            gbs = sum(pts) * 1536 / (sum(ms) / 1e3) / 1e9
+            tf = sum(pts) * 8320 / (sum(ms) / 1e3) / 1e12
+            out['roofline_gather'] = {'kernel': 'decode_fwd_kernel (tri-plane gather + 32-64-33 decoder, colour rows written)', 'bound': 'l2 gather + valu',
+                                      'achieved': gbs, 'peak': 34500.0, 'unit': 'GB/s', 'frac': gbs / 34500.0,
+                                      'valu': {'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3},
+                                      'bytes_per_point_gathered': 1536, 'flop_per_point': 8320, 'launches': len(ms),
+                                      'avg_launch_us': sum(ms) / len(ms) * 1e3, 'points_per_launch': sum(pts) / len(pts),
+                                      'hbm_compulsory_bytes_per_point': 128 + 4 + 4,
+                                      'note': 'effective gather bandwidth at cache level (SURVEY 8d), peak = aggregate L2 bandwidth (MI355X_MICROARCH.md); compulsory HBM traffic '
+                                              'is the 128-B colour row + density written per point (planes stay cache-resident)'}
+        # the tiled decoder backward (bin_points + decode_bwd_tiled + partial reduce): fp32 MFMA.  `achieved` counts the ALGORITHMIC FLOPs per live
+        # point (layer-1 recompute 4096, dY -> dH 4224, dH -> dF 4096; + dW1 4096 + dW2 4224 with decoder gradients); rays whose incoming gradient
+        # is exactly zero are skipped and count as 0.
+        if dbwd_events:
+            ms = [a.elapsed_time(b) for a, b, *_ in dbwd_events]
+            live = [(int(f.sum().item()) if f is not None else r) * s_ for _, _, r, s_, f, _, _ in dbwd_events]
+            flop = [lv * ((12416 if rgb else 8320) + ((8320 if rgb else 4096) if wg else 0)) for lv, (_, _, _, _, _, wg, rgb) in zip(live, dbwd_events)]
+            tf = sum(flop) / (sum(ms) / 1e3) / 1e12
+            full = [(m, f) for m, f, lv, e in zip(ms, flop, live, dbwd_events) if lv == e[2] * e[3] and e[5] and e[6]]
+            out['roofline_decode_bwd'] = {'kernel': 'spi_triplane_decode_bwd_sorted (bin_points_kernel + decode_bwd_tiled_kernel + decoder_partial_reduce_kernel)',
+                                          'bound': 'mfma', 'achieved': tf, 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': tf / 157.3, 'launches': len(ms),
+                                          'avg_launch_us': sum(ms) / len(ms) * 1e3, 'live_points_per_launch': sum(live) / len(live),
+                                          'dense_wgrad_launches_only': ({'launches': len(full), 'avg_launch_us': sum(m for m, _ in full) / len(full) * 1e3,
+                                                                         'achieved': sum(f for _, f in full) / (sum(m for m, _ in full) / 1e3) / 1e12,
+                                                                         'frac': sum(f for _, f in full) / (sum(m for m, _ in full) / 1e3) / 1e12 / 157.3} if full else None),
+                                          'note': 'algorithmic FLOPs of the decoder backward per live point / call time (gather, MLP on the matrix cores, plane-gradient scatter '
+                                                  'all inside the call); the scatter is LDS-atomic / flush bound, see DESIGN.md 3'}
         out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16), global_config.conv_precision)
         if alt is not None:
             out['alt'] = alt
+        if dense is not None:
+            out['dense'] = dense
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, k1, k2)
+                out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, 1 if k1 else 0, 2 if k2 else 0)
             except Exception as e:                                # noqa: BLE001  (a host-side failure must not lose the GPU measurement)
                 out['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(out), flush=True)

@@ -27,8 +27,9 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 3   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
-                             * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes */
+#define SPI_ABI_VERSION 4   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+                             * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
+                             * 4: + spi_sample_from_planes_fwd / _bwd (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -53,6 +54,16 @@ int spi_coarse_depths(const float* xi, int64_t n_rays, int S, float ray_start, f
 /* planes [NP, C, H, W] <-> channels-last [NP, H, W, C] (one 128-B line per texel when C = 32). */
 int spi_nchw_to_nhwc(const float* src, float* dst, int NP, int C, int H, int W, spi_stream_t stream);
 int spi_nhwc_to_nchw(const float* src, float* dst, int NP, int C, int H, int W, spi_stream_t stream);
+
+/* sample_from_planes on its own (renderer.py:55-65; replaces the three F.grid_sample calls of :62-64 for a decoder that is not
+ * the OSG MLP -- ImportanceRenderer takes any decoder callable, renderer.py:88,142-148):
+ *   planes_nhwc [N,3,H,W,32], coords [N,P,3] -> out [N,3,P,32], plane k sampled at (x,y), (x,z), (z,x) of 2/box_warp * coords,
+ *   bilinear, zeros padding, align_corners = False.  _bwd ACCUMULATES d_out [N,3,P,32] into d_planes_nhwc (pre-zeroed by the
+ *   caller) with global atomics.  Not on the SPI hot path (the fused kernels below are). */
+int spi_sample_from_planes_fwd(const float* planes_nhwc, const float* coords, int N, int64_t P, int H, int W, float box_warp, float* out,
+                               spi_stream_t stream);
+int spi_sample_from_planes_bwd(const float* d_out, const float* coords, int N, int64_t P, int H, int W, float box_warp, float* d_planes_nhwc,
+                               spi_stream_t stream);
 
 /* sample_from_planes + OSGDecoder.forward fused: renderer.py:55-65 + triplane.py:123-135.
  *   planes_nhwc [N,3,H,W,32];  points are either explicit `coords` [N,P,3] (ray_o = NULL) or

@@ -4,7 +4,9 @@ TEST INFRASTRUCTURE -- see oracle/__init__.py.
 
 Reference lines followed (relative to /root/reference/eg3d/training):
   rays                 volumetric_rendering/ray_sampler.py:24-63
-  coarse depths        volumetric_rendering/renderer.py:169-192 (scalar ray_start/ray_end branch)
+  coarse depths        volumetric_rendering/renderer.py:169-192 (scalar, per-ray tensor and disparity-space branches)
+  'auto' ray limits    volumetric_rendering/renderer.py:91-97, math_utils.py:44-94 (ray / box slab test), :98-118 (linspace)
+  density noise        volumetric_rendering/renderer.py:146-147
   tri-plane gather     volumetric_rendering/renderer.py:23-65
   OSG decoder          triplane.py:112-135
   ray march            volumetric_rendering/ray_marcher.py:25-57
@@ -47,7 +49,55 @@ def ray_sampler(cam2world, intrinsics, resolution):
     return origin[:, None, :].expand(-1, dirs.shape[1], -1).contiguous(), dirs
 
 
-def coarse_depths(n, m, s, ray_start, ray_end, xi=None, device='cpu'):
+def ray_limits_box(ray_o, ray_d, box_side_length):
+    """math_utils.get_ray_limits_box: slab test of every ray against the axis-aligned cube of side `box_side_length` centred at the
+    origin -> (t_near [N,M,1], t_far [N,M,1]); rays that miss get (-1, -2)."""
+    shape = ray_o.shape
+    o, d = ray_o.detach().reshape(-1, 3), ray_d.detach().reshape(-1, 3)
+    half = box_side_length / 2
+    bounds = torch.tensor([[-half] * 3, [half] * 3], dtype=o.dtype, device=o.device)
+    valid = torch.ones(o.shape[0], dtype=torch.bool, device=o.device)
+    inv = 1 / d
+    sign = (inv < 0).long()
+
+    def slab(ax):
+        near = (bounds.index_select(0, sign[:, ax])[:, ax] - o[:, ax]) * inv[:, ax]
+        far = (bounds.index_select(0, 1 - sign[:, ax])[:, ax] - o[:, ax]) * inv[:, ax]
+        return near, far
+    tmin, tmax = slab(0)
+    for ax in (1, 2):
+        near, far = slab(ax)
+        valid[torch.logical_or(tmin > far, near > tmax)] = False
+        tmin, tmax = torch.max(tmin, near), torch.min(tmax, far)
+    tmin[~valid] = -1
+    tmax[~valid] = -2
+    return tmin.reshape(*shape[:-1], 1), tmax.reshape(*shape[:-1], 1)
+
+
+def auto_ray_limits(ray_o, ray_d, box_warp):
+    """renderer.py:91-97: per-ray limits from the box; rays that miss get [min valid start, max valid START] (sic, :96)."""
+    start, end = ray_limits_box(ray_o, ray_d, box_warp)
+    ok = end > start
+    if torch.any(ok).item():
+        start[~ok] = start[ok].min()
+        end[~ok] = start[ok].max()
+    return start, end
+
+
+def coarse_depths(n, m, s, ray_start, ray_end, xi=None, device='cpu', disparity=False):
+    """sample_stratified (renderer.py:169-192).  ray_start / ray_end: scalars, or per-ray tensors [N,M,1] ('auto')."""
+    if disparity:
+        base = torch.linspace(0, 1, s, device=device).reshape(1, 1, s, 1).repeat(n, m, 1, 1)
+        if xi is None:
+            xi = torch.rand_like(base)
+        t = base + xi * (1 / (s - 1))
+        return 1. / (1. / ray_start * (1. - t) + 1. / ray_end * t)
+    if torch.is_tensor(ray_start):
+        steps = (torch.arange(s, dtype=torch.float32, device=ray_start.device) / (s - 1)).reshape(s, 1, 1, 1)
+        base = (ray_start[None] + steps * (ray_end - ray_start)[None]).permute(1, 2, 0, 3)          # math_utils.linspace -> [N,M,S,1]
+        if xi is None:
+            xi = torch.rand_like(base)
+        return base + xi * ((ray_end - ray_start) / (s - 1))[..., None]
     base = torch.linspace(ray_start, ray_end, s, device=device).reshape(1, 1, s, 1).repeat(n, m, 1, 1)
     if xi is None:
         xi = torch.rand_like(base)
@@ -132,25 +182,35 @@ def merge_samples(d1, c1, s1, d2, c2, s2):
             torch.gather(s, -2, idx))
 
 
-def run_model(P, planes, coords, opts):
-    rgb, sigma = osg_decoder(P, sample_planes(planes, coords, box_warp=opts['box_warp']))
+def run_model(P, planes, coords, opts, eps=None, decoder_fn=None, dirs=None):
+    """eps: the density-noise draw (randn_like(sigma), renderer.py:146-147) when opts['density_noise'] > 0; None draws it.
+    decoder_fn(feats [N,3,P,C], dirs [N,P,3]) -> (rgb, sigma): any decoder callable in place of the OSG MLP (renderer.py:142-145)."""
+    feats = sample_planes(planes, coords, box_warp=opts['box_warp'])
+    rgb, sigma = osg_decoder(P, feats) if decoder_fn is None else decoder_fn(feats, dirs)
+    if opts.get('density_noise', 0) > 0:
+        sigma = sigma + (torch.randn_like(sigma) if eps is None else eps.reshape(sigma.shape)) * opts['density_noise']
     return rgb, sigma
 
 
-def render(P, planes, ray_o, ray_d, opts, xi=None, u=None, return_aux=False):
-    """ImportanceRenderer.forward -> (rgb [N,M,32], depth [N,M,1], weight_sum [N,M,1])."""
+def render(P, planes, ray_o, ray_d, opts, xi=None, u=None, return_aux=False, eps=(None, None), decoder_fn=None):
+    """ImportanceRenderer.forward -> (rgb [N,M,32], depth [N,M,1], weight_sum [N,M,1]).  eps = the two density-noise draws
+    (coarse pass, fine pass) in the reference's order: rand_like (xi), randn_like (eps[0]), rand (u), randn_like (eps[1])."""
     n, m, _ = ray_o.shape
     sc, sf = opts['depth_resolution'], opts['depth_resolution_importance']
-    d_c = coarse_depths(n, m, sc, opts['ray_start'], opts['ray_end'], xi=xi, device=ray_o.device)
+    start, end = opts['ray_start'], opts['ray_end']
+    if isinstance(start, str) and start == end == 'auto':
+        start, end = auto_ray_limits(ray_o, ray_d, opts['box_warp'])
+    d_c = coarse_depths(n, m, sc, start, end, xi=xi, device=ray_o.device, disparity=bool(opts.get('disparity_space_sampling', False)))
     pts = (ray_o.unsqueeze(-2) + d_c * ray_d.unsqueeze(-2)).reshape(n, -1, 3)
-    c_c, s_c = run_model(P, planes, pts, opts)
+    dirs = lambda k: ray_d.unsqueeze(-2).expand(-1, -1, k, -1).reshape(n, -1, 3)
+    c_c, s_c = run_model(P, planes, pts, opts, eps[0], decoder_fn, dirs(sc))
     c_c = c_c.reshape(n, m, sc, -1)
     s_c = s_c.reshape(n, m, sc, 1)
     if sf > 0:
         _, _, w_c = ray_march(c_c, s_c, d_c, opts.get('white_back', False))
         d_f = importance_depths(d_c, w_c, sf, u=u)
         pts = (ray_o.unsqueeze(-2) + d_f * ray_d.unsqueeze(-2)).reshape(n, -1, 3)
-        c_f, s_f = run_model(P, planes, pts, opts)
+        c_f, s_f = run_model(P, planes, pts, opts, eps[1], decoder_fn, dirs(sf))
         c_f = c_f.reshape(n, m, sf, -1)
         s_f = s_f.reshape(n, m, sf, 1)
         d_all, c_all, s_all = merge_samples(d_c, c_c, s_c, d_f, c_f, s_f)
@@ -180,5 +240,6 @@ def synthesis(P, ws, c, opts, neural_rendering_resolution=128, noise_mode='const
     out = {'image_raw': rgb, 'image_depth': depth_img, 'planes': planes}
     if not skip_sr:
         out['image'] = sg.superresolution_8xdc(P, rgb, feat_img, ws,
-                                               noise_mode=opts.get('superresolution_noise_mode', 'none'))
+                                               noise_mode=opts.get('superresolution_noise_mode', 'none'),
+                                               fp16_operands=bool(opts.get('sr_fp16_operands', False)))
     return out

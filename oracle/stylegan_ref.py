@@ -149,14 +149,19 @@ def conv2d_resample(x, w, f=None, up=1, padding=0, groups=1, flip_weight=True):
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, f=None, demodulate=True,
-                     flip_weight=True):
-    """Fused (grouped-conv) path only: the one SPI takes (G.eval(), 'inference_only')."""
+                     flip_weight=True, fp16_operands=False):
+    """Fused (grouped-conv) path only: the one SPI takes (G.eval(), 'inference_only').
+    fp16_operands: the arithmetic of the build's fp16-MFMA blocks (BASELINE config 5, `--sr_fp16`): tensors stay fp32, the two conv
+    operands -- the activation and the modulated (demodulated) weight -- are rounded to fp16, products accumulate in fp32.  (The
+    reference's own use_fp16 blocks also STORE activations in fp16, networks_stylegan2.py:421-461; this is the build's variant.)"""
     n = x.shape[0]
     oc, ic, kh, kw = weight.shape
     w = weight.unsqueeze(0) * styles.reshape(n, 1, ic, 1, 1)
     if demodulate:
         d = (w.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
         w = w * d.reshape(n, oc, 1, 1, 1)
+    if fp16_operands:
+        x, w = x.half().float(), w.half().float()
     x = x.reshape(1, n * ic, *x.shape[2:])
     x = conv2d_resample(x, w.reshape(n * oc, ic, kh, kw), f=f, up=up, padding=padding, groups=n,
                         flip_weight=flip_weight)
@@ -191,7 +196,7 @@ def mapping(P, z, c, prefix='backbone.mapping.', num_layers=2, num_ws=14, lr_mul
     return x.unsqueeze(1).repeat(1, num_ws, 1)
 
 
-def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gain=1.0, noise_rng=None):
+def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gain=1.0, noise_rng=None, fp16_operands=False):
     styles = fully_connected(w, P[pfx + 'affine.weight'], P[pfx + 'affine.bias'])
     noise = None
     if noise_mode == 'const':
@@ -202,32 +207,34 @@ def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gai
         noise = draw * P[pfx + 'noise_strength']
     f = P[pfx + 'resample_filter']
     x = modulated_conv2d(x, P[pfx + 'weight'], styles, noise=noise, up=up, padding=1, f=f,
-                         flip_weight=(up == 1))
+                         flip_weight=(up == 1), fp16_operands=fp16_operands)
     clamp = conv_clamp * gain if conv_clamp is not None else None
     return bias_act(x, P[pfx + 'bias'], act='lrelu', gain=SQRT2 * gain, clamp=clamp)
 
 
-def torgb_layer(P, pfx, x, w, conv_clamp=None):
+def torgb_layer(P, pfx, x, w, conv_clamp=None, fp16_operands=False):
     wt = P[pfx + 'weight']
     styles = fully_connected(w, P[pfx + 'affine.weight'], P[pfx + 'affine.bias'])
     styles = styles * (1.0 / math.sqrt(wt.shape[1] * wt.shape[2] * wt.shape[3]))
-    x = modulated_conv2d(x, wt, styles, demodulate=False)
+    x = modulated_conv2d(x, wt, styles, demodulate=False, fp16_operands=fp16_operands)
     return bias_act(x, P[pfx + 'bias'], clamp=conv_clamp)
 
 
-def synthesis_block(P, pfx, x, img, ws, first=False, noise_mode='const', conv_clamp=None, noise_rng=None):
+def synthesis_block(P, pfx, x, img, ws, first=False, noise_mode='const', conv_clamp=None, noise_rng=None, fp16_operands=False):
     """ws: [N, num_conv+1, 512] (conv0?, conv1, torgb)."""
     wi = 0
     if first:
         x = P[pfx + 'const'].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
     else:
-        x = synthesis_layer(P, pfx + 'conv0.', x, ws[:, wi], up=2, noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng)
+        x = synthesis_layer(P, pfx + 'conv0.', x, ws[:, wi], up=2, noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng,
+                            fp16_operands=fp16_operands)
         wi += 1
-    x = synthesis_layer(P, pfx + 'conv1.', x, ws[:, wi], noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng)
+    x = synthesis_layer(P, pfx + 'conv1.', x, ws[:, wi], noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng,
+                        fp16_operands=fp16_operands)
     wi += 1
     if img is not None:
         img = upsample2d(img, P[pfx + 'resample_filter'])
-    y = torgb_layer(P, pfx + 'torgb.', x, ws[:, wi], conv_clamp=conv_clamp)
+    y = torgb_layer(P, pfx + 'torgb.', x, ws[:, wi], conv_clamp=conv_clamp, fp16_operands=fp16_operands)
     img = y if img is None else img + y
     return x, img
 
@@ -246,12 +253,12 @@ def backbone_synthesis(P, ws, resolutions=(4, 8, 16, 32, 64, 128, 256), noise_mo
     return img
 
 
-def superresolution_8xdc(P, rgb, x, ws, noise_mode='none', conv_clamp=256, prefix='superresolution.'):
+def superresolution_8xdc(P, rgb, x, ws, noise_mode='none', conv_clamp=256, prefix='superresolution.', fp16_operands=False):
     """rgb [N,3,128,128], x [N,32,128,128] -> [N,3,512,512]; every layer driven by ws[:, -1]."""
     w3 = ws[:, -1:, :].repeat(1, 3, 1)
     if x.shape[-1] != 128:     # superresolution.py:282-286 (only reached by reduced-size test configs)
         x = F.interpolate(x, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
         rgb = F.interpolate(rgb, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
-    x, rgb = synthesis_block(P, prefix + 'block0.', x, rgb, w3, noise_mode=noise_mode, conv_clamp=conv_clamp)
-    x, rgb = synthesis_block(P, prefix + 'block1.', x, rgb, w3, noise_mode=noise_mode, conv_clamp=conv_clamp)
+    x, rgb = synthesis_block(P, prefix + 'block0.', x, rgb, w3, noise_mode=noise_mode, conv_clamp=conv_clamp, fp16_operands=fp16_operands)
+    x, rgb = synthesis_block(P, prefix + 'block1.', x, rgb, w3, noise_mode=noise_mode, conv_clamp=conv_clamp, fp16_operands=fp16_operands)
     return rgb

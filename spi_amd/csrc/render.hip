@@ -210,6 +210,55 @@ __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// sample_from_planes as its own operator (renderer.py:55-65): per-PLANE bilinear features [N,3,P,32] at explicit coordinates --
+// what a decoder other than the OSG MLP consumes (ImportanceRenderer accepts any decoder callable, renderer.py:88,142-148).
+// 8 lanes per (point, plane), one float4 of the 32 channels each: every corner fetch is a whole 128-B line; out-of-plane corners
+// take the buffer's out-of-range offset (hardware zeros == padding_mode 'zeros').  Off the SPI hot path, which uses the fused kernels above.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) sample_planes_fwd_kernel(const float* __restrict__ planes, const float* __restrict__ coords, int N, int64_t P,
+                                                                int H, int W, float scale, float* __restrict__ out) {
+    const int sub = threadIdx.x & 7;
+    const int64_t e = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);              // (n, pl, p) flattened, p fastest
+    if (e >= (int64_t)N * 3 * P) return;
+    const int64_t p = e % P;
+    const int pl = (int)((e / P) % 3), n = (int)(e / (3 * P));
+    const float* c = coords + ((int64_t)n * P + p) * 3;
+    float gx, gy;
+    plane_uv(pl, c[0] * scale, c[1] * scale, c[2] * scale, gx, gy);
+    const unsigned plane_bytes = (unsigned)(H * W * DEC_IN * 4);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(planes, (int64_t)N * 3 * plane_bytes);
+    const CornerOff k = corner_offsets(make_corner(gx, gy, W, H), W, H, (unsigned)(n * 3 + pl) * plane_bytes, sub);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    corner_accumulate(acc, rs, k);
+    *reinterpret_cast<float4*>(out + e * DEC_IN + sub * 4) = acc;
+}
+
+__global__ void __launch_bounds__(256) sample_planes_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ coords, int N, int64_t P,
+                                                                int H, int W, float scale, float* __restrict__ d_planes) {
+    const int sub = threadIdx.x & 7;
+    const int64_t e = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
+    if (e >= (int64_t)N * 3 * P) return;
+    const int64_t p = e % P;
+    const int pl = (int)((e / P) % 3), n = (int)(e / (3 * P));
+    const float* c = coords + ((int64_t)n * P + p) * 3;
+    float gx, gy;
+    plane_uv(pl, c[0] * scale, c[1] * scale, c[2] * scale, gx, gy);
+    const Corner k = make_corner(gx, gy, W, H);
+    const float4 d4 = *reinterpret_cast<const float4*>(d_out + e * DEC_IN + sub * 4);
+    float* pb = d_planes + ((int64_t)(n * 3 + pl) * H * W) * DEC_IN + sub * 4;
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy)
+#pragma unroll
+        for (int cx = 0; cx < 2; ++cx) {
+            const int xx = k.x0 + cx, yy = k.y0 + cy;
+            if (xx < 0 || xx >= W || yy < 0 || yy >= H) continue;
+            const float w = (cx ? k.wx1 : k.wx0) * (cy ? k.wy1 : k.wy0);
+            float* q = pb + ((int64_t)yy * W + xx) * DEC_IN;
+            atomicAdd(q + 0, d4.x * w); atomicAdd(q + 1, d4.y * w); atomicAdd(q + 2, d4.z * w); atomicAdd(q + 3, d4.w * w);
+        }
+}
+
 // Decoder MLP.  Both layers walk ROWS of 64 contiguous weights (w1t = W1^T [32][64], w2 [33][64]) in a
 // runtime loop: the row is wave-uniform -> 4 x s_load_dwordx16 + 64 v_fmac with an SGPR operand;
 // the per-point vector that is indexed by the loop variable lives in LDS, the 64 accumulators in
@@ -1570,6 +1619,29 @@ static int fill_decode_args(DecodeArgs& a, const float* planes, const float* coo
     a.planes = planes; a.coords = coords; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths;
     a.N = N; a.P = P; a.S = S > 0 ? S : 1; a.H = H; a.W = W; a.out_S = out_S; a.out_off = out_off;
     a.scale = 2.f / box_warp;
+    return SPI_OK;
+}
+
+int spi_sample_from_planes_fwd(const float* planes_nhwc, const float* coords, int N, int64_t P, int H, int W, float box_warp, float* out,
+                               spi_stream_t stream) {
+    SPI_REQUIRE(planes_nhwc && coords && out, "spi_sample_from_planes_fwd: null tensor");
+    SPI_REQUIRE(N > 0 && P > 0 && H > 0 && W > 0 && box_warp > 0.f, "spi_sample_from_planes_fwd: bad size");
+    SPI_REQUIRE((int64_t)N * 3 * H * W * DEC_IN * 4 < ((int64_t)1 << 31), "spi_sample_from_planes_fwd: the planes tensor must be < 2 GiB (one buffer descriptor)");
+    const int64_t total = (int64_t)N * 3 * P;
+    hipLaunchKernelGGL(sample_planes_fwd_kernel, dim3((unsigned)ceil_div64(total, 32)), dim3(256), 0, as_stream(stream), planes_nhwc, coords, N, P, H, W,
+                       2.f / box_warp, out);
+    SPI_LAUNCH_CHECK("spi_sample_from_planes_fwd");
+    return SPI_OK;
+}
+
+int spi_sample_from_planes_bwd(const float* d_out, const float* coords, int N, int64_t P, int H, int W, float box_warp, float* d_planes_nhwc,
+                               spi_stream_t stream) {
+    SPI_REQUIRE(d_out && coords && d_planes_nhwc, "spi_sample_from_planes_bwd: null tensor");
+    SPI_REQUIRE(N > 0 && P > 0 && H > 0 && W > 0 && box_warp > 0.f, "spi_sample_from_planes_bwd: bad size");
+    const int64_t total = (int64_t)N * 3 * P;
+    hipLaunchKernelGGL(sample_planes_bwd_kernel, dim3((unsigned)ceil_div64(total, 32)), dim3(256), 0, as_stream(stream), d_out, coords, N, P, H, W,
+                       2.f / box_warp, d_planes_nhwc);
+    SPI_LAUNCH_CHECK("spi_sample_from_planes_bwd");
     return SPI_OK;
 }
 

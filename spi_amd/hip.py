@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
-ABI_VERSION = 3          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
+ABI_VERSION = 4          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -33,6 +33,8 @@ _SIGS = {
     'spi_coarse_depths': ([c_p, c_l, c_i, c_f, c_f, c_p, c_p], c_i),
     'spi_nchw_to_nhwc': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
     'spi_nhwc_to_nchw': ([c_p, c_p, c_i, c_i, c_i, c_i, c_p], c_i),
+    'spi_sample_from_planes_fwd': ([c_p, c_p, c_i, c_l, c_i, c_i, c_f, c_p, c_p], c_i),
+    'spi_sample_from_planes_bwd': ([c_p, c_p, c_i, c_l, c_i, c_i, c_f, c_p, c_p], c_i),
     'spi_triplane_decode_fwd': ([c_p] * 9 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_triplane_decode_bwd': ([c_p] * 11 + [c_i, c_l, c_i, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p], c_i),
     'spi_triplane_decode_bwd_sorted': ([c_p] * 13 + [c_i, c_i, c_i, c_i, c_i, c_i, c_f] + [c_p] * 8, c_i),

@@ -89,10 +89,9 @@ class RotBboxCoach(BaseCoach):
     GRAPH_WARMUP = int(os.environ.get('SPI_GRAPH_WARMUP', '1'))          # eager iterations of a kind before its capture
 
     def _graph_ok(self, rng):
-        import torch.distributed as tdist
-        return (global_config.stage2_hip_graph and isinstance(rng, DeviceRNG) and torch.device(self.device).type == 'cuda'
-                and not global_config.concurrent_branches and not getattr(self, '_graph_failed', False)
-                and not (tdist.is_available() and tdist.is_initialized()))
+        from ..projectors.common import graph_policy              # the same answer with and without a process group (multi-GPU = measured path)
+        return (graph_policy(global_config.stage2_hip_graph) and isinstance(rng, DeviceRNG) and torch.device(self.device).type == 'cuda'
+                and not global_config.concurrent_branches and not getattr(self, '_graph_failed', False))
 
     def _graph_train_step(self, i, ctx, w_pivot, rng):
         key = (id(ctx), w_pivot.data_ptr(), id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold),    # (the threshold is baked in,
@@ -108,7 +107,8 @@ class RotBboxCoach(BaseCoach):
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                from ..projectors.common import capture_mode
+                with torch.cuda.graph(g, capture_error_mode=capture_mode()):
                     _, losses = self._forward_backward(i, ctx, w_pivot, rng, flag_buf=flag)
             except Exception as e:                               # noqa: BLE001  (capture is an optimisation: the eager iteration is always valid)
                 import sys

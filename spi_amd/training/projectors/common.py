@@ -96,6 +96,22 @@ class NoiseRegulariser:
         hip.call('spi_noise_renorm', hip.ptr(self.ptrs), hip.ptr(self.res), self.T, hip.stream())
 
 
+def graph_policy(enabled):
+    """Whether the stage-1 step is replayed from a HIP graph.  The same answer with and without an initialised process group: the ranks of a
+    multi-GPU run (one process per GPU, spi_amd/dist.py) take exactly the code path the single-GPU number is measured on.  (Round 2 switched
+    the graph off beside a process group because RCCL's watchdog thread issues HIP calls of its own, which a capture in GLOBAL error mode
+    rejects; the capture now runs in thread-local mode there, see capture_mode().)"""
+    return bool(enabled)
+
+
+def capture_mode():
+    """hipStreamCaptureMode for torch.cuda.graph: 'global' (any thread's unsafe HIP call invalidates the capture -- the strictest check, kept for
+    single-process runs) unless a process group is up: its watchdog thread polls events with hipEventQuery while this thread captures, which
+    is harmless (no collective is in flight during a stage-1 step: the path has no data-path collective) and allowed in 'thread_local' mode."""
+    import torch.distributed as tdist
+    return 'thread_local' if (tdist.is_available() and tdist.is_initialized()) else 'global'
+
+
 class Projection:
     """State of one stage-1 optimisation; ``step(i)`` is the loop body of mirror_projector.py:81-131."""
     def __init__(self, G, cameras, dist_fn, *, w_mode, initial_w, num_steps, w_avg_samples, device, rng=None,
@@ -129,11 +145,7 @@ class Projection:
 
     def _graph_ok(self):
         from ...configs import global_config
-        import torch.distributed as tdist
-        # (not beside an initialised process group: RCCL's watchdog thread issues HIP calls of its own, which a capture in global mode does not
-        #  tolerate; the step is GPU-bound, so the multi-GPU runs lose nothing by enqueueing eagerly)
-        return (global_config.stage1_hip_graph and isinstance(self.rng, DeviceRNG) and self.w_opt.is_cuda and not getattr(self, '_graph_failed', False)
-                and not (tdist.is_available() and tdist.is_initialized()))
+        return graph_policy(global_config.stage1_hip_graph) and isinstance(self.rng, DeviceRNG) and self.w_opt.is_cuda and not getattr(self, '_graph_failed', False)
 
     def _set_hyper(self, step):
         lr, w_noise_scale = stage1_schedule(step, self.num_steps, self.w_std, **self.sched)
@@ -175,7 +187,7 @@ class Projection:
         try:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=capture_mode()):
                 out = self._body(step, device_hyper=True, hyper_is_set=True)
         except Exception as e:                                   # noqa: BLE001  (capture is an optimisation: the eager step is always valid)
             import sys

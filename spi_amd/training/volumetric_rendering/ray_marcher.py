@@ -56,7 +56,13 @@ class MipRayMarcher2(torch.nn.Module):
     def run_forward(self, colors, densities, depths, rendering_options):
         if rendering_options.get('clamp_mode', 'softplus') != 'softplus':
             raise AssertionError('MipRayMarcher only supports `clamp_mode`=`softplus`!')
-        return _RayMarch.apply(colors, densities, depths, bool(rendering_options.get('white_back', False)))
+        c = colors.shape[-1]
+        if c > 32:
+            raise NotImplementedError(f'MipRayMarcher2: at most 32 colour channels (one 128-B row per sample), got {c}')
+        if c < 32:                                               # a decoder with fewer output channels: zero-pad the rows, drop the padding again
+            colors = torch.nn.functional.pad(colors, (0, 32 - c))
+        rgb, depth, weights = _RayMarch.apply(colors, densities, depths, bool(rendering_options.get('white_back', False)))
+        return (rgb[..., :c] if c < 32 else rgb), depth, weights
 
     def forward(self, colors, densities, depths, rendering_options):
         return self.run_forward(colors, densities, depths, rendering_options)

@@ -15,8 +15,17 @@ MI355X-first layout (not the reference's op-by-op graph):
   * the backward recomputes gather + hidden layer instead of saving them.
 The two random draws (``rand_like`` [N,M,Sc,1] then ``rand`` [N*M,Sf], renderer.py:190,237) can be
 injected with ``noise=(xi, u)``; by default they come from the device generator in that order.
-Only the scalar ``ray_start``/``ray_end`` branch (renderer.py:188-190) is implemented -- the one
-the FFHQ configuration takes; 'auto' ray limits and disparity-space sampling raise.
+
+The whole ``ImportanceRenderer`` surface is served (round 3):
+  * scalar ``ray_start`` / ``ray_end`` (renderer.py:188-190): the FFHQ configuration SPI runs -- everything in the fused kernels;
+  * ``ray_start = ray_end = 'auto'`` (:91-97, box limits per ray) and ``disparity_space_sampling`` (:175-182): the coarse depths are
+    computed by tensor ops (math_utils.py) and handed to the same fused kernels; the coarse / fine merge then uses a stable sort
+    instead of the two-run merge kernel (a ray that misses the box may carry descending depths, as in the reference);
+  * ``density_noise`` (:146-147): ``sigma += randn_like(sigma) * density_noise`` after each decoder pass; the draws can be injected as
+    ``noise=(xi, u, eps_coarse, eps_fine)`` (the reference's order: rand_like, randn_like, rand, randn_like);
+  * any decoder callable ``decoder(sampled_features [N,3,P,C], sample_directions) -> {'rgb', 'sigma'}`` (:88,142-148): an
+    ``OSGDecoder``-shaped module takes the fused gather + MLP kernels; anything else goes through ``sample_from_planes`` (its own HIP
+    kernel pair) + the callable under autograd + ``MipRayMarcher2`` -- the reference's op-by-op composition.
 """
 import math
 import os
@@ -28,6 +37,12 @@ from .ray_marcher import MipRayMarcher2, depth_range
 DEC_DUMP_ROWS = 193
 MARCH_EVENTS = None      # bench.py: list collecting (start, end, rays) HIP events around every final-march launch
 MARCH_BWD_EVENTS = None  # bench.py: the same around every march-backward launch with a colour gradient: (start, end, rays, active-ray flags)
+DECODE_FWD_EVENTS = None # bench.py: (start, end, points) around every tri-plane gather + decoder forward launch that evaluates the colour rows
+DECODE_BWD_EVENTS = None # bench.py: (start, end, rays, samples per ray, active-ray flags, wgrad?, rgb?) around every tiled decoder-backward call
+
+
+def _timed(events):
+    return events is not None and not torch.cuda.is_current_stream_capturing()      # (a captured step cannot hold timing events)
 
 
 def decoder_tensors(decoder):
@@ -69,9 +84,17 @@ def _decode_fwd(planes_nhwc, dec, *, coords=None, rays=None, depths=None, box_wa
         p = ray_o.shape[1] * s
         ro, rd, dp = hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(depths)
         rgb, sigma = out
+    timed = _timed(DECODE_FWD_EVENTS) and rgb is not None
+    if timed:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
     hip.call('spi_triplane_decode_fwd', hip.ptr(planes_nhwc), hip.ptr(coords) if coords is not None else None, ro, rd, dp,
              hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), n, p, s, h, w, float(box_warp), out_S, out_off,
              hip.ptr(rgb), hip.ptr(sigma), hip.stream())
+    if timed:
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        DECODE_FWD_EVENTS.append((e0, e1, n * p))
     return rgb, sigma
 
 
@@ -127,14 +150,23 @@ class _Render(torch.autograd.Function):
         box_warp = float(opts['box_warp'])
         white_back = int(bool(opts.get('white_back', False)))
         # coarse pass
-        d_c = torch.empty(n, m, sc, device=dev, dtype=torch.float32)
-        xi = xi.reshape(n, m, sc).contiguous().float()
-        hip.call('spi_coarse_depths', hip.ptr(xi), r, sc, float(opts['ray_start']), float(opts['ray_end']), hip.ptr(d_c), hip.stream())
+        general = opts.get('coarse_depths') is not None          # 'auto' limits / disparity sampling: depths precomputed by ImportanceRenderer
+        if general:
+            d_c = opts['coarse_depths'].reshape(n, m, sc).contiguous().float()
+        else:
+            d_c = torch.empty(n, m, sc, device=dev, dtype=torch.float32)
+            xi = xi.reshape(n, m, sc).contiguous().float()
+            hip.call('spi_coarse_depths', hip.ptr(xi), r, sc, float(opts['ray_start']), float(opts['ray_end']), hip.ptr(d_c), hip.stream())
+        dnoise = float(opts.get('density_noise', 0) or 0)
+        eps_c, eps_f = opts.get('density_eps', (None, None))
         # depth_only (SPI's depth-regularisation branch reads nothing but image_depth): no colour rows are decoded, stored or composited
         depth_only = bool(opts.get('depth_only', False))
         rgb_all = torch.empty(n, m, s, 32, device=dev, dtype=torch.float32) if not depth_only else None
         sig_all = torch.empty(n, m, s, device=dev, dtype=torch.float32)
         _decode_fwd(planes_nhwc, dec, rays=(ray_o, ray_d), depths=d_c, box_warp=box_warp, out=(rgb_all, sig_all), out_S=s, out_off=0)
+        if dnoise > 0:                                           # renderer.py:146-147 (a constant wrt every gradient)
+            e = torch.randn(n, m, sc, device=dev) if eps_c is None else eps_c.to(dev).reshape(n, m, sc).float()
+            sig_all[:, :, :sc] += e * dnoise
         if sf > 0:
             w_c = torch.empty(n, m, sc - 1, device=dev, dtype=torch.float32)
             hip.call('spi_raymarch_fwd', None, hip.ptr(sig_all), hip.ptr(d_c), None, None, r, sc, s, 32, white_back, None, None,
@@ -143,9 +175,18 @@ class _Render(torch.autograd.Function):
             u = u.reshape(n, m, sf).contiguous().float()
             hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), r, sc, sf, hip.ptr(d_f), 1, hip.stream())
             _decode_fwd(planes_nhwc, dec, rays=(ray_o, ray_d), depths=d_f, box_warp=box_warp, out=(rgb_all, sig_all), out_S=s, out_off=sc)
-            d_all = torch.empty(n, m, s, device=dev, dtype=torch.float32)
-            perm = torch.empty(n, m, s, device=dev, dtype=torch.int32)
-            hip.call('spi_merge_sort_depths', hip.ptr(d_c), hip.ptr(d_f), r, sc, sf, hip.ptr(d_all), hip.ptr(perm), hip.stream())
+            if dnoise > 0:
+                e = torch.randn(n, m, sf, device=dev) if eps_f is None else eps_f.to(dev).reshape(n, m, sf).float()
+                sig_all[:, :, sc:] += e * dnoise
+            if general:
+                # per-ray limits: the coarse run of a ray that misses the box may be descending (reference behaviour, renderer.py:95-97),
+                # which the two-ascending-runs merge kernel does not accept -> the reference's own cat + sort (:157-167), kept as a permutation
+                d_all, perm = torch.sort(torch.cat([d_c, d_f], dim=-1), dim=-1, stable=True)
+                d_all, perm = d_all.contiguous(), perm.to(torch.int32).contiguous()
+            else:
+                d_all = torch.empty(n, m, s, device=dev, dtype=torch.float32)
+                perm = torch.empty(n, m, s, device=dev, dtype=torch.int32)
+                hip.call('spi_merge_sort_depths', hip.ptr(d_c), hip.ptr(d_f), r, sc, sf, hip.ptr(d_all), hip.ptr(perm), hip.stream())
         else:
             d_f, d_all, perm = None, d_c, None
         clamp2 = depth_range(d_all)
@@ -218,9 +259,17 @@ class _Render(torch.autograd.Function):
         gw = None
         if want_w:                               # decoder weight gradients come out of the same kernel (no activation dump)
             gw = (torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev))
+        timed_dec = _timed(DECODE_BWD_EVENTS)
+        if timed_dec:
+            f0 = torch.cuda.Event(enable_timing=True)
+            f0.record()
         hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes_nhwc), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(d_all), hip.ptr(perm),
                  hip.ptr(w1t), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), hip.ptr(d_cs), hip.ptr(rgb_all if d_rgb is not None else None), hip.ptr(d_sig), n, m, s, ray_w, hh, ww, box_warp,
                  hip.ptr(d_planes), hip.ptr(ws), *([hip.ptr(g) for g in gw] if want_w else [None] * 4), hip.ptr(active), hip.stream())
+        if timed_dec:
+            f1 = torch.cuda.Event(enable_timing=True)
+            f1.record()
+            DECODE_BWD_EVENTS.append((f0, f1, r, s, active, bool(want_w), d_rgb is not None))
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
         if want_w:
@@ -268,40 +317,200 @@ def _decoder_params(decoder):
     return (l0.weight, l0.bias, l2.weight, l2.bias), gains
 
 
+def _is_osg_decoder(decoder):
+    """True for a module with the OSG decoder's exact arithmetic (triplane.py:112-135): net = [FC 32->64, Softplus, FC 64->33] and the
+    class's own forward -- the only thing the fused gather + MLP kernels compute.  Anything else takes the generic path."""
+    from ..triplane import OSGDecoder
+    net = getattr(decoder, 'net', None)
+    if not isinstance(decoder, OSGDecoder) or type(decoder).forward is not OSGDecoder.forward or net is None or len(net) != 3:
+        return False
+    l0, l2 = net[0], net[2]
+    return (isinstance(net[1], torch.nn.Softplus) and all(hasattr(l, a) for l in (l0, l2) for a in ('weight', 'bias', 'weight_gain', 'bias_gain'))
+            and tuple(l0.weight.shape) == (64, 32) and tuple(l2.weight.shape) == (33, 64) and l0.bias is not None and l2.bias is not None
+            and getattr(l0, 'activation', 'linear') == 'linear' and getattr(l2, 'activation', 'linear') == 'linear')
+
+
+def generate_planes():
+    """The three plane-axis triples (renderer.py:23-37).  The kernels sample plane 0 at (x, y), plane 1 at (x, z), plane 2 at (z, x) --
+    what these axes (through project_onto_planes' inverse, :39-53) amount to."""
+    return torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                         [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
+                         [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32)
+
+
+class _SamplePlanes(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, planes, coords, box_warp):
+        n, _, c, h, w = planes.shape
+        planes_nhwc = planes_to_nhwc(planes.detach())
+        coords = coords.detach().contiguous().float()
+        p = coords.shape[1]
+        out = torch.empty(n, 3, p, c, device=planes.device, dtype=torch.float32)
+        hip.call('spi_sample_from_planes_fwd', hip.ptr(planes_nhwc), hip.ptr(coords), n, p, h, w, float(box_warp), hip.ptr(out), hip.stream())
+        ctx.save_for_backward(coords)
+        ctx.meta = (n, p, c, h, w, float(box_warp))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, d_out):
+        coords, = ctx.saved_tensors
+        n, p, c, h, w, box_warp = ctx.meta
+        d_planes = torch.zeros(n, 3, h, w, c, device=coords.device, dtype=torch.float32)
+        hip.call('spi_sample_from_planes_bwd', hip.ptr(d_out.contiguous().float()), hip.ptr(coords), n, p, h, w, box_warp, hip.ptr(d_planes), hip.stream())
+        return planes_to_nchw(d_planes), None, None
+
+
+def sample_from_planes(plane_axes, plane_features, coordinates, mode='bilinear', padding_mode='zeros', box_warp=None):
+    """renderer.py:55-65: [N,3,C,H,W] planes sampled at [N,P,3] coordinates -> [N,3,P,C] (bilinear, zeros padding, align_corners False).
+    One HIP kernel per direction instead of project_onto_planes + three grid_samples; C = 32 and the default plane axes only."""
+    assert padding_mode == 'zeros' and mode == 'bilinear'
+    if plane_axes is not None and not torch.equal(plane_axes.detach().cpu().float(), generate_planes()):
+        raise NotImplementedError('sample_from_planes: only the EG3D plane axes of generate_planes() are built into the kernels')
+    if plane_features.shape[1] != 3 or plane_features.shape[2] != 32:
+        raise NotImplementedError(f'sample_from_planes: planes must be [N,3,32,H,W], got {tuple(plane_features.shape)}')
+    return _SamplePlanes.apply(plane_features, coordinates, float(box_warp))
+
+
 class ImportanceRenderer(torch.nn.Module):
     def __init__(self):
         super().__init__()
         self.ray_marcher = MipRayMarcher2()
+        self.plane_axes = generate_planes()
         self.last_aux = None
 
     @staticmethod
     def _check(opts):
-        if isinstance(opts.get('ray_start', 0.0), str) or isinstance(opts.get('ray_end', 0.0), str):
-            raise NotImplementedError("ray_start/ray_end='auto' is not on the SPI path (renderer.py:91-96)")
-        if opts.get('disparity_space_sampling', False):
-            raise NotImplementedError('disparity_space_sampling is not on the SPI path (renderer.py:175-182)')
         if opts.get('clamp_mode', 'softplus') != 'softplus':
             raise AssertionError('MipRayMarcher only supports `clamp_mode`=`softplus`!')
-        if opts.get('density_noise', 0) > 0:
-            raise NotImplementedError('density_noise > 0 is not on the SPI path (renderer.py:146-147)')
 
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, noise=None, depth_only=False):
-        """depth_only (extension): returns (None, depth, weight sums) -- the colour half of the decoder and of the composite is skipped."""
-        self._check(rendering_options)
+    # ---- sampling (renderer.py:169-253) ------------------------------------------------------------------------------------------
+    def sample_stratified(self, ray_origins, ray_start, ray_end, depth_resolution, disparity_space_sampling=False, xi=None):
+        """renderer.py:169-192 -> [N,M,S,1]: scalar limits, per-ray tensor limits, or uniform in disparity.  xi: the rand_like draw."""
         n, m, _ = ray_origins.shape
-        sc, sf = int(rendering_options['depth_resolution']), int(rendering_options['depth_resolution_importance'])
-        if noise is None:
-            xi = torch.rand(n, m, sc, 1, device=planes.device)
-            u = torch.rand(n * m, max(sf, 1), device=planes.device)
-        else:
-            xi, u = noise
-            xi, u = xi.to(planes.device), u.to(planes.device)
+        dev = ray_origins.device
+        s = int(depth_resolution)
+        if disparity_space_sampling:
+            t = torch.linspace(0, 1, s, device=dev).reshape(1, 1, s, 1).repeat(n, m, 1, 1)
+            t = t + (torch.rand_like(t) if xi is None else xi.to(dev).reshape(n, m, s, 1)) * (1 / (s - 1))
+            return 1. / (1. / ray_start * (1. - t) + 1. / ray_end * t)
+        if torch.is_tensor(ray_start):
+            from . import math_utils
+            d = math_utils.linspace(ray_start, ray_end, s).permute(1, 2, 0, 3)
+            delta = (ray_end - ray_start) / (s - 1)
+            return d + (torch.rand_like(d) if xi is None else xi.to(dev).reshape(n, m, s, 1)) * delta[..., None]
+        d = torch.linspace(ray_start, ray_end, s, device=dev).reshape(1, 1, s, 1).repeat(n, m, 1, 1)
+        return d + (torch.rand_like(d) if xi is None else xi.to(dev).reshape(n, m, s, 1)) * ((ray_end - ray_start) / (s - 1))
+
+    def sample_importance(self, z_vals, weights, N_importance, u=None):
+        """renderer.py:194-215 on the HIP kernel: [N,M,S,1] depths + [N,M,S-1,1] weights -> [N,M,N_importance,1] fine depths (no grad;
+        emitted ascending per ray -- the same multiset as the reference's unsorted draws).  u: the torch.rand [N*M, N_importance] draw."""
+        with torch.no_grad():
+            n, m, s, _ = z_vals.shape
+            dev = z_vals.device
+            d_c = z_vals.detach().reshape(n, m, s).contiguous().float()
+            w_c = weights.detach().reshape(n, m, s - 1).contiguous().float()
+            u = (torch.rand(n * m, N_importance, device=dev) if u is None else u.to(dev)).reshape(n, m, N_importance).contiguous().float()
+            d_f = torch.empty(n, m, N_importance, device=dev, dtype=torch.float32)
+            hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), n * m, s, N_importance, hip.ptr(d_f), 1, hip.stream())
+        return d_f.unsqueeze(-1)
+
+    def unify_samples(self, depths1, colors1, densities1, depths2, colors2, densities2):
+        """renderer.py:157-167 (generic-decoder path only; the fused path folds this into a permutation the march reads through)."""
+        all_depths = torch.cat([depths1, depths2], dim=-2)
+        all_colors = torch.cat([colors1, colors2], dim=-2)
+        all_densities = torch.cat([densities1, densities2], dim=-2)
+        _, idx = torch.sort(all_depths, dim=-2)
+        return (torch.gather(all_depths, -2, idx), torch.gather(all_colors, -2, idx.expand(-1, -1, -1, all_colors.shape[-1])),
+                torch.gather(all_densities, -2, idx))
+
+    # ---- forward ------------------------------------------------------------------------------------------------------------------
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, noise=None, depth_only=False):
+        """depth_only (extension): returns (None, depth, weight sums) -- the colour half of the decoder and of the composite is skipped.
+        noise (extension): (xi, u) or (xi, u, eps_coarse, eps_fine) -- the reference's draws in its order, injected."""
+        self._check(rendering_options)
+        opts = rendering_options
+        n, m, _ = ray_origins.shape
+        dev = planes.device
+        sc, sf = int(opts['depth_resolution']), int(opts['depth_resolution_importance'])
+        noise = tuple(noise) if noise is not None else ()
+        xi = noise[0].to(dev) if len(noise) > 0 and noise[0] is not None else None
+        u = noise[1].to(dev) if len(noise) > 1 and noise[1] is not None else None
+        eps = (noise[2] if len(noise) > 2 else None, noise[3] if len(noise) > 3 else None)
+        dnoise = float(opts.get('density_noise', 0) or 0)
+        auto = isinstance(opts['ray_start'], str) or isinstance(opts['ray_end'], str)
+        if auto and not (opts['ray_start'] == opts['ray_end'] == 'auto'):
+            raise ValueError("ray_start / ray_end: numbers, or both 'auto' (renderer.py:91)")
+        disparity = bool(opts.get('disparity_space_sampling', False))
+        fused = _is_osg_decoder(decoder)
+        coarse = None
+        if auto or disparity or not fused:
+            # draws in the reference's order: the coarse jitter first
+            if xi is None:
+                xi = torch.rand(n, m, sc, 1, device=dev)
+            if auto:
+                from . import math_utils
+                ray_start, ray_end = math_utils.get_ray_limits_box(ray_origins, ray_directions, box_side_length=opts['box_warp'])
+                ok = ray_end > ray_start
+                if torch.any(ok).item():
+                    ray_start = torch.where(ok, ray_start, ray_start[ok].min())
+                    ray_end = torch.where(ok, ray_end, ray_start[ok].max())      # (sic, renderer.py:96: the largest valid START)
+                coarse = self.sample_stratified(ray_origins, ray_start, ray_end, sc, disparity, xi=xi)
+            else:
+                coarse = self.sample_stratified(ray_origins, opts['ray_start'], opts['ray_end'], sc, disparity, xi=xi)
+        if not fused:
+            if depth_only:
+                raise NotImplementedError('depth_only rendering needs the OSG decoder (fused kernels)')
+            return self._forward_generic(planes, decoder, ray_origins, ray_directions, opts, coarse, u, eps)
+        if xi is None:
+            xi = torch.rand(n, m, sc, 1, device=dev)
+        if dnoise > 0 and eps[0] is None:                        # keep the reference's draw order: rand_like, randn_like, rand, randn_like
+            eps = (torch.randn(n, m * sc, 1, device=dev), None)
+        if u is None:
+            u = torch.rand(n * m, max(sf, 1), device=dev)
+        if dnoise > 0 and eps[1] is None and sf > 0:
+            eps = (eps[0], torch.randn(n, m * sf, 1, device=dev))
         params, gains = _decoder_params(decoder)
-        rgb, depth, wsum = _Render.apply(planes, *params, gains, ray_origins, ray_directions, xi, u, dict(rendering_options, depth_only=bool(depth_only)))
+        ro = dict(opts, depth_only=bool(depth_only), coarse_depths=coarse, density_eps=eps)
+        if auto:
+            ro['ray_start'] = ro['ray_end'] = 0.0                # unused beside coarse_depths
+        rgb, depth, wsum = _Render.apply(planes, *params, gains, ray_origins, ray_directions, xi, u, ro)
         return rgb, depth, wsum
 
-    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+    def _forward_generic(self, planes, decoder, ray_origins, ray_directions, opts, depths_coarse, u, eps):
+        """The reference's composition (renderer.py:103-140) for an arbitrary decoder callable: sample_from_planes (HIP) -> decoder (autograd)
+        -> MipRayMarcher2 (HIP) -> sample_importance (HIP) -> second pass -> unify_samples -> MipRayMarcher2."""
+        n, m, sc, _ = depths_coarse.shape
+        coords = (ray_origins.unsqueeze(-2) + depths_coarse * ray_directions.unsqueeze(-2)).reshape(n, -1, 3)
+        dirs = ray_directions.unsqueeze(-2).expand(-1, -1, sc, -1).reshape(n, -1, 3)
+        out = self.run_model(planes, decoder, coords, dirs, opts, _eps=eps[0])
+        colors_coarse = out['rgb'].reshape(n, m, sc, out['rgb'].shape[-1])
+        dens_coarse = out['sigma'].reshape(n, m, sc, 1)
+        sf = int(opts['depth_resolution_importance'])
+        if sf > 0:
+            _, _, weights = self.ray_marcher(colors_coarse, dens_coarse, depths_coarse, opts)
+            depths_fine = self.sample_importance(depths_coarse, weights, sf, u=u)
+            dirs = ray_directions.unsqueeze(-2).expand(-1, -1, sf, -1).reshape(n, -1, 3)
+            coords = (ray_origins.unsqueeze(-2) + depths_fine * ray_directions.unsqueeze(-2)).reshape(n, -1, 3)
+            out = self.run_model(planes, decoder, coords, dirs, opts, _eps=eps[1])
+            colors_fine = out['rgb'].reshape(n, m, sf, out['rgb'].shape[-1])
+            dens_fine = out['sigma'].reshape(n, m, sf, 1)
+            all_d, all_c, all_s = self.unify_samples(depths_coarse, colors_coarse, dens_coarse, depths_fine, colors_fine, dens_fine)
+            rgb, depth, weights = self.ray_marcher(all_c, all_s, all_d, opts)
+        else:
+            rgb, depth, weights = self.ray_marcher(colors_coarse, dens_coarse, depths_coarse, opts)
+        return rgb, depth, weights.sum(2)
+
+    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options, _eps=None):
         self._check(options)
-        params, gains = _decoder_params(decoder)
-        rgb, sigma = _RunModel.apply(planes, *params, gains, sample_coordinates, float(options['box_warp']))
-        return {'rgb': rgb, 'sigma': sigma}
+        if _is_osg_decoder(decoder):
+            params, gains = _decoder_params(decoder)
+            rgb, sigma = _RunModel.apply(planes, *params, gains, sample_coordinates, float(options['box_warp']))
+            out = {'rgb': rgb, 'sigma': sigma}
+        else:
+            feats = sample_from_planes(self.plane_axes, planes, sample_coordinates, padding_mode='zeros', box_warp=options['box_warp'])
+            out = dict(decoder(feats, sample_directions))
+        if options.get('density_noise', 0) > 0:                  # renderer.py:146-147
+            e = torch.randn_like(out['sigma']) if _eps is None else _eps.to(out['sigma'].device).reshape(out['sigma'].shape)
+            out['sigma'] = out['sigma'] + e * options['density_noise']
+        return out

@@ -283,6 +283,81 @@ def sec_renderer():
     save('renderer', **out)
 
 
+def tiny_decoder_weights():
+    """A decoder that is NOT the OSG MLP (ImportanceRenderer takes any callable, renderer.py:88,142-148): uses the ray directions, 4 colours."""
+    return dict(A=synth_tensor('tiny.A', (32, 16)) * 0.3, B=synth_tensor('tiny.B', (3, 16)), C=synth_tensor('tiny.C', (16, 5)))
+
+
+def tiny_decoder(Wt, feats, dirs):
+    h = torch.tanh(feats.mean(1) @ Wt['A'] + dirs @ Wt['B'])
+    y = h @ Wt['C']
+    return torch.sigmoid(y[..., 1:]), y[..., 0:1]
+
+
+def sec_renderer_options():
+    """ImportanceRenderer options off the SPI path (VERDICT r02 missing #3): 'auto' ray limits, disparity-space sampling, density noise,
+    a decoder callable that is not the OSG MLP.  Reference forward + plane gradients with every draw recorded; oracle pinned."""
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from training.volumetric_rendering.ray_sampler import RaySampler
+    from training.triplane import OSGDecoder
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import camera_utils as cu
+    g = torch.Generator().manual_seed(11)
+    out = {}
+    c = torch.cat([cu.cal_canonical_c(0.4, -0.1), cu.cal_canonical_c(-0.3, 0.2)], 0)
+    ro, rd = RaySampler()(c[:, :16].view(-1, 4, 4), c[:, 16:25].view(-1, 3, 3), 8)
+    dec = OSGDecoder(32, {'decoder_lr_mul': 1, 'decoder_output_dim': 32})
+    dsd = {k: synth_tensor('decoder.' + k, v.shape) for k, v in dec.state_dict().items()}
+    dsd['net.0.bias'] = dsd['net.0.bias'] * 3
+    dsd['net.2.bias'] = dsd['net.2.bias'] * 3
+    dec.load_state_dict(dsd)
+    P = {'decoder.' + k: v for k, v in dsd.items()}
+    planes = torch.randn(2, 3, 32, 16, 16, generator=g)
+    out.update(cam=c, ray_o=ro, ray_d=rd, planes=planes, **{'P_' + k: v for k, v in P.items()})
+    Wt = tiny_decoder_weights()
+    out.update({'tiny_' + k: v for k, v in Wt.items()})
+
+    class Tiny(torch.nn.Module):
+        def forward(self, sampled_features, ray_directions):
+            rgb, sigma = tiny_decoder(Wt, sampled_features, ray_directions)
+            return {'rgb': rgb, 'sigma': sigma}
+    R = ImportanceRenderer()
+    variants = dict(
+        auto=(dict(RK, ray_start='auto', ray_end='auto', box_warp=0.45), dec),          # 0.45: the outer rays of the 8x8 image miss the box
+        disparity=(dict(RK, disparity_space_sampling=True), dec),
+        dnoise=(dict(RK, density_noise=0.7), dec),
+        tiny=(dict(RK), Tiny()),
+        tiny_auto_dnoise=(dict(RK, ray_start='auto', ray_end='auto', box_warp=0.45, density_noise=0.3), Tiny()))
+    for tag, (opts, d) in variants.items():
+        pr = planes.clone().requires_grad_(True)
+        with Recorder() as rec:
+            torch.manual_seed(21)
+            rgb, depth, wsum = R(pr, d, ro, rd, opts)
+        d1, d2 = torch.randn(rgb.shape, generator=g), torch.randn(depth.shape, generator=g)
+        gp, = torch.autograd.grad([rgb, depth], [pr], [d1, d2])
+        draws = rec.draws
+        if opts.get('density_noise', 0) > 0:
+            xi, e0, u, e1 = draws
+            out[tag + '_eps0'], out[tag + '_eps1'] = e0, e1
+        else:
+            (xi, u), e0, e1 = draws, None, None
+        out.update({tag + '_xi': xi, tag + '_u': u, tag + '_rgb': rgb, tag + '_depth': depth, tag + '_wsum': wsum,
+                    tag + '_drgb': d1, tag + '_ddepth': d2, tag + '_gplanes': gp})
+        if tag.startswith('auto'):
+            from training.volumetric_rendering import math_utils
+            s0, e0_ = math_utils.get_ray_limits_box(ro, rd, box_side_length=opts['box_warp'])
+            out['auto_miss_fraction'] = (e0_ <= s0).float().mean()
+            print(f'    auto: {float(out["auto_miss_fraction"]) * 100:.0f} % of the rays miss the box')
+        fn = (lambda f, dd: tiny_decoder(Wt, f, dd)) if tag.startswith('tiny') else None
+        oopts = {k: v for k, v in opts.items() if k in ('depth_resolution', 'depth_resolution_importance', 'ray_start', 'ray_end', 'box_warp',
+                                                        'white_back', 'disparity_space_sampling', 'density_noise')}
+        a, b_, c_ = orr.render(P, planes, ro, rd, oopts, xi=xi, u=u, eps=(e0, e1), decoder_fn=fn)
+        diff(f'{tag}: render rgb', rgb, a)
+        diff(f'{tag}: render depth', depth, b_)
+        diff(f'{tag}: render weight sum', wsum, c_)
+    save('renderer_options', **out)
+
+
 def sec_synthesis():
     """Narrow generator (2.84 M params, rendering res 32, 12+12 samples): outputs + grad wrt ws."""
     sys.path.insert(0, ROOT)
@@ -613,7 +688,7 @@ def sec_bisenet():
          out_mean=out.mean(dim=(2, 3)), out_absmax=out.abs().amax())
 
 
-SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, synthesis=sec_synthesis,
+SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, renderer_options=sec_renderer_options, synthesis=sec_synthesis,
                 geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory, trajectory_sg=sec_trajectory_sg,
                 tv=sec_tv, orbit=sec_orbit, bisenet=sec_bisenet)
 

@@ -148,10 +148,16 @@ def test_stage1_mirror_trajectory_vs_oracle():
     assert w.shape == (1, 14, 512)
 
 
-def test_stage1_hip_graph_replay_equals_eager_steps():
-    """The captured stage-1 step (projectors/common.py: one eager warm-up step, capture, replay) walks the same trajectory as eager
-    steps: same kernels in the same order, the step-dependent scalars (lr, Adam bias corrections, W-noise scale) read from device memory.
-    Draws come from fixed device tensors (a DeviceRNG whose values repeat every step) so both runs see identical randomness."""
+def _full():
+    from spi_amd.training.triplane import TriPlaneGenerator, ffhq512_kwargs
+    G = TriPlaneGenerator(**ffhq512_kwargs(depth_resolution=96, depth_resolution_importance=96)).eval()
+    G.load_state_dict(synth_state_dict(load_manifest('full')))
+    G.neural_rendering_resolution = 128
+    return G.to(DEV).requires_grad_(False)
+
+
+def _stage1_graph_vs_eager(make_G, steps, w_avg_samples=64):
+    """-> {graph: (w_opt, losses per step, noise maps)} for graph in (False, True), identical draws in both runs."""
     from spi_amd.configs import global_config
     from spi_amd.criteria.lpips.lpips import LPIPS
     from spi_amd.training.projectors.common import Projection
@@ -188,21 +194,73 @@ def test_stage1_hip_graph_replay_equals_eager_steps():
         for graph in (False, True):
             global_config.stage1_hip_graph = graph
             cameras, dist_fn = mirror_setup(target, c, lp, torch.device(DEV))
-            proj = Projection(_narrow(), cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=40, w_avg_samples=64, device=torch.device(DEV),
+            proj = Projection(make_G(), cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=500, w_avg_samples=w_avg_samples, device=torch.device(DEV),
                               rng=FixedDraws(DEV))
             for buf in proj.noise_bufs.values():                 # the constructor re-initialised them from the cache: same in both runs
                 assert buf.requires_grad
-            outs = [proj.step(i) for i in range(7)]
+            outs = [proj.step(25 + i) for i in range(steps)]     # (past the 5 % lr ramp-up of a 500-step schedule, like bench.py)
             assert (getattr(proj, '_graph', None) is not None) == graph, 'graph capture did not happen' if graph else 'unexpected graph'
-            assert proj.optimizer.step_count == 7
+            assert proj.optimizer.step_count == steps
             runs[graph] = (proj.w_opt.detach().clone(), [o['loss'].item() for o in outs], [b.detach().clone() for b in proj.noise_bufs.values()])
+            del proj
+            torch.cuda.empty_cache()
     finally:
         global_config.stage1_hip_graph = old
+    return runs
+
+
+def test_stage1_hip_graph_replay_equals_eager_steps():
+    """The captured stage-1 step (projectors/common.py: one eager warm-up step, capture, replay) walks the same trajectory as eager
+    steps: same kernels in the same order, the step-dependent scalars (lr, Adam bias corrections, W-noise scale) read from device memory.
+    Draws come from fixed device tensors (a DeviceRNG whose values repeat every step) so both runs see identical randomness."""
+    runs = _stage1_graph_vs_eager(_narrow, 7)
     for a, b in zip(runs[True][1], runs[False][1]):
         assert abs(a - b) <= 1e-5 * abs(b), (runs[True][1], runs[False][1])
     assert_close(runs[True][0], runs[False][0], 1e-5, 'w+ after 7 steps, graph vs eager')
     for a, b in zip(runs[True][2], runs[False][2]):
         assert_close(a, b, 1e-4, 'noise maps after 7 steps, graph vs eager')
+
+
+@pytest.mark.timeout(1800)
+def test_stage1_hip_graph_replay_equals_eager_steps_full_size():
+    """The path 1/3 of bench.py's timed steps take: the FULL-SIZE mirror-projector step (ffhqrebalanced512-128 widths,
+    512^2, 96+96 samples, N = 2 views from one w+) replayed from its HIP graph -- 1 eager step, the capture step, then 24 back-to-back
+    replays -- against 26 eager steps on identical draws: every step's loss within 1e-5, w+ after the 26 Adam steps within 1e-4
+    (the split-K / scatter atomics sum in a different order from run to run; nothing else differs)."""
+    runs = _stage1_graph_vs_eager(_full, 26, w_avg_samples=64)
+    worst = max(abs(a - b) / abs(b) for a, b in zip(runs[True][1], runs[False][1]))
+    assert worst <= 1e-5, (worst, runs[True][1], runs[False][1])
+    assert_close(runs[True][0], runs[False][0], 1e-4, 'w+ after 26 full-size steps, graph vs eager')
+    for a, b in zip(runs[True][2], runs[False][2]):
+        assert_close(a, b, 1e-3, 'noise maps after 26 full-size steps, graph vs eager')
+
+
+def test_stage1_hip_graph_captures_beside_an_rccl_process_group():
+    """Multi-GPU ranks take the measured code path: with an initialised RCCL process group (watchdog thread
+    running, communicator created by a first collective) the stage-1 step is still captured -- in thread-local capture mode -- and its
+    replays match eager steps.  World size 1 here (the box has one GPU); the 8-GPU run is the driver's."""
+    import os
+    import torch.distributed as td
+    from spi_amd.training.projectors.common import capture_mode
+    assert not td.is_initialized()
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ['MASTER_PORT'] = str(29600 + os.getpid() % 300)
+    td.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        t = torch.ones(8, device=DEV)
+        td.all_reduce(t)                                         # creates the communicator; the watchdog now has work records to poll
+        td.barrier()
+        torch.cuda.synchronize()
+        assert capture_mode() == 'thread_local'
+        runs = _stage1_graph_vs_eager(_narrow, 6)                # asserts inside that the graph run really captured
+        td.all_reduce(t)                                         # collectives still work after the capture
+        torch.cuda.synchronize()
+        assert float(t[0]) == 1.0
+    finally:
+        td.destroy_process_group()
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert abs(a - b) <= 1e-5 * abs(b)
+    assert_close(runs[True][0], runs[False][0], 1e-5, 'w+ graph vs eager beside a process group')
 
 
 @pytest.mark.timeout(2400)

@@ -154,6 +154,48 @@ def test_full_render_golden_fwd_bwd(golden):
         assert_close(gv, g['fr_g_' + k], 5e-5, 'render grad ' + k)
 
 
+@pytest.mark.parametrize('tag', ['auto', 'disparity', 'dnoise', 'tiny', 'tiny_auto_dnoise'])
+def test_render_options_vs_reference_golden(golden, tag):
+    """The ImportanceRenderer surface off the SPI path (VERDICT r02 missing #3): 'auto' ray limits (renderer.py:91-97), disparity-space
+    sampling (:175-182), density noise (:146-147) on the fused kernels, and a decoder callable that is not the OSG MLP (:88,142-148)
+    through sample_from_planes (its own HIP kernels) + the callable + MipRayMarcher2 -- against the REFERENCE's outputs and plane
+    gradients with its recorded draws replayed."""
+    from spi_amd.training.volumetric_rendering.renderer import ImportanceRenderer
+    from render_variants import RENDER_VARIANTS, tiny_decoder
+    g = golden('renderer_options')
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12, **RENDER_VARIANTS[tag])
+
+    class Tiny(torch.nn.Module):
+        def forward(self, sampled_features, ray_directions):
+            rgb, sigma = tiny_decoder(g, sampled_features, ray_directions)
+            return {'rgb': rgb, 'sigma': sigma}
+    dec = Tiny() if tag.startswith('tiny') else _decoder(_P(g))
+    planes = g['planes'].to(DEV).requires_grad_(True)
+    noise = [g[tag + '_xi'], g[tag + '_u']] + ([g[tag + '_eps0'], g[tag + '_eps1']] if 'dnoise' in tag else [])
+    rgb, depth, wsum = ImportanceRenderer()(planes, dec, g['ray_o'].to(DEV), g['ray_d'].to(DEV), opts, noise=noise)
+    assert rgb.shape == g[tag + '_rgb'].shape
+    assert_close(rgb, g[tag + '_rgb'], 2e-5, tag + ' rgb')
+    assert_close(depth, g[tag + '_depth'], 2e-5, tag + ' depth')
+    assert_close(wsum, g[tag + '_wsum'], 2e-5, tag + ' weight sum')
+    gp, = torch.autograd.grad([rgb, depth], [planes], [g[tag + '_drgb'].to(DEV), g[tag + '_ddepth'].to(DEV)])
+    assert_close(gp, g[tag + '_gplanes'], 1e-4, tag + ' grad planes')
+
+
+def test_sample_from_planes_golden_fwd_bwd(golden):
+    """sample_from_planes as its own operator (renderer.py:55-65) against the reference's per-plane features and their plane gradient."""
+    from spi_amd.training.volumetric_rendering.renderer import sample_from_planes, generate_planes
+    g = golden('renderer')
+    planes = g['planes'].to(DEV).requires_grad_(True)
+    feats = sample_from_planes(generate_planes(), planes, g['coords'].to(DEV), padding_mode='zeros', box_warp=1)
+    assert_close(feats, g['gd_feats'], 1e-6, 'sample_from_planes')
+    gen = torch.Generator().manual_seed(3)
+    d = torch.randn(feats.shape, generator=gen)
+    ref_planes = g['planes'].clone().requires_grad_(True)
+    gref, = torch.autograd.grad(orr.sample_planes(ref_planes, g['coords']), ref_planes, d)
+    ggpu, = torch.autograd.grad(feats, planes, d.to(DEV))
+    assert_close(ggpu, gref, 1e-5, 'sample_from_planes plane gradient')
+
+
 @pytest.mark.parametrize('depth', [96, 128])
 def test_full_render_config_size_vs_oracle(depth):
     """BASELINE config 2 (96+96) and config 5 (128+128 = the kernels' 256-sample limit) on a ray subset: 256^2 planes,

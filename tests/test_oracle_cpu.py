@@ -81,6 +81,27 @@ def test_oracle_full_render(golden):
     assert_close(gp, g['fr_gplanes'], 1e-5, 'grad planes')
 
 
+from render_variants import RENDER_VARIANTS, tiny_decoder  # noqa: E402
+
+
+@pytest.mark.parametrize('tag', list(RENDER_VARIANTS))
+def test_oracle_render_options_vs_reference_golden(golden, tag):
+    """ImportanceRenderer's branches off the SPI path -- 'auto' ray limits (renderer.py:91-97), disparity-space sampling (:175-182),
+    density noise (:146-147), a decoder callable that is not the OSG MLP (:142-145) -- against the reference's outputs with its
+    recorded draws replayed (30 % of the 'auto' rays miss the box)."""
+    g = golden('renderer_options')
+    opts = dict(orr.DEFAULT_RENDERING, depth_resolution=12, depth_resolution_importance=12, **RENDER_VARIANTS[tag])
+    planes = g['planes'].requires_grad_(True)
+    eps = (g[tag + '_eps0'], g[tag + '_eps1']) if 'dnoise' in tag else (None, None)
+    fn = (lambda f, d: tiny_decoder(g, f, d)) if tag.startswith('tiny') else None
+    rgb, depth, wsum = orr.render(_P(g), planes, g['ray_o'], g['ray_d'], opts, xi=g[tag + '_xi'], u=g[tag + '_u'], eps=eps, decoder_fn=fn)
+    assert_close(rgb, g[tag + '_rgb'], 1e-6, 'rgb'); assert_close(depth, g[tag + '_depth'], 1e-6, 'depth'); assert_close(wsum, g[tag + '_wsum'], 1e-6, 'wsum')
+    gp, = torch.autograd.grad([rgb, depth], [planes], [g[tag + '_drgb'], g[tag + '_ddepth']])
+    assert_close(gp, g[tag + '_gplanes'], 1e-5, 'grad planes')
+    if tag == 'auto':
+        assert 0.2 < float(g['auto_miss_fraction']) < 0.5
+
+
 def test_oracle_synthesis_narrow(golden):
     g = golden('synthesis_narrow')
     P = synth_state_dict(load_manifest('narrow'))

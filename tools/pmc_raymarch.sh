@@ -1,5 +1,7 @@
 #!/bin/bash
-# separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only
+# usage: tools/pmc_raymarch.sh <tag>  -- separate --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), kernel-trace only;
+# writes gpurun_out/pmc/raymarch_pmc.json (copy to profiles/raymarch_pmc.json: bench.py's roofline.traffic reads it)
+tag=${1:-untagged}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/pmc
@@ -9,4 +11,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   f=$(find /tmp/pmc_$c -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then grep -E "raymarch|Counter_Name|Kernel_Name" "$f" | head -30 > gpurun_out/pmc/${c}_raymarch.csv; fi
 done
-head -3 gpurun_out/pmc/FETCH_SIZE_raymarch.csv | cut -c1-400
+python tools/pmc_raymarch_json.py gpurun_out/pmc/FETCH_SIZE_raymarch.csv gpurun_out/pmc/WRITE_SIZE_raymarch.csv "$tag" > gpurun_out/pmc/raymarch_pmc.json
+cat gpurun_out/pmc/raymarch_pmc.json
