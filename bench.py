@@ -459,7 +459,7 @@ def main():
                        'NOT the benchmark value'}
         marks.clear(); marks.update(main_marks)
         global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
-    dense = None
+    dense_leg = None
     if not args.dense and not args.no_dense_leg and ok and k2 and not os.environ.get('SPI_TORCH_PROFILE'):
         # the dense bound of the same step: the stage-2 iterations once more with the data-driven skipping of exactly-zero gradients /
         # unneeded SR tiles switched off (stage 1 has no masked branch: its rate is the main run's).  Reported beside `value`, never as it.
@@ -476,7 +476,7 @@ def main():
         torch.cuda.synchronize(); sdist.barrier()
         d_s = sdist.reduce_stats([marks.get('stage2_s', 0.0)], device=dev, op='max')[0]
         bad = sdist.reduce_stats([0.0 if dense_err is None else 1.0], device=dev)[0]
-        dense = {'error': dense_err or 'failed on another rank'} if bad else {
+        dense_leg = {'error': dense_err or 'failed on another rank'} if bad else {
             'value': mix_value(main_stage_s[0], d_s), 'unit': 'iters/s', 'stage2_rotbbox_iters_per_s_per_gpu': k2 / d_s,
             'stage1_mir_iters_per_s_per_gpu': (k1 / main_stage_s[0]) if k1 else None,
             'note': 'dense bound: every ray, gradient segment and SR tile of the masked rot / mirror-rot branches processed (global_config.exploit_sparsity '
@@ -581,8 +581,8 @@ def main():
         out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16), global_config.conv_precision)
         if alt is not None:
             out['alt'] = alt
-        if dense is not None:
-            out['dense'] = dense
+        if dense_leg is not None:
+            out['dense'] = dense_leg
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, 1 if k1 else 0, 2 if k2 else 0)

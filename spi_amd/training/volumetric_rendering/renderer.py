@@ -176,7 +176,12 @@ class _Render(torch.autograd.Function):
             hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), r, sc, sf, hip.ptr(d_f), 1, hip.stream())
             _decode_fwd(planes_nhwc, dec, rays=(ray_o, ray_d), depths=d_f, box_warp=box_warp, out=(rgb_all, sig_all), out_S=s, out_off=sc)
             if dnoise > 0:
-                e = torch.randn(n, m, sf, device=dev) if eps_f is None else eps_f.to(dev).reshape(n, m, sf).float()
+                if eps_f is None:
+                    e = torch.randn(n, m, sf, device=dev)
+                else:       # an injected draw is indexed like the reference's UNSORTED fine samples (draw order); ours are emitted ascending:
+                    raw = torch.empty_like(d_f)                  # the same samples in draw order -> the kernel's stable rank order
+                    hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), r, sc, sf, hip.ptr(raw), 0, hip.stream())
+                    e = torch.gather(eps_f.to(dev).reshape(n, m, sf).float(), -1, torch.argsort(raw, dim=-1, stable=True))
                 sig_all[:, :, sc:] += e * dnoise
             if general:
                 # per-ray limits: the coarse run of a ray that misses the box may be descending (reference behaviour, renderer.py:95-97),
@@ -402,9 +407,10 @@ class ImportanceRenderer(torch.nn.Module):
         d = torch.linspace(ray_start, ray_end, s, device=dev).reshape(1, 1, s, 1).repeat(n, m, 1, 1)
         return d + (torch.rand_like(d) if xi is None else xi.to(dev).reshape(n, m, s, 1)) * ((ray_end - ray_start) / (s - 1))
 
-    def sample_importance(self, z_vals, weights, N_importance, u=None):
+    def sample_importance(self, z_vals, weights, N_importance, u=None, return_order=False):
         """renderer.py:194-215 on the HIP kernel: [N,M,S,1] depths + [N,M,S-1,1] weights -> [N,M,N_importance,1] fine depths (no grad;
-        emitted ascending per ray -- the same multiset as the reference's unsorted draws).  u: the torch.rand [N*M, N_importance] draw."""
+        emitted ascending per ray -- the same multiset as the reference's unsorted draws).  u: the torch.rand [N*M, N_importance] draw.
+        return_order: also the index [N,M,N_importance] of each emitted sample in the reference's draw order."""
         with torch.no_grad():
             n, m, s, _ = z_vals.shape
             dev = z_vals.device
@@ -413,6 +419,10 @@ class ImportanceRenderer(torch.nn.Module):
             u = (torch.rand(n * m, N_importance, device=dev) if u is None else u.to(dev)).reshape(n, m, N_importance).contiguous().float()
             d_f = torch.empty(n, m, N_importance, device=dev, dtype=torch.float32)
             hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), n * m, s, N_importance, hip.ptr(d_f), 1, hip.stream())
+            if return_order:
+                raw = torch.empty_like(d_f)
+                hip.call('spi_importance_sample', hip.ptr(d_c), hip.ptr(w_c), hip.ptr(u), n * m, s, N_importance, hip.ptr(raw), 0, hip.stream())
+                return d_f.unsqueeze(-1), torch.argsort(raw, dim=-1, stable=True)
         return d_f.unsqueeze(-1)
 
     def unify_samples(self, depths1, colors1, densities1, depths2, colors2, densities2):
@@ -489,10 +499,13 @@ class ImportanceRenderer(torch.nn.Module):
         sf = int(opts['depth_resolution_importance'])
         if sf > 0:
             _, _, weights = self.ray_marcher(colors_coarse, dens_coarse, depths_coarse, opts)
-            depths_fine = self.sample_importance(depths_coarse, weights, sf, u=u)
+            depths_fine, order = self.sample_importance(depths_coarse, weights, sf, u=u, return_order=True)
             dirs = ray_directions.unsqueeze(-2).expand(-1, -1, sf, -1).reshape(n, -1, 3)
             coords = (ray_origins.unsqueeze(-2) + depths_fine * ray_directions.unsqueeze(-2)).reshape(n, -1, 3)
-            out = self.run_model(planes, decoder, coords, dirs, opts, _eps=eps[1])
+            e1 = eps[1]
+            if e1 is not None:                                   # injected draw: indexed like the reference's unsorted fine samples (see _Render.forward)
+                e1 = torch.gather(e1.to(planes.device).reshape(n, m, sf), -1, order)
+            out = self.run_model(planes, decoder, coords, dirs, opts, _eps=e1)
             colors_fine = out['rgb'].reshape(n, m, sf, out['rgb'].shape[-1])
             dens_fine = out['sigma'].reshape(n, m, sf, 1)
             all_d, all_c, all_s = self.unify_samples(depths_coarse, colors_coarse, dens_coarse, depths_fine, colors_fine, dens_fine)

@@ -156,7 +156,7 @@ def _full():
     return G.to(DEV).requires_grad_(False)
 
 
-def _stage1_graph_vs_eager(make_G, steps, w_avg_samples=64):
+def _stage1_graph_vs_eager(make_G, steps, w_avg_samples=64, num_steps=40, first_step=0):
     """-> {graph: (w_opt, losses per step, noise maps)} for graph in (False, True), identical draws in both runs."""
     from spi_amd.configs import global_config
     from spi_amd.criteria.lpips.lpips import LPIPS
@@ -194,11 +194,11 @@ def _stage1_graph_vs_eager(make_G, steps, w_avg_samples=64):
         for graph in (False, True):
             global_config.stage1_hip_graph = graph
             cameras, dist_fn = mirror_setup(target, c, lp, torch.device(DEV))
-            proj = Projection(make_G(), cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=500, w_avg_samples=w_avg_samples, device=torch.device(DEV),
+            proj = Projection(make_G(), cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=num_steps, w_avg_samples=w_avg_samples, device=torch.device(DEV),
                               rng=FixedDraws(DEV))
             for buf in proj.noise_bufs.values():                 # the constructor re-initialised them from the cache: same in both runs
                 assert buf.requires_grad
-            outs = [proj.step(25 + i) for i in range(steps)]     # (past the 5 % lr ramp-up of a 500-step schedule, like bench.py)
+            outs = [proj.step(first_step + i) for i in range(steps)]
             assert (getattr(proj, '_graph', None) is not None) == graph, 'graph capture did not happen' if graph else 'unexpected graph'
             assert proj.optimizer.step_count == steps
             runs[graph] = (proj.w_opt.detach().clone(), [o['loss'].item() for o in outs], [b.detach().clone() for b in proj.noise_bufs.values()])
@@ -227,7 +227,7 @@ def test_stage1_hip_graph_replay_equals_eager_steps_full_size():
     512^2, 96+96 samples, N = 2 views from one w+) replayed from its HIP graph -- 1 eager step, the capture step, then 24 back-to-back
     replays -- against 26 eager steps on identical draws: every step's loss within 1e-5, w+ after the 26 Adam steps within 1e-4
     (the split-K / scatter atomics sum in a different order from run to run; nothing else differs)."""
-    runs = _stage1_graph_vs_eager(_full, 26, w_avg_samples=64)
+    runs = _stage1_graph_vs_eager(_full, 26, w_avg_samples=64, num_steps=500, first_step=25)   # past the 5 % lr ramp-up, like bench.py
     worst = max(abs(a - b) / abs(b) for a, b in zip(runs[True][1], runs[False][1]))
     assert worst <= 1e-5, (worst, runs[True][1], runs[False][1])
     assert_close(runs[True][0], runs[False][0], 1e-4, 'w+ after 26 full-size steps, graph vs eager')
