@@ -102,9 +102,9 @@ int spi_triplane_decode_bwd(const float* planes_nhwc, const float* coords, const
  * dw1 == NULL (all four) = decoder frozen.  d_rgb == NULL = the colour gradient is zero (depth-only loss): the colour
  * layer is skipped.  d_rgb_scale == NULL: d_rgb is the per-sample gradient [N*M*S,32] (row mapping as above).  d_rgb_scale
  * != NULL (what spi_raymarch_bwd's d_color_scale output is for): d_rgb is PER RAY [N*M,32] and the gradient of sample row i
- * of ray r is d_rgb[r,:] * d_rgb_scale[i] -- the [N*M*S,32] tensor never exists.  colors (optional): the forward's colour rows
- * [N*M*S,32] as spi_triplane_decode_fwd wrote them; the colour layer's sigmoid is then read back ((c + 0.001) / 1.002) instead of
- * recomputed (a quarter of the kernel's MFMAs).  ray_active (optional, int32 [N*M] from
+ * of ray r is d_rgb[r,:] * d_rgb_scale[i] -- the [N*M*S,32] tensor never exists.  colors (required with d_rgb): the forward's colour rows
+ * [N*M*S,32] as spi_triplane_decode_fwd wrote them; the colour layer's sigmoid is read back ((c + 0.001) / 1.002) instead of
+ * recomputed.  ray_active (optional, int32 [N*M] from
  * spi_raymarch_bwd): rays flagged 0 are dropped before the tiles are formed.  `workspace` must hold spi_triplane_decode_bwd_sorted_ws(...) floats
  * (weight fragments + per-wave partial sums; contents undefined afterwards).  d_planes_nhwc is accumulated into. */
 int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o, const float* ray_d,

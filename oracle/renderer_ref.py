@@ -237,7 +237,7 @@ def synthesis(P, ws, c, opts, neural_rendering_resolution=128, noise_mode='const
     feat_img = feat.permute(0, 2, 1).reshape(n, feat.shape[-1], r, r).contiguous()
     depth_img = depth.permute(0, 2, 1).reshape(n, 1, r, r)
     rgb = feat_img[:, :3]
-    out = {'image_raw': rgb, 'image_depth': depth_img, 'planes': planes}
+    out = {'image_raw': rgb, 'image_depth': depth_img, 'planes': planes, 'feature_image': feat_img}
     if not skip_sr:
         out['image'] = sg.superresolution_8xdc(P, rgb, feat_img, ws,
                                                noise_mode=opts.get('superresolution_noise_mode', 'none'),

@@ -450,11 +450,12 @@ constexpr int WIN = 16;                       // window edge in texels; WIN*WIN*
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
 // weight fragments, one 64-lane row per MFMA k-step (built by decoder_frag_kernel for every call)
-constexpr int FRAG_A1 = 0;                          // [2][16][64]  W1[mt*32+q][2s+h]                      (A of H1, B of H2)
-constexpr int FRAG_A2 = FRAG_A1 + 2 * 16 * 64;      // [32][64]     W2[1+q][mt'*32+rowmap(r',h)]            (A of Y1, B of Y2)
-constexpr int FRAG_A3 = FRAG_A2 + 32 * 64;          // [2][17][64]  W2[1+rowmap(r',h)][mt*32+q]; step 16: sigma row in half 0   (A of dH1, B of dH2)
+constexpr int FRAG_A1 = 0;                          // [2][16][64]  W1[mt*32+q][2s+h]                      (A of H1)
+constexpr int FRAG_A3 = FRAG_A1 + 2 * 16 * 64;      // [2][17][64]  W2[1+rowmap(r',h)][mt*32+q]; step 16: sigma row in half 0   (A of dH1)
 constexpr int FRAG_A4 = FRAG_A3 + 2 * 17 * 64;      // [32][64]     W1[mt'*32+rowmap(r',h)][q]              (A of dF)
-constexpr int FRAG_TOTAL = FRAG_A4 + 32 * 64;       // 8320 floats
+constexpr int FRAG_TOTAL = FRAG_A4 + 32 * 64;       // 6272 floats
+constexpr int TSTRIDE = 34;                         // row stride (floats) of a wave's 32 x 32 transposition tile: 8-byte aligned rows, conflict-free
+constexpr int TTILE = 32 * TSTRIDE;                 //   ds_write_b32 columns / ds_read_b64 rows
 constexpr int PART_ROW = 4352;                      // scratch row per wave: dW1 2048 | dW2 2112 | db1 64 | db2 33 | pad
 constexpr int PART_DW2 = 2048, PART_DB1 = 4160, PART_DB2 = 4224;
 constexpr int BWD_MAX_GRID = 512;
@@ -465,12 +466,9 @@ __global__ void decoder_frag_kernel(const float* __restrict__ w1t, const float* 
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < FRAG_TOTAL; idx += gridDim.x * blockDim.x) {
         const int lane = idx & 63, q = lane & 31, h = lane >> 5;
         float v;
-        if (idx < FRAG_A2) {
+        if (idx < FRAG_A3) {
             const int st = idx >> 6, mt = st >> 4, s2 = st & 15;
             v = w1t[(2 * s2 + h) * DEC_HID + mt * 32 + q];                               // W1[j][i] = w1t[i][j]
-        } else if (idx < FRAG_A3) {
-            const int st = (idx - FRAG_A2) >> 6, mt = st >> 4, r = st & 15;
-            v = w2[(1 + q) * DEC_HID + mt * 32 + rowmap(r, h)];
         } else if (idx < FRAG_A4) {
             const int st = (idx - FRAG_A3) >> 6, mt = st / 17, r = st - mt * 17;
             v = r < 16 ? w2[(1 + rowmap(r, h)) * DEC_HID + mt * 32 + q] : (h == 0 ? w2[mt * 32 + q] : 0.f);
@@ -611,20 +609,29 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                                                                  const float* __restrict__ d_rgb_scale, const float* __restrict__ colors,
                                                                  const float* __restrict__ d_sigma, float* __restrict__ d_planes,
                                                                  float* __restrict__ part) {
-    // colors != NULL: the forward's colour rows [R*S, 32] (= sigmoid(y) * 1.002 - 0.001).  The sigmoid the colour layer's derivative needs is
-    // read back from them instead of recomputing the layer's pre-activations: 32 of the 130 MFMAs per 32 points disappear (64 of 292 with
-    // weight gradients) for one 128-byte row per point.
+    // colors: the forward's colour rows [R*S, 32] (= sigmoid(y) * 1.002 - 0.001), required with d_rgb.  The sigmoid the colour layer's
+    // derivative needs is read back from them instead of recomputing the layer's pre-activations (32 MFMAs per 32 points) for one
+    // 128-byte row per point.
     // d_rgb_scale == NULL: d_rgb is the materialised per-sample gradient [R*S, 32].  Otherwise the gradient of sample row i of
     // ray r is d_rgb[r][:] * d_rgb_scale[i] (what the ray marcher's backward produces: a per-ray vector times a per-sample
     // scalar); the 2 MB per-ray array stays in L2 and the 128 B per point of gradient traffic disappears.
-    __shared__ __attribute__((aligned(16))) float feat[DT * FS];   // rows [point][36]: features 0..31 | d_sigma at col 32; phase B overwrites 0..31 with d_feat
-    __shared__ __attribute__((aligned(16))) float gbuf[DT * FS];   // phase B: the weight fragments (8320 floats); phase C: the scatter window
-    __shared__ float s_x[DT], s_y[DT], s_z[DT];
-    __shared__ int s_row[DT];                 // row index into the [R*S] sample arrays (-1 = padding point)
-    static_assert(FRAG_TOTAL <= DT * FS, "fragments must fit the second row buffer");
-    __shared__ int s_cxy[DT];                 // per plane: window-relative corner (x0 - wx0) | (y0 - wy0) << 16, biased by +0x4000
-    __shared__ float s_wx[DT], s_wy[DT];      // per plane: bilinear fractions
-    __shared__ int s_acc[8];
+    //
+    // LDS map (floats; one array so that the regions phase B borrows are contiguous):
+    //   feat  [DT][FS]   rows [point][36]: features 0..31 | d_sigma 32 | ray 33 | colour-gradient scale 34; phase B overwrites 0..31 with d_feat
+    //   gbuf  [DT][FS]   phase B: weight fragments (FRAG_TOTAL = 6272) then, WGRAD, the waves' transposition tiles; phase C: the scatter window
+    //   small 6 x [DT]   s_x s_y s_z (phase A: coordinates; phase C: s_x = fast-path base) | s_cxy s_wx s_wy (phase C) -- free in phase B: the
+    //                    transposition tiles run on from gbuf's tail into them (4 x 1088 floats from offset FRAG_TOTAL of gbuf)
+    //   s_row [DT], s_acc [8]
+    constexpr int LDS_GBUF = DT * FS, LDS_SMALL = 2 * DT * FS, LDS_ROW = LDS_SMALL + 6 * DT, LDS_ACC = LDS_ROW + DT;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_ACC + 8];
+    float* const feat = lds;
+    float* const gbuf = lds + LDS_GBUF;
+    float* const s_x = lds + LDS_SMALL; float* const s_y = s_x + DT; float* const s_z = s_y + DT;
+    int* const s_cxy = reinterpret_cast<int*>(s_z + DT);      // per plane: window-relative corner (x0 - wx0) | (y0 - wy0) << 16, biased by +0x4000
+    float* const s_wx = s_z + 2 * DT; float* const s_wy = s_wx + DT;      // per plane: bilinear fractions
+    int* const s_row = reinterpret_cast<int*>(lds + LDS_ROW);  // row index into the [R*S] sample arrays (-1 = padding point)
+    int* const s_acc = reinterpret_cast<int*>(lds + LDS_ACC);
+    static_assert(FRAG_TOTAL + 4 * TTILE <= DT * FS + 6 * DT, "fragments + transposition tiles must fit gbuf and the small arrays");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, q = lane & 31, hh = lane >> 5;
     const int64_t plane_sz = (int64_t)a.H * a.W * DEC_IN;
@@ -738,58 +745,84 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) H1[mt][r] = softplus_fast(H1[mt][r]);
-        // Y1[o][p] (orientation 1) and, for the weight gradients, Y2[p][o] (orientation 2) from the same fragments
-        f32x16_t Y1, Y2;
-        float dr2[16];                                         // orientation 2: d_rgb[point rowmap(r,h)][channel q_], coalesced over q_
-        // RGB == false: only the density gradient is non-zero (SPI's depth branch) -> the whole colour layer drops out
-        if (WGRAD && RGB) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p2 = pbase + rowmap(r, hh_);
-                const int prow2 = s_row[p2];
-                const int64_t grow2 = d_rgb_scale ? (int64_t)__float_as_int(feat[p2 * FS + 33]) : (int64_t)max(prow2, 0);
-                const float v = d_rgb[grow2 * DEC_IN + q_] * (d_rgb_scale ? feat[p2 * FS + 34] : 1.f);
-                dr2[r] = prow2 >= 0 ? v : 0.f;
-            }
-        }
-        if (RGB && colors) {
-            // sigmoid from the saved colour rows: (c + 0.001) / 1.002, in both orientations (the same addressing as the gradient rows)
+        // dY1[o][p] (orientation 1: lane <-> point) = d_rgb * d(sigmoid * 1.002 - 0.001), the sigmoid read back from the saved colour rows:
+        // (c + 0.001) / 1.002.  RGB == false: only the density gradient is non-zero (SPI's depth branch) -> the whole colour layer drops out.
+        f32x16_t Y1;
+        if (RGB) {
             const float4* crp = reinterpret_cast<const float4*>(colors + (int64_t)max(myrow, 0) * DEC_IN + 4 * hh_);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const float4 c4 = crp[2 * g];
                 Y1[4 * g] = c4.x; Y1[4 * g + 1] = c4.y; Y1[4 * g + 2] = c4.z; Y1[4 * g + 3] = c4.w;
             }
-            if (WGRAD) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Y2[r] = colors[(int64_t)max(s_row[pbase + rowmap(r, hh_)], 0) * DEC_IN + q_];
-            }
-        } else if (RGB) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { Y1[r] = b2[1 + rowmap(r, hh_)]; Y2[r] = b2[1 + q_]; }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float wf = frag[FRAG_A2 + (mt * 16 + r) * 64 + lane_];
-                Y1 = SPI_MFMA(wf, H1[mt][r], Y1);
-                if (WGRAD) Y2 = SPI_MFMA(H1[mt][r], wf, Y2);
+                const float sg = (Y1[r] + 0.001f) * (1.f / 1.002f);
+                const float4 d4 = dr[r >> 2];
+                const float dv1 = (r & 3) == 0 ? d4.x : ((r & 3) == 1 ? d4.y : ((r & 3) == 2 ? d4.z : d4.w));      // channel rowmap(r,hh_) = (r&3) + 8(r>>2) + 4hh
+                Y1[r] = dv1 * 1.002f * sg * (1.f - sg);
             }
         }
-        // dY = d_rgb * d(sigmoid * 1.002 - 0.001)
-        const bool saved = colors != nullptr;
+        // ---- weight gradients, part 1: dW2[o][j] += sum_p dY[o][p] H1[j][p] (contraction over the tile's 32 points).
+        // The MFMA wants the contracted index on the K axis, i.e. both operands with the FEATURE in the lane position ("orientation 2"),
+        // while H1 sits in accumulator layout (lane <-> point).  Round 2 recomputed the activations in orientation 2 (H2 = F W1^T,
+        // dH2 = dY W2: 66 extra MFMAs per 32 points = 4 224 matrix-pipe cycles); now each 32 x 32 tile is transposed through a 4.25 KB
+        // LDS tile of the wave's own (16 ds_write_b32 + 8 ds_read_b64, ~10^2 cycles).  dY in orientation 2 comes straight from the
+        // global gradient / colour rows (32 lanes read one 128-byte row).
+        float* const tsc = gbuf + FRAG_TOTAL + wave * TTILE;       // this wave's transposition tile [32][TSTRIDE]
+        auto transpose = [&](const f32x16_t& v, f32x16_t& out) {
+            // in : lane (p = q_, hh_) holds v[r]   = X[rowmap(r, hh_)][p]
+            // out: lane (j = q_, hh_) holds out[r] = X[j][rowmap(r, hh_)]     (rowmap(r,h) = (r&3) + 8(r>>2) + 4h: r, r+1 are adjacent columns)
 #pragma unroll
-        for (int r = 0; RGB && r < 16; ++r) {
-            const float sg = saved ? (Y1[r] + 0.001f) * (1.f / 1.002f) : sigmoid_fast(Y1[r]);
-            const float4 d4 = dr[r >> 2];
-            const float dv1 = (r & 3) == 0 ? d4.x : ((r & 3) == 1 ? d4.y : ((r & 3) == 2 ? d4.z : d4.w));      // channel rowmap(r,hh_) = (r&3) + 8(r>>2) + 4hh
-            Y1[r] = dv1 * 1.002f * sg * (1.f - sg);
-            if (WGRAD) {
-                const float sg2 = saved ? (Y2[r] + 0.001f) * (1.f / 1.002f) : sigmoid_fast(Y2[r]);
-                Y2[r] = dr2[r] * 1.002f * sg2 * (1.f - sg2);
+            for (int r = 0; r < 16; ++r) tsc[rowmap(r, hh_) * TSTRIDE + q_] = v[r];
+            asm volatile("" ::: "memory");                     // one wave's LDS operations execute in order: no wait needed, only no reordering
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float2 t2 = *reinterpret_cast<const float2*>(tsc + q_ * TSTRIDE + 8 * (g >> 1) + 4 * hh_ + 2 * (g & 1));
+                out[2 * g] = t2.x; out[2 * g + 1] = t2.y;
+            }
+            asm volatile("" ::: "memory");
+        };
+        if (WGRAD) {
+            f32x16_t Y2;                                           // orientation 2: dY[1 + q_][point rowmap(r, hh_)]
+            if (RGB) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int p2 = pbase + rowmap(r, hh_);
+                    const int prow2 = s_row[p2];
+                    const int64_t grow2 = d_rgb_scale ? (int64_t)__float_as_int(feat[p2 * FS + 33]) : (int64_t)max(prow2, 0);
+                    const float dv = d_rgb[grow2 * DEC_IN + q_] * (d_rgb_scale ? feat[p2 * FS + 34] : 1.f);
+                    const float sg2 = (colors[(int64_t)max(prow2, 0) * DEC_IN + q_] + 0.001f) * (1.f / 1.002f);
+                    Y2[r] = prow2 >= 0 ? dv * 1.002f * sg2 * (1.f - sg2) : 0.f;
+                    s_b2 += Y2[r];
+                }
+            }
+            s_d += dsq;
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                f32x16_t HT, aW2;
+                // running sum of this wave's dW2 tile: one base pointer per tile + compile-time offsets (global_load ... offset:imm)
+                float* const pw2 = pr + PART_DW2 + (1 + 4 * hh_) * DEC_HID + i * 32 + q_;              // dW2[o][j]: o = 1 + rowmap(r,h), j = i*32 + q_
+                float* const pw2b = pw2 + 16 * DEC_HID;                                               // rows 16.. (keeps every offset < 4 KB)
+                if (RGB) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) aW2[r] = r < 8 ? pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] : pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID];
+                }
+                transpose(H1[i], HT);                              // HT[r] = H1[i*32 + q_][point rowmap(r, hh_)]
+                float ls = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (RGB) aW2 = SPI_MFMA(Y2[r], HT[r], aW2);
+                    ls = fmaf(feat[(pbase + rowmap(r, hh_)) * FS + 32], HT[r], ls);       // sigma row of dW2
+                }
+                if (RGB) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { if (r < 8) pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] = aW2[r]; else pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID] = aW2[r]; }
+                }
+                s_sig[0] += i == 0 ? ls : 0.f; s_sig[1] += i == 0 ? 0.f : ls;
             }
         }
-        // dH1[j][p] = W2^T dY1 (+ sigma row) -> dpre1 -> dF[i][p] = W1^T dpre1
+        // dH1[j][p] = W2^T dY1 (+ sigma row) -> dpre1 = dH1 * softplus'(pre1)
         f32x16_t dH1[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -805,6 +838,27 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dH1[mt][r] *= (H1[mt][r] > 20.f) ? 1.f : (1.f - exp_fast(-H1[mt][r]));
+        // ---- weight gradients, part 2: dW1[j][c] += sum_p dpre1[j][p] F[c][p]; the B operand is read from the feature rows (still F)
+        if (WGRAD) {
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                f32x16_t DT_, aW1;
+                float* const pw1 = pr + (i * 32 + 4 * hh_) * DEC_IN + q_;                             // dW1[j][c]: j = i*32 + rowmap(r,h), c = q_
+#pragma unroll
+                for (int r = 0; r < 16; ++r) aW1[r] = pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN];
+                transpose(dH1[i], DT_);                            // DT_[r] = dpre1[i*32 + q_][point rowmap(r, hh_)]
+                float lb = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    aW1 = SPI_MFMA(DT_[r], feat[(pbase + rowmap(r, hh_)) * FS + q_], aW1);
+                    lb += DT_[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN] = aW1[r];
+                s_b1[0] += i == 0 ? lb : 0.f; s_b1[1] += i == 0 ? 0.f : lb;
+            }
+        }
+        // dF[i][p] = W1^T dpre1
         f32x16_t dF;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dF[r] = 0.f;
@@ -814,63 +868,7 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
             for (int r = 0; r < 16; ++r) {
                 dF = SPI_MFMA(frag[FRAG_A4 + (mt * 16 + r) * 64 + lane_], dH1[mt][r], dF);
             }
-        __builtin_amdgcn_sched_barrier(0);
-        if (WGRAD) {
-            // per j-half i: dH2[p][j] = dY W2 (+ sigma row), H2[p][j] = softplus(F W1^T + b1), dpre2 = dH2 * softplus'
-            // then dW2[:, j-half] += dY2^T H2 and dW1[j-half, :] += dpre2^T F (contraction over the tile's 32 points)
-#pragma unroll 1
-            for (int i = 0; i < 2; ++i) {
-                f32x16_t dH2, H2, aW1, aW2;
-                float ls = 0.f, lb = 0.f;
-                // running sums of this wave's dW tiles: arrive while dH2 / H2 are computed.  One base pointer per tile + compile-time
-                // offsets (global_load ... offset:imm): with per-element 64-bit addresses the 32 address pairs stay live from the
-                // loads to the stores and cost 64 VGPRs.
-                float* const pw1 = pr + (i * 32 + 4 * hh_) * DEC_IN + q_;                             // dW1[j][c]: j = i*32 + rowmap(r,h), c = q_
-                float* const pw2 = pr + PART_DW2 + (1 + 4 * hh_) * DEC_HID + i * 32 + q_;              // dW2[o][j]: o = 1 + rowmap(r,h), j = i*32 + q_
-                float* const pw2b = pw2 + 16 * DEC_HID;                                               // rows 16.. (keeps every offset < 4 KB)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    aW1[r] = pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN];
-                    if (RGB) aW2[r] = r < 8 ? pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] : pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { dH2[r] = 0.f; H2[r] = b1[i * 32 + q_]; }
-#pragma unroll
-                for (int r = RGB ? 0 : 16; r < 17; ++r) {
-                    const float av = r < 16 ? Y1[r & 15] : dsq;
-                    dH2 = SPI_MFMA(av, frag[FRAG_A3 + (i * 17 + r) * 64 + lane_], dH2);
-                }
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    H2 = SPI_MFMA(frow[2 * s + hh_], frag[FRAG_A1 + (i * 16 + s) * 64 + lane_], H2);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float hv = softplus_fast(H2[r]);
-                    H2[r] = hv;
-                    dH2[r] *= (hv > 20.f) ? 1.f : (1.f - exp_fast(-hv));               // -> dpre2
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int prow = (pbase + rowmap(r, hh_)) * FS;
-                    if (RGB) aW2 = SPI_MFMA(Y2[r], H2[r], aW2);
-                    aW1 = SPI_MFMA(dH2[r], feat[prow + q_], aW1);
-                    ls = fmaf(feat[prow + 32], H2[r], ls);
-                    lb += dH2[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN] = aW1[r];
-                    if (RGB) { if (r < 8) pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] = aW2[r]; else pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID] = aW2[r]; }
-                }
-                s_sig[0] += i == 0 ? ls : 0.f; s_sig[1] += i == 0 ? 0.f : ls;
-                s_b1[0] += i == 0 ? lb : 0.f; s_b1[1] += i == 0 ? 0.f : lb;
-            }
-#pragma unroll
-            for (int r = 0; RGB && r < 16; ++r) s_b2 += Y2[r];
-            s_d += dsq;
-        }
-        // this tile's feature rows are dead now (both orientations are done with them): d_feat takes their place
+        // this tile's feature rows are dead now (the weight gradients are done with them): d_feat takes their place
 #pragma unroll
         for (int r = 0; r < 16; ++r) frow[rowmap(r, hh_)] = dF[r] / 3.f;           // the plane mean contributes the 1/3
     }
@@ -1686,6 +1684,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     const bool wgrad = dw1 != nullptr;
     SPI_REQUIRE(!wgrad || (db1 && dw2 && db2), "spi_triplane_decode_bwd_sorted: the four decoder gradient outputs come together");
     SPI_REQUIRE(d_rgb || !d_rgb_scale, "spi_triplane_decode_bwd_sorted: d_rgb_scale given without the per-ray d_rgb");
+    SPI_REQUIRE(!d_rgb || colors, "spi_triplane_decode_bwd_sorted: d_rgb needs the forward's colour rows (colors)");
     TiledArgs a;
     a.planes = planes_nhwc; a.ray_o = ray_o; a.ray_d = ray_d; a.depths = depths_sorted; a.perm = perm; a.ray_active = ray_active;
     a.N = N; a.M = M; a.S = S; a.H = H; a.W = W; a.scale = 2.f / box_warp; a.ray_w = ray_w;

@@ -197,8 +197,8 @@ def test_fp16_sr_full_size_128_vs_fp16_rounding_oracle():
     """BASELINE configs[4] at full size with its arithmetic: 128 + 128 samples and fp16-MFMA super-resolution
     (`--sr_fp16`: fp32 tensors, both conv operands of every SR layer rounded to fp16 on their way into v_mfma_f32_32x32x8_f16, fp32
     accumulation) against an oracle super-resolution network that rounds the SAME operands (oracle/stylegan_ref.modulated_conv2d
-    `fp16_operands`; superresolution.py:264-290) -- image within 1e-3, and distinguishable from the fp32 image (the test would
-    otherwise pass with the flag ignored).  Then one PLAIN stage-2 iteration (i = 1: L2 + LPIPS, rot_bbox_cx_coach.py:68-85) in that
+    `fp16_operands`; superresolution.py:264-290): every SR layer on the oracle's own fp16-path input within 1e-4, the whole image
+    statistically (see the comment below: fp16 rounding decorrelates two implementations after a few layers).  Then one PLAIN stage-2 iteration (i = 1: L2 + LPIPS, rot_bbox_cx_coach.py:68-85) in that
     arithmetic: both loss values within 1e-2 of the oracle's iteration with the same draws."""
     from oracle import losses_ref as olo, loops_ref as olp
     from spi_amd.configs import global_config, hyperparameters, paths_config
@@ -229,13 +229,35 @@ def test_fp16_sr_full_size_128_vs_fp16_rounding_oracle():
     print('fp16-SR full size, rms-relative  :', {k: f'{v:.2e}' for k, v in erms.items()})
     assert_close(out16['image_raw'], ref16['image_raw'], 1e-3, 'fp16-SR run: image_raw (fp32 path)')
     assert_close(out16['image_depth'], ref16['image_depth'], 1e-3, 'fp16-SR run: depth (fp32 path)')
-    # Rounding to fp16 is discontinuous: where the fp32 inputs of a layer differ by 1e-6 between the two implementations, a share of the
-    # operands rounds to the NEIGHBOURING fp16 value (2^-11 relative), and through the six SR layers those flips decorrelate the two
-    # fp16 computations pixel by pixel.  The bar that is meaningful for "same arithmetic" is therefore statistical: the HIP fp16 image
-    # must sit several times closer to the fp16-rounding oracle than any fp32 image does (rms), and within 1e-3 rms-relative / 3e-3 max.
-    assert erms['hip16_vs_oracle16'] <= 1e-3, erms
-    assert emax['hip16_vs_oracle16'] <= 3e-3, emax
-    assert erms['hip16_vs_oracle16'] * 2 <= min(erms['hip32_vs_oracle16'], erms['oracle32_vs_oracle16']), erms
+    # Rounding to fp16 is discontinuous: where the fp32 inputs of a layer differ by 1e-6 between two implementations, ~0.1 % of the operands
+    # round to the NEIGHBOURING fp16 value (2^-10 relative, 3.5 rounding sigmas), the next layer's inputs then differ by 1e-4 and flip
+    # another 10 %: after two or three of the six SR layers two fp16 computations are decorrelated pixel by pixel however equal their
+    # arithmetic is (observed: rms 9e-4 between the HIP image and the oracle's, 1.5e-3 between either and the fp32 image -- correlation
+    # 0.83; two unrelated roundings would give 2.2e-3).  Hence two checks: (1) end to end, statistical: the HIP fp16 image sits clearly
+    # closer to the fp16-rounding oracle than the fp32 images do; (2) layer by layer, exact: every SR layer fed with the ORACLE's fp16-path
+    # input reproduces the oracle's output to 1e-4 (no flips can build up inside one layer).
+    assert erms['hip16_vs_oracle16'] <= 1.5e-3 and emax['hip16_vs_oracle16'] <= 5e-3, (erms, emax)
+    assert erms['hip16_vs_oracle16'] <= 0.75 * min(erms['hip32_vs_oracle16'], erms['oracle32_vs_oracle16']), erms
+    from oracle import stylegan_ref as sg
+    global_config.enable_fp16_blocks = True
+    with torch.no_grad():
+        w_last = ws[:, -1]                                        # every SR layer is driven by the last W+ row (superresolution.py:279)
+        x_ref, worst_layer = ref16['feature_image'], 0.0
+        for bname, block in (('block0', G.superresolution.block0), ('block1', G.superresolution.block1)):
+            pfx = f'superresolution.{bname}.'
+            y0_ref = sg.synthesis_layer(P, pfx + 'conv0.', x_ref, w_last, up=2, noise_mode='none', conv_clamp=256, fp16_operands=True)
+            y0 = block.conv0(x_ref.to(DEV), w_last.to(DEV), noise_mode='none', fp16=True)
+            y1_ref = sg.synthesis_layer(P, pfx + 'conv1.', y0_ref, w_last, noise_mode='none', conv_clamp=256, fp16_operands=True)
+            y1 = block.conv1(y0_ref.to(DEV), w_last.to(DEV), noise_mode='none', fp16=True)
+            rgb_ref = sg.torgb_layer(P, pfx + 'torgb.', y1_ref, w_last, conv_clamp=256, fp16_operands=True)
+            rgb = block.torgb(y1_ref.to(DEV), w_last.to(DEV), fp16=True)
+            for nm, a_, b_ in (('conv0', y0, y0_ref), ('conv1', y1, y1_ref), ('torgb', rgb, rgb_ref)):
+                e = rel_err(a_, b_)
+                worst_layer = max(worst_layer, e)
+                print(f'  fp16 SR layer {bname}.{nm} on the oracle input: {e:.2e}')
+                assert e <= 1e-4, (bname, nm, e)
+            x_ref = y1_ref
+    global_config.enable_fp16_blocks = False
 
     # one plain stage-2 iteration in that arithmetic
     global_config.enable_fp16_blocks = True

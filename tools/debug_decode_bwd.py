@@ -21,6 +21,10 @@ if len(sys.argv) > 1 and sys.argv[1] == 'sigonly':
 if len(sys.argv) > 1 and sys.argv[1] == 'rgbonly':
     d_sig.zero_()
 
+# the forward's colour rows (the tiled backward reads the colour layer's sigmoid back from them)
+colors = torch.empty(N, M, S, 32, device=dev); sig_fwd = torch.empty(N, M, S, device=dev)
+hip.call('spi_triplane_decode_fwd', hip.ptr(planes), None, hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(depths), hip.ptr(w1t), hip.ptr(b1),
+         hip.ptr(w2), hip.ptr(b2), N, M * S, S, H, H, 1.0, 0, 0, hip.ptr(colors), hip.ptr(sig_fwd), hip.stream())
 dp_ref = torch.zeros_like(planes)
 dump = torch.zeros(193, N * M * S, device=dev)
 hip.call('spi_triplane_decode_bwd', hip.ptr(planes), None, hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(depths), hip.ptr(w1t), hip.ptr(b1),
@@ -33,7 +37,7 @@ for wgrad in (False, True):
     ws = torch.empty(hip.lib().spi_triplane_decode_bwd_sorted_ws(N, M, S, res), device=dev)
     gw = [torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev)]
     hip.call('spi_triplane_decode_bwd_sorted', hip.ptr(planes), hip.ptr(ray_o), hip.ptr(ray_d), hip.ptr(depths), None, hip.ptr(w1t), hip.ptr(b1),
-             hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), None, None, hip.ptr(d_sig), N, M, S, res, H, H, 1.0, hip.ptr(dp), hip.ptr(ws),
+             hip.ptr(w2), hip.ptr(b2), hip.ptr(d_rgb), None, hip.ptr(colors), hip.ptr(d_sig), N, M, S, res, H, H, 1.0, hip.ptr(dp), hip.ptr(ws),
              *([hip.ptr(g) for g in gw] if wgrad else [None] * 4), None, hip.stream())
     torch.cuda.synchronize()
     e = (dp - dp_ref).abs()
