@@ -7,80 +7,133 @@ lists -- the layout ``plyfile`` writes for the reference); ``write_mrc`` / ``rea
 
 The reference delegates the surface extraction to ``skimage.measure.marching_cubes`` and the files to ``plyfile`` / ``mrcfile``:
 third-party code that is neither under /root/reference nor installed here ("parity unpinned" at that edge).
-The extraction here is marching TETRAHEDRA (each cell split into six tetrahedra around its main diagonal, linear
-interpolation on the cut edges, vertices shared through their grid-edge key): the same iso-surface up to the triangulation
-inside a cell, closed and consistently oriented (tests/test_host_cpu.py checks it on an analytic sphere).  Host-side numpy:
-post-processing, not the hot path.
+The extraction here is a table-driven MARCHING CUBES (round 3; rounds 1-2 had marching tetrahedra, whose vertices also sit on the
+cells' diagonals and are therefore not comparable with the reference's mesh): one vertex per grid edge crossing the level, linearly
+interpolated -- the vertex set every marching-cubes variant, skimage's included, produces (its Lewiner variant adds a cell-centre
+vertex in a few ambiguous configurations) -- 256-case table with consistently resolved face ambiguities, closed and consistently
+oriented (tests/test_host_cpu.py: analytic sphere, a two-blob field with ambiguous faces, the vertex-count identity).  Host-side
+numpy: post-processing, not the hot path.
 """
 import os
 import struct
 
 import numpy as np
 
+# ---- marching cubes tables, generated at import (no 256-row literal to mistype) -----------------------------------------------------
+# Cube corners in the classic numbering (Lorensen & Cline 1987 / Bourke's public tables): bottom face 0-1-2-3 counter-clockwise seen
+# from above, top face 4-5-6-7 over it; the 12 edges in the classic order.
 _CORNERS = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [0, 0, 1], [1, 0, 1], [1, 1, 1], [0, 1, 1]], dtype=np.int64)
-_TETS = np.array([[0, 5, 1, 6], [0, 1, 2, 6], [0, 2, 3, 6], [0, 3, 7, 6], [0, 7, 4, 6], [0, 4, 5, 6]], dtype=np.int64)
-# per inside-mask (bit i = corner i of the tetrahedron is >= level): triangles as triples of edges (a, b) between tet corners
-_E = {(0, 1): 0, (1, 2): 1, (0, 2): 2, (0, 3): 3, (1, 3): 4, (2, 3): 5}
-_EDGE_ENDS = np.array([[0, 1], [1, 2], [0, 2], [0, 3], [1, 3], [2, 3]], dtype=np.int64)
+_EDGES = np.array([[0, 1], [1, 2], [2, 3], [3, 0], [4, 5], [5, 6], [6, 7], [7, 4], [0, 4], [1, 5], [2, 6], [3, 7]], dtype=np.int64)
+# the six faces, corners counter-clockwise as seen from OUTSIDE the cube
+_FACES = [(0, 3, 2, 1), (4, 5, 6, 7), (0, 1, 5, 4), (1, 2, 6, 5), (2, 3, 7, 6), (3, 0, 4, 7)]
+_EDGE_ID = {(int(a_), int(b_)): i for i, (a_, b_) in enumerate(_EDGES)}
+_EDGE_ID.update({(b_, a_): i for (a_, b_), i in list(_EDGE_ID.items())})
 
 
-def _e(a, b):
-    return _E[(min(a, b), max(a, b))]
+def _on_common_face(ea, eb):
+    ca, cb = set(_EDGES[ea].tolist()), set(_EDGES[eb].tolist())
+    return any(ca <= set(f) and cb <= set(f) for f in _FACES)
 
 
-_CASES = {
-    0x1: [(_e(0, 1), _e(0, 2), _e(0, 3))],
-    0x2: [(_e(1, 0), _e(1, 3), _e(1, 2))],
-    0x4: [(_e(2, 0), _e(2, 1), _e(2, 3))],
-    0x8: [(_e(3, 0), _e(3, 2), _e(3, 1))],
-    0x3: [(_e(0, 3), _e(0, 2), _e(1, 3)), (_e(1, 3), _e(0, 2), _e(1, 2))],
-    0x5: [(_e(0, 1), _e(2, 3), _e(0, 3)), (_e(0, 1), _e(1, 2), _e(2, 3))],
-    0x6: [(_e(0, 1), _e(1, 3), _e(2, 3)), (_e(0, 1), _e(2, 3), _e(0, 2))],
-}
-for _m in (0x1, 0x2, 0x4, 0x8, 0x3, 0x5, 0x6):          # complementary masks cut the same edges
-    _CASES[0xF ^ _m] = _CASES[_m]
+def _triangulate(loop):
+    """Triangles (same orientation as the loop) of a closed loop of cut edges such that no DIAGONAL joins two cut edges of one cube face:
+    such a diagonal lies in that face, the neighbouring cell may draw the same one, and the mesh edge would then carry four triangles."""
+    n = len(loop)
+    if n == 3:
+        return [tuple(loop)]
+    for k in range(1, n - 1):                                    # triangle (loop[0], loop[k], loop[n-1]) + the two sub-polygons on its sides
+        if (k > 1 and _on_common_face(loop[0], loop[k])) or (k < n - 2 and _on_common_face(loop[k], loop[n - 1])):
+            continue
+        left = _triangulate(loop[:k + 1]) if k > 1 else []
+        right = _triangulate(loop[k:]) if k < n - 2 else []
+        if left is not None and right is not None:
+            return left + [(loop[0], loop[k], loop[n - 1])] + right
+    return None
 
 
-def marching_tetrahedra(vol, level=0.0, spacing=(1.0, 1.0, 1.0), slab=32):
-    """-> (verts float64 [V,3] in index units * spacing, faces int64 [F,3]).  Triangles are oriented with their normal pointing
-    from values >= level towards values < level.  Works slab by slab over the first axis, touching only the cut cells."""
+def _build_mc_table():
+    """table[mask] = triangles (triples of edge ids) of the iso-surface in a cell whose corner i is inside (value >= level) iff bit i of
+    mask is set.  Per face the cut edges are joined around every run of inside corners (an ambiguous face -- two diagonal inside corners
+    -- separates them: the choice depends on the face's four flags only, so both cells sharing a face draw the same segments and the
+    surface is watertight, unlike the original 1987 table); segments run from the edge where a counter-clockwise walk along the face
+    boundary ENTERS the inside run to the edge where it leaves it, which orients every loop with its normal towards the outside
+    (lower values); the closed loops are triangulated without diagonals inside a cube face (_triangulate).  Unambiguous cases are the
+    classic ones up to the choice of diagonals."""
+    table = []
+    for mask in range(256):
+        inside = [(mask >> i) & 1 for i in range(8)]
+        nxt = {}
+        for f in _FACES:
+            flags = [inside[c] for c in f]
+            if sum(flags) in (0, 4):
+                continue
+            for i in range(4):
+                if flags[i] and not flags[i - 1]:                # a run of inside corners starts at corner i: entered through edge (i-1, i)
+                    j = i
+                    while flags[(j + 1) % 4]:
+                        j += 1
+                    enter = _EDGE_ID[(f[i - 1], f[i])]
+                    leave = _EDGE_ID[(f[j % 4], f[(j + 1) % 4])]
+                    assert enter not in nxt
+                    nxt[enter] = leave
+        tris, seen = [], set()
+        for e0 in sorted(nxt):
+            if e0 in seen:
+                continue
+            loop, e = [], e0
+            while e not in seen:
+                seen.add(e)
+                loop.append(e)
+                e = nxt[e]
+            assert e == e0 and len(loop) >= 3
+            t_ = _triangulate(loop)
+            assert t_ is not None, (mask, loop)
+            tris += t_
+        assert len(seen) == sum(1 for a_, b_ in _EDGES if inside[a_] != inside[b_])          # every cut edge carries exactly one vertex
+        table.append(tris)
+    width = max(len(t) for t in table)
+    arr = np.full((256, width, 3), -1, dtype=np.int64)
+    for m, t in enumerate(table):
+        if t:
+            arr[m, :len(t)] = t
+    return arr
+
+
+_MC_TABLE = _build_mc_table()                                    # [256, T, 3] edge ids, -1 padded
+
+
+def marching_cubes(vol, level=0.0, spacing=(1.0, 1.0, 1.0), slab=32):
+    """Table-driven marching cubes: -> (verts float64 [V,3] in index units * spacing, faces int64 [F,3]).
+    One vertex per grid edge that crosses ``level`` (linear interpolation along the edge, what skimage.measure.marching_cubes -- the
+    reference's extractor, eg3d/shape_utils.py:60-62 -- places there too), shared between the cells around the edge; triangles are
+    oriented with their normal pointing from values >= level towards values < level (skimage's default gradient_direction='descent').
+    Works slab by slab over the first axis, touching only the cut cells."""
     vol = np.asarray(vol)
     assert vol.ndim == 3 and min(vol.shape) >= 2
     nx, ny, nz = vol.shape
-    node_id = lambda i, j, k: (i * ny + j) * nz + k
-    tri_keys = []                  # [T, 3, 2] grid-node pairs of the three cut edges
-    tri_in = []                    # [T] a node on the inside (>= level) of the tetrahedron, for the orientation
+    nn = nx * ny * nz
+    tri_keys = []                                                # [T, 3, 2] grid-node pairs of the three cut edges
     for x0 in range(0, nx - 1, slab):
         x1 = min(x0 + slab, nx - 1)
         sub = vol[x0:x1 + 1]
         c = [sub[dx:sub.shape[0] - 1 + dx, dy:ny - 1 + dy, dz:nz - 1 + dz] for dx, dy, dz in _CORNERS]
-        lo, hi = np.minimum.reduce(c), np.maximum.reduce(c)
-        ii, jj, kk = np.nonzero((lo < level) & (hi >= level))
+        mask = np.zeros(c[0].shape, dtype=np.int64)
+        for i, cc in enumerate(c):
+            mask |= (cc >= level).astype(np.int64) << i
+        ii, jj, kk = np.nonzero((mask != 0) & (mask != 255))
         if ii.size == 0:
             continue
-        vals = np.stack([cc[ii, jj, kk] for cc in c], axis=1).astype(np.float64)                 # [A, 8]
-        nodes = np.stack([node_id(ii + x0 + dx, jj + dy, kk + dz) for dx, dy, dz in _CORNERS], axis=1)     # [A, 8]
-        for tet in _TETS:
-            tv, tn = vals[:, tet], nodes[:, tet]
-            inside = tv >= level
-            mask = inside[:, 0] * 1 + inside[:, 1] * 2 + inside[:, 2] * 4 + inside[:, 3] * 8
-            for m, tris in _CASES.items():
-                sel = np.nonzero(mask == m)[0]
-                if sel.size == 0:
-                    continue
-                first_in = int(np.log2(m & -m))                                                    # lowest set bit: an inside corner
-                for tri in tris:
-                    ends = _EDGE_ENDS[list(tri)]                                                   # [3, 2] tet-corner indices
-                    tri_keys.append(np.stack([tn[sel][:, ends[:, 0]], tn[sel][:, ends[:, 1]]], axis=-1))
-                    tri_in.append(tn[sel, first_in])
+        nodes = np.stack([((ii + x0 + dx) * ny + (jj + dy)) * nz + (kk + dz) for dx, dy, dz in _CORNERS], axis=1)        # [A, 8]
+        tris = _MC_TABLE[mask[ii, jj, kk]]                       # [A, T, 3] edge ids
+        cell, slot = np.nonzero(tris[:, :, 0] >= 0)
+        ends = _EDGES[tris[cell, slot]]                          # [n, 3, 2] corner ids
+        tri_keys.append(np.take_along_axis(nodes[cell][:, None, :], ends.reshape(len(cell), 1, 6), axis=2).reshape(-1, 3, 2))
     if not tri_keys:
         return np.zeros((0, 3)), np.zeros((0, 3), dtype=np.int64)
-    keys = np.concatenate(tri_keys)                                                               # [T, 3, 2]
-    inside_node = np.concatenate(tri_in)
-    keys = np.sort(keys, axis=-1)
+    keys = np.sort(np.concatenate(tri_keys), axis=-1)            # an edge = its (smaller, larger) node
     flat = keys.reshape(-1, 2)
-    uniq, inv = np.unique(flat[:, 0] * (nx * ny * nz) + flat[:, 1], return_inverse=True)
-    a, b = uniq // (nx * ny * nz), uniq % (nx * ny * nz)
+    uniq, inv = np.unique(flat[:, 0] * nn + flat[:, 1], return_inverse=True)
+    a, b = uniq // nn, uniq % nn
 
     def pos(n):
         return np.stack([n // (ny * nz), (n // nz) % ny, n % nz], axis=1).astype(np.float64)
@@ -88,11 +141,7 @@ def marching_tetrahedra(vol, level=0.0, spacing=(1.0, 1.0, 1.0), slab=32):
     t = np.where(vb != va, (level - va) / np.where(vb != va, vb - va, 1.0), 0.5)[:, None]
     verts = (pos(a) * (1 - t) + pos(b) * t) * np.asarray(spacing, dtype=np.float64)
     faces = inv.reshape(-1, 3).astype(np.int64)
-    p = verts[faces]
-    nrm = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
-    flip = np.einsum('ij,ij->i', nrm, p.mean(1) - pos(inside_node) * np.asarray(spacing, dtype=np.float64)) < 0
-    faces[flip] = faces[flip][:, ::-1]
-    keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])          # a value exactly on a node
+    keep = (faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])
     return verts, faces[keep]
 
 
@@ -125,7 +174,7 @@ def read_ply(path):
 def convert_sdf_samples_to_ply(numpy_3d_sdf_tensor, voxel_grid_origin, voxel_size, ply_filename_out, offset=None, scale=None, level=0.0):
     """eg3d/shape_utils.py:40-100: iso-surface at ``level`` with spacing ``voxel_size``, shifted by the grid origin, then
     ``/ scale`` and ``- offset`` when given."""
-    verts, faces = marching_tetrahedra(np.asarray(numpy_3d_sdf_tensor), level=level, spacing=[voxel_size] * 3)
+    verts, faces = marching_cubes(np.asarray(numpy_3d_sdf_tensor), level=level, spacing=[voxel_size] * 3)
     pts = verts + np.asarray(voxel_grid_origin, dtype=np.float64).reshape(1, 3)
     if scale is not None:
         pts = pts / scale

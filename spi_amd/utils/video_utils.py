@@ -6,8 +6,9 @@ yaw +-0.7 / pitch +-0.4 orbit around the look-at point (0, 0, 0.2), radius 2.7, 
 generator in batches with ONE ``w`` (``TriPlaneGenerator.synthesis`` shares the backbone and the weight modulation across the
 views), under ``no_grad``.  Only the single-latent 1x1 grid SPI uses is implemented; keyframe interpolation over several
 latents (the reference's scipy ``interp1d`` over seeds) is not.
-Output: ``imageio`` is not a dependency -- frames are written as ``<mp4 stem>_frames/%04d.jpg`` (PIL), plus the mp4 when
-imageio happens to be importable.  ``gen_shapes`` exports the density grid of frame 0 like video_utils.py:198-218: the
+Output: frames are written as ``<mp4 stem>_frames/%04d.jpg`` (PIL).  The ``.mp4`` container itself needs ``imageio`` + ffmpeg/libx264
+(the reference's writer, video_utils.py:141), which are NOT dependencies of this package: with imageio importable the file is encoded,
+otherwise the run prints where the frames are and the ffmpeg command that encodes them (stated dependency, no silent skip).  ``gen_shapes`` exports the density grid of frame 0 like video_utils.py:198-218: the
 iso-surface at level 10 as ``interpolation_shape/0000_shape.ply`` (``output_ply=True`` there; ``shape_format='mrc'`` for the
 other branch), through utils/shape_utils.py, plus the raw grid as ``.npy`` and the camera path as ``_trajectory.npy``.
 """
@@ -18,6 +19,8 @@ import numpy as np
 import torch
 
 from . import camera_utils as cu
+
+_warned_no_imageio = False
 
 
 def orbit_cameras(num_frames, yaw_range=0.7, pitch_range=0.4, lookat=(0.0, 0.0, 0.2), radius=2.7, device='cpu'):
@@ -85,8 +88,10 @@ def sigma_grid(G, w, resolution=128, max_batch=1 << 22):
 
 @torch.no_grad()
 def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_shapes=False, batch=4, device=None,
-                     voxel_resolution=128, save_frames=True, shape_format='ply', shape_level=10, **_unused):
-    """Orbit video of ONE latent.  Returns the frames as uint8 [F,H,W,3] (numpy)."""
+                     voxel_resolution=128, save_frames=True, shape_format='ply', shape_level=10, render_noise=None, return_float=False, **_unused):
+    """Orbit video of ONE latent.  Returns the frames as uint8 [F,H,W,3] (numpy).
+    render_noise (extension, tests): callable frame index -> (xi [1,M,Sc,1], u [M,Sf]) or None -- the renderer's two draws of that frame
+    (the reference draws them with torch.rand inside G.synthesis, once per frame); return_float: also the float frames before uint8."""
     w = G_kwargs['w']
     if w.ndim == 2:
         w = w.unsqueeze(0)
@@ -94,11 +99,19 @@ def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_
         raise NotImplementedError('keyframe interpolation over several latents is not implemented (SPI renders one latent per video)')
     device = device or w.device
     cams = orbit_cameras(w_frames, device=device)
-    frames = []
+    frames, floats = [], []
+    m, rk = G.neural_rendering_resolution ** 2, G.rendering_kwargs
     for i in range(0, w_frames, batch):
         c = cams[i:i + batch]
-        out = G.synthesis(w.to(device), c, noise_mode='const')[image_mode]          # one w, len(c) cameras: backbone shared
+        noise = None
+        if render_noise is not None:
+            per = [render_noise(k) for k in range(i, i + len(c))]
+            per = [p if p is not None else (torch.rand(1, m, int(rk['depth_resolution']), 1), torch.rand(m, max(int(rk['depth_resolution_importance']), 1))) for p in per]
+            noise = (torch.cat([p[0].reshape(1, m, -1, 1) for p in per]).to(device), torch.cat([p[1].reshape(m, -1) for p in per]).to(device))
+        out = G.synthesis(w.to(device), c, noise_mode='const', render_noise=noise)[image_mode]      # one w, len(c) cameras: backbone shared
         frames.append(to_uint8(out, image_mode).cpu())
+        if return_float:
+            floats.append(out.float().cpu())
     frames = torch.cat(frames).numpy()
     stem = os.path.splitext(mp4)[0]
     if save_frames:
@@ -106,13 +119,22 @@ def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_
         os.makedirs(stem + '_frames', exist_ok=True)
         for i, f in enumerate(frames):
             Image.fromarray(f).save(os.path.join(stem + '_frames', f'{i:04d}.jpg'))
-        try:                                                                         # the container itself only if imageio exists
+        # The .mp4 container needs imageio + an ffmpeg build with libx264 (what the reference uses, video_utils.py:141); neither is a
+        # dependency of this package.  With imageio installed the same file is written; without it the frames above ARE the output, and
+        # the run says so once instead of silently dropping the video.
+        try:
             import imageio
+        except ImportError:
+            imageio = None
+            global _warned_no_imageio
+            if not _warned_no_imageio:
+                _warned_no_imageio = True
+                print(f'[spi_amd] imageio is not installed: {os.path.basename(mp4)} is not encoded, its {len(frames)} frames are in {stem}_frames/ '
+                      '(ffmpeg -framerate 60 -i %04d.jpg -c:v libx264 makes the same file)', flush=True)
+        if imageio is not None:
             with imageio.get_writer(mp4, mode='I', fps=60, codec='libx264') as vw:
                 for f in frames:
                     vw.append_data(f)
-        except ImportError:
-            pass
     if gen_shapes:
         from . import shape_utils
         outdir = os.path.join(os.path.dirname(mp4) or '.', 'interpolation_shape')
@@ -124,4 +146,4 @@ def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_
         else:                                                                        # :215-217
             shape_utils.write_mrc(os.path.join(outdir, '0000_shape.mrc'), sigmas)
         np.save(stem + '_trajectory.npy', cams[:, :16].reshape(-1, 4, 4).cpu().numpy())
-    return frames
+    return (frames, torch.cat(floats)) if return_float else frames

@@ -646,6 +646,64 @@ def sec_orbit():
     print('    (create_samples in the reference uses float division: columns 0/1 are fractional positions, kept as data)')
     save('orbit', **out)
 
+def mesh_stats(verts, faces):
+    """vertex / face count, area, signed volume, Euler characteristic and closedness of a triangle mesh (numpy)."""
+    p = verts[faces]
+    nrm = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), axis=1)
+    ue, cnt = np.unique(e[:, 0] * (len(verts) + 1) + e[:, 1], return_counts=True)
+    return dict(verts=len(verts), faces=len(faces), area=0.5 * np.linalg.norm(nrm, axis=1).sum(),
+                volume=np.einsum('ij,ij->i', p[:, 0], nrm).sum() / 6, euler=len(verts) - len(ue) + len(faces), closed=bool((cnt == 2).all()))
+
+
+def sec_orbit_frames():
+    """SURVEY 8f-1, what BaseCoach.post_process produces (spi/utils/video_utils.py:74-230 -- the module needs imageio / mrcfile and
+    cannot be imported; its loop body is driven here with the reference's own generator): frames 0, 37 and 119 of the 120-frame
+    orbit = G.synthesis(w, c_k, noise_mode='const') (:170-172) on the narrow reference generator with the renderer's draws recorded,
+    and the density grid of :185-207 = G.sample_mixed on create_samples' points, flipped and border-cleaned, at 32^3.  The iso-surface
+    itself comes from skimage in the reference (absent here): the grid is the pinned quantity, the mesh statistics below are those of
+    the build's marching cubes on the REFERENCE's grid (regression values + topological invariants)."""
+    sys.path.insert(0, ROOT)
+    from spi_amd.utils import video_utils as vu, shape_utils as su
+    G = build_ref_generator(True)
+    G.neural_rendering_resolution = 32
+    g = torch.Generator().manual_seed(77)
+    ws = torch.randn(1, 14, 512, generator=g) * 0.8
+    cams = torch.from_numpy(np.load(os.path.join(HERE, 'orbit.npz'))['cams_120'])
+    out = dict(ws=ws, frame_ids=np.array([0, 37, 119]))
+    P = {k: v for k, v in G.state_dict().items()}
+    with torch.no_grad():
+        for k in (0, 37, 119):
+            with Recorder() as rec:
+                torch.manual_seed(0)
+                o = G.synthesis(ws=ws, c=cams[k:k + 1], noise_mode='const')
+            xi, u = rec.draws
+            oo = orr.synthesis(P, ws, cams[k:k + 1], dict(RK), neural_rendering_resolution=32, xi=xi, u=u)
+            for nm in ('image', 'image_raw', 'image_depth'):
+                diff(f'frame {k}: {nm}', o[nm], oo[nm])
+            out.update({f'f{k}_xi': xi, f'f{k}_u': u, f'f{k}_image_sub': o['image'][:, :, ::4, ::4], f'f{k}_image_raw': o['image_raw'],
+                        f'f{k}_image_depth': o['image_depth'], f'f{k}_image_mean': o['image'].mean(), f'f{k}_image_absmean': o['image'].abs().mean()})
+        N = 32
+        samples, _, _ = vu.create_samples(N=N, voxel_origin=[0, 0, 0], cube_length=G.rendering_kwargs['box_warp'])   # (pinned by orbit.npz)
+        dirs = torch.zeros(1, samples.shape[1], 3)
+        dirs[..., -1] = -1
+        torch.manual_seed(0)
+        sigma = G.sample_mixed(samples, dirs, ws, truncation_psi=1, noise_mode='const')['sigma']
+        _, so = orr.run_model(P, osg.backbone_synthesis(P, ws).reshape(1, 3, 32, 256, 256), samples, dict(RK))
+        diff('sigma grid (sample_mixed on create_samples)', sigma, so)
+    raw = sigma.reshape(N, N, N).numpy()
+    sig = np.flip(raw, 0).copy()                                  # video_utils.py:198-207
+    pad, pad_top = int(30 * N / 256), int(38 * N / 256)
+    sig[:pad] = 0; sig[-pad:] = 0; sig[:, :pad] = 0; sig[:, -pad_top:] = 0; sig[:, :, :pad] = 0; sig[:, :, -pad:] = 0
+    level = float(np.percentile(sig[sig != 0], 60))               # a level that cuts this random-init field (the reference uses 10 on trained weights)
+    verts, faces = su.marching_cubes(np.transpose(sig, (2, 1, 0)), level=level)
+    st = mesh_stats(verts, faces)
+    print('    sigma grid mesh at level %.4f:' % level, st)
+    out.update(sigma_raw=raw, sigma_grid=sig, mesh_level=np.array(level), mesh_verts=np.array(st['verts']), mesh_faces=np.array(st['faces']),
+               mesh_area=np.array(st['area']), mesh_volume=np.array(st['volume']), mesh_euler=np.array(st['euler']), mesh_closed=np.array(st['closed']))
+    save('orbit_frames', **out)
+
+
 def sec_bisenet():
     """the reference's own BiSeNet (third_part/bisenet) on seeded synthetic weights (no bisenet.pth offline), eval mode.
     Two import-time obstacles, both outside the arithmetic: `import torchvision` at the top of bisenet.py (never used in the file; the
@@ -690,7 +748,7 @@ def sec_bisenet():
 
 SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, renderer_options=sec_renderer_options, synthesis=sec_synthesis,
                 geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory, trajectory_sg=sec_trajectory_sg,
-                tv=sec_tv, orbit=sec_orbit, bisenet=sec_bisenet)
+                tv=sec_tv, orbit=sec_orbit, orbit_frames=sec_orbit_frames, bisenet=sec_bisenet)
 
 if __name__ == '__main__':
     todo = sys.argv[1:] or list(SECTIONS)

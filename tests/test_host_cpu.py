@@ -384,7 +384,7 @@ def test_shape_export_iso_surface_ply_and_mrc(tmp_path):
     assert abs(area / (4 * np.pi * R * R) - 1) < 0.01
     # scale / offset arguments (shape_utils.py:72-76)
     pts2, _ = su.convert_sdf_samples_to_ply(vol, [0, 0, 0], 0.5, str(tmp_path / 's2.ply'), offset=np.array([1.0, 2.0, 3.0]), scale=2.0, level=0.0)
-    verts0, _ = su.marching_tetrahedra(vol, 0.0, [0.5] * 3)
+    verts0, _ = su.marching_cubes(vol, 0.0, [0.5] * 3)
     assert np.allclose(pts2, verts0 / 2.0 - np.array([1.0, 2.0, 3.0]))
     # .mrc: header fields + round trip + convert_mrc == direct extraction of the transposed grid
     mrc = str(tmp_path / 'v.mrc')
@@ -393,9 +393,59 @@ def test_shape_export_iso_surface_ply_and_mrc(tmp_path):
     assert len(raw) == 1024 + vol.size * 4 and raw[208:212] == b'MAP ' and np.frombuffer(raw, '<i4', 4, 0).tolist() == [n, n, n, 2]
     assert np.array_equal(su.read_mrc(mrc), vol)
     pm, fm = su.convert_mrc(mrc, str(tmp_path / 'm.ply'), isosurface_level=0)
-    vt, ft = su.marching_tetrahedra(np.transpose(vol, (2, 1, 0)), 0.0)
+    vt, ft = su.marching_cubes(np.transpose(vol, (2, 1, 0)), 0.0)
     assert np.allclose(pm, vt) and np.array_equal(fm, ft)
-    assert su.marching_tetrahedra(np.zeros((4, 4, 4)), level=1.0)[1].shape == (0, 3)      # nothing crosses the level
+    assert su.marching_cubes(np.zeros((4, 4, 4)), level=1.0)[1].shape == (0, 3)      # nothing crosses the level
+    # marching cubes places exactly one vertex on every grid edge that crosses the level -- the vertex set skimage's extractor (the
+    # reference's, eg3d/shape_utils.py:60-62) produces too
+    cut = sum(int(((np.take(vol, range(0, n - 1), axis=a) >= 0) != (np.take(vol, range(1, n), axis=a) >= 0)).sum()) for a in range(3))
+    assert len(pts) == cut
+
+
+def _mesh_stats(verts, faces):
+    import numpy as np
+    p = verts[faces]
+    nrm = np.cross(p[:, 1] - p[:, 0], p[:, 2] - p[:, 0])
+    e = np.sort(np.concatenate([faces[:, [0, 1]], faces[:, [1, 2]], faces[:, [2, 0]]]), axis=1)
+    ue, cnt = np.unique(e[:, 0] * (len(verts) + 1) + e[:, 1], return_counts=True)
+    return dict(verts=len(verts), faces=len(faces), area=0.5 * np.linalg.norm(nrm, axis=1).sum(), volume=np.einsum('ij,ij->i', p[:, 0], nrm).sum() / 6,
+                euler=len(verts) - len(ue) + len(faces), closed=bool((cnt == 2).all()))
+
+
+def test_marching_cubes_table_ambiguous_faces_and_reference_sigma_grid(golden):
+    """The 256-case table (generated, utils/shape_utils._build_mc_table): every case closes its loops over all cut edges; fields with
+    ambiguous faces (two diagonal inside corners) still give a closed, consistently oriented surface -- where the original 1987 table
+    leaves holes; and on the REFERENCE's density grid (golden/orbit_frames.npz: G.sample_mixed on create_samples' points, flipped and
+    border-cleaned like spi/utils/video_utils.py:198-207) the mesh is closed with the recorded vertex / face count, area and Euler number."""
+    import numpy as np
+    from spi_amd.utils import shape_utils as su
+    T = su._MC_TABLE
+    assert T.shape[0] == 256 and (T[0] < 0).all() and (T[255] < 0).all()
+    for m in range(256):
+        used = set(int(e) for e in T[m].reshape(-1) if e >= 0)
+        cut = {i for i, (a, b) in enumerate(su._EDGES) if ((m >> a) & 1) != ((m >> b) & 1)}
+        assert used == cut, m
+    # a field full of ambiguous faces: checkerboard-like product of sines, plus two blobs that touch diagonally
+    ax = np.linspace(0, 4 * np.pi, 40)
+    X, Y, Z = np.meshgrid(ax, ax + 0.3, ax + 0.7, indexing='ij')
+    vol = np.sin(X) * np.sin(Y) * np.sin(Z) + 0.05 * np.cos(3 * X + Y)
+    vol[:2] = vol[-2:] = -1; vol[:, :2] = vol[:, -2:] = -1; vol[:, :, :2] = vol[:, :, -2:] = -1          # keep the surface off the border
+    c = [vol[dx:39 + dx, dy:39 + dy, dz:39 + dz] >= 0.0 for dx, dy, dz in su._CORNERS]
+    amb = sum(int(((c[a] & c[cc] & ~c[b] & ~c[d]) | (~c[a] & ~c[cc] & c[b] & c[d])).sum()) for a, b, cc, d in su._FACES)
+    assert amb > 20                                                   # the test field really contains ambiguous faces
+    v, f = su.marching_cubes(vol, 0.0)
+    st = _mesh_stats(v, f)
+    assert st['closed'] and st['volume'] > 0 and st['euler'] % 2 == 0, st
+    d = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    assert len(np.unique(d[:, 0] * (len(v) + 1) + d[:, 1])) == len(d)   # every directed edge once: consistently oriented
+    g = golden('orbit_frames')
+    sig, level = g['sigma_grid'].numpy(), float(g['mesh_level'])
+    v, f = su.marching_cubes(np.transpose(sig, (2, 1, 0)), level=level)
+    st = _mesh_stats(v, f)
+    assert st['closed'] and st['verts'] == int(g['mesh_verts']) and st['faces'] == int(g['mesh_faces']) and st['euler'] == int(g['mesh_euler'])
+    assert abs(st['area'] / float(g['mesh_area']) - 1) < 1e-9 and abs(st['volume'] / float(g['mesh_volume']) - 1) < 1e-9
+    cut = sum(int(((np.take(sig, range(0, 31), axis=a) >= level) != (np.take(sig, range(1, 32), axis=a) >= level)).sum()) for a in range(3))
+    assert st['verts'] == cut
 
 
 def test_preprocess_driver_layout_feeds_the_dataset(tmp_path):
