@@ -598,6 +598,7 @@ struct TiledArgs {
     int ray_w; int patch2d;                   // ray grid width; 1 = 8x8 patches over the (M/ray_w) x ray_w grid, 0 = 64 consecutive rays
     int patches; int kchunks; int tiles;
     const uint16_t* order; const int32_t* count;   // depth-binned point order of every ray patch (bin_points_kernel)
+    float* dfeat;                             // split scatter (plane_scatter_kernel): d_feat rows [patch][pos][32] in the patches' depth-binned order
     int dbg;                                  // tools/bench_render.py only: 1 = skip scatter, 4 = skip the MLP, 8 = no flush, 16 = skip points that leave the window, 32 = no LDS atomics, 64 = skip the plane gather
 };
 
@@ -607,8 +608,7 @@ template <bool WGRAD, bool RGB>
 __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, const float* __restrict__ frag_g, const float* __restrict__ b1_g,
                                                                  const float* __restrict__ b2_g, const float* __restrict__ d_rgb,
                                                                  const float* __restrict__ d_rgb_scale, const float* __restrict__ colors,
-                                                                 const float* __restrict__ d_sigma, float* __restrict__ d_planes,
-                                                                 float* __restrict__ part) {
+                                                                 const float* __restrict__ d_sigma, float* __restrict__ part) {
     // colors: the forward's colour rows [R*S, 32] (= sigmoid(y) * 1.002 - 0.001), required with d_rgb.  The sigmoid the colour layer's
     // derivative needs is read back from them instead of recomputing the layer's pre-activations (32 MFMAs per 32 points) for one
     // 128-byte row per point.
@@ -634,7 +634,6 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     static_assert(FRAG_TOTAL + 4 * TTILE <= DT * FS + 6 * DT, "fragments + transposition tiles must fit gbuf and the small arrays");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, q = lane & 31, hh = lane >> 5;
-    const int64_t plane_sz = (int64_t)a.H * a.W * DEC_IN;
     // Weight-gradient accumulators: the four 32x32 tiles of a wave live in its scratch row in global memory (L2 / MALL) and
     // are pulled into registers only around their own MFMAs (loaded as the accumulator's initial value, stored back right
     // after).  Keeping 64 accumulator registers alive across the gather and scatter phases made the compiler spill inside
@@ -873,110 +872,18 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         for (int r = 0; r < 16; ++r) frow[rowmap(r, hh_)] = dF[r] / 3.f;           // the plane mean contributes the 1/3
     }
     }
-    // ---- phase C: per plane, accumulate in an LDS window (reusing `gbuf`), then flush it.
-    // LDS float atomics are ~30x slower than integer ones on gfx950 (ds_add_f32: ~190 cycles per
-    // wave-instruction, ds_add_u32/u64: ~10; tools/ubench/lds_atomic.hip), so the window holds 32-bit
-    // fixed-point sums scaled by a per-tile power of two (resolution 2^-21 of the tile's largest |gradient|,
-    // headroom for 256 full-weight contributions per texel); the sum is order-independent and is converted
-    // back to fp32 once at the flush.  32-bit cells make the window 16 x 16 texels in the LDS that held 12 x 12
-    // 64-bit ones: an 8 x 8 ray patch spans ~15 texels, and every point that leaves the window costs four
-    // tested corners and global atomics (0.8 of 2.65 ms per image with the 12-texel window).
+    // ---- hand-over to plane_scatter_kernel: this tile's 256 d_feat rows (contiguous: 32 KB; rows of padding points are zero).  The
+    // scatter into the plane gradients wants windows that SURVIVE from one depth slab of a ray patch to the next (64 KB of fp64 per plane)
+    // -- there is no room for them beside the rows, the fragments and the transposition tiles, so it is a kernel of its own.
     if (a.dbg & 1) continue;
-    static_assert(WIN * WIN * DEC_IN * 4 <= DT * FS * 4, "window must fit the fragment buffer");
-    int* win = reinterpret_cast<int*>(gbuf);
-    __syncthreads();                                       // phase B done in every wave: fragments dead, feat rows = d_feat
-    const float* growt = feat + t * FS;
-    float amax = 0.f;
+    __syncthreads();                                       // phase B done in every wave: feat rows = d_feat
+    {
+        float* drow = a.dfeat + ((int64_t)pidx * (64 * a.S) + (int64_t)kc * DT) * DEC_IN;
 #pragma unroll
-    for (int i = 0; i < DEC_IN; ++i) amax = fmaxf(amax, fabsf(growt[i]));
-    amax = wave_max(amax);
-    if (t < 8) s_acc[t] = 0;
-    __syncthreads();
-    if ((t & 63) == 0) atomicMax(&s_acc[4], __float_as_int(amax));        // amax >= 0: int order == float order
-    __syncthreads();
-    const float tile_max = __int_as_float(s_acc[4]);
-    if (!(tile_max > 0.f)) continue;                        // all gradients zero (block-uniform)
-    const int e2 = ilogbf(tile_max);
-    const float to_fix = ldexpf(1.f, 21 - e2);              // |dv * to_fix| < 2^22
-    const float from_fix = ldexpf(1.f, e2 - 21);
-    const int half = lane >> 5, ch = lane & 31;
-    int* s_base = reinterpret_cast<int*>(s_x);                 // phase A is over: s_x is free (this thread's x,y,z live in registers)
-    // float -> fixed point in 2 instructions: fma(v, w, 1.5*2^23) leaves round-to-nearest-even(v*w) in the low mantissa bits
-    // (two's complement for negative values), so bits(.) - bits(1.5*2^23) is the integer.  |v*w| < 2^22 here.
-    constexpr float MAGIC = 12582912.f;
-    auto add_fix = [&](int* p, float dvs, float w) {
-        atomicAdd(p, __float_as_int(fmaf(dvs, w, MAGIC)) - 0x4B400000);                                   // ds_add_u32
-    };
-    for (int pl = 0; pl < 3; ++pl) {
-        __syncthreads();                                   // previous flush done
-        if (t < 4) s_acc[t] = 0;
-        for (int i = t; i < WIN * WIN * DEC_IN / 4; i += DT) reinterpret_cast<int4*>(win)[i] = make_int4(0, 0, 0, 0);
-        float gx, gy;
-        plane_uv(pl, x, y, z, gx, gy);
-        const Corner c = make_corner(gx, gy, a.W, a.H);
-        // points whose four corners all lie outside the plane image contribute nothing to this plane (padding_mode zeros)
-        const bool vin = valid && c.x0 + 1 >= 0 && c.x0 < a.W && c.y0 + 1 >= 0 && c.y0 < a.H;
-        const int cx0 = c.x0, cy0 = c.y0;
-        // window centred on the mean corner of the tile's contributing points (sums are exact in fp32: < 2^24)
-        const float sx = wave_sum(vin ? (float)cx0 : 0.f), sy = wave_sum(vin ? (float)cy0 : 0.f), sc = wave_sum(vin ? 1.f : 0.f);
-        __syncthreads();
-        if (lane == 0) { atomicAdd(&s_acc[0], (int)sx); atomicAdd(&s_acc[1], (int)sy); atomicAdd(&s_acc[2], (int)sc); }
-        __syncthreads();
-        const int cnt = max(s_acc[2], 1);
-        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;
-        const int lxo = cx0 - wx0, lyo = cy0 - wy0;
-        // fast path: all four corners inside the image AND inside the window -> no per-corner tests in the loop
-        const bool fast = vin && lxo >= 0 && lxo + 1 < WIN && lyo >= 0 && lyo + 1 < WIN &&
-                          c.x0 >= 0 && c.x0 + 1 < a.W && c.y0 >= 0 && c.y0 + 1 < a.H;
-        s_base[t] = fast ? (lyo * WIN + lxo) * DEC_IN : (vin ? -2 : -1);
-        s_cxy[t] = ((lxo + 0x4000) & 0xffff) | ((lyo + 0x4000) << 16);
-        s_wx[t] = c.wx1; s_wy[t] = c.wy1;
-        __syncthreads();
-        float* gplane = d_planes + (int64_t)(n * 3 + pl) * plane_sz;
-        // a half-wave (32 lanes = the 32 channels of one 128-B texel row) per point
-#pragma unroll 2
-        for (int i = 0; i < 64; i += 2) {
-            const int sp = wave * 64 + i + half;
-            const int base = s_base[sp];
-            if (base == -1) continue;
-            const float dv = feat[sp * FS + ch];
-            const float fx1 = s_wx[sp], fy1 = s_wy[sp];
-            const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
-            if (base >= 0) {
-                if (a.dbg & 32) continue;
-                const float dvs = dv * to_fix;
-                int* wp = win + base + ch;
-                add_fix(wp, dvs, fx0 * fy0);
-                add_fix(wp + DEC_IN, dvs, fx1 * fy0);
-                add_fix(wp + WIN * DEC_IN, dvs, fx0 * fy1);
-                add_fix(wp + (WIN + 1) * DEC_IN, dvs, fx1 * fy1);
-                continue;
-            }
-            if (a.dbg & 16) continue;
-            const int pk = s_cxy[sp];
-            const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int cx = qq & 1, cy = qq >> 1;
-                const int xl = lx + cx, yl = ly + cy;
-                const int xx = xl + wx0, yy = yl + wy0;
-                if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-                const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
-                if (xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
-                    if (!(a.dbg & 32)) add_fix(&win[(yl * WIN + xl) * DEC_IN + ch], dv * to_fix, wq);
-                } else if (!(a.dbg & 128)) {
-                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dv * wq);                  // rare: straight to HBM
-                }
-            }
-        }
-        __syncthreads();
-        if (a.dbg & 8) continue;
-        for (int j = 0; j < (WIN * WIN) / 8; ++j) {                    // flush: one half-wave per texel row (128 B)
-            const int tex = j * 8 + wave * 2 + half;
-            const int xx = wx0 + (tex % WIN), yy = wy0 + (tex / WIN);
-            if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-            const int qv = win[tex * DEC_IN + ch];
-            if (qv != 0) atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, (float)qv * from_fix);
+        for (int it = 0; it < 8; ++it) {
+            const int e = it * DT + t;                     // float4 index within the tile
+            const int sp = e >> 3, q4 = e & 7;
+            *reinterpret_cast<float4*>(drow + e * 4) = *reinterpret_cast<const float4*>(feat + sp * FS + q4 * 4);
         }
     }
     }   // tile loop
@@ -993,6 +900,174 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         const float sd = wave_sum(s_d);
         if (lane == 0) pr[PART_DB2] = sd;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Plane-gradient scatter of the tiled decoder backward (round 3: its own kernel).
+//   One block per (ray patch, plane) walks the patch's tiles -- 256 points each, thin slabs of the view frustum in depth order -- and
+//   adds every point's d_feat row to its four bilinear corners in that plane.
+//   Round 2 did this at the end of decode_bwd_tiled_kernel with ONE 16 x 16-texel LDS window per plane and TILE: zeroed, filled with
+//   32-bit fixed-point LDS atomics (ds_add_f32 costs ~190 cycles per wave-instruction on gfx950), converted and flushed to HBM after
+//   every tile -- 12 288 tiles x 3 windows x ~120 non-zero texel rows of 128-byte global atomics per image, ~20x the compulsory write
+//   traffic (profiles/r02t_pmc_render_summary.txt), 0.87 ms of a 2.5 ms backward.
+//   Two measurements changed the design (tools/ubench/lds_atomic.hip, round 3): (1) ds_add_f64 runs at 9.4 cycles per conflict-free
+//   wave-instruction -- 20x faster than ds_add_f32, 1.5x the 32-bit integer add -- so the sums can simply be DOUBLES: no per-tile
+//   scale, no zeroing, no conversion pass, and more exact than fp32; (2) a patch's footprint in a plane moves by only a few texels
+//   from one slab to the next, so the window can live as long as the block: 16 x 16 texels x 32 channels of fp64 = 64 KB, addressed
+//   modulo 16 in both axes (it follows the footprint without copying); a texel row goes to HBM once, when the footprint has moved
+//   past it, not once per tile.  Three persistent windows do not fit beside the decoder's rows / fragments in one CU's LDS, hence the
+//   split: decode_bwd_tiled_kernel leaves the tile's 256 d_feat rows in HBM (403 MB per image, read back once per plane).
+//   Points whose corners leave the window go straight to HBM atomics (rare), so the result never depends on window placement.
+//   LDS: 64 KB + 4 KB of point data -> two blocks of 512 threads per CU.
+// ------------------------------------------------------------------------------------------------
+constexpr int SCT = 512;                                     // threads per block: 16 half-waves, one 128-byte texel row each
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier: hipcc drains EVERY outstanding
+// memory operation before it (s_waitcnt vmcnt(0)), i.e. also the next tile's rows this kernel requests a whole tile ahead -- their full
+// HBM latency was exposed once per tile (7 us per tile instead of ~2).  Here only the LDS counter is drained; loads stay in flight
+// across the barrier (the hardware does not need them drained) and are awaited where their registers are first used.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, float* __restrict__ d_planes) {
+    __shared__ __attribute__((aligned(16))) double pwin[WIN * WIN * DEC_IN];        // the persistent window: cell ((y & 15) << 4 | (x & 15)), 32 channels each
+    __shared__ int s_base[DT], s_cxy[DT];
+    __shared__ float s_wx[DT], s_wy[DT];
+    __shared__ int s_acc[8];
+    const int t = threadIdx.x;
+    const int lane = t & 63, hw = t >> 5, ch = t & 31;
+    const int pidx = blockIdx.x, pl = blockIdx.y;
+    const int n = pidx / a.patches, patch = pidx - n * a.patches;
+    const int live_pts = a.count[pidx];
+    if (live_pts <= 0) return;
+    float* const gplane = d_planes + (int64_t)(n * 3 + pl) * ((int64_t)a.H * a.W * DEC_IN);
+    for (int i = t; i < WIN * WIN * DEC_IN / 2; i += SCT) reinterpret_cast<double2*>(pwin)[i] = make_double2(0.0, 0.0);
+    int ox = 0, oy = 0;                                      // window origin (texels), valid once `placed`
+    bool placed = false;
+    // one texel row of the window -> HBM (non-zero entries only), then cleared
+    auto flush_cell = [&](int cell, int xx, int yy) {
+        double* pc = pwin + cell * DEC_IN + ch;
+        const double v = *pc;
+        if (v != 0.0) {
+            if (!(a.dbg & 8)) atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, (float)v);
+            *pc = 0.0;
+        }
+    };
+    // The point of thread t (t < 256) in tile kc is entry kc * 256 + t of the patch's depth-binned order.  Its coordinates come out of a
+    // chain of dependent loads (order -> depth / ray), and a wave issues in order: a chain resolved inside one iteration stalls the whole
+    // tile for two memory latencies (measured: 9 us per tile).  So the chain is spread over THREE iterations -- the id two tiles ahead,
+    // the depth / ray one tile ahead, the arithmetic on arrival -- and nothing in the loop waits for a load issued in the same iteration.
+    // Every prefetch is UNCONDITIONAL (clamped indices instead of guards): a load inside a divergent `if` makes hipcc lose count of what is
+    // outstanding, and it then waits with s_waitcnt vmcnt(0) -- for the loads it has just issued for the next tile as well.
+    const int ntiles = (live_pts + DT - 1) / DT;
+    auto load_id = [&](int kc) -> int {
+        const int pos = min(min(kc, ntiles - 1) * DT + (t & (DT - 1)), live_pts - 1);
+        return (int)a.order[(int64_t)pidx * (64 * a.S) + pos];
+    };
+    struct RawPoint { float dpt, o0, o1, o2, d0, d1, d2; };
+    auto load_raw = [&](int id, RawPoint& r) {
+        const int rl = id >> 8, k = id & 255;
+        const int64_t ray = (int64_t)n * a.M + min(patch_ray(patch, rl & 63, a.ray_w, a.patch2d), a.M - 1);
+        r.dpt = a.depths[ray * a.S + min(k, a.S - 1)];
+        const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
+        r.o0 = o[0]; r.o1 = o[1]; r.o2 = o[2]; r.d0 = d[0]; r.d1 = d[1]; r.d2 = d[2];
+    };
+    const float* drows = a.dfeat + (int64_t)pidx * (64 * a.S) * DEC_IN;
+    // this half-wave's 16 rows of a tile, one channel per lane; the NEXT tile's rows are requested while this one is scattered
+    float dv[16], dvn[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dvn[j] = drows[((int64_t)hw * 16 + j) * DEC_IN + ch];
+    int id_cur = load_id(0), id_n = load_id(1);
+    RawPoint raw_n;
+    load_raw(id_cur, raw_n);
+    for (int kc = 0; kc < ntiles; ++kc) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dv[j] = dvn[j];
+        const RawPoint raw = raw_n;
+        const bool valid = t < DT && kc * DT + t < live_pts;
+        id_cur = id_n;
+        id_n = load_id(kc + 2);
+        {
+            const int64_t rowbase = (int64_t)min(kc + 1, ntiles - 1) * DT + hw * 16;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) dvn[j] = drows[(rowbase + j) * DEC_IN + ch];
+        }
+        load_raw(id_cur, raw_n);                             // (id_cur was requested during the previous iteration)
+        float gx, gy;
+        plane_uv(pl, (raw.o0 + raw.dpt * raw.d0) * a.scale, (raw.o1 + raw.dpt * raw.d1) * a.scale, (raw.o2 + raw.dpt * raw.d2) * a.scale, gx, gy);
+        lds_barrier();                                       // the previous tile's atomics are done: s_* and s_acc are free
+        if (t < 4) s_acc[t] = 0;
+        const Corner c = make_corner(gx, gy, a.W, a.H);
+        // points whose four corners all lie outside the plane image contribute nothing to this plane (padding_mode zeros)
+        const bool vin = valid && c.x0 + 1 >= 0 && c.x0 < a.W && c.y0 + 1 >= 0 && c.y0 < a.H;
+        const int cx0 = c.x0, cy0 = c.y0;
+        // window centred on the mean corner of the tile's contributing points (sums are exact in fp32: < 2^24)
+        const float sx = wave_sum(vin ? (float)cx0 : 0.f), sy = wave_sum(vin ? (float)cy0 : 0.f), sc = wave_sum(vin ? 1.f : 0.f);
+        lds_barrier();
+        if (lane == 0 && t < DT) { atomicAdd(&s_acc[0], (int)sx); atomicAdd(&s_acc[1], (int)sy); atomicAdd(&s_acc[2], (int)sc); }
+        lds_barrier();
+        const int cnt = s_acc[2];
+        if (cnt == 0) continue;                              // no point of the tile touches this plane (block-uniform)
+        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;
+        // ---- move the window: texel rows that fall out of [wx0, wx0 + 16) x [wy0, wy0 + 16) go to HBM
+        if (placed && (wx0 != ox || wy0 != oy)) {
+            for (int cell = hw; cell < WIN * WIN; cell += SCT / 32) {
+                const int xo = ox + (((cell & (WIN - 1)) - ox) & (WIN - 1)), yo = oy + (((cell >> 4) - oy) & (WIN - 1));    // the texel this cell holds
+                if (xo < wx0 || xo >= wx0 + WIN || yo < wy0 || yo >= wy0 + WIN) flush_cell(cell, xo, yo);
+            }
+        }
+        ox = wx0; oy = wy0; placed = true;
+        const int lxo = cx0 - wx0, lyo = cy0 - wy0;
+        // fast path: all four corners inside the image AND inside the window -> no per-corner tests in the loop
+        const bool fast = vin && lxo >= 0 && lxo + 1 < WIN && lyo >= 0 && lyo + 1 < WIN &&
+                          c.x0 >= 0 && c.x0 + 1 < a.W && c.y0 >= 0 && c.y0 + 1 < a.H;
+        if (t < DT) {
+            s_base[t] = fast ? (((cy0 & (WIN - 1)) << 4) | (cx0 & (WIN - 1))) : (vin ? -2 : -1);    // the cell of corner (x0, y0)
+            s_cxy[t] = ((lxo + 0x4000) & 0xffff) | ((lyo + 0x4000) << 16);
+            s_wx[t] = c.wx1; s_wy[t] = c.wy1;
+        }
+        lds_barrier();
+        // ---- a half-wave (32 lanes = the 32 channels of one texel row) per point: four ds_add_f64 of 32 consecutive doubles
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int sp = hw * 16 + j;
+            const int base = s_base[sp];
+            if (base == -1) continue;
+            const float fx1 = s_wx[sp], fy1 = s_wy[sp];
+            const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
+            const double dvd = (double)dv[j];
+            if (base >= 0) {
+                if (a.dbg & 32) continue;
+                const int c01 = (base & ~(WIN - 1)) | ((base + 1) & (WIN - 1));            // x + 1, wrapped inside the row
+                const int c10 = (base + WIN) & (WIN * WIN - 1), c11 = (c01 + WIN) & (WIN * WIN - 1);     // y + 1, wrapped
+                atomicAdd(pwin + base * DEC_IN + ch, dvd * (double)(fx0 * fy0));
+                atomicAdd(pwin + c01 * DEC_IN + ch, dvd * (double)(fx1 * fy0));
+                atomicAdd(pwin + c10 * DEC_IN + ch, dvd * (double)(fx0 * fy1));
+                atomicAdd(pwin + c11 * DEC_IN + ch, dvd * (double)(fx1 * fy1));
+                continue;
+            }
+            if (a.dbg & 16) continue;
+            const int pk = s_cxy[sp];
+            const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int cx = qq & 1, cy = qq >> 1;
+                const int xl = lx + cx, yl = ly + cy;
+                const int xx = xl + wx0, yy = yl + wy0;
+                if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
+                const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
+                if (xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
+                    if (!(a.dbg & 32)) atomicAdd(pwin + (((yy & (WIN - 1)) << 4) | (xx & (WIN - 1))) * DEC_IN + ch, dvd * (double)wq);
+                } else if (!(a.dbg & 128)) {
+                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dv[j] * wq);                  // rare: straight to HBM
+                }
+            }
+        }
+    }
+    // ---- the patch is done: everything still resident goes to HBM
+    __syncthreads();
+    if (placed)
+        for (int cell = hw; cell < WIN * WIN; cell += SCT / 32)
+            flush_cell(cell, ox + (((cell & (WIN - 1)) - ox) & (WIN - 1)), oy + (((cell >> 4) - oy) & (WIN - 1)));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1699,14 +1774,16 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     const unsigned grid = (unsigned)std::min<int64_t>(tiles, BWD_MAX_GRID);
     hipStream_t st = as_stream(stream);
     float* frag = workspace;
-    float* part = workspace + FRAG_TOTAL;
+    float* part = workspace + FRAG_TOTAL + 32;                  // (FRAG_TOTAL is a multiple of 64 floats; keep every region 128-byte aligned)
     int32_t* count = reinterpret_cast<int32_t*>(part + (int64_t)grid * 4 * PART_ROW);
-    uint16_t* order = reinterpret_cast<uint16_t*>(count + (((int64_t)N * a.patches + 3) & ~(int64_t)3));
+    uint16_t* order = reinterpret_cast<uint16_t*>(count + (((int64_t)N * a.patches + 31) & ~(int64_t)31));
+    const int64_t order_floats = (((int64_t)N * a.patches * 64 * S + 1) / 2 + 31) & ~(int64_t)31;
+    a.dfeat = reinterpret_cast<float*>(order) + order_floats;
     a.order = order; a.count = count;
     hipLaunchKernelGGL(bin_points_kernel, dim3((unsigned)(N * a.patches)), dim3(256), 0, st, depths_sorted, ray_active, M, S, ray_w, a.patch2d,
                        a.patches, order, count);
     hipLaunchKernelGGL(decoder_frag_kernel, dim3(9), dim3(1024), 0, st, w1t, w2, frag);
-#define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, colors, d_sigma, d_planes_nhwc, part)
+#define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, colors, d_sigma, part)
     if (wgrad) {
         if (d_rgb) SPI_BWD_LAUNCH(true, true); else SPI_BWD_LAUNCH(true, false);
         spi_zero_async(dw1, 64 * 32, st); spi_zero_async(db1, 64, st);
@@ -1716,6 +1793,8 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
         if (d_rgb) SPI_BWD_LAUNCH(false, true); else SPI_BWD_LAUNCH(false, false);
     }
 #undef SPI_BWD_LAUNCH
+    if (!(a.dbg & 1))                                          // (tools/bench_render.py: 1 = decoder only)
+        hipLaunchKernelGGL(plane_scatter_kernel, dim3((unsigned)(N * a.patches), 3), dim3(SCT), 0, st, a, d_planes_nhwc);
     SPI_LAUNCH_CHECK("spi_triplane_decode_bwd_sorted");
     return SPI_OK;
 }
@@ -1724,9 +1803,10 @@ int64_t spi_triplane_decode_bwd_sorted_ws(int N, int M, int S, int ray_w) {
     const bool p2d = (M % ray_w == 0) && (ray_w % 8 == 0) && ((M / ray_w) % 8 == 0);
     const int64_t patches = p2d ? M / 64 : (M + 63) / 64;
     const int64_t tiles = (int64_t)N * patches * ((S + 3) / 4);
-    const int64_t counts = ((int64_t)N * patches + 3) & ~(int64_t)3;                 // int32 per patch (kept 16-byte aligned)
-    const int64_t order = ((int64_t)N * patches * 64 * S + 1) / 2;                   // uint16 per point, in floats
-    return FRAG_TOTAL + std::min<int64_t>(tiles, BWD_MAX_GRID) * 4 * PART_ROW + counts + order;
+    const int64_t counts = ((int64_t)N * patches + 31) & ~(int64_t)31;               // int32 per patch (regions kept 128-byte aligned)
+    const int64_t order = (((int64_t)N * patches * 64 * S + 1) / 2 + 31) & ~(int64_t)31;     // uint16 per point, in floats
+    const int64_t dfeat = (int64_t)N * patches * 64 * S * DEC_IN;                    // the d_feat rows handed from the decoder kernel to the scatter kernel
+    return FRAG_TOTAL + 32 + std::min<int64_t>(tiles, BWD_MAX_GRID) * 4 * PART_ROW + counts + order + dfeat;
 }
 
 int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, float* dw2, float* db2, spi_stream_t stream) {

@@ -16,6 +16,7 @@ __global__ void __launch_bounds__(256) k(float* out, int iters, int stride) {
         else if (MODE == 1) win[idx] += v;
         else if (MODE == 2) atomicAdd(reinterpret_cast<int*>(win) + idx, (int)v);
         else if (MODE == 3) atomicAdd(reinterpret_cast<unsigned long long*>(win) + (idx >> 1), (unsigned long long)v);
+        else if (MODE == 4) atomicAdd(reinterpret_cast<double*>(win) + (idx >> 1), (double)v);
         idx = (idx + 97 * 32) & 8191;           // move to another texel row each iteration
     }
     __syncthreads();
@@ -47,6 +48,7 @@ int main() {
         run<1>("plain RMW", d, stride);
         run<2>("ds_add_u32 (atomicAdd int)", d, stride);
         run<3>("ds_add_u64", d, stride);
+        run<4>("ds_add_f64 (atomicAdd double)", d, stride);
     }
     return 0;
 }
