@@ -634,14 +634,19 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     static_assert(FRAG_TOTAL + 4 * TTILE <= DT * FS + 6 * DT, "fragments + transposition tiles must fit gbuf and the small arrays");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, q = lane & 31, hh = lane >> 5;
-    // Weight-gradient accumulators: the four 32x32 tiles of a wave live in its scratch row in global memory (L2 / MALL) and
-    // are pulled into registers only around their own MFMAs (loaded as the accumulator's initial value, stored back right
-    // after).  Keeping 64 accumulator registers alive across the gather and scatter phases made the compiler spill inside
-    // the scatter loop.
+    // Weight-gradient accumulators: the four 32x32 tiles of a wave (dW1 rows 0-31 / 32-63, dW2 colour rows x hidden 0-31 / 32-63) stay
+    // in 64 registers for the whole kernel and go to the wave's scratch row once, at the end.
     float s_sig[2] = {0.f, 0.f}, s_b1[2] = {0.f, 0.f}, s_b2 = 0.f, s_d = 0.f;
     float* const pr = part + ((int64_t)blockIdx.x * 4 + wave) * PART_ROW;     // this wave's scratch row
-    if (WGRAD)
-        for (int e = lane; e < PART_ROW; e += 64) pr[e] = 0.f;
+    // (Round 2 kept them in that row and pulled them through L2 around their own MFMAs: 64 loads + 64 stores per lane and 32 points.
+    //  2048 rows x 17 KB do not fit the 4 MB of L2 an XCD has: 2 GB per image went out to memory and came back -- the "20x write
+    //  amplification" PMC showed was mostly this, not the scatter.  With the scatter in its own kernel the decoder phases leave room for
+    //  the 64 accumulator registers; the row is written once, at the end.)
+    f32x16_t accW1[2], accW2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accW1[i][r] = 0.f; accW2[i][r] = 0.f; }
     for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     __syncthreads();                                           // LDS of the previous tile is no longer in use
     const int n = tile / (a.patches * a.kchunks);
@@ -797,28 +802,17 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 }
             }
             s_d += dsq;
-#pragma unroll 1
-            for (int i = 0; i < 2; ++i) {
-                f32x16_t HT, aW2;
-                // running sum of this wave's dW2 tile: one base pointer per tile + compile-time offsets (global_load ... offset:imm)
-                float* const pw2 = pr + PART_DW2 + (1 + 4 * hh_) * DEC_HID + i * 32 + q_;              // dW2[o][j]: o = 1 + rowmap(r,h), j = i*32 + q_
-                float* const pw2b = pw2 + 16 * DEC_HID;                                               // rows 16.. (keeps every offset < 4 KB)
-                if (RGB) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) aW2[r] = r < 8 ? pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] : pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID];
-                }
+            for (int i = 0; i < 2; ++i) {
+                f32x16_t HT;
                 transpose(H1[i], HT);                              // HT[r] = H1[i*32 + q_][point rowmap(r, hh_)]
                 float ls = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    if (RGB) aW2 = SPI_MFMA(Y2[r], HT[r], aW2);
+                    if (RGB) accW2[i] = SPI_MFMA(Y2[r], HT[r], accW2[i]);       // dW2[o][j]: o = 1 + rowmap(r',h), j = i*32 + q_
                     ls = fmaf(feat[(pbase + rowmap(r, hh_)) * FS + 32], HT[r], ls);       // sigma row of dW2
                 }
-                if (RGB) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { if (r < 8) pw2[((r & 3) + 8 * (r >> 2)) * DEC_HID] = aW2[r]; else pw2b[((r & 3) + 8 * ((r >> 2) - 2)) * DEC_HID] = aW2[r]; }
-                }
-                s_sig[0] += i == 0 ? ls : 0.f; s_sig[1] += i == 0 ? 0.f : ls;
+                s_sig[i] += ls;
             }
         }
         // dH1[j][p] = W2^T dY1 (+ sigma row) -> dpre1 = dH1 * softplus'(pre1)
@@ -839,22 +833,17 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
             for (int r = 0; r < 16; ++r) dH1[mt][r] *= (H1[mt][r] > 20.f) ? 1.f : (1.f - exp_fast(-H1[mt][r]));
         // ---- weight gradients, part 2: dW1[j][c] += sum_p dpre1[j][p] F[c][p]; the B operand is read from the feature rows (still F)
         if (WGRAD) {
-#pragma unroll 1
-            for (int i = 0; i < 2; ++i) {
-                f32x16_t DT_, aW1;
-                float* const pw1 = pr + (i * 32 + 4 * hh_) * DEC_IN + q_;                             // dW1[j][c]: j = i*32 + rowmap(r,h), c = q_
 #pragma unroll
-                for (int r = 0; r < 16; ++r) aW1[r] = pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN];
+            for (int i = 0; i < 2; ++i) {
+                f32x16_t DT_;
                 transpose(dH1[i], DT_);                            // DT_[r] = dpre1[i*32 + q_][point rowmap(r, hh_)]
                 float lb = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    aW1 = SPI_MFMA(DT_[r], feat[(pbase + rowmap(r, hh_)) * FS + q_], aW1);
+                    accW1[i] = SPI_MFMA(DT_[r], feat[(pbase + rowmap(r, hh_)) * FS + q_], accW1[i]);       // dW1[j][c]: j = i*32 + rowmap(r',h), c = q_
                     lb += DT_[r];
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pw1[((r & 3) + 8 * (r >> 2)) * DEC_IN] = aW1[r];
-                s_b1[0] += i == 0 ? lb : 0.f; s_b1[1] += i == 0 ? 0.f : lb;
+                s_b1[i] += lb;
             }
         }
         // dF[i][p] = W1^T dpre1
@@ -888,7 +877,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     }
     }   // tile loop
     if (WGRAD) {
-        // bias / sigma-row sums -> the wave's scratch row (the dW tiles are already there); decoder_partial_reduce_kernel sums the rows
+        // the wave's four dW tiles + bias / sigma-row sums -> its scratch row; decoder_partial_reduce_kernel sums the rows
+        for (int e = lane; e < PART_ROW; e += 64) pr[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pr[(i * 32 + rowmap(r, hh)) * DEC_IN + q] = accW1[i][r];
+                if (RGB) pr[PART_DW2 + (1 + rowmap(r, hh)) * DEC_HID + i * 32 + q] = accW2[i][r];
+            }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const float sg = s_sig[i] + __shfl_xor(s_sig[i], 32, WAVE);
@@ -923,24 +920,44 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
 constexpr int SCT = 512;                                     // threads per block: 16 half-waves, one 128-byte texel row each
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + barrier: hipcc drains EVERY outstanding
-// memory operation before it (s_waitcnt vmcnt(0)), i.e. also the next tile's rows this kernel requests a whole tile ahead -- their full
-// HBM latency was exposed once per tile (7 us per tile instead of ~2).  Here only the LDS counter is drained; loads stay in flight
-// across the barrier (the hardware does not need them drained) and are awaited where their registers are first used.
+// memory operation before it (s_waitcnt vmcnt(0)), i.e. also the rows this kernel requests a whole tile ahead.  Here only the LDS
+// counter is drained; loads stay in flight across the barrier and are awaited where their registers are first used.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// value of lane `j` of the caller's own half-wave (j: compile-time constant 0..31): two v_readlane + a select, no LDS round trip
+__device__ __forceinline__ int half_bcast(int v, int j, bool upper) {
+    const int lo = __builtin_amdgcn_readlane(v, j), hi = __builtin_amdgcn_readlane(v, j + 32);
+    return upper ? hi : lo;
+}
+__device__ __forceinline__ float half_bcast(float v, int j, bool upper) { return __int_as_float(half_bcast(__float_as_int(v), j, upper)); }
+
 __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, float* __restrict__ d_planes) {
+    // Structure (what the first versions of this kernel got wrong, measured -- profiles/r03*):
+    //  * a tile is only 256 points x 4 row-atomics, so anything paid per tile dominates.  A block-wide reduction for the window centre,
+    //    point data handed from the computing thread to the scattering lanes through LDS arrays and four barriers cost 17 k cycles per
+    //    tile for 5 k cycles of atomics.  Now the window position comes from block-UNIFORM data -- the patch's four corner rays at the
+    //    depth of the tile's first and last point -- so every wave computes it by itself and the window only moves when that footprint
+    //    no longer fits; only such a move needs barriers (the rows that leave are flushed by their owners between two of them).
+    //  * every half-wave prepares the corners of its own 16 points in lanes 0..15 and takes them from there with v_readlane: no LDS arrays.
+    //    What is left is VALU-issue bound (profiles/r03l_pmc_scatter_summary.txt: ~1000 vector instructions per tile and wave at 4 cycles
+    //    each = 93 % of the SIMD's time; a 64-lane variant with one point per wave-instruction and weights prepared once per point
+    //    needed as many -- the per-tile set-up outweighs the shorter loop -- and ran slower).
     __shared__ __attribute__((aligned(16))) double pwin[WIN * WIN * DEC_IN];        // the persistent window: cell ((y & 15) << 4 | (x & 15)), 32 channels each
-    __shared__ int s_base[DT], s_cxy[DT];
-    __shared__ float s_wx[DT], s_wy[DT];
-    __shared__ int s_acc[8];
     const int t = threadIdx.x;
-    const int lane = t & 63, hw = t >> 5, ch = t & 31;
+    const int hw = t >> 5, ch = t & 31;
+    const bool upper = (t & 32) != 0;
     const int pidx = blockIdx.x, pl = blockIdx.y;
     const int n = pidx / a.patches, patch = pidx - n * a.patches;
     const int live_pts = a.count[pidx];
     if (live_pts <= 0) return;
+    // blockIdx.z splits the patch's tiles into consecutive ranges (own window each): 256 patches x 3 planes = 768 blocks would fill the
+    // chip's 512 slots 1.5 times (the second half-round runs on half the chip); 1536 blocks are exactly three rounds.
+    const int ntiles = (live_pts + DT - 1) / DT;
+    const int kc_begin = (int)((int64_t)ntiles * blockIdx.z / gridDim.z), kc_end = (int)((int64_t)ntiles * (blockIdx.z + 1) / gridDim.z);
+    if (kc_begin >= kc_end) return;
     float* const gplane = d_planes + (int64_t)(n * 3 + pl) * ((int64_t)a.H * a.W * DEC_IN);
     for (int i = t; i < WIN * WIN * DEC_IN / 2; i += SCT) reinterpret_cast<double2*>(pwin)[i] = make_double2(0.0, 0.0);
+    __syncthreads();
     int ox = 0, oy = 0;                                      // window origin (texels), valid once `placed`
     bool placed = false;
     // one texel row of the window -> HBM (non-zero entries only), then cleared
@@ -952,118 +969,134 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
             *pc = 0.0;
         }
     };
-    // The point of thread t (t < 256) in tile kc is entry kc * 256 + t of the patch's depth-binned order.  Its coordinates come out of a
-    // chain of dependent loads (order -> depth / ray), and a wave issues in order: a chain resolved inside one iteration stalls the whole
-    // tile for two memory latencies (measured: 9 us per tile).  So the chain is spread over THREE iterations -- the id two tiles ahead,
-    // the depth / ray one tile ahead, the arithmetic on arrival -- and nothing in the loop waits for a load issued in the same iteration.
     // Every prefetch is UNCONDITIONAL (clamped indices instead of guards): a load inside a divergent `if` makes hipcc lose count of what is
-    // outstanding, and it then waits with s_waitcnt vmcnt(0) -- for the loads it has just issued for the next tile as well.
-    const int ntiles = (live_pts + DT - 1) / DT;
-    auto load_id = [&](int kc) -> int {
-        const int pos = min(min(kc, ntiles - 1) * DT + (t & (DT - 1)), live_pts - 1);
-        return (int)a.order[(int64_t)pidx * (64 * a.S) + pos];
-    };
+    // outstanding, and it then waits with s_waitcnt vmcnt(0) -- for the loads it has just issued for the next tile as well.  The chain
+    // order -> depth / ray is spread over three iterations (id two tiles ahead, depth / ray one tile ahead, arithmetic on arrival): a
+    // wave issues in order, and a dependent chain resolved inside one iteration would stall the tile for two memory latencies.
+    const uint16_t* porder = a.order + (int64_t)pidx * (64 * a.S);
+    auto load_id = [&](int kc, int p) -> int { return (int)porder[min(min(kc, ntiles - 1) * DT + p, live_pts - 1)]; };
+    auto ray_of = [&](int id) -> int64_t { return (int64_t)n * a.M + min(patch_ray(patch, (id >> 8) & 63, a.ray_w, a.patch2d), a.M - 1); };
     struct RawPoint { float dpt, o0, o1, o2, d0, d1, d2; };
     auto load_raw = [&](int id, RawPoint& r) {
-        const int rl = id >> 8, k = id & 255;
-        const int64_t ray = (int64_t)n * a.M + min(patch_ray(patch, rl & 63, a.ray_w, a.patch2d), a.M - 1);
-        r.dpt = a.depths[ray * a.S + min(k, a.S - 1)];
+        const int64_t ray = ray_of(id);
+        r.dpt = a.depths[ray * a.S + min(id & 255, a.S - 1)];
         const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
         r.o0 = o[0]; r.o1 = o[1]; r.o2 = o[2]; r.d0 = d[0]; r.d1 = d[1]; r.d2 = d[2];
     };
+    auto uv_of = [&](const RawPoint& r, float dpt, float& gx, float& gy) {
+        plane_uv(pl, (r.o0 + dpt * r.d0) * a.scale, (r.o1 + dpt * r.d1) * a.scale, (r.o2 + dpt * r.d2) * a.scale, gx, gy);
+    };
+    // the patch's four corner rays (rays (0,0), (0,7), (7,0), (7,7) of the 8 x 8 patch): block-uniform, they bound its footprint
+    RawPoint corner[4];
+    load_raw(0 << 8, corner[0]); load_raw(7 << 8, corner[1]); load_raw(56 << 8, corner[2]); load_raw(63 << 8, corner[3]);
+    const int myp = hw * 16 + (t & 15);                      // the point whose corner this lane prepares (lanes 16..31 of a half-wave mirror 0..15)
     const float* drows = a.dfeat + (int64_t)pidx * (64 * a.S) * DEC_IN;
-    // this half-wave's 16 rows of a tile, one channel per lane; the NEXT tile's rows are requested while this one is scattered
-    float dv[16], dvn[16];
+    // this half-wave's 16 rows of a tile, one channel per lane, requested TWO tiles ahead (one tile is ~1.5 us of work, less than an HBM
+    // round trip under load)
+    float dv[16], dvn[16], dvnn[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dvn[j] = drows[((int64_t)hw * 16 + j) * DEC_IN + ch];
-    int id_cur = load_id(0), id_n = load_id(1);
+    for (int j = 0; j < 16; ++j) dvn[j] = drows[((int64_t)kc_begin * DT + hw * 16 + j) * DEC_IN + ch];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dvnn[j] = drows[((int64_t)min(kc_begin + 1, ntiles - 1) * DT + hw * 16 + j) * DEC_IN + ch];
+    int id_cur = load_id(kc_begin, myp), id_n = load_id(kc_begin + 1, myp);
+    int idf_cur = load_id(kc_begin, 0), idl_cur = load_id(kc_begin, DT - 1), idf_n = load_id(kc_begin + 1, 0), idl_n = load_id(kc_begin + 1, DT - 1);      // first / last entry of the tile: uniform
     RawPoint raw_n;
     load_raw(id_cur, raw_n);
-    for (int kc = 0; kc < ntiles; ++kc) {
+    float dfirst_n = a.depths[ray_of(idf_cur) * a.S + min(idf_cur & 255, a.S - 1)];
+    float dlast_n = a.depths[ray_of(idl_cur) * a.S + min(idl_cur & 255, a.S - 1)];
+    constexpr int CELL_SKIP = -1, CELL_SLOW = -2;
+    for (int kc = kc_begin; kc < kc_end; ++kc) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) dv[j] = dvn[j];
+        for (int j = 0; j < 16; ++j) { dv[j] = dvn[j]; dvn[j] = dvnn[j]; }
         const RawPoint raw = raw_n;
-        const bool valid = t < DT && kc * DT + t < live_pts;
-        id_cur = id_n;
-        id_n = load_id(kc + 2);
+        const float dfirst = dfirst_n, dlast = dlast_n;
+        const bool valid = kc * DT + myp < live_pts;
+        id_cur = id_n; idf_cur = idf_n; idl_cur = idl_n;
+        id_n = load_id(kc + 2, myp); idf_n = load_id(kc + 2, 0); idl_n = load_id(kc + 2, DT - 1);
         {
-            const int64_t rowbase = (int64_t)min(kc + 1, ntiles - 1) * DT + hw * 16;
+            const int64_t rowbase = (int64_t)min(kc + 2, ntiles - 1) * DT + hw * 16;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) dvn[j] = drows[(rowbase + j) * DEC_IN + ch];
+            for (int j = 0; j < 16; ++j) dvnn[j] = drows[(rowbase + j) * DEC_IN + ch];
         }
         load_raw(id_cur, raw_n);                             // (id_cur was requested during the previous iteration)
+        dfirst_n = a.depths[ray_of(idf_cur) * a.S + min(idf_cur & 255, a.S - 1)];
+        dlast_n = a.depths[ray_of(idl_cur) * a.S + min(idl_cur & 255, a.S - 1)];
+        // ---- the tile's footprint in this plane: the four corner rays at the depths of its first and last point (block-uniform)
+        int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                float cgx, cgy;
+                uv_of(corner[r], e ? dlast : dfirst, cgx, cgy);
+                const Corner cc = make_corner(cgx, cgy, a.W, a.H);
+                bx0 = min(bx0, cc.x0); bx1 = max(bx1, cc.x0 + 1); by0 = min(by0, cc.y0); by1 = max(by1, cc.y0 + 1);
+            }
+        bx0 -= 1; by0 -= 1; bx1 += 1; by1 += 1;           // (a depth bin is not infinitely thin: one texel of slack)
+        const bool fits = placed && bx0 >= ox && bx1 < ox + WIN && by0 >= oy && by1 < oy + WIN;
+        if (!fits) {
+            const int wx0 = (bx0 + bx1 + 1) / 2 - WIN / 2, wy0 = (by0 + by1 + 1) / 2 - WIN / 2;      // centred on the footprint
+            if (placed) {
+                // ---- move the window: texel rows that fall out of [wx0, wx0 + 16) x [wy0, wy0 + 16) go to HBM.  The only barriers of the loop.
+                lds_barrier();                               // every wave's atomics of the earlier tiles have landed
+                for (int cell = hw; cell < WIN * WIN; cell += SCT / 32) {
+                    const int xo = ox + (((cell & (WIN - 1)) - ox) & (WIN - 1)), yo = oy + (((cell >> 4) - oy) & (WIN - 1));    // the texel this cell holds
+                    if (xo < wx0 || xo >= wx0 + WIN || yo < wy0 || yo >= wy0 + WIN) flush_cell(cell, xo, yo);
+                }
+                lds_barrier();                               // the freed cells are zero before anybody adds to them
+            }
+            ox = wx0; oy = wy0; placed = true;
+        }
+        // ---- this lane's point: corner, bilinear fractions, window cell
         float gx, gy;
-        plane_uv(pl, (raw.o0 + raw.dpt * raw.d0) * a.scale, (raw.o1 + raw.dpt * raw.d1) * a.scale, (raw.o2 + raw.dpt * raw.d2) * a.scale, gx, gy);
-        lds_barrier();                                       // the previous tile's atomics are done: s_* and s_acc are free
-        if (t < 4) s_acc[t] = 0;
+        uv_of(raw, raw.dpt, gx, gy);
         const Corner c = make_corner(gx, gy, a.W, a.H);
         // points whose four corners all lie outside the plane image contribute nothing to this plane (padding_mode zeros)
         const bool vin = valid && c.x0 + 1 >= 0 && c.x0 < a.W && c.y0 + 1 >= 0 && c.y0 < a.H;
-        const int cx0 = c.x0, cy0 = c.y0;
-        // window centred on the mean corner of the tile's contributing points (sums are exact in fp32: < 2^24)
-        const float sx = wave_sum(vin ? (float)cx0 : 0.f), sy = wave_sum(vin ? (float)cy0 : 0.f), sc = wave_sum(vin ? 1.f : 0.f);
-        lds_barrier();
-        if (lane == 0 && t < DT) { atomicAdd(&s_acc[0], (int)sx); atomicAdd(&s_acc[1], (int)sy); atomicAdd(&s_acc[2], (int)sc); }
-        lds_barrier();
-        const int cnt = s_acc[2];
-        if (cnt == 0) continue;                              // no point of the tile touches this plane (block-uniform)
-        const int wx0 = s_acc[0] / cnt - WIN / 2 + 1, wy0 = s_acc[1] / cnt - WIN / 2 + 1;
-        // ---- move the window: texel rows that fall out of [wx0, wx0 + 16) x [wy0, wy0 + 16) go to HBM
-        if (placed && (wx0 != ox || wy0 != oy)) {
-            for (int cell = hw; cell < WIN * WIN; cell += SCT / 32) {
-                const int xo = ox + (((cell & (WIN - 1)) - ox) & (WIN - 1)), yo = oy + (((cell >> 4) - oy) & (WIN - 1));    // the texel this cell holds
-                if (xo < wx0 || xo >= wx0 + WIN || yo < wy0 || yo >= wy0 + WIN) flush_cell(cell, xo, yo);
-            }
-        }
-        ox = wx0; oy = wy0; placed = true;
-        const int lxo = cx0 - wx0, lyo = cy0 - wy0;
+        const int lxo = c.x0 - ox, lyo = c.y0 - oy;
         // fast path: all four corners inside the image AND inside the window -> no per-corner tests in the loop
         const bool fast = vin && lxo >= 0 && lxo + 1 < WIN && lyo >= 0 && lyo + 1 < WIN &&
                           c.x0 >= 0 && c.x0 + 1 < a.W && c.y0 >= 0 && c.y0 + 1 < a.H;
-        if (t < DT) {
-            s_base[t] = fast ? (((cy0 & (WIN - 1)) << 4) | (cx0 & (WIN - 1))) : (vin ? -2 : -1);    // the cell of corner (x0, y0)
-            s_cxy[t] = ((lxo + 0x4000) & 0xffff) | ((lyo + 0x4000) << 16);
-            s_wx[t] = c.wx1; s_wy[t] = c.wy1;
-        }
-        lds_barrier();
+        const int my_base = fast ? (((c.y0 & (WIN - 1)) << 4) | (c.x0 & (WIN - 1))) : (vin ? CELL_SLOW : CELL_SKIP);       // the cell of corner (x0, y0)
+        const int my_xy = ((c.x0 + 0x4000) & 0xffff) | ((c.y0 + 0x4000) << 16);
+        const float my_wx = c.wx1, my_wy = c.wy1;
         // ---- a half-wave (32 lanes = the 32 channels of one texel row) per point: four ds_add_f64 of 32 consecutive doubles
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const int sp = hw * 16 + j;
-            const int base = s_base[sp];
-            if (base == -1) continue;
-            const float fx1 = s_wx[sp], fy1 = s_wy[sp];
+            const int base = half_bcast(my_base, j, upper);
+            if (base == CELL_SKIP) continue;
+            const float fx1 = half_bcast(my_wx, j, upper), fy1 = half_bcast(my_wy, j, upper);
             const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
-            const double dvd = (double)dv[j];
+            const float dvj = dv[j];
             if (base >= 0) {
                 if (a.dbg & 32) continue;
                 const int c01 = (base & ~(WIN - 1)) | ((base + 1) & (WIN - 1));            // x + 1, wrapped inside the row
                 const int c10 = (base + WIN) & (WIN * WIN - 1), c11 = (c01 + WIN) & (WIN * WIN - 1);     // y + 1, wrapped
-                atomicAdd(pwin + base * DEC_IN + ch, dvd * (double)(fx0 * fy0));
-                atomicAdd(pwin + c01 * DEC_IN + ch, dvd * (double)(fx1 * fy0));
-                atomicAdd(pwin + c10 * DEC_IN + ch, dvd * (double)(fx0 * fy1));
-                atomicAdd(pwin + c11 * DEC_IN + ch, dvd * (double)(fx1 * fy1));
+                // the product in fp32 (what grid_sample's backward forms too), the SUM in fp64
+                atomicAdd(pwin + base * DEC_IN + ch, (double)(dvj * (fx0 * fy0)));
+                atomicAdd(pwin + c01 * DEC_IN + ch, (double)(dvj * (fx1 * fy0)));
+                atomicAdd(pwin + c10 * DEC_IN + ch, (double)(dvj * (fx0 * fy1)));
+                atomicAdd(pwin + c11 * DEC_IN + ch, (double)(dvj * (fx1 * fy1)));
                 continue;
             }
             if (a.dbg & 16) continue;
-            const int pk = s_cxy[sp];
-            const int lx = (pk & 0xffff) - 0x4000, ly = (pk >> 16) - 0x4000;
+            const int pk = half_bcast(my_xy, j, upper);
+            const int x0 = (pk & 0xffff) - 0x4000, y0 = (pk >> 16) - 0x4000;
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int cx = qq & 1, cy = qq >> 1;
-                const int xl = lx + cx, yl = ly + cy;
-                const int xx = xl + wx0, yy = yl + wy0;
+                const int xx = x0 + cx, yy = y0 + cy;
                 if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
                 const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
-                if (xl >= 0 && xl < WIN && yl >= 0 && yl < WIN) {
-                    if (!(a.dbg & 32)) atomicAdd(pwin + (((yy & (WIN - 1)) << 4) | (xx & (WIN - 1))) * DEC_IN + ch, dvd * (double)wq);
+                if (xx >= ox && xx < ox + WIN && yy >= oy && yy < oy + WIN) {
+                    if (!(a.dbg & 32)) atomicAdd(pwin + (((yy & (WIN - 1)) << 4) | (xx & (WIN - 1))) * DEC_IN + ch, (double)(dvj * wq));
                 } else if (!(a.dbg & 128)) {
-                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dv[j] * wq);                  // rare: straight to HBM
+                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dvj * wq);                    // rare: straight to HBM
                 }
             }
         }
     }
-    // ---- the patch is done: everything still resident goes to HBM
+    // ---- the block's tiles are done: everything still resident goes to HBM
     __syncthreads();
     if (placed)
         for (int cell = hw; cell < WIN * WIN; cell += SCT / 32)
@@ -1794,7 +1827,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     }
 #undef SPI_BWD_LAUNCH
     if (!(a.dbg & 1))                                          // (tools/bench_render.py: 1 = decoder only)
-        hipLaunchKernelGGL(plane_scatter_kernel, dim3((unsigned)(N * a.patches), 3), dim3(SCT), 0, st, a, d_planes_nhwc);
+        hipLaunchKernelGGL(plane_scatter_kernel, dim3((unsigned)(N * a.patches), 3, 2), dim3(SCT), 0, st, a, d_planes_nhwc);
     SPI_LAUNCH_CHECK("spi_triplane_decode_bwd_sorted");
     return SPI_OK;
 }
