@@ -1244,6 +1244,7 @@ constexpr int MAXS = 256;
 constexpr int RM_WAVES = 4;
 
 struct MarchLds { float sig[MAXS]; float dep[MAXS]; float w[MAXS]; float q[MAXS]; int row[MAXS]; };
+struct MarchLdsFwd : MarchLds { float sraw[MAXS]; };          // + the ray's densities in storage order (forward)
 
 __device__ __forceinline__ int64_t row_of(const int32_t* perm, int64_t r, int S, int S_store, int k) {
     return r * S_store + (perm ? perm[r * S + k] : k);
@@ -1311,11 +1312,11 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
         const int32_t* __restrict__ perm, const float* __restrict__ clamp2, int64_t R, int S, int S_store, int white_back,
         float* __restrict__ rgb, float* __restrict__ depth_out, float* __restrict__ weights, float* __restrict__ wsum_out) {
-    __shared__ MarchLds lds[RM_WAVES];
+    __shared__ MarchLdsFwd lds[RM_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
     if (r >= R) return;
-    MarchLds& L = lds[wave];
+    MarchLdsFwd& L = lds[wave];
     // Round trip 1: the ray's sort permutation and depths.  Round trip 2: the densities they point to AND all colour rows of
     // the ray (NCH*8 float4 per lane, 8 rows = 1 KB per wave-instruction), requested together so that the ~24 KB stream is in
     // flight while the densities arrive and the scans and exponentials run.  All loads are unconditional on clamped indices.
@@ -1329,14 +1330,22 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
             pk[c] = perm ? perm[r * S + k] : k;
             dp[c] = depths[r * S + k];
         }
+        // the ray's densities in STORAGE order, coalesced, in the same round trip as the permutation; the permutation is applied from LDS
+        // (gathering them through perm from global memory was a second, dependent round trip: final march 0.75 -> 0.80 of the HBM roofline,
+        // and the depth-only marches read nothing else)
+        float sr[MAXS / 64];
+#pragma unroll
+        for (int c = 0; c < MAXS / 64; ++c) sr[c] = densities[r * S_store + min(c * 64 + lane, S_store - 1)];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int k = c * 64 + lane;
             if (k < S) { L.row[k] = pk[c]; L.dep[k] = dp[c]; }
         }
+#pragma unroll
+        for (int c = 0; c < MAXS / 64; ++c) { const int k = c * 64 + lane; if (k < S_store) L.sraw[k] = sr[c]; }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) sg[c] = densities[r * S_store + pk[c]];
+        for (int c = 0; c < NCH; ++c) sg[c] = L.sraw[pk[c]];
         if (rgb != nullptr) {
 #pragma unroll
             for (int it = 0; it < NCH * 8; ++it) {
