@@ -49,7 +49,9 @@ conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
 stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'
 
 # stage 2: the same for the RotBbox iteration (rot_bbox_cx_coach.py): one graph for the plain iteration, one for the iteration with the
-# rot / mirror-rot / depth branches; the early-stop test and the Adam launch stay on the host.  OPT-IN (SPI_STAGE2_GRAPH=1): correct
-# at reduced size (test_stage2_hip_graph_replay_equals_eager_iterations) and for the plain iteration at full size, but the replayed
-# branch iteration faults inside torch's min-reduction backward at full size on ROCm 7.0 / torch 2.10 -- eager by default.
+# rot / mirror-rot / depth branches; the early-stop test and the Adam launch stay on the host.  OPT-IN (SPI_STAGE2_GRAPH=1).  Since round 3
+# it replays correctly at full size (BoxCX uses amin / amax: the index scatter of torch.min's backward faulted under replay;
+# test_stage2_hip_graph_replay_equals_eager_iterations_full_size), but it is SLOWER than eager enqueueing -- 33.0 vs 35.0 it/s: the host
+# reads the early-stop flag after every replay before it may launch Adam and the next 3 500-node graph, and the GPU idles meanwhile --
+# so eager stays the default; what it buys is host time (one graph launch instead of ~25 ms of enqueue work per iteration).
 stage2_hip_graph = os.environ.get('SPI_STAGE2_GRAPH', '0') == '1'

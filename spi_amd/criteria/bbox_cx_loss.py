@@ -100,7 +100,10 @@ def compute_cosine_distance(x, y):
 
 
 def compute_relative_distance(dist_raw):
-    dist_min, _ = torch.min(dist_raw, dim=2, keepdim=True)
+    # amin, not min(dim)[0] as the reference writes it (bbox_cx_loss.py:113): the same value; the backward is a mask multiply instead of an
+    # index scatter through the saved argmin -- which is what faulted when the iteration was replayed from a captured HIP graph.
+    # (Exact ties share the gradient instead of giving it to the first index: measure zero on float features.)
+    dist_min = torch.amin(dist_raw, dim=2, keepdim=True)
     return torch.clamp(dist_raw / (dist_min + 1e-5), max=10., min=-10)
 
 
@@ -156,6 +159,6 @@ class BoxCXLoss(torch.nn.Module):
         yn = F.normalize(fy5 - y_mu, p=2, dim=2).reshape(nb * n, c, fh * fw)
         dist = 1 - torch.bmm(xn.transpose(1, 2), yn)
         cx = compute_cx(compute_relative_distance(dist), self.band_width)
-        cx = torch.mean(torch.max(cx, dim=1)[0], dim=1)                             # [nb * n]
+        cx = torch.mean(torch.amax(cx, dim=1), dim=1)                               # [nb * n]  (amax: see compute_relative_distance)
         loss = (-torch.log(cx + 1e-5)).reshape(nb, n).mean(dim=1).sum()
         return loss * 0.1

@@ -647,38 +647,66 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { accW1[i][r] = 0.f; accW2[i][r] = 0.f; }
+    // The weight fragments go to LDS ONCE (round 2 re-copied the 25 KB for every tile: the scatter phase used to overwrite them).
+    if (!(a.dbg & 4))
+        for (int i = t; i < FRAG_TOTAL; i += DT) gbuf[i] = frag_g[i];
+    // A tile's point data comes out of a chain of dependent loads: count -> order -> permutation / depth / ray -> gradient rows.  A wave issues
+    // in order, so a chain resolved at the top of a tile stalls it for three memory latencies (and a load inside a divergent `if` makes hipcc
+    // wait for everything outstanding).  The chain is spread over the tile loop instead -- the id two tiles ahead, permutation / depth / ray
+    // one tile ahead -- with unconditional loads on clamped indices; the gradient rows of the current tile are requested at its top and
+    // written to LDS after the gather phase, which hides them.
+    const int tpp = a.patches * a.kchunks;
+    auto tile_pidx = [&](int tl, int& kc_) -> int { const int tc = min(tl, a.tiles - 1); const int n_ = tc / tpp; const int rem_ = tc - n_ * tpp; const int patch_ = rem_ / a.kchunks; kc_ = rem_ - patch_ * a.kchunks; return n_ * a.patches + patch_; };
+    auto load_live = [&](int tl) -> int { int kc_; return a.count[tile_pidx(tl, kc_)]; };
+    auto load_id = [&](int tl, int live) -> int {
+        int kc_; const int pidx_ = tile_pidx(tl, kc_);
+        return (int)a.order[(int64_t)pidx_ * (64 * a.S) + max(min(kc_ * DT + t, live - 1), 0)];
+    };
+    struct RawPoint { int prow; float dpt, o0, o1, o2, d0, d1, d2; };
+    auto load_raw = [&](int tl, int id, RawPoint& r) {
+        int kc_; const int pidx_ = tile_pidx(tl, kc_);
+        const int n_ = pidx_ / a.patches, patch_ = pidx_ - n_ * a.patches;
+        const int k_ = min(id & 255, a.S - 1);
+        const int64_t ray = (int64_t)n_ * a.M + min(patch_ray(patch_, (id >> 8) & 63, a.ray_w, a.patch2d), a.M - 1);
+        const int64_t si = ray * a.S + k_;
+        r.prow = a.perm ? a.perm[si] : k_;                    // (block-uniform branch)
+        r.dpt = a.depths[si];
+        const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
+        r.o0 = o[0]; r.o1 = o[1]; r.o2 = o[2]; r.d0 = d[0]; r.d1 = d[1]; r.d2 = d[2];
+    };
+    const int G = (int)gridDim.x;
+    int live_cur = load_live(blockIdx.x), live_n = load_live(blockIdx.x + G), live_nn = load_live(blockIdx.x + 2 * G);
+    int id_cur = load_id(blockIdx.x, live_cur), id_n = load_id(blockIdx.x + G, live_n);
+    RawPoint raw_n;
+    load_raw(blockIdx.x, id_cur, raw_n);
     for (int tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     __syncthreads();                                           // LDS of the previous tile is no longer in use
-    const int n = tile / (a.patches * a.kchunks);
-    const int rem = tile - n * (a.patches * a.kchunks);
+    const int n = tile / tpp;
+    const int rem = tile - n * tpp;
     const int patch = rem / a.kchunks, kc = rem - patch * a.kchunks;
-    // ---- point owned by this thread: entry kc * 256 + t of the patch's depth-binned order
     const int pidx = n * a.patches + patch;
-    const int live_pts = a.count[pidx];
+    // ---- rotate the prefetch pipeline (before any early exit)
+    const RawPoint raw = raw_n;
+    const int id = id_cur, live_pts = live_cur;
+    id_cur = id_n; live_cur = live_n; live_n = live_nn;
+    live_nn = load_live(tile + 3 * G);
+    id_n = load_id(tile + 2 * G, live_n);
+    load_raw(tile + G, id_cur, raw_n);
     if (kc * DT >= live_pts) continue;                         // past the patch's last live point (block-uniform)
+    // ---- point owned by this thread: entry kc * 256 + t of the patch's depth-binned order
     const int pos = kc * DT + t;
     const bool valid = pos < live_pts;
-    const int id = valid ? (int)a.order[(int64_t)pidx * (64 * a.S) + pos] : 0;
-    const int rl = id >> 8, k = id & 255;
-    const int m = patch_ray(patch, rl, a.ray_w, a.patch2d);
-    int row = -1;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (valid) {
-        const int64_t ray = (int64_t)n * a.M + m;
-        const int64_t si = ray * a.S + k;
-        row = (int)(ray * a.S + (a.perm ? a.perm[si] : k));
-        const float dpt = a.depths[si];
-        const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
-        x = (o[0] + dpt * d[0]) * a.scale; y = (o[1] + dpt * d[1]) * a.scale; z = (o[2] + dpt * d[2]) * a.scale;
-    }
+    const int rl = (id >> 8) & 63, k = min(id & 255, a.S - 1);
+    const int m = min(patch_ray(patch, rl, a.ray_w, a.patch2d), a.M - 1);
+    const int64_t ray = (int64_t)n * a.M + m;
+    const int row = valid ? (int)(ray * a.S + raw.prow) : -1;
+    const float x = valid ? (raw.o0 + raw.dpt * raw.d0) * a.scale : 0.f, y = valid ? (raw.o1 + raw.dpt * raw.d1) * a.scale : 0.f,
+                z = valid ? (raw.o2 + raw.dpt * raw.d2) * a.scale : 0.f;
     s_x[t] = x; s_y[t] = y; s_z[t] = z; s_row[t] = row;
-    feat[t * FS + 32] = valid ? d_sigma[row] : 0.f;
-    if (RGB && d_rgb_scale) {                                  // columns 33 / 34 of the point's LDS row: its ray and its colour-gradient scale
-        feat[t * FS + 33] = __int_as_float(valid ? n * a.M + m : 0);
-        feat[t * FS + 34] = valid ? d_rgb_scale[row] : 0.f;
-    }
-    if (!(a.dbg & 4))
-        for (int i = t; i < FRAG_TOTAL; i += DT) gbuf[i] = frag_g[i];      // weight fragments -> LDS (L2-resident source, same for every tile)
+    // the point's gradient scalars: requested now (clamped row), stored to its LDS row after the gather phase
+    const int64_t rowc = ray * a.S + raw.prow;
+    const float g_sigma = d_sigma[rowc];
+    const float g_scale = (RGB && d_rgb_scale) ? d_rgb_scale[rowc] : 0.f;
     __syncthreads();
     // ---- phase A: gather features, 8 lanes per point
     {
@@ -696,6 +724,11 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         }
         *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
     }
+    }
+    feat[t * FS + 32] = valid ? g_sigma : 0.f;                 // columns 32..34 of the point's LDS row: d_sigma | its ray | its colour-gradient scale
+    if (RGB && d_rgb_scale) {
+        feat[t * FS + 33] = __int_as_float(valid ? n * a.M + m : 0);
+        feat[t * FS + 34] = valid ? g_scale : 0.f;
     }
     __syncthreads();
     // ---- phase B: decoder forward + backward on the matrix cores, 32 points (one MFMA N tile) at a time per wave.

@@ -268,6 +268,67 @@ def test_stage1_hip_graph_captures_beside_an_rccl_process_group():
     assert_close(runs[True][0], runs[False][0], 1e-5, 'w+ graph vs eager beside a process group')
 
 
+@pytest.mark.timeout(1800)
+def test_stage2_hip_graph_replay_equals_eager_iterations_full_size():
+    """The opt-in stage-2 graphs at the benchmark's size (ffhqrebalanced512-128 widths, 512^2, 96+96 samples, all three pseudo-view branches):
+    9 iterations -- eager 0 (branches) and 1, capture of the plain iteration at 2, of the branch iteration at 4, replays of both kinds after --
+    against 9 eager iterations on identical draws.  Until round 3 the replayed mirror-rot branch faulted inside the index scatter of
+    torch.min's backward (BoxCX, bbox_cx_loss.py:113); `amin` / `amax` have a mask backward and the whole iteration replays."""
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.criteria.bbox_cx_loss import BoxCXLoss
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.data.images_dataset import SyntheticDataset
+    from spi_amd.utils.rng import DeviceRNG
+    from spi_amd.configs import hyperparameters, paths_config, global_config
+    import tempfile
+
+    class FixedDraws(DeviceRNG):
+        def __init__(self, device):
+            super().__init__(device)
+            self.cache, self.gen = {}, torch.Generator().manual_seed(9)
+
+        def rand(self, *shape):
+            if shape not in self.cache:
+                self.cache[shape] = torch.rand(*shape, generator=self.gen).to(self.device)
+            return self.cache[shape]
+
+    W, W19 = olo.make_vgg16_weights(seed=0), olo.make_vgg19_head_weights(seed=1)
+    data = SyntheticDataset(1)[0]
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in data.items()}
+    w_pivot = (torch.randn(1, 14, 512, generator=torch.Generator().manual_seed(6)) * 0.7).to(DEV)
+    tmp = tempfile.mkdtemp()
+    for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
+        setattr(paths_config, k, f'{tmp}/{k}/')
+    hyperparameters.first_inv_type, hyperparameters.G_1_type = 'mir', 'RotBbox'
+    hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda = 0.1, 0.05, 1.0
+    hyperparameters.LPIPS_value_threshold = -1.0
+    runs = {}
+    for graph in (False, True):
+        global_config.stage2_hip_graph = graph
+        coach = RotBboxCoach(None, False, G=_full(), lpips_loss=LPIPS(weights=W), box_cx_loss=BoxCXLoss(weights=W19))
+        ctx = coach.prepare_image(data)
+        rng = FixedDraws(DEV)
+        hist = []
+        for i in range(9):
+            stop, losses = coach.train_step(i, ctx, w_pivot, rng=rng)
+            assert not stop
+            hist.append({k: float(v) for k, v in losses.items()})
+        kinds = getattr(coach, '_g2', {})
+        assert (all(kinds.get(k, {}).get('graph') is not None for k in ('plain', 'branch'))) == graph, kinds.keys()
+        runs[graph] = (hist, {k: v.detach().clone() for k, v in coach.G.state_dict().items() if v.dtype.is_floating_point and 'noise_const' not in k})
+        del coach, ctx
+        torch.cuda.empty_cache()
+    worst = 0.0
+    for a, b in zip(runs[True][0], runs[False][0]):
+        assert a.keys() == b.keys() and {'l2', 'lpips'} <= set(a)
+        for k in a:
+            worst = max(worst, abs(a[k] - b[k]) / (abs(b[k]) + 1e-12))
+    errs = {k: rel_err(runs[True][1][k], v) for k, v in runs[False][1].items()}
+    print(f'full-size stage-2 graph vs eager over 9 iterations: worst loss difference {worst:.2e}, worst parameter difference {max(errs.values()):.2e}')
+    assert worst <= 2e-4, worst                                    # (the iterations feed on each other's Adam steps: run-to-run atomics noise grows slowly)
+    assert max(errs.values()) <= 2e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+
+
 @pytest.mark.timeout(2400)
 def test_stage2_rotbbox_iteration_vs_oracle():
     """One full stage-2 iteration (i = 0: main + rot + mirror-rot + depth branches) and one plain iteration."""
