@@ -108,6 +108,35 @@ __device__ __forceinline__ void buf_load12_f32x4(__amdgpu_buffer_rsrc_t rs, cons
                    "v"(o[11]), "s"(rs)
                  : "memory");
 }
+// The same twelve loads WITHOUT the wait, and the wait as its own block: whatever the compiler issues in between (the next pass's coordinate
+// loads in gather_tile) is in flight together with the gathers.  The wait is vmcnt(0) -- loads complete in order, so it covers both -- and
+// takes the twelve destination registers as read-write operands so that nothing uses them before it.  (The compiler's own waitcnt
+// bookkeeping does not see the assembly's loads; its waits for its own, younger loads are therefore conservative, never too short.)
+__device__ __forceinline__ void buf_load12_f32x4_nowait(__amdgpu_buffer_rsrc_t rs, const unsigned (&o)[12], f32x4_t (&v)[12]) {
+    asm volatile("buffer_load_dwordx4 %0, %12, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %1, %13, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %2, %14, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %3, %15, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %4, %16, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %5, %17, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %6, %18, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %7, %19, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %8, %20, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %9, %21, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %10, %22, %24, 0 offen\n\t"
+                 "buffer_load_dwordx4 %11, %23, %24, 0 offen"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7]), "=&v"(v[8]),
+                   "=&v"(v[9]), "=&v"(v[10]), "=&v"(v[11])
+                 : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]), "v"(o[7]), "v"(o[8]), "v"(o[9]), "v"(o[10]),
+                   "v"(o[11]), "s"(rs)
+                 : "memory");
+}
+__device__ __forceinline__ void buf_wait_gathers(f32x4_t (&v)[12]) {
+    asm volatile("s_waitcnt vmcnt(0)"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+                   "+v"(v[10]), "+v"(v[11])
+                 :: "memory");
+}
 __device__ __forceinline__ void buf_load4_f32x4(__amdgpu_buffer_rsrc_t rs, unsigned o0, unsigned o1, unsigned o2, unsigned o3,
                                                f32x4_t& v0, f32x4_t& v1, f32x4_t& v2, f32x4_t& v3) {
     asm volatile("buffer_load_dwordx4 %0, %4, %8, 0 offen\n\t"

@@ -192,20 +192,46 @@ __device__ __forceinline__ float4 gather_point(__amdgpu_buffer_rsrc_t rs, int n,
 }
 
 // Phase A shared by forward and backward: feat[s][0..31] = mean over planes of the bilinear samples.
+// Software-pipelined over the 8 passes of a tile: the coordinates of pass p + 1 (depth / ray loads) are requested right behind the twelve
+// corner gathers of pass p, so a pass costs ONE memory round trip instead of two (coordinates, then gathers).  All loads are unconditional
+// on a clamped point index -- a guarded load would sit in an exec-masked region that hipcc closes with s_waitcnt vmcnt(0).
 __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, int64_t total, float* feat) {
     const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);          // host: < 2 GiB
-#pragma unroll 2
+    int n_next; float xn, yn, zn;
+    point_xyz(a, min(base + grp, total - 1), n_next, xn, yn, zn);
+#pragma unroll
     for (int pass = 0; pass < DT / 32; ++pass) {
         const int s = pass * 32 + grp;
         const int64_t g = base + s;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g < total) {
-            int n; float x, y, z;
-            point_xyz(a, g, n, x, y, z);
-            acc = gather_point(rs, n, x, y, z, a.W, a.H, plane_bytes, sub);
+        const int n = n_next;
+        const float x = xn, y = yn, z = zn;
+        // twelve corner rows of this pass in flight ...
+        unsigned o[12]; float w[12];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            float gx, gy;
+            plane_uv(pl, x, y, z, gx, gy);
+            const CornerOff k = corner_offsets(make_corner(gx, gy, a.W, a.H), a.W, a.H, (unsigned)(n * 3 + pl) * plane_bytes, sub);
+            o[4 * pl] = k.o00; o[4 * pl + 1] = k.o01; o[4 * pl + 2] = k.o10; o[4 * pl + 3] = k.o11;
+            w[4 * pl] = k.w00; w[4 * pl + 1] = k.w01; w[4 * pl + 2] = k.w10; w[4 * pl + 3] = k.w11;
         }
+        f32x4_t v[12];
+        buf_load12_f32x4_nowait(rs, o, v);
+        // ... and the next pass's coordinates behind them
+        if (pass + 1 < DT / 32) point_xyz(a, min(g + 32, total - 1), n_next, xn, yn, zn);
+        buf_wait_gathers(v);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {                       // same summation order as gather_point: per plane, then across planes
+            acc.x += v[4 * pl].x * w[4 * pl] + v[4 * pl + 1].x * w[4 * pl + 1] + v[4 * pl + 2].x * w[4 * pl + 2] + v[4 * pl + 3].x * w[4 * pl + 3];
+            acc.y += v[4 * pl].y * w[4 * pl] + v[4 * pl + 1].y * w[4 * pl + 1] + v[4 * pl + 2].y * w[4 * pl + 2] + v[4 * pl + 3].y * w[4 * pl + 3];
+            acc.z += v[4 * pl].z * w[4 * pl] + v[4 * pl + 1].z * w[4 * pl + 1] + v[4 * pl + 2].z * w[4 * pl + 2] + v[4 * pl + 3].z * w[4 * pl + 3];
+            acc.w += v[4 * pl].w * w[4 * pl] + v[4 * pl + 1].w * w[4 * pl + 1] + v[4 * pl + 2].w * w[4 * pl + 2] + v[4 * pl + 3].w * w[4 * pl + 3];
+        }
+        acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+        if (g >= total) acc = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
     }
 }
