@@ -357,9 +357,10 @@ def main():
         torch.cuda.synchronize()
 
     # set-up, not warm-up: reserve the allocator's pool.  Workspace sizes of the masked branches depend on the iteration's random cameras, so
-    # a later iteration can ask the caching allocator for a block it has not seen yet; a first-time hipMalloc of GBs on a fresh box was
-    # measured as a one-off 80 ms stall inside the timed region (`SPI_BENCH_ITER_TIMES=1`).  One large block allocated and released here stays
-    # in torch's cache and is carved up on demand -- what a long-running inversion service does once at start-up (288 GB of HBM per GPU).
+    # a later iteration can ask the caching allocator for a block it has not seen yet, and a first-time hipMalloc of GBs is a host-side stall.
+    # One large block allocated and released here stays in torch's cache and is carved up on demand -- what a long-running inversion service
+    # does once at start-up (288 GB of HBM per GPU).  (The one-off pause that was actually measured inside the timed region turned out to be
+    # Python's garbage collector, see below; this is the precaution against the other source.)
     pool_gib = 0
     try:
         free_b, _total_b = torch.cuda.mem_get_info(dev)
@@ -406,8 +407,10 @@ def main():
     run(w1, w2, 25, 0)                                           # untimed warm-up (past the 5 % lr ramp-up)
     if os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0':
         # A full (generation-2) collection of the Python heap -- modules, the generator's parameter objects, autograd nodes -- was measured as a
-        # one-off 50-80 ms pause inside the timed region of the FIRST process on a fresh box (more objects alive: byte-compilation); what a
+        # one-off 50-80 ms pause inside the timed region of the FIRST process on a fresh box (`SPI_BENCH_ITER_TIMES=1`: the fifth branch
+        # iteration took 150 ms instead of 70; a 24-step run read 37.6 instead of 40.2 it/s; gone with the two lines below).  What a
         # long-running service does: collect once, then move everything alive into the permanent generation so later collections are cheap.
+        # A real 1500-iteration job pays such a pause a few times = 0.1 %; only a sub-second benchmark window sees it.
         import gc
         gc.collect()
         gc.freeze()
@@ -549,7 +552,7 @@ def main():
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'value_mix': 'stage1:stage2 = 1:2 exact (500:1000), computed from the per-stage rates' if (k1 and k2) else 'single stage', 'timed_steps': {'stage1_mir': k1, 'stage2_rotbbox': k2}},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
-                       'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'stage2_hip_graph': bool(global_config.stage2_hip_graph),
+                       'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph),
                        'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
                                    if global_config.conv_winograd and global_config.conv_precision in (0, 3) else 'implicit GEMM'),
                        'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else
