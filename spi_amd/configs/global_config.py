@@ -55,3 +55,7 @@ stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'
 # reads the early-stop flag after every replay before it may launch Adam and the next 3 500-node graph, and the GPU idles meanwhile --
 # so eager stays the default; what it buys is host time (one graph launch instead of ~25 ms of enqueue work per iteration).
 stage2_hip_graph = os.environ.get('SPI_STAGE2_GRAPH', '0') == '1'
+
+# host side: freeze Python's garbage collector state around the optimisation loops (torch_utils/misc.quiet_gc): a full collection over the
+# whole heap costs 50-80 ms = two or three iterations whenever it strikes inside a loop.
+freeze_gc_in_loops = os.environ.get('SPI_GC_FREEZE', '1') != '0'

@@ -50,3 +50,22 @@ def profiled_function(fn):
         with trace_range(fn.__name__):
             return fn(*args, **kwargs)
     return decorator
+
+
+@contextlib.contextmanager
+def quiet_gc():
+    """Around an optimisation loop: collect once, then move everything alive (modules, parameters, the loss networks) into Python's
+    permanent generation, so that the generation-2 collections triggered by the loop's own churn of autograd nodes stay cheap.  A full
+    collection over the whole heap was measured as a 50-80 ms pause -- two or three iterations' worth -- whenever it struck inside the loop
+    (bench.py, `SPI_BENCH_ITER_TIMES=1`).  ``global_config.freeze_gc_in_loops = False`` / ``SPI_GC_FREEZE=0`` leaves the collector alone."""
+    from ..configs import global_config
+    if not getattr(global_config, 'freeze_gc_in_loops', True):
+        yield
+        return
+    import gc
+    gc.collect()
+    gc.freeze()
+    try:
+        yield
+    finally:
+        gc.unfreeze()

@@ -65,15 +65,17 @@ class SingleIDCoach(BaseCoach):
             feats = self.lpips_loss.features(image)
             iters = 0
             log_images_counter = 0
-            for i in range(hyperparameters.G_1_step):
-                stop, losses = self.train_step(image, camera, w_pivot, feats)
-                iters += 1
-                if stop:
-                    break
-                if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:81-82)
-                    self.log_image_from_w(w_pivot, camera, self.G, f'{image_name}_G1_inv_{log_images_counter}')
-                global_config.training_step += 1
-                log_images_counter += 1
+            from ...torch_utils.misc import quiet_gc
+            with quiet_gc():
+                for i in range(hyperparameters.G_1_step):
+                    stop, losses = self.train_step(image, camera, w_pivot, feats)
+                    iters += 1
+                    if stop:
+                        break
+                    if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:81-82)
+                        self.log_image_from_w(w_pivot, camera, self.G, f'{image_name}_G1_inv_{log_images_counter}')
+                    global_config.training_step += 1
+                    log_images_counter += 1
             self.image_counter += 1
             self.finish_image(image_name, image, camera, w_pivot)
             stats.append(dict(name=image_name, iters=iters, stage1_iters=0 if embedding_loaded else hyperparameters.first_inv_steps))

@@ -308,15 +308,17 @@ class RotBboxCoach(BaseCoach):
             w_pivot = self.get_inversion(image_name, ctx['image'], ctx['camera'], fg_mask=ctx['fg_mask'])
             iters = 0
             log_images_counter = 0
-            for i in range(hyperparameters.G_1_step):
-                stop, losses = self.train_step(i, ctx, w_pivot)
-                iters += 1
-                if stop:
-                    break
-                if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:153-154)
-                    self.log_image_from_w(w_pivot, ctx['camera'], self.G, f'{image_name}_G1_inv_{log_images_counter}')
-                global_config.training_step += 1
-                log_images_counter += 1
+            from ...torch_utils.misc import quiet_gc
+            with quiet_gc():
+                for i in range(hyperparameters.G_1_step):
+                    stop, losses = self.train_step(i, ctx, w_pivot)
+                    iters += 1
+                    if stop:
+                        break
+                    if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:153-154)
+                        self.log_image_from_w(w_pivot, ctx['camera'], self.G, f'{image_name}_G1_inv_{log_images_counter}')
+                    global_config.training_step += 1
+                    log_images_counter += 1
             self.image_counter += 1
             self.finish_image(image_name, ctx['image'], ctx['camera'], w_pivot)
             st = dict(name=image_name, iters=iters, stage1_iters=0 if embedding_loaded else hyperparameters.first_inv_steps)

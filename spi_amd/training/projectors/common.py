@@ -241,8 +241,10 @@ def run_projection(G, cameras, dist_fn, *, w_mode, initial_w, num_steps, w_avg_s
     """Generic stage-1 loop.  ``cameras`` [B,25]; ``dist_fn(images [B,3,R,R]) -> scalar``; w_mode 'w' | 'w+'."""
     proj = Projection(G, cameras, dist_fn, w_mode=w_mode, initial_w=initial_w, num_steps=num_steps, w_avg_samples=w_avg_samples,
                       device=device, rng=rng, regularize_noise_weight=regularize_noise_weight, schedule_kwargs=schedule_kwargs)
-    for step in range(num_steps):
-        out = proj.step(step)
-        if log is not None:
-            log.append(dict(out, w=proj.w_opt.detach().clone(), grad_w=proj.w_opt.grad.detach().clone()))
+    from ...torch_utils.misc import quiet_gc
+    with quiet_gc():
+        for step in range(num_steps):
+            out = proj.step(step)
+            if log is not None:
+                log.append(dict(out, w=proj.w_opt.detach().clone(), grad_w=proj.w_opt.grad.detach().clone()))
     return proj.w_opt
