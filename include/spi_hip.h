@@ -27,7 +27,7 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 4   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 5   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive) */
 int         spi_abi_version(void);
@@ -338,11 +338,31 @@ int spi_lpips_layer_fwd(const float* fx, const float* fy, const float* lin, int 
 int spi_lpips_layer_bwd(const float* fx, const float* fy, const float* lin, const float* d_out, int N,
                         int C, int64_t HW, float* d_fx, spi_stream_t stream);
 
+/* Contextual-loss chain of BoxCXLoss, bbox_cx_loss.py:93-129 (compute_cosine_distance's `1 - sim`, compute_relative_distance,
+ * compute_cx, and the max / mean of compute_cx_loss before its -log), fused row-wise:
+ *   out[b] = mean_j max_i cx[b,i,j],  cx = softmax_j((1 - rel)/band_width),  rel = clamp((1-sim)/(min_j(1-sim) + 1e-5), -10, 10)
+ *   sim [B,P1,P2] cosine matrix (the torch.bmm of the normalised features stays with the caller); out [B].
+ * Saved for the backward: row_min / row_sum [B,P1] (min_j dist, sum_j w), row_argmin [B,P1], col_argmax [B,P2] (int32).
+ * workspace: spi_contextual_workspace_bytes(B,P1,P2) bytes of device scratch.  P2 <= 16384.  Exact ties of a minimum / maximum give
+ * their gradient to the first index (torch.amin / amax split it evenly). */
+int64_t spi_contextual_workspace_bytes(int B, int P1, int P2);
+int spi_contextual_fwd(const float* sim, int B, int P1, int P2, float band_width, float* out, float* row_min,
+                       float* row_sum, int32_t* row_argmin, int32_t* col_argmax, void* workspace, spi_stream_t stream);
+/* d_out [B] -> d_sim [B,P1,P2] (every element written). */
+int spi_contextual_bwd(const float* sim, const float* d_out, int B, int P1, int P2, float band_width,
+                       const float* row_min, const float* row_sum, const int32_t* row_argmin,
+                       const int32_t* col_argmax, float* d_sim, spi_stream_t stream);
+
 /* torch.optim.Adam (no amsgrad, no weight decay) over a list of tensors in one launch.
  *   ptrs: device array of 4*T pointers {param, grad, exp_avg, exp_avg_sq} per tensor; sizes: device int64 [T].
  *   step is the 1-based step count used for bias correction. */
 int spi_adam_multi(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, float lr, float beta1,
                    float beta2, float eps, int step, spi_stream_t stream);
+/* spi_adam_multi predicated on a DEVICE byte: *skip != 0 -> nothing is written.  The reference tests `loss_lpips <= threshold` on the
+ * host before optimizer.step() (rot_bbox_cx_coach.py:148-151); a loop that enqueues iterations ahead of that read leaves the decision in
+ * device memory and lets this launch honour it, so the parameters end exactly where the reference's break leaves them. */
+int spi_adam_multi_pred(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, float lr, float beta1,
+                        float beta2, float eps, int step, const unsigned char* skip, spi_stream_t stream);
 /* The same launch with its step-dependent scalars in DEVICE memory: hyper = {lr, 1 - beta1^step, sqrt(1 - beta2^step)} (3 floats).
  * A stage-1 step captured in a HIP graph replays this launch unchanged; the host refreshes `hyper` (one 12-byte copy) before
  * each replay. */

@@ -167,16 +167,22 @@ def roi_align(x, boxes, out=80):
     return torch.stack(res)
 
 
-def contextual_loss(fx, fy, band_width=0.5):
-    mu = fy.mean(dim=(0, 2, 3), keepdim=True)
-    xn = F.normalize(fx - mu, p=2, dim=1).flatten(2)
-    yn = F.normalize(fy - mu, p=2, dim=1).flatten(2)
-    dist = 1 - torch.bmm(xn.transpose(1, 2), yn)
+def contextual_cx(sim, band_width=0.5):
+    """[B,P1,P2] cosine matrix -> mean_j max_i CX [B]: compute_relative_distance, compute_cx and the max / mean of compute_cx_loss
+    (spi/criteria/bbox_cx_loss.py:111-129)."""
+    dist = 1 - sim
     dmin = dist.min(dim=2, keepdim=True)[0]
     dt = torch.clamp(dist / (dmin + 1e-5), max=10., min=-10)
     wgt = torch.exp((1 - dt) / band_width)
     cx = wgt / wgt.sum(dim=2, keepdim=True)
-    cx = cx.max(dim=1)[0].mean(dim=1)
+    return cx.max(dim=1)[0].mean(dim=1)
+
+
+def contextual_loss(fx, fy, band_width=0.5):
+    mu = fy.mean(dim=(0, 2, 3), keepdim=True)
+    xn = F.normalize(fx - mu, p=2, dim=1).flatten(2)
+    yn = F.normalize(fy - mu, p=2, dim=1).flatten(2)
+    cx = contextual_cx(torch.bmm(xn.transpose(1, 2), yn), band_width)
     return torch.mean(-torch.log(cx + 1e-5))
 
 

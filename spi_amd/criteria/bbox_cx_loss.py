@@ -112,6 +112,44 @@ def compute_cx(dist_tilde, band_width):
     return w / torch.sum(w, dim=2, keepdim=True)
 
 
+class _ContextualCX(torch.autograd.Function):
+    """sim [B,P1,P2] -> mean_j max_i cx  [B]: `1 - sim`, compute_relative_distance, compute_cx and the max / mean of the reference's
+    compute_cx_loss (bbox_cx_loss.py:93-129) in two launches forward, one backward (csrc/losses.hip) instead of ~25 ATen passes."""
+
+    @staticmethod
+    def forward(ctx, sim, band_width):
+        from .. import hip
+        sim = sim.contiguous()
+        b, p1, p2 = sim.shape
+        dev = sim.device
+        out = torch.empty(b, device=dev)
+        stats = torch.empty(2, b, p1, device=dev)
+        row_argmin = torch.empty(b, p1, dtype=torch.int32, device=dev)
+        col_argmax = torch.empty(b, p2, dtype=torch.int32, device=dev)
+        ws = torch.empty(hip.lib().spi_contextual_workspace_bytes(b, p1, p2), dtype=torch.uint8, device=dev)
+        hip.call('spi_contextual_fwd', hip.ptr(sim), b, p1, p2, float(band_width), hip.ptr(out), hip.ptr(stats[0]), hip.ptr(stats[1]),
+                 row_argmin.data_ptr(), col_argmax.data_ptr(), ws.data_ptr(), hip.stream())
+        ctx.save_for_backward(sim, stats, row_argmin, col_argmax)
+        ctx.band_width = float(band_width)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        from .. import hip
+        sim, stats, row_argmin, col_argmax = ctx.saved_tensors
+        b, p1, p2 = sim.shape
+        d_sim = torch.empty_like(sim)
+        hip.call('spi_contextual_bwd', hip.ptr(sim), hip.ptr(d_out.contiguous().float()), b, p1, p2, ctx.band_width, hip.ptr(stats[0]), hip.ptr(stats[1]),
+                 row_argmin.data_ptr(), col_argmax.data_ptr(), hip.ptr(d_sim), hip.stream())
+        return d_sim, None
+
+
+def contextual_cx(sim, band_width):
+    """mean_j max_i CX of a cosine matrix sim [B,P1,P2] -> [B] as one fused HIP op (GPU tensors only, like every kernel of this package).
+    ``compute_relative_distance`` / ``compute_cx`` above keep the reference's step-by-step functions."""
+    return _ContextualCX.apply(sim, band_width)
+
+
 class BoxCXLoss(torch.nn.Module):
     def __init__(self, band_width=0.5, weights=None, seed=1):
         super().__init__()
@@ -157,8 +195,6 @@ class BoxCXLoss(torch.nn.Module):
         y_mu = fy5.mean(dim=(1, 3, 4), keepdim=True)                               # per box: mean over its batch and positions (:93)
         xn = F.normalize(fx5 - y_mu, p=2, dim=2).reshape(nb * n, c, fh * fw)
         yn = F.normalize(fy5 - y_mu, p=2, dim=2).reshape(nb * n, c, fh * fw)
-        dist = 1 - torch.bmm(xn.transpose(1, 2), yn)
-        cx = compute_cx(compute_relative_distance(dist), self.band_width)
-        cx = torch.mean(torch.amax(cx, dim=1), dim=1)                               # [nb * n]  (amax: see compute_relative_distance)
+        cx = contextual_cx(torch.bmm(xn.transpose(1, 2), yn), self.band_width)      # [nb * n]
         loss = (-torch.log(cx + 1e-5)).reshape(nb, n).mean(dim=1).sum()
         return loss * 0.1

@@ -810,8 +810,12 @@ __global__ void __launch_bounds__(1024) lpips_bwd_kernel(const float* __restrict
 // denom = sqrt(v)/sqrt(bc2) + eps, p -= lr/bc1 * m/denom) for T tensors in one launch.
 // ------------------------------------------------------------------------------------------------
 // hyper != NULL: {lr, bc1, bc2_sqrt} are read from device memory (a captured HIP graph replays the launch with new values each step)
+// skip != NULL: a device byte; non-zero -> the launch changes nothing (the early-stop decision of a loop that runs ahead of its host, see
+// spi_adam_multi_pred)
 __global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t* __restrict__ sizes, float lr, float beta1,
-                                  float beta2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ hyper) {
+                                  float beta2, float eps, float bc1, float bc2_sqrt, const float* __restrict__ hyper,
+                                  const unsigned char* __restrict__ skip) {
+    if (skip && *skip) return;
     if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }
     const int t = blockIdx.y;
     const int64_t n = sizes[t];
@@ -1267,8 +1271,20 @@ int spi_adam_multi(void* const* ptrs, const int64_t* sizes, int T, int64_t max_s
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(max_size, 256 * 4), 2048);
     hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)T), dim3(256), 0, as_stream(stream), ptrs, sizes, lr, beta1, beta2, eps, bc1, bc2_sqrt,
-                       (const float*)nullptr);
+                       (const float*)nullptr, (const unsigned char*)nullptr);
     SPI_LAUNCH_CHECK("spi_adam_multi");
+    return SPI_OK;
+}
+
+int spi_adam_multi_pred(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, float lr, float beta1, float beta2,
+                        float eps, int step, const unsigned char* skip, spi_stream_t stream) {
+    SPI_REQUIRE(ptrs && sizes && skip && T > 0 && max_size > 0 && step >= 1, "spi_adam_multi_pred: bad argument");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    const unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(max_size, 256 * 4), 2048);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)T), dim3(256), 0, as_stream(stream), ptrs, sizes, lr, beta1, beta2, eps, bc1, bc2_sqrt,
+                       (const float*)nullptr, skip);
+    SPI_LAUNCH_CHECK("spi_adam_multi_pred");
     return SPI_OK;
 }
 
@@ -1276,7 +1292,7 @@ int spi_adam_multi_dev(void* const* ptrs, const int64_t* sizes, int T, int64_t m
                        float eps, spi_stream_t stream) {
     SPI_REQUIRE(ptrs && sizes && hyper && T > 0 && max_size > 0, "spi_adam_multi_dev: bad argument");
     const unsigned gx = (unsigned)std::min<int64_t>(ceil_div64(max_size, 256 * 4), 2048);
-    hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)T), dim3(256), 0, as_stream(stream), ptrs, sizes, 0.f, beta1, beta2, eps, 1.f, 1.f, hyper);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(gx, (unsigned)T), dim3(256), 0, as_stream(stream), ptrs, sizes, 0.f, beta1, beta2, eps, 1.f, 1.f, hyper, (const unsigned char*)nullptr);
     SPI_LAUNCH_CHECK("spi_adam_multi_dev");
     return SPI_OK;
 }

@@ -1,0 +1,199 @@
+// Contextual-loss chain of BoxCXLoss (spi/criteria/bbox_cx_loss.py:93-129) as two row-wise kernels per direction.
+//
+// The reference runs, on a [B, P1, P2] cosine matrix (P1 = P2 = 1600 for the 40x40 VGG19 maps):
+//     dist = 1 - sim                                          (compute_cosine_distance, :93-108)
+//     rel  = clamp(dist / (min_j dist + 1e-5), -10, 10)       (compute_relative_distance, :111-115)
+//     w    = exp((1 - rel) / band_width);  cx = w / sum_j w   (compute_cx, :118-121)
+//     out[b] = mean_j max_i cx[b, i, j]                       (compute_cx_loss, :124-129, before the -log)
+// i.e. ~10 elementwise / reduction launches forward and ~15 backward over 10 MB per matrix.  Here one wave owns one row i: the
+// row's minimum, its normaliser and its cx values are three passes over 6.4 KB that stay in L1 / L2; the column maximum is kept
+// in LDS per block of 32 rows (ds_max_u64 on {cx bits, ~i}, so the row index of the maximum comes with it) and a second small kernel
+// finishes the maximum over the blocks and the mean.  The backward recomputes cx from the saved row statistics and writes d sim
+// once.  HBM-bound: algorithmic bytes = 4 B * P1 * P2 per matrix forward (read sim), 8 B backward (read sim, write d sim).
+//
+// Ties: torch.amax / amin split the gradient evenly over exact ties, these kernels give it to the first index -- measure zero on
+// float features (the same remark as criteria/bbox_cx_loss.py makes for amin vs min(dim)[0]).
+#include "common.hpp"
+
+namespace {
+
+constexpr int CX_ROWS = 32;       // rows per block (4 waves x 8 rows)
+constexpr int CX_THREADS = 256;
+constexpr int CX_CACHE_COLS = 4096;  // widest row whose weights are cached in LDS between the passes (4 strips + column maxima = 96 KB)
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// rel and w of one element, written once so that forward and backward round identically
+__device__ __forceinline__ float cx_weight(float sim, float m, float inv_bw, float& d, bool& clamped) {
+    d = 1.f - sim;
+    float t = d / m;
+    clamped = t > 10.f || t < -10.f;
+    t = t > 10.f ? 10.f : (t < -10.f ? -10.f : t);
+    return expf((1.f - t) * inv_bw);
+}
+
+// CACHE: the row's weights w_ij of pass 2 are kept in LDS (one P2-float strip per wave) for pass 3; without it (P2 > CX_CACHE_COLS) they are recomputed.
+template <bool CACHE>
+__global__ void __launch_bounds__(CX_THREADS) cx_rows_kernel(const float* __restrict__ sim, int P1, int P2, float inv_bw, float* __restrict__ row_min,
+                                                            float* __restrict__ row_sum, int32_t* __restrict__ row_argmin,
+                                                            unsigned long long* __restrict__ part) {
+    extern __shared__ unsigned long long colmax[];           // [P2]  {float bits of cx, ~row}   (+ CACHE: 4 x [P2] floats)
+    const int b = blockIdx.y, blk = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* wrow = reinterpret_cast<float*>(colmax + P2) + (int64_t)wv * P2;
+    for (int j = threadIdx.x; j < P2; j += CX_THREADS) colmax[j] = 0ull;
+    __syncthreads();
+    const float* sb = sim + (int64_t)b * P1 * P2;
+    for (int r = wv; r < CX_ROWS; r += CX_THREADS / 64) {
+        const int i = blk * CX_ROWS + r;
+        if (i >= P1) break;
+        const float* row = sb + (int64_t)i * P2;
+        float best = INFINITY;
+        int bj = 0x7fffffff;
+        for (int j = lane; j < P2; j += 64) {
+            float d = 1.f - row[j];
+            if (d < best) { best = d; bj = j; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            float ov = __shfl_xor(best, o);
+            int oj = __shfl_xor(bj, o);
+            if (ov < best || (ov == best && oj < bj)) { best = ov; bj = oj; }
+        }
+        const float m = best + 1e-5f;
+        float s = 0.f;
+        for (int j = lane; j < P2; j += 64) {
+            float d; bool c;
+            float w = cx_weight(row[j], m, inv_bw, d, c);
+            if (CACHE) wrow[j] = w;                           // read back by the same lane: no barrier
+            s += w;
+        }
+        s = wave_sum(s);
+        const unsigned inv_i = 0xffffffffu - (unsigned)i;
+        for (int j = lane; j < P2; j += 64) {
+            float d; bool c;
+            float cx = (CACHE ? wrow[j] : cx_weight(row[j], m, inv_bw, d, c)) / s;
+            atomicMax(&colmax[j], ((unsigned long long)__float_as_uint(cx) << 32) | inv_i);     // cx >= 0: its bits order like the value
+        }
+        if (lane == 0) {
+            row_min[(int64_t)b * P1 + i] = best;
+            row_sum[(int64_t)b * P1 + i] = s;
+            row_argmin[(int64_t)b * P1 + i] = bj;
+        }
+    }
+    __syncthreads();
+    unsigned long long* pb = part + ((int64_t)b * gridDim.x + blk) * P2;
+    for (int j = threadIdx.x; j < P2; j += CX_THREADS) pb[j] = colmax[j];
+}
+
+// maximum over the row blocks, and the mean over the columns: out[b] += sum over this block's 256 columns / P2   (out zeroed by the caller)
+__global__ void __launch_bounds__(CX_THREADS) cx_cols_kernel(const unsigned long long* __restrict__ part, int nblk, int P2, int32_t* __restrict__ col_argmax,
+                                                            float* __restrict__ out) {
+    __shared__ float red[CX_THREADS / 64];
+    const int b = blockIdx.y, j = blockIdx.x * CX_THREADS + threadIdx.x;
+    const unsigned long long* pb = part + (int64_t)b * nblk * P2;
+    float s = 0.f;
+    if (j < P2) {
+        unsigned long long best = 0ull;
+        for (int k = 0; k < nblk; ++k) {
+            unsigned long long v = pb[(int64_t)k * P2 + j];
+            best = v > best ? v : best;
+        }
+        col_argmax[(int64_t)b * P2 + j] = (int32_t)(0xffffffffu - (unsigned)(best & 0xffffffffull));
+        s = __uint_as_float((unsigned)(best >> 32));
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < CX_THREADS / 64; ++k) t += red[k];
+        atomicAdd(out + b, t / (float)P2);
+    }
+}
+
+__global__ void __launch_bounds__(CX_THREADS) cx_bwd_kernel(const float* __restrict__ sim, const float* __restrict__ d_out, int P1, int P2, float inv_bw,
+                                                           const float* __restrict__ row_min, const float* __restrict__ row_sum,
+                                                           const int32_t* __restrict__ row_argmin, const int32_t* __restrict__ col_argmax,
+                                                           float* __restrict__ d_sim) {
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (CX_THREADS / 64) + (threadIdx.x >> 6);
+    if (i >= P1) return;
+    const float* row = sim + ((int64_t)b * P1 + i) * P2;
+    float* drow = d_sim + ((int64_t)b * P1 + i) * P2;
+    const int32_t* arg = col_argmax + (int64_t)b * P2;
+    const float g = d_out[b] / (float)P2;                    // d out / d (column maximum)
+    const float m = row_min[(int64_t)b * P1 + i] + 1e-5f, R = row_sum[(int64_t)b * P1 + i];
+    // A = sum_j G_ij cx_ij over the columns whose maximum sits in this row; most rows own no column: their gradient is zero
+    float a = 0.f;
+    bool any = false;
+    for (int j = lane; j < P2; j += 64)
+        if (arg[j] == i) {
+            float d; bool c;
+            a += g * (cx_weight(row[j], m, inv_bw, d, c) / R);
+            any = true;
+        }
+    if (!__any(any)) {
+        for (int j = lane; j < P2; j += 64) drow[j] = 0.f;
+        return;
+    }
+    a = wave_sum(a);
+    float dm = 0.f;
+    for (int j = lane; j < P2; j += 64) {
+        float d; bool c;
+        float w = cx_weight(row[j], m, inv_bw, d, c);
+        float dw = ((arg[j] == i ? g : 0.f) - a) / R;
+        float dt = c ? 0.f : dw * w * -inv_bw;
+        dm -= dt * d / (m * m);
+        drow[j] = -(dt / m);
+    }
+    dm = wave_sum(dm);
+    const int js = row_argmin[(int64_t)b * P1 + i];
+    if (lane == (js & 63)) drow[js] -= dm;                   // the lane that wrote column js: d min_j dist -> d sim at the arg-minimum
+}
+
+}  // namespace
+
+extern "C" int64_t spi_contextual_workspace_bytes(int B, int P1, int P2) {
+    if (B <= 0 || P1 <= 0 || P2 <= 0) return 0;
+    return (int64_t)B * ceil_div64(P1, CX_ROWS) * P2 * 8;
+}
+
+extern "C" int spi_contextual_fwd(const float* sim, int B, int P1, int P2, float band_width, float* out, float* row_min, float* row_sum,
+                                  int32_t* row_argmin, int32_t* col_argmax, void* workspace, spi_stream_t stream) {
+    SPI_REQUIRE(sim && out && row_min && row_sum && row_argmin && col_argmax && workspace, "spi_contextual_fwd: null pointer");
+    SPI_REQUIRE(B > 0 && P1 > 0 && P2 > 0 && band_width > 0.f, "spi_contextual_fwd: bad shape or band width");
+    SPI_REQUIRE(P2 <= 16384 && B <= 65535, "spi_contextual_fwd: P2 %d > 16384 columns (the column maxima of a block live in LDS) or B %d > 65535", P2, B);
+    const int nblk = (int)ceil_div64(P1, CX_ROWS);
+    const bool cache = P2 <= CX_CACHE_COLS;
+    const size_t lds = (size_t)P2 * 8 + (cache ? (size_t)P2 * 4 * (CX_THREADS / 64) : 0);
+    const void* fn = cache ? reinterpret_cast<const void*>(cx_rows_kernel<true>) : reinterpret_cast<const void*>(cx_rows_kernel<false>);
+    if (lds > 48 * 1024) {                                   // per call, not once per process: the attribute is per device
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { spi_set_error("spi_contextual_fwd: %s", hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+    }
+    if (int rc = spi_zero_async(out, B, as_stream(stream))) return rc;
+    if (cache)
+        hipLaunchKernelGGL(cx_rows_kernel<true>, dim3(nblk, B), dim3(CX_THREADS), lds, as_stream(stream), sim, P1, P2, 1.f / band_width, row_min, row_sum,
+                           row_argmin, (unsigned long long*)workspace);
+    else
+        hipLaunchKernelGGL(cx_rows_kernel<false>, dim3(nblk, B), dim3(CX_THREADS), lds, as_stream(stream), sim, P1, P2, 1.f / band_width, row_min, row_sum,
+                           row_argmin, (unsigned long long*)workspace);
+    SPI_LAUNCH_CHECK("spi_contextual_fwd");
+    hipLaunchKernelGGL(cx_cols_kernel, dim3((unsigned)ceil_div64(P2, CX_THREADS), B), dim3(CX_THREADS), 0, as_stream(stream), (const unsigned long long*)workspace, nblk, P2, col_argmax, out);
+    SPI_LAUNCH_CHECK("spi_contextual_fwd");
+    return SPI_OK;
+}
+
+extern "C" int spi_contextual_bwd(const float* sim, const float* d_out, int B, int P1, int P2, float band_width, const float* row_min, const float* row_sum,
+                                  const int32_t* row_argmin, const int32_t* col_argmax, float* d_sim, spi_stream_t stream) {
+    SPI_REQUIRE(sim && d_out && row_min && row_sum && row_argmin && col_argmax && d_sim, "spi_contextual_bwd: null pointer");
+    SPI_REQUIRE(B > 0 && B <= 65535 && P1 > 0 && P2 > 0 && band_width > 0.f, "spi_contextual_bwd: bad shape or band width");
+    hipLaunchKernelGGL(cx_bwd_kernel, dim3((unsigned)ceil_div64(P1, CX_THREADS / 64), B), dim3(CX_THREADS), 0, as_stream(stream), sim, d_out, P1, P2,
+                       1.f / band_width, row_min, row_sum, row_argmin, col_argmax, d_sim);
+    SPI_LAUNCH_CHECK("spi_contextual_bwd");
+    return SPI_OK;
+}

@@ -82,34 +82,68 @@ class RotBboxCoach(BaseCoach):
     # ---- HIP-graph replay (MI355X-first; the eager iteration below is the definition) --------------------------------------------
     # An iteration is ~1000 launches (every 4th: ~3500) whose sequence depends on nothing the GPU computes -- the data-driven skipping
     # happens inside the kernels -- so after one eager iteration of its kind (plain / with the pseudo-view branches) the next one is
-    # CAPTURED (forward, losses, every backward, gradient folding) and later ones are a single graph launch.  The early-stop test
-    # stays on the host, where the reference has it, BEFORE the optimiser step: the graph leaves `lpips <= threshold` in a device
-    # byte, the host reads it after the replay and only then launches Adam (one eager launch, host scalars).  Graphs are keyed to
-    # the image's tensors, the pivot and the generator / optimiser instances and dropped when any of them changes.
+    # CAPTURED (forward, losses, every backward, gradient folding) and later ones are a single graph launch: ~25 ms of enqueue work per
+    # iteration leave the host, which otherwise cannot keep the GPU fed through the backward passes (the eager loop idles the GPU for
+    # ~13 % of a plain iteration, tools/trace_gaps.py).
+    # The early-stop test (`loss_lpips <= threshold: break` BEFORE optimizer.step(), :148-151) is the loop's one host decision.  Reading it
+    # after every replay would drain the GPU before each launch; instead the graph ORs the comparison into a sticky device byte, the Adam
+    # launch that follows is PREDICATED on that byte (spi_adam_multi_pred: once it is set, no step changes anything any more), and the
+    # host reads the byte of iteration i - GRAPH_LAG when it launches iteration i.  Parameters, moments and the reported iteration count
+    # end exactly where the reference's break leaves them; what differs is up to GRAPH_LAG speculative iterations of discarded GPU work
+    # after a stop (and as many extra draws from the renderer's random stream).  Graphs are keyed to the image's tensors, the pivot and
+    # the generator / optimiser instances and dropped when any of them changes.
     GRAPH_WARMUP = int(os.environ.get('SPI_GRAPH_WARMUP', '1'))          # eager iterations of a kind before its capture
+    GRAPH_LAG = max(1, int(os.environ.get('SPI_STAGE2_GRAPH_LAG', '2')))  # iterations the host may run ahead of the early-stop byte it has read
 
     def _graph_ok(self, rng):
         from ..projectors.common import graph_policy              # the same answer with and without a process group (multi-GPU = measured path)
         return (graph_policy(global_config.stage2_hip_graph) and isinstance(rng, DeviceRNG) and torch.device(self.device).type == 'cuda'
                 and not global_config.concurrent_branches and not getattr(self, '_graph_failed', False))
 
+    def _resolve_pending(self, keep):
+        """Wait for the early-stop bytes of all but the newest `keep` replays in flight.  -> (iteration, losses) of the FIRST one that had it set."""
+        pend = self._g2.get('pending') if getattr(self, '_g2', None) else None
+        while pend and len(pend) > keep:
+            it, ev, host, losses = pend.popleft()
+            ev.synchronize()
+            if bool(host[0]):
+                pend.clear()                                     # everything launched after it was speculative
+                return it, losses
+        return None
+
+    def drain_pipeline(self):
+        """After the loop: the early stop that pipelined replays found late (or still have pending).  -> (iteration index, its losses) or None.
+        The caller counts its iterations like the reference's loop: the stop belongs to THAT iteration."""
+        late = getattr(self, '_late_stop', None)
+        self._late_stop = None
+        if late is None and getattr(self, '_g2', None):
+            late = self._resolve_pending(0)
+        return late
+
     def _graph_train_step(self, i, ctx, w_pivot, rng):
+        import collections
         key = (id(ctx), w_pivot.data_ptr(), id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold),    # (the threshold is baked in,
                global_config.conv_precision, global_config.conv_winograd, global_config.enable_fp16_blocks, global_config.exploit_sparsity)   # and so is the arithmetic)
         if getattr(self, '_g2_key', None) != key:
-            self._g2_key, self._g2 = key, {}
+            self._g2_key = key
+            self._g2 = dict(stop=torch.zeros(1, device=self.device, dtype=torch.uint8), pending=collections.deque(),
+                            host=[torch.zeros(1, dtype=torch.uint8).pin_memory() for _ in range(self.GRAPH_LAG + 1)])
+            self._late_stop = None
         st = self._g2.setdefault('branch' if i % self.rot_bs == 0 else 'plain', dict(eager=0, graph=None))
         if st['graph'] is None:
+            late = self._resolve_pending(0)                      # eager iterations and captures start from a drained pipeline
+            if late is not None:
+                self._late_stop = late
+                return True, late[1]
             if st['eager'] < self.GRAPH_WARMUP:                  # the first iterations of a kind run eagerly (lazy initialisations, allocator
                 st['eager'] += 1                                 # warm-up, the frozen generator's tri-plane cache of the depth branch)
                 return self._eager_train_step(i, ctx, w_pivot, rng)
-            flag = torch.zeros(1, device=self.device, dtype=torch.uint8)
             try:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 from ..projectors.common import capture_mode
                 with torch.cuda.graph(g, capture_error_mode=capture_mode()):
-                    _, losses = self._forward_backward(i, ctx, w_pivot, rng, flag_buf=flag)
+                    _, losses = self._forward_backward(i, ctx, w_pivot, rng, flag_buf=self._g2['stop'])
             except Exception as e:                               # noqa: BLE001  (capture is an optimisation: the eager iteration is always valid)
                 import sys
                 self._graph_failed = True
@@ -118,15 +152,19 @@ class RotBboxCoach(BaseCoach):
                 import traceback
                 print(''.join(traceback.format_tb(e.__traceback__)[-6:]), file=sys.stderr)
                 return self._eager_train_step(i, ctx, w_pivot, rng)
-            st.update(graph=g, losses=losses, flag=flag, flag_host=torch.zeros(1, dtype=torch.uint8).pin_memory(), event=torch.cuda.Event())
+            st.update(graph=g, losses=losses)
+        late = self._resolve_pending(self.GRAPH_LAG - 1)         # the byte of iteration i - GRAPH_LAG, before iteration i is launched
+        if late is not None:
+            self._late_stop = late
+            return True, late[1]
         st['graph'].replay()
-        st['flag_host'].copy_(st['flag'], non_blocking=True)
-        st['event'].record()
-        st['event'].synchronize()                                # the loop's one host read (:148), here after the whole iteration
         losses = {k: v.clone() for k, v in st['losses'].items()}  # the graph's outputs are overwritten by the next replay
-        if bool(st['flag_host'][0]):
-            return True, losses
-        self.optimizer.step()
+        self.optimizer.step(skip=self._g2['stop'])               # predicated on the device: a stop of THIS iteration (or an earlier one) freezes it
+        host = self._g2['host'][i % (self.GRAPH_LAG + 1)]
+        host.copy_(self._g2['stop'], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._g2['pending'].append((i, ev, host, losses))
         return False, losses
 
     def train_step(self, i, ctx, w_pivot, rng=None):
@@ -177,7 +215,7 @@ class RotBboxCoach(BaseCoach):
             if flag_buf is None:
                 stop_flag = self._async_flag(losses['lpips'] <= hp.LPIPS_value_threshold)
             else:
-                flag_buf.copy_((losses['lpips'].detach() <= hp.LPIPS_value_threshold).reshape(1).to(torch.uint8))
+                flag_buf.bitwise_or_((losses['lpips'].detach() <= hp.LPIPS_value_threshold).reshape(1).to(torch.uint8))      # sticky
         # The reference calls backward() once per loss (:69,85,105,131): every parameter's .grad is read-modify-written once per
         # call (~150 tiny add_ launches each).  Here each call returns its gradients as fresh tensors (autograd.grad) and they are
         # folded into .grad in the reference's order with one multi-tensor add per call: the same sums.
@@ -288,6 +326,30 @@ class RotBboxCoach(BaseCoach):
         # graph still referenced, ending a HIP-graph capture of the next one crashed inside the runtime)
         return stop_flag, {k: v.detach() for k, v in losses.items()}
 
+    def optimise_image(self, ctx, w_pivot, image_name='', rng=None):
+        """The per-image loop (:57-157): up to G_1_step iterations, early stop on LPIPS.  -> (iterations counted like the reference's loop -- the one
+        that stopped included --, losses of the last one)."""
+        iters = completed = 0
+        losses = {}
+        log_images_counter = 0
+        from ...torch_utils.misc import quiet_gc
+        with quiet_gc():
+            for i in range(hyperparameters.G_1_step):
+                stop, losses = self.train_step(i, ctx, w_pivot, rng=rng)
+                iters += 1
+                if stop:
+                    break
+                if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:153-154)
+                    self.log_image_from_w(w_pivot, ctx['camera'], self.G, f'{image_name}_G1_inv_{log_images_counter}')
+                global_config.training_step += 1
+                log_images_counter += 1
+                completed = i + 1
+            late = self.drain_pipeline()                         # pipelined graph replays report an early stop GRAPH_LAG iterations late
+            if late is not None:                                 # count like the reference's loop: it broke in iteration late[0], before that step
+                iters, losses = late[0] + 1, late[1]
+                global_config.training_step -= completed - late[0]
+        return iters, losses
+
     def train(self):
         paths_config.experiments_output_dir += f'{self.coach_name}'
         output_dir = paths_config.experiments_output_dir
@@ -306,19 +368,7 @@ class RotBboxCoach(BaseCoach):
             embedding_loaded = hyperparameters.load_embedding_coach_name is not None and os.path.isfile(
                 f"{paths_config.embedding_base_dir}/{hyperparameters.load_embedding_coach_name}/{image_name}.pt")
             w_pivot = self.get_inversion(image_name, ctx['image'], ctx['camera'], fg_mask=ctx['fg_mask'])
-            iters = 0
-            log_images_counter = 0
-            from ...torch_utils.misc import quiet_gc
-            with quiet_gc():
-                for i in range(hyperparameters.G_1_step):
-                    stop, losses = self.train_step(i, ctx, w_pivot)
-                    iters += 1
-                    if stop:
-                        break
-                    if self.use_wandb and log_images_counter % global_config.log_snapshot == 0:        # (:153-154)
-                        self.log_image_from_w(w_pivot, ctx['camera'], self.G, f'{image_name}_G1_inv_{log_images_counter}')
-                    global_config.training_step += 1
-                    log_images_counter += 1
+            iters, losses = self.optimise_image(ctx, w_pivot, image_name)
             self.image_counter += 1
             self.finish_image(image_name, ctx['image'], ctx['camera'], w_pivot)
             st = dict(name=image_name, iters=iters, stage1_iters=0 if embedding_loaded else hyperparameters.first_inv_steps)

@@ -75,9 +75,11 @@ class Adam:
         return f32(grp['lr']), bc1, bc2
 
     @torch.no_grad()
-    def step(self, hyper=None):
+    def step(self, hyper=None, skip=None):
         """hyper: optional DEVICE tensor [lr, 1 - beta1^t, sqrt(1 - beta2^t)] (see `hyper_values`): the launch then carries no step-dependent
-        host scalar and can be replayed from a captured HIP graph."""
+        host scalar and can be replayed from a captured HIP graph.
+        skip: optional DEVICE uint8 [1]; non-zero when the kernel runs -> this step changes nothing (`spi_adam_multi_pred`: the early-stop decision
+        of a loop whose host runs ahead of the GPU)."""
         off = 0
         for p in self.params:               # gradients that autograd placed elsewhere are folded back in
             n = p.numel()
@@ -102,6 +104,11 @@ class Adam:
         if hyper is not None:
             hip.call('spi_adam_multi_dev', hip.ptr(self._table), hip.ptr(self._sizes), 1, self._total, hip.ptr(hyper), float(grp['betas'][0]),
                      float(grp['betas'][1]), float(grp['eps']), hip.stream())
+            return
+        if skip is not None:
+            assert skip.dtype == torch.uint8 and skip.is_cuda
+            hip.call('spi_adam_multi_pred', hip.ptr(self._table), hip.ptr(self._sizes), 1, self._total, float(grp['lr']), float(grp['betas'][0]),
+                     float(grp['betas'][1]), float(grp['eps']), self.step_count, skip.data_ptr(), hip.stream())
             return
         hip.call('spi_adam_multi', hip.ptr(self._table), hip.ptr(self._sizes), 1, self._total, float(grp['lr']), float(grp['betas'][0]),
                  float(grp['betas'][1]), float(grp['eps']), self.step_count, hip.stream())

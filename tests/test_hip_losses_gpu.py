@@ -2,6 +2,7 @@
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import assert_close, rel_err
 from synth_weights import load_manifest, synth_state_dict
@@ -86,6 +87,32 @@ def test_box_cx_vs_oracle():
     assert abs(out.item() - ref.item()) <= 1e-3 * abs(ref.item())
     gg, = torch.autograd.grad(out, xg)
     assert_close(gg, gref, 5e-3, 'boxcx grad')
+
+
+@pytest.mark.parametrize('b,p1,p2,c,bw', [(3, 1600, 1600, 128, 0.5), (2, 70, 130, 16, 0.5), (1, 33, 7000, 8, 0.3), (2, 200, 100, 4, 1.0)])
+def test_contextual_cx_kernels_vs_oracle(b, p1, p2, c, bw):
+    """The fused contextual chain (csrc/losses.hip: spi_contextual_fwd / _bwd) against the oracle's step-by-step chain (bbox_cx_loss.py:111-129) on cosine
+    matrices of random unit features: the loop's 1600 x 1600 shape, rectangular ones, > 48 KB of column maxima in LDS, and (c = 4: near-parallel
+    features exist, so min_j dist ~ 0) rows where the +-10 clamp is active."""
+    from spi_amd.criteria.bbox_cx_loss import contextual_cx
+    gen = torch.Generator().manual_seed(b * 1000 + p1)
+    fx = F.normalize(torch.randn(b, c, p1, generator=gen), dim=1)
+    fy = F.normalize(torch.randn(b, c, p2, generator=gen), dim=1)
+    sim = torch.bmm(fx.transpose(1, 2), fy).requires_grad_(True)
+    coef = torch.rand(b, generator=gen) + 0.5
+    ref = olo.contextual_cx(sim.double(), bw)
+    gref, = torch.autograd.grad((-torch.log(ref + 1e-5) * coef.double()).sum(), sim)
+    ref32 = olo.contextual_cx(sim, bw)
+    sg = sim.detach().to(DEV).requires_grad_(True)
+    out = contextual_cx(sg, bw)
+    assert out.shape == (b,)
+    err32 = (ref32.double() - ref).abs().max().item()
+    assert (out.cpu().double() - ref).abs().max().item() <= max(4 * err32, 1e-6 * ref.abs().max().item())         # as close to fp64 as the fp32 chain of the oracle is
+    gg, = torch.autograd.grad((-torch.log(out + 1e-5) * coef.to(DEV)).sum(), sg)
+    assert_close(gg, gref.float(), 2e-4, 'contextual d sim')
+    if c == 4:
+        d = 1 - sim.detach()
+        assert ((d / (d.min(dim=2, keepdim=True)[0] + 1e-5)) > 10).float().mean().item() > 0.05                   # the clamp branch was exercised
 
 
 def test_fused_adam_vs_torch():
@@ -447,8 +474,11 @@ def test_stage2_hip_graph_replay_equals_eager_iterations():
         before = {k: v.detach().clone() for k, v in coach.G.state_dict().items()}
         stop, _ = coach.train_step(11, ctx, w_pivot, rng=rng)
         assert stop and not coach._g2 .get('plain', {}).get('graph') and all(torch.equal(v, before[k]) for k, v in coach.G.state_dict().items())
-        # and a replayed iteration stops too: two eager-free kinds later the plain graph exists again with the new threshold baked in
-        assert coach.train_step(13, ctx, w_pivot, rng=rng)[0] and coach.train_step(14, ctx, w_pivot, rng=rng)[0]
+        # and replayed iterations stop too, GRAPH_LAG calls late: the plain graph exists again with the new threshold baked in, the stop of iteration 13
+        # sits in the sticky device byte, the predicated Adam launches of 13 and 14 change nothing, and the call for 15 reports it
+        assert [coach.train_step(j, ctx, w_pivot, rng=rng)[0] for j in (13, 14, 15)] == [False, False, True]
+        late = coach.drain_pipeline()
+        assert late is not None and late[0] == 13 and coach.drain_pipeline() is None
         assert coach._g2['plain']['graph'] is not None and all(torch.equal(v, before[k]) for k, v in coach.G.state_dict().items())
     finally:
         global_config.stage2_hip_graph, hyperparameters.LPIPS_value_threshold = old, old_thr
@@ -460,6 +490,69 @@ def test_stage2_hip_graph_replay_equals_eager_iterations():
     for k, v in runs[False][1].items():
         if v.dtype.is_floating_point and 'noise_const' not in k:
             assert_close(runs[True][1][k], v, 2e-3, f'{k} after 10 iterations, graph vs eager')
+            moved += 1
+    assert moved > 50
+
+
+def test_stage2_pipelined_graph_early_stop_counts_like_eager():
+    """`loss_lpips <= threshold: break` before optimizer.step() (rot_bbox_cx_coach.py:148-151) under the pipelined graph replays: the host learns of the
+    stop GRAPH_LAG iterations late, the device-predicated Adam (spi_adam_multi_pred) has frozen the parameters at the stop, and `optimise_image`
+    reports the iteration count, the losses and global_config.training_step of the reference's loop -- the same as the eager loop on the same draws."""
+    from spi_amd.criteria.lpips.lpips import LPIPS
+    from spi_amd.criteria.bbox_cx_loss import BoxCXLoss
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.data.images_dataset import SyntheticDataset
+    from spi_amd.utils.rng import DeviceRNG
+    from spi_amd.configs import hyperparameters, paths_config, global_config
+    import tempfile
+
+    class FixedDraws(DeviceRNG):
+        def __init__(self, device):
+            super().__init__(device)
+            self.cache, self.gen = {}, torch.Generator().manual_seed(9)
+
+        def rand(self, *shape):
+            if shape not in self.cache:
+                self.cache[shape] = torch.rand(*shape, generator=self.gen).to(self.device)
+            return self.cache[shape]
+
+    W, W19 = olo.make_vgg16_weights(seed=0), olo.make_vgg19_head_weights(seed=1)
+    data = SyntheticDataset(1)[0]
+    data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in data.items()}
+    w_pivot = torch.randn(1, 14, 512, generator=torch.Generator().manual_seed(6)).to(DEV)
+    tmp = tempfile.mkdtemp()
+    for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
+        setattr(paths_config, k, f'{tmp}/{k}/')
+    hyperparameters.first_inv_type, hyperparameters.G_1_type = 'mir', 'RotBbox'
+    hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda = 0.1, 0.05, 1.0
+    hyperparameters.G_1_step = 14
+
+    def run(graph, thr):
+        global_config.stage2_hip_graph, hyperparameters.LPIPS_value_threshold, global_config.training_step = graph, thr, 0
+        coach = RotBboxCoach(None, False, G=_narrow(), lpips_loss=LPIPS(weights=W), box_cx_loss=BoxCXLoss(weights=W19))
+        ctx = coach.prepare_image(data)
+        rng = FixedDraws(DEV)
+        if thr < 0:                                               # dry run: the LPIPS of every iteration
+            return [float(coach.train_step(i, ctx, w_pivot, rng=rng)[1]['lpips']) for i in range(hyperparameters.G_1_step)]
+        iters, losses = coach.optimise_image(ctx, w_pivot, rng=rng)
+        return iters, {k: float(v) for k, v in losses.items()}, global_config.training_step, {k: v.detach().clone() for k, v in coach.G.state_dict().items()}
+
+    lp = run(False, -1.0)
+    # an iteration whose LPIPS is clearly the first below a threshold, late enough that both graph kinds are replaying (captures at 2 and 4)
+    cands = [(min(lp[:k]) - lp[k], k) for k in range(7, 12) if lp[k] < min(lp[:k])]
+    assert cands, lp
+    gap, k = max(cands)
+    assert gap > 20 * 2e-4 * lp[k], (gap, lp)                     # far above the run-to-run noise of the atomics' summation order
+    thr = lp[k] + 0.5 * gap
+    e_iters, e_losses, e_steps, e_params = run(False, thr)
+    g_iters, g_losses, g_steps, g_params = run(True, thr)
+    assert e_iters == k + 1 and e_steps == k, (e_iters, e_steps, k)
+    assert (g_iters, g_steps) == (e_iters, e_steps), (g_iters, g_steps, e_iters, e_steps)
+    assert g_losses['lpips'] <= thr and abs(g_losses['lpips'] - e_losses['lpips']) <= 2e-4 * e_losses['lpips']
+    moved = 0
+    for name, v in e_params.items():
+        if v.dtype.is_floating_point and 'noise_const' not in name:
+            assert_close(g_params[name], v, 2e-3, f'{name} at the early stop, pipelined graph vs eager')
             moved += 1
     assert moved > 50
 

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""GPU idle time between kernels of a rocprofv3 kernel_trace.csv: where the device waits for the host.
+usage: trace_gaps.py <kernel_trace.csv> [window_ms_from_end]
+
+Kernels are sorted by start time; a gap is start[i+1] - max(end[0..i]).  Reported: busy / idle totals over the last `window` ms of the trace
+(default: everything), a histogram of gap lengths, and the kernels most often found AFTER a gap > 20 us (the launch the host was late with)."""
+import csv
+import sys
+from collections import defaultdict
+
+rows = []
+with open(sys.argv[1], newline='') as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'].split('(')[0][-50:]))
+rows.sort()
+if len(sys.argv) > 2:
+    t_end = max(r[1] for r in rows)
+    rows = [r for r in rows if r[0] >= t_end - float(sys.argv[2]) * 1e6]
+span = max(r[1] for r in rows) - rows[0][0]
+busy = 0
+hist = defaultdict(lambda: [0, 0])
+after = defaultdict(lambda: [0, 0])
+cur_end = rows[0][0]
+for s, e, name in rows:
+    if s > cur_end:
+        g = s - cur_end
+        b = '<2us' if g < 2000 else '2-5us' if g < 5000 else '5-20us' if g < 20000 else '20-100us' if g < 100000 else '0.1-1ms' if g < 1000000 else '>1ms'
+        hist[b][0] += 1
+        hist[b][1] += g
+        if g >= 20000:
+            after[name][0] += 1
+            after[name][1] += g
+        busy += e - s
+        cur_end = e
+    else:
+        busy += max(0, e - cur_end)
+        cur_end = max(cur_end, e)
+print(f'kernels {len(rows)}  span {span / 1e6:.2f} ms  busy {busy / 1e6:.2f} ms ({100 * busy / span:.1f} %)  idle {(span - busy) / 1e6:.2f} ms')
+for b in ('<2us', '2-5us', '5-20us', '20-100us', '0.1-1ms', '>1ms'):
+    n, t = hist[b]
+    print(f'  gaps {b:9s} n={n:6d}  total {t / 1e6:8.2f} ms ({100 * t / span:5.1f} % of span)')
+print('kernels launched late (after a gap >= 20 us):')
+for name, (n, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:25]:
+    print(f'  {t / 1e6:8.2f} ms n={n:5d}  {name}')
