@@ -43,6 +43,8 @@ struct WinoParams {
 int64_t spi_wino_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));
 int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const Epilogue& ep, void* workspace, hipStream_t st)
     __attribute__((visibility("hidden")));
+// F(3x3, 2x2) weight gradient of the same problem (x [N,Ci,H,W], dy [N,Mo,H,W]) added into a zeroed dw
+int spi_wino_wgrad_launch(const WinoParams& P, const float* x, const float* dy, float* dw, hipStream_t st) __attribute__((visibility("hidden")));
 
 // Zero `n_floats` floats on `st` with a kernel.  Not hipMemsetAsync: as a node of a captured HIP graph a memset whose byte count is not a
 // multiple of 16 (the decoder's 33-float bias gradient) leaves garbage behind on replays (ROCm 7.0; tools/ubench/graph_memset.py),

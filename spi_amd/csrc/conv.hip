@@ -999,11 +999,32 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
     return blocks >= 256 && P.Mo >= 48;
 }
 
+// Winograd F(3x3, 2x2) eligibility of a weight-gradient problem (P = make_forward(d)): 3x3, stride 1, pad 1, exact fp32, dense gradient
+// (the masked branches keep the implicit GEMM, which skips their zero segments), rows of at least one 32-pixel strip, and enough tile rows
+// per block for the 64 x 64 x 16 accumulators' prologue / 144-atomic epilogue to amortise.
+static bool make_wino_wgrad(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
+    if (d->transposed || d->kh != 3 || d->pad != 1 || (d->compute_f16 != 0 && d->compute_f16 != 3) || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
+    if (d->dy_seg_flags || P.IH != P.OH || P.IW != P.OW || P.OW < 32 || P.OH < 16) return false;
+    if ((int64_t)P.OH * P.OW * 64 * 4 >= (1ll << 31) || P.Mo < 32 || P.Ci < 32) return false;
+    Wp.N = P.N; Wp.nw = d->w_batch_stride ? P.N : 1; Wp.Mo = P.Mo; Wp.Ci = P.Ci; Wp.H = P.OH; Wp.W = P.OW;
+    Wp.bx = Wp.by = 0; Wp.ocp = 0;
+    Wp.in_bs = P.in_bs; Wp.out_bs = P.out_bs; Wp.wbs = P.wbs; Wp.u_bs = 0; Wp.wsm = P.wsm; Wp.wsc = P.wsc;
+    const TapSet& T = P.cls[0].taps;
+    for (int t = 0; t < 9; ++t) {
+        if (T.dy[t] < -1 || T.dy[t] > 1 || T.dx[t] < -1 || T.dx[t] > 1) return false;
+        Wp.widx[(T.dy[t] + 1) * 3 + (T.dx[t] + 1)] = T.widx[t];
+    }
+    Wp.seg_flags = nullptr; Wp.out_flags = nullptr; Wp.nseg = 0;
+    return true;
+}
+constexpr int64_t WINO_WGRAD_WS = 16;      // the pass needs no scratch; a (nominal) workspace is the caller's opt-in, as for the other passes
+
 extern "C" {
 
 int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass) {
-    if (validate(d, "spi_conv2d_workspace_bytes") || pass < 0 || pass > 1) return 0;
+    if (validate(d, "spi_conv2d_workspace_bytes") || pass < 0 || pass > 2) return 0;
     IGemmParams P; WinoParams Wp;
+    if (pass == 2) { make_forward(d, P); return make_wino_wgrad(d, P, Wp) ? WINO_WGRAD_WS : 0; }
     if (pass == 0) make_forward(d, P); else make_dgrad(d, P);
     return make_wino(d, P, Wp) ? spi_wino_workspace_bytes(Wp) : 0;
 }
@@ -1058,6 +1079,14 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     const int64_t nw = (d->w_batch_stride == 0) ? 1 : d->N;
     if (!d->dw_zeroed) {
         spi_zero_async(dw, nw * wsz, as_stream(stream));
+    }
+    {
+        WinoParams Wp;
+        if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_wino_wgrad(d, P, Wp)) {
+            rc = spi_wino_wgrad_launch(Wp, x, dy, dw, as_stream(stream)); if (rc) return rc;
+            SPI_LAUNCH_CHECK("spi_conv2d_wgrad (winograd)");
+            return SPI_OK;
+        }
     }
     // tile 128 x 128; split the pixel reduction so the grid has ~>= 1024 blocks
     // (a 32-row tile for layers with <= 32 output channels -- the 3-channel torgb layers: a 128-row tile spends 97 % of its MFMAs on

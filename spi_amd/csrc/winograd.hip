@@ -327,6 +327,230 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
     }
 }
 
+// =================================================================================================
+// Weight gradient of the same convolutions: minimal filtering F(3x3, 2x2).
+//
+//     dW[ky][kx] = sum over 2x2 tiles of  sum_{jy,jx} dY[jy][jx] * X[jy + ky][jx + kx]        (X: the tile's 4x4 input patch)
+//                = A^T [ sum_tiles (G dY G^T) (.) (B^T X B) ] A        A^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]   (3x4)
+//                                                                      G   = [1 0; 1/2 1/2; 1/2 -1/2; 0 1]
+//                                                                      B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]
+// 16 multiplications per (in, out) channel pair and tile instead of 36, as 16 independent GEMMs M_f[oc][ic] = sum_t D_f[oc][t] X_f[ic][t]
+// whose reduction index is the TILE: v_mfma_f32_32x32x2_f32 with k = 2 tiles.  The halves of G are folded into the output transform
+// (G' = [1 0; 1 1; 1 -1; 0 1], M_f scaled by s_a s_b, s = [1, 1/2, 1/2, 1]), so both operand transforms only add.
+//
+// One block = 64 output x 64 input channels x 16 frequencies = 65536 accumulators (256 per lane, AGPRs, one wave per SIMD) over a
+// 32-pixel-wide strip of the image, walked one tile row (16 tiles) per step.  Per step:
+//   * raw rows go global -> LDS directly (buffer_load_dword ... lds, out-of-image / out-of-range channels arrive as 0): the 2 new input rows
+//     and the 2 gradient rows of the NEXT step into ring buffers (6 input rows, 4 gradient rows, [row][64 channels][34 floats]);
+//   * a lane of MFMA row / column c and k-half h reads the raw 2x2 gradient tile resp. 4x4 input patch of ITS channel and tile from LDS
+//     (8-byte reads, channel stride 34 floats: conflict-free), transforms it in registers (12 resp. 32 adds) and the 16 results ARE its
+//     A resp. B operands of the 16 frequencies -- the transformed operands never touch LDS;
+//   * every wave runs 128 MFMAs (16 frequencies x 8 tile pairs) on its 32 x 32 channel quadrant; the reads and transforms of tile pair
+//     p + 1 and the step's 34 row transfers are issued in micro-slots behind the MFMAs of pair p.
+// The reduction over the image is split across blocks (strips x row chunks x samples); each block applies the output transform to its
+// partial sums in registers and adds the 9 taps into dW with fp32 atomics (dW zeroed by the caller side, like the implicit-GEMM kernel).
+// =================================================================================================
+constexpr int GPX = 34;                 // floats per LDS row of a channel: 32 strip pixels + 2 (input rows: the halo pair; gradient rows: unused)
+constexpr int GROW = 64 * GPX;          // floats of one ring row [64 channels][34] = 34 wave transfers
+constexpr int GXR = 6, GDR = 4;         // ring depths: input rows (4 in use + 2 arriving), gradient rows (2 + 2)
+constexpr int GLDS = (GXR + GDR) * GROW; // 21760 floats = 85 KB
+
+struct WinoWgradParams {
+    int N, nw, Mo, Ci, H, W;
+    int strips, nci;                    // 32-pixel strips per row; 64-channel input blocks
+    int tiles_per_chunk;                // tile rows per block
+    int64_t in_bs, out_bs, wbs;
+    int wsm, wsc, widx[9];              // dw[n*wbs + m*wsm + c*wsc + widx[ky*3 + kx]]
+};
+
+__global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dw) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];        // X ring [6][64][34] | D ring [4][64][34]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l32 = lane & 31;
+    const int ocw = wave >> 1, icw = wave & 1;                         // MFMA quadrant: 32 output x 32 input channels
+    const int n = blockIdx.z;
+    const int cob = (blockIdx.y / P.nci) * 64, cib = (blockIdx.y % P.nci) * 64;
+    const int strip = blockIdx.x % P.strips, chunk = blockIdx.x / P.strips;
+    const int px0 = strip * 32;
+    const int tiles_y = (P.H + 1) >> 1;
+    const int ty_beg = chunk * P.tiles_per_chunk, ty_end = min(ty_beg + P.tiles_per_chunk, tiles_y);
+    if (ty_beg >= ty_end) return;
+    const int HW = P.H * P.W;
+    // the block's 64 channels of each operand as their own buffers: channels past the tensor's end are out of range = 0
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(x + (int64_t)n * P.in_bs + (int64_t)cib * HW, (int64_t)min(64, P.Ci - cib) * HW * 4);
+    const __amdgpu_buffer_rsrc_t rsD = make_rsrc(dy + (int64_t)n * P.out_bs + (int64_t)cob * HW, (int64_t)min(64, P.Mo - cob) * HW * 4);
+
+    // ---- row transfers.  A row PAIR (two consecutive image rows into two consecutive ring rows) is 68 wave transfers, transfer t = 4 i + wave
+    //      (i = 0..16) of it is this wave's: ring row r = t / 34, slots (t % 34) * 64 + lane = (channel, pixel) of that row.  The per-lane
+    //      offsets are fixed for the whole kernel; the image row rides in the scalar offset (not range-checked by the hardware, so rows outside
+    //      the image select the out-of-range lane offset instead).
+    unsigned patX[17], patD[17];
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+        const int t = 4 * i + wave, q = t % 34;
+        const int slot = q * 64 + lane, ch = slot / GPX, px = slot - ch * GPX;
+        const int gx = px0 - 1 + px, gd = px0 + px;
+        patX[i] = (gx >= 0 && gx < P.W) ? (unsigned)((ch * HW + gx) * 4) : BUF_OOB;
+        patD[i] = (px < 32 && gd < P.W) ? (unsigned)((ch * HW + gd) * 4) : BUF_OOB;
+    }
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    // transfer i of the pair whose first image row is y0, into ring rows slot0, slot0 + 1 of the X (kind 0) or D (kind 1) ring
+    auto xfer = [&](int kind, int y0, int slot0, int i) {
+        const int t = 4 * i + wave;
+        const int r = t >= 34 ? 1 : 0;                                 // (wave-uniform: t is)
+        const int q = t - 34 * r;
+        const int y = y0 + r;
+        const bool rok = y >= 0 && y < P.H;
+        const unsigned vo = rok ? (kind ? patD[i] : patX[i]) : BUF_OOB;
+        const int soff = __builtin_amdgcn_readfirstlane(rok ? y * P.W * 4 : 0);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((kind ? GXR * GROW : 0) + (slot0 + r) * GROW + q * 64) * 4));
+        if (kind) asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rsD), "s"(soff) : "memory", "m0");
+        else      asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rsX), "s"(soff) : "memory", "m0");
+    };
+
+    // ---- operands: raw patch of (channel l32 of the quadrant, tile 2 p + h) -> 16 frequencies, in registers
+    float rx[16], rd[4];
+    float opa[2][16], opb[2][16];
+    const float* xrow[4]; const float* drow[2];
+    auto set_rows = [&](int ty) {                                     // ring rows of tile row ty: input rows 2 ty - 1 .. 2 ty + 2, gradient rows 2 ty, 2 ty + 1
+        const int xs = (2 * ty) % GXR, ds = (2 * ty) % GDR;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xrow[k] = lds + ((xs + k) % GXR) * GROW + (icw * 32 + l32) * GPX + 2 * h;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) drow[k] = lds + (GXR + ds + k) * GROW + (ocw * 32 + l32) * GPX + 2 * h;
+    };
+    auto read_x = [&](int p, int k) {                                 // row k of the input patch of tile pair p
+        const float2 lo = *reinterpret_cast<const float2*>(xrow[k] + 4 * p), hi = *reinterpret_cast<const float2*>(xrow[k] + 4 * p + 2);
+        rx[k * 4 + 0] = lo.x; rx[k * 4 + 1] = lo.y; rx[k * 4 + 2] = hi.x; rx[k * 4 + 3] = hi.y;
+    };
+    auto read_d = [&](int p, int k) {
+        const float2 v = *reinterpret_cast<const float2*>(drow[k] + 4 * p);
+        rd[k * 2 + 0] = v.x; rd[k * 2 + 1] = v.y;
+    };
+    // B^T X B, row group a (4 of the 16 frequencies)
+    auto xform_x = [&](float (&o)[16], int a) {
+        float t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            t[c] = a == 0 ? rx[0 + c] - rx[8 + c] : a == 1 ? rx[4 + c] + rx[8 + c] : a == 2 ? rx[8 + c] - rx[4 + c] : rx[12 + c] - rx[4 + c];
+        o[a * 4 + 0] = t[0] - t[2]; o[a * 4 + 1] = t[1] + t[2]; o[a * 4 + 2] = t[2] - t[1]; o[a * 4 + 3] = t[3] - t[1];
+        // pinned: without a side effect LLVM sinks these adds to their use, i.e. in front of the NEXT pair's MFMAs (a dependent VALU op + s_nop
+        // before each) and keeps the raw patch alive until then
+        asm volatile("" : "+v"(o[a * 4 + 0]), "+v"(o[a * 4 + 1]), "+v"(o[a * 4 + 2]), "+v"(o[a * 4 + 3]));
+    };
+    // G' dY G'^T (the halves of G live in the output transform)
+    auto xform_d = [&](float (&o)[16]) {
+        const float u[4][2] = {{rd[0], rd[1]}, {rd[0] + rd[2], rd[1] + rd[3]}, {rd[0] - rd[2], rd[1] - rd[3]}, {rd[2], rd[3]}};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            o[a * 4 + 0] = u[a][0]; o[a * 4 + 1] = u[a][0] + u[a][1]; o[a * 4 + 2] = u[a][0] - u[a][1]; o[a * 4 + 3] = u[a][1];
+            asm volatile("" : "+v"(o[a * 4 + 0]), "+v"(o[a * 4 + 1]), "+v"(o[a * 4 + 2]), "+v"(o[a * 4 + 3]));
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // ---- prologue: the first tile row's 4 input rows and 2 gradient rows; its first tile pair transformed
+    {
+        const int y = 2 * ty_beg;
+#pragma unroll
+        for (int i = 0; i < 17; ++i) { xfer(0, y - 1, y % GXR, i); xfer(0, y + 1, (y + 2) % GXR, i); xfer(1, y, y % GDR, i); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        set_rows(ty_beg);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) read_x(0, k);
+        read_d(0, 0); read_d(0, 1);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) xform_x(opb[0], a);
+        xform_d(opa[0]);
+    }
+
+    for (int ty = ty_beg; ty < ty_end; ++ty) {
+        const int yn = 2 * ty + 2;                                    // first gradient row of the next tile row
+        // 8 tile pairs x 16 frequencies.  Behind every MFMA one micro-slot of side work (an MFMA holds the pipe for 64 cycles after a 4-cycle
+        // issue): slots 0..5 of a pair read the raw patch of the next pair, slots 6..10 transform it, the 34 row transfers of the next step are
+        // spread over pairs 0..6, and pair 7 waits for them, meets the other waves and prepares the next step's first pair.  No branch in the
+        // body: after the block's last tile row the same work runs once more on rows nobody reads (transfers of rows outside the image are zeros).
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float (&ca)[16] = opa[p & 1];
+            float (&cb)[16] = opb[p & 1];
+            float (&na)[16] = opa[(p + 1) & 1];
+            float (&nb)[16] = opb[(p + 1) & 1];
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[f], cb[f], acc[f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (p < 7) {
+                    if (f < 4) read_x(p + 1, f);
+                    else if (f < 6) read_d(p + 1, f - 4);
+                    else if (f < 10) xform_x(nb, f - 6);
+                    else if (f == 10) xform_d(na);
+                    else {                                            // slots 11..15 of pairs 0..6: 35 places for the 34 transfers
+                        const int j = p * 5 + (f - 11);
+                        if (j < 17) xfer(0, yn + 1, (yn + 2) % GXR, j);
+                        else if (j < 34) xfer(1, yn, yn % GDR, j - 17);
+                    }
+                } else {
+                    if (f == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); set_rows(ty + 1); }
+                    else if (f < 5) read_x(0, f - 1);
+                    else if (f < 7) read_d(0, f - 5);
+                    else if (f < 11) xform_x(nb, f - 7);
+                    else if (f == 11) xform_d(na);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- output transform A^T (s s^T (.) M) A and the atomic adds.  C/D layout: col = lane & 31 (input channel), row = (r & 3) + 8 (r >> 2) + 4 h.
+    //      The accumulators leave the AGPRs through LDS (ds_write takes an AGPR as its data operand), four rows r at a time, and every lane reads
+    //      its own 16 frequencies of a row back into VGPRs.  Doing the arithmetic on the accumulators directly makes the register allocator copy all
+    //      16 tuples (256 registers) to VGPRs at the loop's exit and spill the main loop's operands to make room (106 spills, reloads in front of
+    //      the MFMAs); with the detour the kernel needs ~110 VGPRs and none.  The ring buffers are free: the last step waited for its transfers.
+    const int c = cib + icw * 32 + l32;
+    float* dwn = dw + (P.nw > 1 ? (int64_t)n * P.wbs : 0) + (int64_t)c * P.wsc;
+    float* stage = lds + wave * 4096 + lane;                          // [16 f][4 r][64 lanes] per wave
+#pragma unroll
+    for (int rc = 0; rc < 4; ++rc) {
+#pragma unroll
+        for (int f = 0; f < 16; ++f)
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) stage[(f * 4 + rr) * 64] = acc[f][rc * 4 + rr];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rc * 4 + rr;
+            const int m = cob + ocw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float cc[3][4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float m0 = stage[((0 + b) * 4 + rr) * 64], m1 = 0.5f * stage[((4 + b) * 4 + rr) * 64], m2 = 0.5f * stage[((8 + b) * 4 + rr) * 64],
+                            m3 = stage[((12 + b) * 4 + rr) * 64];
+                cc[0][b] = m0 + m1 + m2; cc[1][b] = m1 - m2; cc[2][b] = m1 + m2 + m3;
+            }
+            // no branch around the atomics: rows / columns past the tensor (only in a layer whose channel counts are not multiples of 64) add 0 to dw[0]
+            const bool ok = m < P.Mo && c < P.Ci;
+            float* q = ok ? dwn + (int64_t)m * P.wsm : dw;
+            const float sc = ok ? 1.f : 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float e1 = 0.5f * cc[ky][1], e2 = 0.5f * cc[ky][2];
+                atomicAdd(q + (ok ? P.widx[ky * 3 + 0] : 0), sc * (cc[ky][0] + e1 + e2));
+                atomicAdd(q + (ok ? P.widx[ky * 3 + 1] : 0), sc * (e1 - e2));
+                atomicAdd(q + (ok ? P.widx[ky * 3 + 2] : 0), sc * (e1 + e2 + cc[ky][3]));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 int64_t spi_wino_workspace_bytes(const WinoParams& P) { return (int64_t)P.nw * P.u_bs_of() * 4; }
 
@@ -349,5 +573,27 @@ int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, c
     }
     dim3 grid((unsigned)(P.bx * P.by), (unsigned)(P.ocp / WOC), (unsigned)P.N);
     hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), lds_bytes, st, P, in, U, out, ep);
+    return SPI_OK;
+}
+
+// Weight-gradient launch.  Returns SPI_OK; the caller has zeroed dw.
+int spi_wino_wgrad_launch(const WinoParams& Wp, const float* x, const float* dy, float* dw, hipStream_t st) {
+    WinoWgradParams P;
+    P.N = Wp.N; P.nw = Wp.nw; P.Mo = Wp.Mo; P.Ci = Wp.Ci; P.H = Wp.H; P.W = Wp.W;
+    P.strips = (Wp.W + 31) / 32; P.nci = (Wp.Ci + 63) / 64;
+    P.in_bs = Wp.in_bs; P.out_bs = Wp.out_bs; P.wbs = Wp.wbs; P.wsm = Wp.wsm; P.wsc = Wp.wsc;
+    for (int t = 0; t < 9; ++t) P.widx[t] = Wp.widx[t];
+    const int tiles_y = (Wp.H + 1) / 2;
+    const int cc = ((Wp.Mo + 63) / 64) * P.nci;
+    // one block per CU (85 KB of LDS, 512 registers per lane): split the tile rows so that one round of blocks fills the 256 CUs
+    const int64_t base = (int64_t)cc * P.strips * Wp.N;
+    int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(base, 1), tiles_y / 4));
+    P.tiles_per_chunk = (tiles_y + chunks - 1) / chunks;
+    chunks = (tiles_y + P.tiles_per_chunk - 1) / P.tiles_per_chunk;
+    constexpr size_t lds_bytes = GLDS * sizeof(float);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) { spi_set_error("winograd wgrad: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+    dim3 grid((unsigned)(P.strips * chunks), (unsigned)cc, (unsigned)Wp.N);
+    hipLaunchKernelGGL(wino_wgrad_kernel, grid, dim3(256), lds_bytes, st, P, x, dy, dw);
     return SPI_OK;
 }

@@ -71,7 +71,7 @@ def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, n
 
 
 def _workspace(d, pass_id, device):
-    """Scratch memory with which `pass_id` (0 forward, 1 dgrad) of the conv `d` takes its Winograd path (None: it has none, or
+    """Scratch memory with which `pass_id` (0 forward, 1 dgrad, 2 wgrad) of the conv `d` takes its Winograd path (None: it has none, or
     ``global_config.conv_winograd`` is off).  Comes from torch's caching allocator: no device allocation after warm-up."""
     from ...configs import global_config
     if not global_config.conv_winograd or d.kh != 3 or d.transposed or d.compute_f16 not in (0, 3):
@@ -140,6 +140,7 @@ class _Conv2d(torch.autograd.Function):
             hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w), hip.ptr(dx), hip.stream())
         if ctx.needs_input_grad[1]:
             dw = zbuf[n_tail:].view(w.shape)
+            ws2 = _workspace(d, 2, x.device)            # noqa: F841  (opt-in to the F(3x3, 2x2) weight-gradient kernel)
             hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(dz), hip.ptr(dw), hip.stream())
         return dx, dw, d_bias, d_noise, d_strength, None, None, None, None, None, None, None, None, None
 

@@ -360,6 +360,54 @@ def test_conv_winograd_vs_oracle_and_implicit_gemm(case):
             assert float((diff > 1e-5).float().mean()) < 5e-3 and float(diff.median()) < 1e-6, what
 
 
+WINO_WGRAD_CASES = [  # N, I, O, H, W, flip, per_sample, tap_major
+    (1, 64, 64, 64, 64, False, True, 1),            # one 64 x 64 channel block, two strips, whole tiles
+    (2, 96, 40, 50, 70, True, True, 1),             # ragged: 40 of 64 output rows, 1.5 input blocks, a partial third strip, per-sample weights
+    (3, 32, 32, 33, 45, False, False, 1),           # odd height and width (tiles hanging over both edges), batch summed into ONE weight set
+    (1, 128, 128, 256, 256, True, True, 0),         # a real layer size (b256.conv1), [O,I,3,3] weight layout
+    (4, 64, 128, 128, 128, True, False, 1),         # the pseudo-view branches' shape: 4 images sharing one weight set
+]
+
+
+@pytest.mark.parametrize('case', WINO_WGRAD_CASES)
+def test_conv_winograd_wgrad_vs_oracle_and_implicit_gemm(case):
+    """The F(3x3, 2x2) weight-gradient kernel (winograd.hip: wino_wgrad_kernel) against the CPU oracle (autograd of F.conv2d) and against the
+    implicit-GEMM weight gradient on the same inputs, through the C ABI (spi_conv2d_wgrad with / without the opt-in workspace).  fp32
+    throughout; both kernels reduce 10^3..10^5 products per weight with atomics, so the bar is 1e-5 of the tensor's max vs the oracle
+    (2e-5 for the 65 536-pixel layer) and the two HIP paths agree as closely."""
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    N, I, O, H, W, flip, per, tap_major = case
+    torch.set_num_threads(min(__import__('os').cpu_count() or 1, 32))
+    gen = torch.Generator().manual_seed(N * 1000 + O + H)
+    x = torch.randn(N, I, H, W, generator=gen)
+    w = (torch.randn(*((N,) if per else ()), O, I, 3, 3, generator=gen) / (I * 9) ** 0.5).requires_grad_(True)
+    dy = torch.randn(N, O, H, W, generator=gen)
+    gw, = torch.autograd.grad(_ref_conv(x.double(), w.double(), 1, False, flip), [w], dy.double())
+    xg, dyg = x.to(DEV), dy.to(DEV)
+    got = {}
+    for wino in (True, False):
+        d = conv2d_mfma._desc(N, I, O, H, W, 3, 1, False, flip, O * I * 9 if per else 0, tap_major=tap_major)
+        if wino:
+            nbytes = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2)
+            assert nbytes > 0, 'the shape must take the Winograd weight-gradient path'
+            ws = torch.empty(nbytes, device=DEV, dtype=torch.uint8)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        dw = torch.full((*((N,) if per else ()), O, 3, 3, I) if tap_major else w.shape, 7.0, device=DEV)       # dirty: the call zeroes it
+        hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(xg), hip.ptr(dyg), hip.ptr(dw), hip.stream())
+        got[wino] = dw.movedim(-1, -3) if tap_major else dw
+    tol = 2e-5 if H * W * (1 if per else N) >= 65536 else 1e-5
+    assert_close(got[True], gw.float(), tol, 'winograd wgrad vs oracle')
+    assert_close(got[False], gw.float(), tol, 'implicit-GEMM wgrad vs oracle')
+    assert_close(got[True], got[False], tol, 'winograd vs implicit-GEMM wgrad')
+    # not offered where it does not apply: masked (sparse) gradients, 1x1 / transposed convs, rows shorter than a strip
+    d = conv2d_mfma._desc(1, 64, 64, 16, 16, 3, 1, False, False, 0, tap_major=1)
+    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0
+    d = conv2d_mfma._desc(1, 64, 64, 64, 64, 3, 0, True, False, 0, tap_major=1)
+    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0
+
+
 def test_conv_wgrad_zeroes_a_dirty_buffer_itself():
     """spi_conv2d_wgrad with dw_zeroed = 0 clears dw with the library's own kernel (spi_zero_async; not hipMemsetAsync, whose captured
     form misbehaves for odd byte counts on ROCm 7.0): a dirty, odd-sized (135-float) buffer ends up holding exactly the gradient."""

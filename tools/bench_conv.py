@@ -75,7 +75,11 @@ def main():
         reps = 3 if flops > 2e10 else 10
         f = timeit(lambda: hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), s), reps)
         g = timeit(lambda: hip.call('spi_conv2d_dgrad', ctypes.byref(dg), hip.ptr(y), hip.ptr(w), hip.ptr(dx), s), reps)
-        h = timeit(lambda: hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(x), hip.ptr(y), hip.ptr(dw), s), reps) if per else float('nan')
+        dwg = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
+        wsw = cm._workspace(dwg, 2, x.device) if (wino and os.environ.get('SPI_BENCH_WINO_WGRAD', '1') != '0') else None
+        if wsw is not None:
+            name += '[Wg]'
+        h = timeit(lambda: hip.call('spi_conv2d_wgrad', ctypes.byref(dwg), hip.ptr(x), hip.ptr(y), hip.ptr(dw), s), reps) if per else float('nan')
         tf = lambda ms: flops / ms / 1e9
         print(f'{name:34s} {flops / 1e9:7.1f} | {f:8.3f} {tf(f):6.1f} | {g:8.3f} {tf(g):6.1f} | {h:8.3f} {tf(h):6.1f}', flush=True)
 
