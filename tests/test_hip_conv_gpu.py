@@ -481,8 +481,10 @@ def test_conv_winograd_is_not_offered_where_it_does_not_apply():
                      ((1, 64, 64, 256, 256, 3, 1, False, False, 0), dict(f16=1))]:        # fp16 operands requested
         d = conv2d_mfma._desc(*args, tap_major=1, **kw)
         assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 0) == 0, args
+        assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0, args                 # (< 32 input channels / rows shorter than a strip for the weight gradient)
     d = conv2d_mfma._desc(1, 64, 64, 256, 256, 3, 1, False, False, 0, tap_major=1)
-    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0                  # no Winograd weight-gradient pass (yet)
+    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 16                 # the weight-gradient pass (round 3): a nominal opt-in workspace
+    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 3) == 0                  # no such pass
 
 
 SPLIT_CASES = [(1, 64, 128, 40, 3, 1, False, True, True), (2, 32, 48, 24, 3, 0, True, False, True), (1, 128, 128, 96, 3, 1, False, True, True),
