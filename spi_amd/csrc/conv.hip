@@ -996,7 +996,7 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
     }
     Wp.seg_flags = P.seg_flags; Wp.out_flags = P.out_flags; Wp.nseg = P.seg_flags ? P.nseg : P.out_nseg;
     const int64_t blocks = (int64_t)Wp.bx * Wp.by * (Wp.ocp / 64) * P.N;
-    return blocks >= 256 && P.Mo >= 48;
+    return blocks >= 128 && P.Mo >= 48;
 }
 
 // Winograd F(3x3, 2x2) eligibility of a weight-gradient problem (P = make_forward(d)): 3x3, stride 1, pad 1, exact fp32, dense gradient
