@@ -999,12 +999,12 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
     return blocks >= 128 && P.Mo >= 48;
 }
 
-// Winograd F(3x3, 2x2) eligibility of a weight-gradient problem (P = make_forward(d)): 3x3, stride 1, pad 1, exact fp32, dense gradient
-// (the masked branches keep the implicit GEMM, which skips their zero segments), rows of at least one 32-pixel strip, and enough tile rows
-// per block for the 64 x 64 x 16 accumulators' prologue / 144-atomic epilogue to amortise.
+// Winograd F(3x3, 2x2) eligibility of a weight-gradient problem (P = make_forward(d)): 3x3, stride 1, pad 1, exact fp32, rows of at least one
+// 32-pixel strip, and enough tile rows per block for the 64 x 64 x 16 accumulators' prologue / 144-atomic epilogue to amortise.  A masked
+// gradient (dy_seg_flags) is handled inside the kernel: tile rows without a flagged segment are skipped.
 static bool make_wino_wgrad(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
     if (d->transposed || d->kh != 3 || d->pad != 1 || (d->compute_f16 != 0 && d->compute_f16 != 3) || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
-    if (d->dy_seg_flags || P.IH != P.OH || P.IW != P.OW || P.OW < 32 || P.OH < 16) return false;
+    if (P.IH != P.OH || P.IW != P.OW || P.OW < 32 || P.OH < 16) return false;
     if ((int64_t)P.OH * P.OW * 64 * 4 >= (1ll << 31) || P.Mo < 32 || P.Ci < 32) return false;
     Wp.N = P.N; Wp.nw = d->w_batch_stride ? P.N : 1; Wp.Mo = P.Mo; Wp.Ci = P.Ci; Wp.H = P.OH; Wp.W = P.OW;
     Wp.bx = Wp.by = 0; Wp.ocp = 0;
@@ -1014,7 +1014,8 @@ static bool make_wino_wgrad(const spi_conv_desc* d, const IGemmParams& P, WinoPa
         if (T.dy[t] < -1 || T.dy[t] > 1 || T.dx[t] < -1 || T.dx[t] > 1) return false;
         Wp.widx[(T.dy[t] + 1) * 3 + (T.dx[t] + 1)] = T.widx[t];
     }
-    Wp.seg_flags = nullptr; Wp.out_flags = nullptr; Wp.nseg = 0;
+    Wp.seg_flags = d->dy_seg_flags; Wp.out_flags = nullptr;
+    Wp.nseg = d->dy_seg_flags ? (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS) : 0;
     return true;
 }
 constexpr int64_t WINO_WGRAD_WS = 16;      // the pass needs no scratch; a (nominal) workspace is the caller's opt-in, as for the other passes

@@ -361,6 +361,7 @@ struct WinoWgradParams {
     int tiles_per_chunk;                // tile rows per block
     int64_t in_bs, out_bs, wbs;
     int wsm, wsc, widx[9];              // dw[n*wbs + m*wsm + c*wsc + widx[ky*3 + kx]]
+    const int32_t* seg_flags; int nseg; // optional zero-segment map of dy ([N, nseg] over flat pixels / 16, spi_conv_desc.dy_seg_flags) or NULL
 };
 
 __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, const float* __restrict__ x, const float* __restrict__ dy,
@@ -455,23 +456,42 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
 
-    // ---- prologue: the first tile row's 4 input rows and 2 gradient rows; its first tile pair transformed
-    {
-        const int y = 2 * ty_beg;
+    // ---- (re)start of the pipeline at tile row ty: its 4 input rows and 2 gradient rows, and its first tile pair transformed
+    auto prime = [&](int ty) {
+        const int y = 2 * ty;
 #pragma unroll
         for (int i = 0; i < 17; ++i) { xfer(0, y - 1, y % GXR, i); xfer(0, y + 1, (y + 2) % GXR, i); xfer(1, y, y % GDR, i); }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        set_rows(ty_beg);
+        set_rows(ty);
 #pragma unroll
         for (int k = 0; k < 4; ++k) read_x(0, k);
         read_d(0, 0); read_d(0, 1);
 #pragma unroll
         for (int a = 0; a < 4; ++a) xform_x(opb[0], a);
         xform_d(opa[0]);
-    }
+    };
+    // masked losses: a tile row whose two gradient rows hold no flagged 16-pixel segment inside the strip multiplies by zeros -- skipped,
+    // and the pipeline restarts at the next row that does (block-uniform: the flags come through scalar loads)
+    const int32_t* fl = P.seg_flags ? P.seg_flags + (int64_t)n * P.nseg : nullptr;
+    auto flagged = [&](int ty) {
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int y = 2 * ty + k;
+            if (y < P.H) {
+                const int a = (y * P.W + px0) >> 4, b = (y * P.W + min(px0 + 31, P.W - 1)) >> 4;
+                for (int sg = a; sg <= b; ++sg) any |= fl[sg];
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(any) != 0;
+    };
 
+    bool primed = false, any_step = false;
     for (int ty = ty_beg; ty < ty_end; ++ty) {
+        if (fl && !flagged(ty)) { primed = false; continue; }
+        if (!primed) prime(ty);
+        primed = any_step = true;
         const int yn = 2 * ty + 2;                                    // first gradient row of the next tile row
         // 8 tile pairs x 16 frequencies.  Behind every MFMA one micro-slot of side work (an MFMA holds the pipe for 64 cycles after a 4-cycle
         // issue): slots 0..5 of a pair read the raw patch of the next pair, slots 6..10 transform it, the 34 row transfers of the next step are
@@ -509,6 +529,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
         }
     }
 
+    if (!any_step) return;                                            // nothing flagged in this block's rows: its partial sums are zero
     // ---- output transform A^T (s s^T (.) M) A and the atomic adds.  C/D layout: col = lane & 31 (input channel), row = (r & 3) + 8 (r >> 2) + 4 h.
     //      The accumulators leave the AGPRs through LDS (ds_write takes an AGPR as its data operand), four rows r at a time, and every lane reads
     //      its own 16 frequencies of a row back into VGPRs.  Doing the arithmetic on the accumulators directly makes the register allocator copy all
@@ -583,6 +604,7 @@ int spi_wino_wgrad_launch(const WinoParams& Wp, const float* x, const float* dy,
     P.strips = (Wp.W + 31) / 32; P.nci = (Wp.Ci + 63) / 64;
     P.in_bs = Wp.in_bs; P.out_bs = Wp.out_bs; P.wbs = Wp.wbs; P.wsm = Wp.wsm; P.wsc = Wp.wsc;
     for (int t = 0; t < 9; ++t) P.widx[t] = Wp.widx[t];
+    P.seg_flags = Wp.seg_flags; P.nseg = Wp.nseg;
     const int tiles_y = (Wp.H + 1) / 2;
     const int cc = ((Wp.Mo + 63) / 64) * P.nci;
     // one block per CU (85 KB of LDS, 512 registers per lane): split the tile rows so that one round of blocks fills the 256 CUs

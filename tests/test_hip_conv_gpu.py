@@ -401,7 +401,25 @@ def test_conv_winograd_wgrad_vs_oracle_and_implicit_gemm(case):
     assert_close(got[True], gw.float(), tol, 'winograd wgrad vs oracle')
     assert_close(got[False], gw.float(), tol, 'implicit-GEMM wgrad vs oracle')
     assert_close(got[True], got[False], tol, 'winograd vs implicit-GEMM wgrad')
-    # not offered where it does not apply: masked (sparse) gradients, 1x1 / transposed convs, rows shorter than a strip
+    # masked gradient (the pseudo-view branches): dy is zero outside a blob, the zero-segment map lets the kernel skip the tile rows of a strip
+    # that hold nothing -- the pipeline restarts after every gap (here: two blobs per image, one touching the border, plus a lone pixel)
+    mask = torch.zeros(N, 1, H, W)
+    mask[:, :, H // 5:H // 2, W // 6:W // 2] = 1
+    mask[:, :, H - H // 4:, W // 3:] = 1
+    mask[:, :, 1, W - 1] = 1
+    dym = dy * mask
+    gwm, = torch.autograd.grad(_ref_conv(x.double(), w.double(), 1, False, flip), [w], dym.double())
+    dymg = dym.to(DEV)
+    flags = conv2d_mfma.seg_flags(dymg)
+    for wino in (True, False):
+        d = conv2d_mfma._desc(N, I, O, H, W, 3, 1, False, flip, O * I * 9 if per else 0, tap_major=tap_major, dy_flags=flags)
+        if wino:
+            assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) > 0
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+        dw = torch.full((*((N,) if per else ()), O, 3, 3, I) if tap_major else w.shape, 7.0, device=DEV)
+        hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(xg), hip.ptr(dymg), hip.ptr(dw), hip.stream())
+        assert_close(dw.movedim(-1, -3) if tap_major else dw, gwm.float(), tol, f'masked wgrad vs oracle (winograd={wino})')
+    # not offered where it does not apply: 1x1 / transposed convs, rows shorter than a strip
     d = conv2d_mfma._desc(1, 64, 64, 16, 16, 3, 1, False, False, 0, tap_major=1)
     assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0
     d = conv2d_mfma._desc(1, 64, 64, 64, 64, 3, 0, True, False, 0, tap_major=1)
