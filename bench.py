@@ -175,7 +175,7 @@ def conv_roofline(dev, f16, prec=0):
         avg = sum(ms) / len(ms)
         res[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12}
     worst = min(v['achieved'] for v in res.values())
-    out = {'kernel': 'igemm_kernel / wgrad_kernel on SR b512.conv1 (128->128, 3x3, 512^2, N=1)', 'bound': 'mfma', 'achieved': worst, 'peak': peak,
+    out = {'kernel': 'igemm_kernel / wgrad_kernel (implicit GEMM, the kernels of the 1x1 / transposed / small layers) on SR b512.conv1 (128->128, 3x3, 512^2, N=1)', 'bound': 'mfma', 'achieved': worst, 'peak': peak,
            'unit': 'TFLOP/s', 'frac': worst / peak, 'flop_per_launch': flop, 'passes': res,
            'note': 'achieved = slowest of the three passes; wgrad includes its memset of dw'}
     # the same layer on the Winograd F(2x2, 3x3) path the loop actually takes for forward / dgrad of the >= 128^2 3x3 layers (exact fp32
@@ -184,7 +184,8 @@ def conv_roofline(dev, f16, prec=0):
     if global_config.conv_winograd and not f16 and prec in (0, 3):
         wres = {}
         for name, pid, fn in (('fwd', 0, lambda dd: hip.call('spi_conv2d_fwd', ctypes.byref(dd), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())),
-                              ('dgrad', 1, lambda dd: hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(y), hip.ptr(w), hip.ptr(dx), hip.stream()))):
+                              ('dgrad', 1, lambda dd: hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(y), hip.ptr(w), hip.ptr(dx), hip.stream())),
+                              ('wgrad', 2, lambda dd: hip.call('spi_conv2d_wgrad', ctypes.byref(dd), hip.ptr(x), hip.ptr(y), hip.ptr(dw), hip.stream()))):
             dd = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1)
             ws = cm._workspace(dd, pid, x.device)
             if ws is None:
@@ -198,8 +199,9 @@ def conv_roofline(dev, f16, prec=0):
             avg = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
             wres[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12, 'executed': flop / 2.25 / (avg * 1e-3) / 1e12,
                           'frac_executed': flop / 2.25 / (avg * 1e-3) / 1e12 / peak}
-        out['winograd'] = {'kernel': 'wino_weight_kernel + wino_conv_kernel, same layer', 'passes': wres,
-                           'note': 'fp32 operands and accumulation; 16 MFMA multiplications per 2x2 output tile and channel pair instead of 36'}
+        out['winograd'] = {'kernel': 'wino_weight_kernel + wino_conv_kernel (F(2x2,3x3): fwd, dgrad), wino_wgrad_kernel (F(3x3,2x2): wgrad, incl. its memset of dw), same layer',
+                           'passes': wres,
+                           'note': 'fp32 operands and accumulation; 16 MFMA multiplications per 2x2 tile and channel pair instead of 36; these are the kernels the loop runs for this layer'}
     return out
 
 
