@@ -472,24 +472,37 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
         xform_d(opa[0]);
     };
     // masked losses: a tile row whose two gradient rows hold no flagged 16-pixel segment inside the strip multiplies by zeros -- skipped,
-    // and the pipeline restarts at the next row that does (block-uniform: the flags come through scalar loads)
-    const int32_t* fl = P.seg_flags ? P.seg_flags + (int64_t)n * P.nseg : nullptr;
-    auto flagged = [&](int ty) {
-        int any = 0;
+    // and the pipeline restarts at the next row that does.  The block's rows are classified ONCE, here (lane i of wave 0 looks at tile row
+    // ty_beg + 64 j + i, the ballots live in SGPRs): a per-step flag load would expose a scalar-memory round trip in front of every step.
+    unsigned long long rowmask[4] = {~0ull, ~0ull, ~0ull, ~0ull};     // host: tiles_per_chunk <= 256
+    if (P.seg_flags) {
+        const int32_t* fl = P.seg_flags + (int64_t)n * P.nseg;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int y = 2 * ty + k;
-            if (y < P.H) {
-                const int a = (y * P.W + px0) >> 4, b = (y * P.W + min(px0 + 31, P.W - 1)) >> 4;
-                for (int sg = a; sg <= b; ++sg) any |= fl[sg];
+        for (int j = 0; j < 4; ++j) {
+            const int ty = ty_beg + 64 * j + lane;
+            int any = 0;
+            if (ty < ty_end) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int y = 2 * ty + k;
+                    if (y < P.H) {
+                        const int a = (y * P.W + px0) >> 4, b = (y * P.W + min(px0 + 31, P.W - 1)) >> 4;
+                        for (int sg = a; sg <= b; ++sg) any |= fl[sg];
+                    }
+                }
             }
+            rowmask[j] = __ballot(any != 0);
         }
-        return __builtin_amdgcn_readfirstlane(any) != 0;
+    }
+    auto flagged = [&](int ty) {
+        const int r = ty - ty_beg;
+        const unsigned long long m = (r >> 6) == 0 ? rowmask[0] : (r >> 6) == 1 ? rowmask[1] : (r >> 6) == 2 ? rowmask[2] : rowmask[3];
+        return ((m >> (r & 63)) & 1ull) != 0;
     };
 
     bool primed = false, any_step = false;
     for (int ty = ty_beg; ty < ty_end; ++ty) {
-        if (fl && !flagged(ty)) { primed = false; continue; }
+        if (!flagged(ty)) { primed = false; continue; }
         if (!primed) prime(ty);
         primed = any_step = true;
         const int yn = 2 * ty + 2;                                    // first gradient row of the next tile row
@@ -610,7 +623,7 @@ int spi_wino_wgrad_launch(const WinoParams& Wp, const float* x, const float* dy,
     // one block per CU (85 KB of LDS, 512 registers per lane): split the tile rows so that one round of blocks fills the 256 CUs
     const int64_t base = (int64_t)cc * P.strips * Wp.N;
     int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(base, 1), tiles_y / 4));
-    P.tiles_per_chunk = (tiles_y + chunks - 1) / chunks;
+    P.tiles_per_chunk = std::min((tiles_y + chunks - 1) / chunks, 256);          // (the kernel's row classification holds 4 x 64 rows)
     chunks = (tiles_y + P.tiles_per_chunk - 1) / P.tiles_per_chunk;
     constexpr size_t lds_bytes = GLDS * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

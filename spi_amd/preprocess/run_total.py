@@ -1,12 +1,13 @@
 """Dataset preparation driver (mirror of preprocess/run_total.py:16-91): ``--input_root`` photos -> ``--output_root``/{input, crop, c, lm, mask}/
 <name>/target.*, the layout ``PTIDataset`` reads (spi/data/images_dataset.py:102-147).
 
-Of its three producers only the parsing mask is arithmetic this repository owns (BiSeNet on the MI355X conv kernels,
-preprocess/extract_mask.py).  The other two wrap third-party trained networks that are neither in the reference tree nor installable
-offline -- `face_alignment` (68 landmarks, preprocess/extract_landmark.py:11-24) and Deep3DFaceRecon + BFM (crop + camera,
-preprocess/extract_camera.py:52-186) -- so they are INJECTED: ``landmark_fn(PIL image 256^2) -> float32 [68, 2]`` and
-``camera_fn(image_path, crop_outdir, c_outdir, mode) -> None`` (must write ``target.<mode>`` into crop_outdir and ``target.npy`` (25 floats)
-into c_outdir).  Without them the driver stops with an explanation instead of producing a partial dataset.
+Producers: the parsing mask (BiSeNet, preprocess/extract_mask.py) and the crop + camera (alignment, the Deep3DFaceRecon ResNet-50
+regressor and the camera arithmetic, preprocess/extract_camera.py) run on the MI355X conv kernels of this package; their trained weights
+(`bisenet.pth`, `checkpoints/model_name/epoch_20.pth`, the BFM landmark file) are third-party files the user supplies, as for the reference.
+The 68-landmark detector is the third-party `face_alignment` package (preprocess/extract_landmark.py:11-24), neither in the reference tree
+nor installable offline: ``landmark_fn(PIL image) -> float32 [68, 2]`` is injected (with the package installed the reference's own call is
+built).  ``camera_fn(image_path, crop_outdir, c_outdir, mode)`` may replace the whole crop + camera step.  A missing file or detector stops
+the driver with an explanation instead of producing a partial dataset.
 """
 import argparse
 import glob
@@ -24,25 +25,18 @@ def parse_args(argv=None):
     return parser.parse_args(argv)
 
 
-def extract_landmark(input_dir, output_dir, mode='png', landmark_fn=None):
-    """preprocess/extract_landmark.py:27-40: RGB, resized to 256^2, one [68,2] .npy per image."""
-    from PIL import Image
-    if landmark_fn is None:
-        raise RuntimeError('no landmark detector: the reference uses the third-party `face_alignment` package (extract_landmark.py:11); '
-                           'pass landmark_fn(image_256) -> [68, 2]')
-    os.makedirs(output_dir, exist_ok=True)
-    for image_path in sorted(glob.glob(f'{input_dir}/*.{mode}')):
-        image = Image.open(image_path).convert('RGB').resize((256, 256))
-        lm = np.asarray(landmark_fn(image), dtype=np.float32)
-        assert lm.shape == (68, 2), lm.shape
-        np.save(os.path.join(output_dir, os.path.basename(image_path).split('.')[0] + '.npy'), lm)
-
-
-def run(input_root, output_root, mode='jpg', camera_fn=None, landmark_fn=None, bisenet=None, device=None):
+def run(input_root, output_root, mode='jpg', camera_fn=None, landmark_fn=None, bisenet=None, device=None, model_paths=None, recon_state_dict=None,
+        lm3d_std=None):
+    from .extract_landmark import extract_landmark
     from .extract_mask import extract_mask
-    if camera_fn is None:
-        raise RuntimeError('no crop / camera extractor: the reference uses Deep3DFaceRecon + BFM checkpoints (extract_camera.py:52-60); '
-                           'pass camera_fn(image_path, crop_outdir, c_outdir, mode)')
+    if camera_fn is None:                                         # preprocess/run_total.py:40: one extractor for the whole run
+        from .extract_camera import CameraExtractor
+        extractor = CameraExtractor(None, None, None, model_paths=model_paths, landmark_fn=landmark_fn, device=device or 'cuda',
+                                    state_dict=recon_state_dict, lm3d_std=lm3d_std)
+
+        def camera_fn(path, crop_dir, c_dir, md):
+            extractor.set_path(crop_outdir=crop_dir, c_outdir=c_dir, mode=md)
+            extractor.extract(path)
     dirs = {k: os.path.join(output_root, k) for k in ('input', 'c', 'crop', 'lm', 'mask')}
     for d in dirs.values():
         os.makedirs(d, exist_ok=True)

@@ -746,9 +746,54 @@ def sec_bisenet():
          out_mean=out.mean(dim=(2, 3)), out_absmax=out.abs().amax())
 
 
+def sec_recon():
+    """SURVEY 8f-4, crop + camera producer: the reference's 3DMM regressor (third_part/Deep3DFaceRecon_pytorch/models/networks.py:
+    ReconNetWrapper('resnet50')) on seeded synthetic weights (the trained epoch_20.pth is not available offline), eval mode, and
+    preprocess/process_camera.py.  One import-time obstacle outside the arithmetic: networks.py does `from kornia.geometry import warp_affine`
+    for RecogNetWrapper.resize_n_crop, which this path never calls; the package does not exist here -> an empty placeholder module is
+    registered for the import (the same treatment as `torchvision` in sec_bisenet).  preprocess/extract_3dmm.py / extract_camera.py are NOT
+    importable here (face_alignment, cv2, torchvision; the detector is instantiated at import): align_img / cal_camera stay unpinned by
+    import, oracle/recon_ref.py says so."""
+    import types
+    kg = types.ModuleType('kornia.geometry')
+    kg.warp_affine = None
+    sys.modules.setdefault('kornia', types.ModuleType('kornia'))
+    sys.modules.setdefault('kornia.geometry', kg)
+    from third_part.Deep3DFaceRecon_pytorch.models.networks import ReconNetWrapper
+    from preprocess.process_camera import process_camera as ref_process_camera
+    from oracle import recon_ref as orr2
+    net = ReconNetWrapper('resnet50', use_last_fc=False)
+    man = {k: list(v.shape) for k, v in net.state_dict().items()}
+    with open(os.path.join(HERE, 'manifest_recon.json'), 'w') as f:
+        json.dump(man, f, indent=0)
+    sd = orr2.synthetic_state_dict(man, seed=0)
+    net.load_state_dict(sd)
+    net.eval()
+    g = torch.Generator().manual_seed(71)
+    img = F.interpolate(torch.rand(2, 3, 28, 28, generator=g), size=(224, 224), mode='bicubic', align_corners=False).clamp(0, 1)
+    with torch.no_grad():
+        out = net(img)
+        ref = orr2.recon_net(sd, img)
+    diff('recon coefficients', out, ref)
+    print('    coefficient scale: |angle| %.3f |trans| %.3f' % (out[:, 224:227].abs().max(), out[:, 254:].abs().max()))
+    # camera label from a pose / intrinsics pair
+    rng = np.random.default_rng(5)
+    pose = np.eye(4)
+    pose[:3, :3] = np.linalg.qr(rng.standard_normal((3, 3)))[0]
+    pose[:3, 3] = rng.standard_normal(3)
+    K = np.eye(3)
+    K[0, 0] = K[1, 1] = 2985.29
+    K[0, 2] = K[1, 2] = 512.0
+    cam = ref_process_camera(pose.tolist(), K.tolist())
+    mine = orr2.process_camera(pose.tolist(), K.tolist())
+    print('    pin process_camera: max|ref-oracle| = %.3e' % np.abs(cam - mine).max())
+    assert np.array_equal(cam, mine)
+    save('recon', seed=np.array([0]), img_seed=np.array([71]), coeffs=out, pose=pose, K=K, camera=cam)
+
+
 SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, renderer_options=sec_renderer_options, synthesis=sec_synthesis,
                 geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory, trajectory_sg=sec_trajectory_sg,
-                tv=sec_tv, orbit=sec_orbit, orbit_frames=sec_orbit_frames, bisenet=sec_bisenet)
+                tv=sec_tv, orbit=sec_orbit, orbit_frames=sec_orbit_frames, bisenet=sec_bisenet, recon=sec_recon)
 
 if __name__ == '__main__':
     todo = sys.argv[1:] or list(SECTIONS)

@@ -449,9 +449,9 @@ def test_marching_cubes_table_ambiguous_faces_and_reference_sigma_grid(golden):
 
 
 def test_preprocess_driver_layout_feeds_the_dataset(tmp_path):
-    """preprocess/run_total.py: photos -> {input, crop, c, lm, mask}/<name>/target.* -- exactly what PTIDataset reads back; the third-party
-    producers (Deep3DFaceRecon camera / crop, face_alignment landmarks) are injected, the mask producer is the BiSeNet path (a CPU stand-in
-    network here: the real one needs the GPU kernels)."""
+    """preprocess/run_total.py: photos -> {input, crop, c, lm, mask}/<name>/target.* -- exactly what PTIDataset reads back; here the crop / camera
+    step and the landmark detector are injected callables and the mask producer is a CPU stand-in network (the real producers need the GPU
+    kernels: tests/test_hip_preprocess_gpu.py)."""
     import numpy as np
     from PIL import Image
     from spi_amd.preprocess import run_total
@@ -461,8 +461,8 @@ def test_preprocess_driver_layout_feeds_the_dataset(tmp_path):
     rng = np.random.RandomState(0)
     for nm in ('a', 'b'):
         Image.fromarray(rng.randint(0, 255, (300, 280, 3), dtype=np.uint8)).save(src / f'{nm}.png')
-    with pytest.raises(RuntimeError):
-        run_total.run(str(src), str(tmp_path / 'ds'), 'png')
+    with pytest.raises(FileNotFoundError):                       # no Deep3DFaceRecon checkpoint / BFM file: the crop + camera step says so
+        run_total.run(str(src), str(tmp_path / 'ds'), 'png', device='cpu')
 
     def camera_fn(path, crop_dir, c_dir, mode):
         Image.open(path).resize((512, 512)).save(os.path.join(crop_dir, f'target.{mode}'))
@@ -484,6 +484,67 @@ def test_preprocess_driver_layout_feeds_the_dataset(tmp_path):
     assert d['lm'].shape == (68, 2) and np.asarray(d['c']).shape == (25,) and int(d['mask'].max()) == 18
     args = run_total.parse_args([])
     assert (args.input_root, args.output_root, args.mode) == ('./test/images/', './test/dataset/', 'jpg')
+
+
+def test_crop_camera_producer_arithmetic(golden):
+    """SURVEY 8f-4, crop + camera producer on the host: the oracle's ResNet-50 regressor reproduces the reference network's coefficients
+    (golden/recon.npz), `process_camera` (product and oracle) reproduces the reference's label bit for bit, and the parts whose reference
+    modules cannot be imported here (align_img, cal_camera: oracle/recon_ref.py header) hold their known answers and agree between product and oracle."""
+    import json
+    import numpy as np
+    from PIL import Image
+    from conftest import ROOT
+    from oracle import recon_ref as orr2
+    from spi_amd.preprocess import process_camera as pc, extract_3dmm as e3
+    from spi_amd.preprocess.extract_camera import compute_rotation, CameraExtractor
+    g = golden('recon')
+    man = {k: tuple(v) for k, v in json.load(open(os.path.join(ROOT, 'tests', 'golden', 'manifest_recon.json'))).items()}
+    sd = orr2.synthetic_state_dict(man, seed=int(g['seed'][0]))
+    gen = torch.Generator().manual_seed(int(g['img_seed'][0]))
+    img = torch.nn.functional.interpolate(torch.rand(2, 3, 28, 28, generator=gen), size=(224, 224), mode='bicubic', align_corners=False).clamp(0, 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    with torch.no_grad():
+        out = orr2.recon_net(sd, img)
+    assert (out - g['coeffs']).abs().max().item() <= 1e-5 * g['coeffs'].abs().max().item()
+    pose, K = g['pose'].numpy(), g['K'].numpy()
+    for fn in (pc.process_camera, orr2.process_camera):
+        assert np.array_equal(fn(pose.tolist(), K.tolist()), g['camera'].numpy())
+    cam = pc.process_camera(pose.tolist(), K.tolist())
+    assert abs(np.linalg.norm(cam[:16].reshape(4, 4)[:3, 3]) - 2.7) < 1e-12 and np.allclose(cam[16:], [2985.29 / 700, 0, .5, 0, 2985.29 / 700, .5, 0, 0, 1])
+    # POS recovers a similarity transform from its own points: xp = s * P x + t with P the first two rows of a rotation
+    rng = np.random.default_rng(3)
+    x3 = rng.standard_normal((3, 5))
+    Rm = np.linalg.qr(rng.standard_normal((3, 3)))[0]
+    xp = 1.7 * (Rm[:2] @ x3) + np.array([[12.0], [-5.0]])
+    for fn in (e3.POS, orr2.pos):
+        t, s_ = fn(xp, x3)
+        assert abs(s_ - 1.7) < 1e-9 and np.allclose(t.ravel(), [12.0, -5.0], atol=1e-9)
+    # align_img: product == oracle on a synthetic photo (same PIL calls), 224^2 / 1024^2 outputs, landmarks land inside the crop
+    photo = Image.fromarray((rng.random((300, 280, 3)) * 255).astype(np.uint8))
+    lm = np.stack([140 + 60 * np.cos(np.linspace(0, 6.2, 68)), 150 + 70 * np.sin(np.linspace(0, 6.2, 68))], axis=1)
+    lm3d = np.concatenate([(e3.extract_5p(lm) - lm.mean(0)) / 100.0, np.zeros((5, 1))], axis=1) * [1, 1, 1]
+    tp, im224, lm224, _, im1024 = e3.align_img(photo, lm.copy(), lm3d)
+    tp_o, im224_o, lm224_o, im1024_o = orr2.align_img(photo, lm.copy(), lm3d)
+    assert im224.size == (224, 224) and im1024.size == (1024, 1024) and np.array_equal(np.array(im224), np.array(im224_o)) and np.array_equal(np.array(im1024), np.array(im1024_o))
+    assert np.allclose(tp, tp_o) and np.allclose(lm224, lm224_o) and tp.shape == (5,)
+    assert abs(np.linalg.norm(np.diff(e3.extract_5p(lm224)[:2], axis=0)) * 1024 / 224 / np.linalg.norm(np.diff(lm3d[:2, :2], axis=0)) - 466.285) < 1.0   # the standard face size
+    # rotations: orthonormal, the transposed product R_z R_y R_x, the identity at zero
+    ang = torch.tensor([[0.3, -0.5, 0.2]])
+    R = compute_rotation(ang).numpy()
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-6) and np.allclose(compute_rotation(torch.zeros(1, 3)).numpy(), np.eye(3))
+    assert np.allclose(R, orr2.compute_rotation(ang).numpy())
+    cx, sx = np.cos(0.3), np.sin(0.3)
+    assert np.allclose(compute_rotation(torch.tensor([[0.3, 0.0, 0.0]])).numpy(), np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]).T, atol=1e-6)
+    # cal_camera: product == oracle; a frontal face (zero angles, zero translation) looks down -z from (0, 0.006, 2.7 + 0.161) before the radius fix
+    ce = CameraExtractor.__new__(CameraExtractor)
+    co = {'angle': ang.clone(), 'trans': torch.tensor([[0.1, -0.2, 0.3]])}
+    mine = ce.cal_camera(co)
+    ref = orr2.cal_camera(ang.clone(), torch.tensor([0.1, -0.2, 0.3]))
+    assert np.allclose(mine['pose'], ref['pose']) and mine['intrinsics'] == ref['intrinsics'] and np.allclose(mine['angle'], ref['angle'])
+    front = ce.cal_camera({'angle': torch.zeros(1, 3), 'trans': torch.zeros(1, 3)})
+    assert np.allclose(np.array(front['pose'])[:3, 3], [0, 0.006, 2.7 + 0.161], atol=1e-6) and np.allclose(np.array(front['pose'])[:3, :3], np.diag([1, -1, -1]))
+    c25 = pc.process_camera(front['pose'], front['intrinsics'])
+    assert np.allclose(ce._cal_mirror_c(c25), orr2.mirror_camera(c25)) and np.allclose(ce._cal_mirror_c(ce._cal_mirror_c(c25)), c25)
 
 
 def test_tracing_helpers_mirror_the_reference_decorator():
