@@ -623,6 +623,8 @@ int spi_wino_wgrad_launch(const WinoParams& Wp, const float* x, const float* dy,
     // one block per CU (85 KB of LDS, 512 registers per lane): split the tile rows so that one round of blocks fills the 256 CUs
     const int64_t base = (int64_t)cc * P.strips * Wp.N;
     int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(256 / std::max<int64_t>(base, 1), tiles_y / 4));
+    // (masked gradient: cutting the rows finer -- 16 tile rows per block, so that the dispatcher balances the flagged part of the image -- was
+    //  measured slower: every extra block pays the 4-row prologue and the 144-atomic epilogue; tools/bench_wgrad_masked.py)
     P.tiles_per_chunk = std::min((tiles_y + chunks - 1) / chunks, 256);          // (the kernel's row classification holds 4 x 64 rows)
     chunks = (tiles_y + P.tiles_per_chunk - 1) / P.tiles_per_chunk;
     constexpr size_t lds_bytes = GLDS * sizeof(float);
