@@ -273,8 +273,9 @@ typedef struct spi_conv_desc {
     int dw_zeroed;            /* spi_conv2d_wgrad only: 1 = the caller already zeroed dw (saves the memset launch when dw is a slice of
                                * a buffer that was cleared together with other small gradients) */
     /* optional scratch memory (device, 16-byte aligned).  With at least spi_conv2d_workspace_bytes(d, pass) bytes the 3x3 / stride-1 /
-     * pad-1 forward and data-gradient passes of large layers run as Winograd F(2x2, 3x3) -- fp32 operands, fp32 accumulation, 2.25x fewer
-     * MFMAs; the result differs from the direct sum by a few fp32 roundings (what cuDNN runs for the reference's fp32 3x3 convs).
+     * pad-1 forward and data-gradient passes of large layers run as Winograd F(2x2, 3x3) and the weight-gradient pass as F(3x3, 2x2) -- fp32
+     * operands, fp32 accumulation, 2.25x fewer MFMAs; the result differs from the direct sum by a few fp32 roundings (what cuDNN runs for
+     * the reference's fp32 3x3 convs).  The weight-gradient pass needs no scratch: its spi_conv2d_workspace_bytes is a nominal 16.
      * NULL / too small: the implicit-GEMM kernels run.  The workspace holds the transformed weights of THIS call only.  Offered for
      * compute_f16 = 0 and 3 (the 6-product split asks for fp32-equivalent products, which fp32 Winograd delivers faster on these layers). */
     void* workspace;
