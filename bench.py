@@ -425,9 +425,16 @@ def main():
     if os.environ.get('SPI_TORCH_PROFILE'):                      # debugging aid: per-op device time / launch counts per stage (stderr)
         from torch.profiler import profile, ProfilerActivity
         for tag, a1, a2 in (('stage 1', k1, 0), ('stage 2', 0, k2)):
-            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            shapes = os.environ.get('SPI_TORCH_PROFILE') == 'shapes'
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=shapes) as prof:
                 run(a1, a2, 25 + w1, ((w2 + 3) // 4) * 4)
                 torch.cuda.synchronize()
+            if shapes:                                            # which tensors the small ATen launches work on
+                print(f'==== {tag}: small ATen ops by input shape', file=sys.stderr)
+                for e in sorted(prof.key_averages(group_by_input_shape=True), key=lambda e: -e.count):
+                    if e.key in ('aten::fill_', 'aten::mul', 'aten::add', 'aten::copy_', 'aten::add_', 'aten::mul_', 'aten::sum', 'aten::div', 'aten::sub',
+                                 'aten::neg', 'aten::cat', 'aten::clone', 'aten::contiguous', 'aten::index_select', 'aten::where', 'aten::mean') and e.count >= 3:
+                        print(f'{e.count:6d}  dev {e.device_time_total / 1e3:8.2f} ms  {e.key:20s} {str(e.input_shapes)[:150]}', file=sys.stderr)
             ka = prof.key_averages()
             print(f'==== {tag}: {a1 + a2} steps, by device time', file=sys.stderr)
             print(ka.table(sort_by='cuda_time_total', row_limit=45, max_name_column_width=60), file=sys.stderr)

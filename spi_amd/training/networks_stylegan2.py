@@ -202,6 +202,30 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                                         padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
 
 
+class _LinearGain(torch.autograd.Function):
+    """y = bias + gain * x W^T as ONE library GEMM each way.  torch's own addmm backward scales the weight gradient with a separate [out, in]
+    elementwise launch and materialises the broadcast bias gradient through a fill; with 29 affine layers per generator pass that was 58 of the
+    ~5 us launches of every stage-2 iteration (SPI_TORCH_PROFILE=shapes).  Here the gain rides as the GEMMs' alpha in both directions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gain):
+        ctx.save_for_backward(x, weight)
+        ctx.gain = float(gain)
+        return torch.addmm(bias.unsqueeze(0), x, weight.t(), alpha=ctx.gain)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.addmm(g.new_empty(x.shape), g, weight, beta=0, alpha=ctx.gain)            # beta = 0: the input tensor is ignored
+        if ctx.needs_input_grad[1]:
+            dw = torch.addmm(g.new_empty(weight.shape), g.t(), x, beta=0, alpha=ctx.gain)
+        if ctx.needs_input_grad[2]:
+            db = g[0] if g.shape[0] == 1 else g.sum(0)
+        return dx, dw, db, None
+
+
 class FullyConnectedLayer(torch.nn.Module):
     def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
         super().__init__()
@@ -219,7 +243,7 @@ class FullyConnectedLayer(torch.nn.Module):
             b = b * self.bias_gain
         if self.activation == 'linear' and b is not None:
             # plain library GEMM; the weight gain rides along as alpha instead of a [out, in] elementwise pass each way
-            return torch.addmm(b.unsqueeze(0), x, self.weight.to(x.dtype).t(), alpha=self.weight_gain)
+            return _LinearGain.apply(x, self.weight.to(x.dtype), b, self.weight_gain)
         w = self.weight.to(x.dtype) * self.weight_gain
         return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
 
