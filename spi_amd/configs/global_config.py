@@ -26,11 +26,11 @@ concurrent_branches = False
 
 # arithmetic of the dense convolutions (spi_conv_desc.compute_f16 of every conv that does not ask for fp16):
 #   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32, 157 TF peak) -- the default.  Bit-for-bit fp32 FMA chains ONLY together with
-#      conv_winograd = False (SPI_CONV_WINOGRAD=0): with the Winograd default below, the forward / dgrad passes of the large 3x3 layers
+#      conv_winograd = False (SPI_CONV_WINOGRAD=0): with the Winograd default below, the forward / dgrad / weight-gradient passes of the 3x3 layers
 #      are fp32 minimal filtering, which rounds differently from the direct sums (a few fp32 ulps; tested to 1e-5 of the tensor maximum)
 #   3  fp32 operands split into THREE bf16 pieces, the six significant piece products on the bf16 matrix cores with fp32 accumulation
-#      (error ~2^-23 per product: fp32-level; 2.7x less matrix-pipe time).  With conv_winograd on, the large 3x3 forward / dgrad passes
-#      of this mode are served by the fp32 Winograd kernel (at least as precise, and faster there); SPI_CONV_WINOGRAD=0 forces the split
+#      (error ~2^-23 per product: fp32-level; 2.7x less matrix-pipe time).  With conv_winograd on, the 3x3 forward / dgrad / weight-gradient passes
+#      of this mode are served by the fp32 Winograd kernels (at least as precise, and faster there); SPI_CONV_WINOGRAD=0 forces the split
 #      kernels everywhere
 #   2  two pieces, three products (error ~2^-16 per product; 5.3x less matrix-pipe time)
 # `--conv_precision {f32,bf16x6,bf16x3}` / `bench.py --conv-precision`.
@@ -40,8 +40,8 @@ conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[os.environ.get('SPI_CONV_P
 # Results are equal either way (tested); False = dense bound: every ray, gradient segment and SR tile is processed (`bench.py --dense`).
 exploit_sparsity = True
 
-# Winograd F(2x2, 3x3) for the 3x3 / stride-1 forward and data-gradient passes of the large layers (winograd.hip): fp32 operands and
-# accumulation, 2.25x fewer MFMAs; results differ from the direct sums by a few fp32 roundings.  Off = implicit GEMM everywhere.
+# Winograd F(2x2, 3x3) for the 3x3 / stride-1 forward and data-gradient passes of the large layers and F(3x3, 2x2) for their weight
+# gradients (winograd.hip): fp32 operands and accumulation, 2.25x fewer MFMAs; results differ from the direct sums by a few fp32 roundings.  Off = implicit GEMM everywhere.
 conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
 
 # stage 1: capture the projector step in a HIP graph after an eager warm-up step and replay it (projectors/common.py).  The step is
@@ -52,8 +52,10 @@ stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'
 # rot / mirror-rot / depth branches; the early-stop test and the Adam launch stay on the host.  OPT-IN (SPI_STAGE2_GRAPH=1).  Since round 3
 # it replays correctly at full size (BoxCX uses amin / amax: the index scatter of torch.min's backward faulted under replay;
 # test_stage2_hip_graph_replay_equals_eager_iterations_full_size), but it is SLOWER than eager enqueueing -- 33.0 vs 35.0 it/s: the host
-# reads the early-stop flag after every replay before it may launch Adam and the next 3 500-node graph, and the GPU idles meanwhile --
-# so eager stays the default; what it buys is host time (one graph launch instead of ~25 ms of enqueue work per iteration).
+# read the early-stop flag after every replay before it launched Adam and the next 3 500-node graph.  The replays are PIPELINED now (sticky
+# device-side stop byte, predicated Adam, the host reads the byte of iteration i - 2: rot_bbox_cx_coach.py): 35.8 vs 35.4 it/s in steady state,
+# 38.8 vs 39.3 over a whole 1 500-iteration job with its two captures -- the iteration is GPU-bound, so eager stays the default and the
+# graph buys host time (one graph launch instead of ~25 ms of enqueue work per iteration).
 stage2_hip_graph = os.environ.get('SPI_STAGE2_GRAPH', '0') == '1'
 
 # host side: freeze Python's garbage collector state around the optimisation loops (torch_utils/misc.quiet_gc): a full collection over the
