@@ -49,13 +49,12 @@ conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
 stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'
 
 # stage 2: the same for the RotBbox iteration (rot_bbox_cx_coach.py): one graph for the plain iteration, one for the iteration with the
-# rot / mirror-rot / depth branches; the early-stop test and the Adam launch stay on the host.  OPT-IN (SPI_STAGE2_GRAPH=1).  Since round 3
-# it replays correctly at full size (BoxCX uses amin / amax: the index scatter of torch.min's backward faulted under replay;
-# test_stage2_hip_graph_replay_equals_eager_iterations_full_size), but it is SLOWER than eager enqueueing -- 33.0 vs 35.0 it/s: the host
-# read the early-stop flag after every replay before it launched Adam and the next 3 500-node graph.  The replays are PIPELINED now (sticky
-# device-side stop byte, predicated Adam, the host reads the byte of iteration i - 2: rot_bbox_cx_coach.py): 35.8 vs 35.4 it/s in steady state,
-# 38.8 vs 39.3 over a whole 1 500-iteration job with its two captures -- the iteration is GPU-bound, so eager stays the default and the
-# graph buys host time (one graph launch instead of ~25 ms of enqueue work per iteration).
+# rot / mirror-rot / depth branches.  OPT-IN (SPI_STAGE2_GRAPH=1).  It replays correctly at full size since round 3 (BoxCX uses amin / amax:
+# the index scatter of torch.min's backward faulted under replay; test_stage2_hip_graph_replay_equals_eager_iterations_full_size) and the
+# replays are PIPELINED: the early-stop comparison is ORed into a sticky device byte, the Adam launch is predicated on it, and the host
+# reads the byte of iteration i - 2 when it launches iteration i.  Measured: 35.8 vs 35.4 it/s eager in steady state, 38.8 vs 39.3 over a
+# whole 1 500-iteration job with its two captures (the first version, which read the flag after every replay, ran 33.0 vs 35.0) -- the
+# iteration is GPU-bound, so eager stays the default and the graph buys host time (one graph launch instead of ~25 ms of enqueue work).
 stage2_hip_graph = os.environ.get('SPI_STAGE2_GRAPH', '0') == '1'
 
 # host side: freeze Python's garbage collector state around the optimisation loops (torch_utils/misc.quiet_gc): a full collection over the
