@@ -223,6 +223,16 @@ int spi_filtered_lrelu(const float* x, const float* fu, const float* fd, const f
                        int up, int down, int px0, int px1, int py0, int py1, float gain, float slope,
                        float clamp, int flip, int outH, int outW, spi_stream_t stream);
 
+/* The same operator in ONE launch (what filtered_lrelu.cu:119-1105 does: up-FIR, activation and down-FIR fused through shared memory; no
+ * upsampled tensor in memory, no `tmp`).  mode 0: no sign tensor; mode 1: also WRITE the reference's bit-packed signs of the upsampled
+ * samples (uint8 [N*C, sH, sW/4], 2 bits per sample: 1 = negative, 2 = clamped; sH >= midH, sW >= midW, sW % 4 == 0 -- the reference rounds
+ * sW to 16); mode 2 (gradient pass, filtered_lrelu.py:246-262): READ them at (col + sx, row + sy) instead of applying lrelu / clamp.
+ * N*C <= 65535; filters up to 256 taps whose windows fit 48 KB of LDS (12-tap filters at up = down = 2 use 31 KB). */
+int spi_filtered_lrelu_fused(const float* x, const float* fu, const float* fd, const float* b, uint8_t* signs, float* y, int N,
+                             int C, int inH, int inW, int fuH, int fuW, int fdH, int fdW, int up, int down, int px0, int px1,
+                             int py0, int py1, float gain, float slope, float clamp, int flip, int mode, int sH, int sW, int sx,
+                             int sy, int outH, int outW, spi_stream_t stream);
+
 /* filtered_lrelu.cpp:217 `filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, writeSigns) -> so`: the activation stage alone, IN PLACE on the
  * upsampled tensor x [NC, xH, xW], with the reference's bit-packed sign tensor (uint8 [NC, sH, sW/4]: 2 bits per element, 1 = negative,
  * 2 = clamped; sW a multiple of 4 -- the reference rounds it to 16).  mode 0: x = clamp(lrelu(x * gain)); mode 1: the same and WRITE the

@@ -50,6 +50,7 @@ _SIGS = {
     'spi_bias_act': ([c_p] * 6 + [c_l, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_upfirdn2d': ([c_p] * 3 + [c_i] * 15 + [c_f, c_i, c_i] + [c_p] * 3 + [c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_filtered_lrelu': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f, c_i, c_i, c_i, c_p], c_i),
+    'spi_filtered_lrelu_fused': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f] + [c_i] * 8 + [c_p], c_i),
     'spi_filtered_lrelu_act': ([c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_p], c_i),
     'spi_conv2d_workspace_bytes': ([ctypes.POINTER(ConvDesc), c_i], c_l),
     'spi_conv2d_fwd': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),

@@ -2,14 +2,13 @@
 
 Same surface as the reference's ``filtered_lrelu`` (eg3d/torch_utils/ops/filtered_lrelu.py:58-118).
 The op is on the reference's *import* path only (networks_stylegan3, never instantiated by the
-StyleGAN2 / 8XDC generator).  Without gradients it is the fused two-pass kernel sequence
-``spi_filtered_lrelu`` (no global device state: the reference's constant-memory filter buffer makes it
-non-reentrant across streams, filtered_lrelu.cu:81-82).  When a gradient is required it runs like the
-reference's plugin op (filtered_lrelu.py:180-270, generic variant :229-236): bias -> ``upfirdn2d`` (up) ->
-``filtered_lrelu_act_`` IN PLACE, which also writes the bit-packed SIGN tensor (2 bits per element of the upsampled
-buffer: negative / clamped, ``spi_filtered_lrelu_act``) -> ``upfirdn2d`` (down); only the filters and the signs are
-kept for the backward, which is the same op with up / down swapped, flipped filters, gain * up^2 / down^2, no
-clamp, and the signs READ at the offset the reference computes (:258-262) -- no full-size activation is stored.
+StyleGAN2 / 8XDC generator).  Since round 3 it is ONE launch either way, ``spi_filtered_lrelu_fused`` (csrc/flrelu.hip: up-FIR, activation and down-FIR through LDS like
+the reference's kernel, filtered_lrelu.cu:119-1105; no upsampled tensor in memory; no global device state -- the reference's
+constant-memory filter buffer makes it non-reentrant across streams, :81-82).  When a gradient is required the launch also writes the
+bit-packed SIGN tensor (2 bits per upsampled sample: negative / clamped), like the reference's plugin op (filtered_lrelu.py:180-270);
+only the filters and the signs are kept for the backward, which is the same launch with up / down swapped, flipped filters,
+gain * up^2 / down^2, no clamp, and the signs READ at the offset the reference computes (:258-262) -- no full-size activation is stored.
+(The two-pass ``spi_filtered_lrelu`` and the stand-alone activation ``spi_filtered_lrelu_act`` stay exported.)
 ``filtered_lrelu_act_(x, si, sx, sy, gain, slope, clamp, write_signs)`` is exported with the plugin's meaning.
 Separable 1-D filters take the reference's decomposition on the differentiable HIP ops (:121-176).
 """
@@ -40,6 +39,40 @@ def filtered_lrelu_act_(x, si=None, sx=0, sy=0, gain=math.sqrt(2), slope=0.2, cl
     return so
 
 
+def _fused(x, fu, fd, b, up, down, padding, gain, slope, clamp, flip_filter, si, sx, sy, write_signs):
+    """One launch of `spi_filtered_lrelu_fused` (csrc/flrelu.hip): -> (y, sign tensor written or an empty uint8 tensor).  Planes go down in
+    chunks of 65 535 (the kernel's grid.y)."""
+    px0, px1, py0, py1 = padding
+    x = x.contiguous().float()
+    n, c, ih, iw = x.shape
+    fu, fd = fu.to(x.device).float().contiguous(), fd.to(x.device).float().contiguous()
+    mid_h = ih * up + py0 + py1 - fu.shape[0] + 1
+    mid_w = iw * up + px0 + px1 - fu.shape[1] + 1
+    oh = (mid_h - fd.shape[0] + down) // down
+    ow = (mid_w - fd.shape[1] + down) // down
+    read = si is not None and si.numel() > 0
+    assert not (read and write_signs)
+    so = torch.empty(0, dtype=torch.uint8, device=x.device)
+    s, mode, sh, sw = None, 0, 0, 0
+    if write_signs:
+        sw = (mid_w + 15) & ~15                               # width rounded up to a multiple of 16 elements (filtered_lrelu.cpp:89)
+        s = so = torch.empty(n, c, mid_h, sw >> 2, dtype=torch.uint8, device=x.device)
+        mode, sh = 1, mid_h
+    elif read:
+        assert si.dtype == torch.uint8 and si.is_contiguous() and si.ndim == 4 and si.shape[:2] == (n, c)
+        s, mode, sh, sw = si, 2, si.shape[2], si.shape[3] << 2
+    bb = b.detach().contiguous().float() if b is not None else None
+    y = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32)
+    assert c <= 65535
+    step = max(1, 65535 // c)
+    for n0 in range(0, n, step):
+        n1 = min(n0 + step, n)
+        hip.call('spi_filtered_lrelu_fused', hip.ptr(x[n0:n1]), hip.ptr(fu), hip.ptr(fd), hip.ptr(bb), None if s is None else s[n0:n1].data_ptr(),
+                 hip.ptr(y[n0:n1]), n1 - n0, c, ih, iw, fu.shape[0], fu.shape[1], fd.shape[0], fd.shape[1], int(up), int(down), px0, px1, py0, py1,
+                 float(gain), float(slope), float(-1 if clamp is None else clamp), int(flip_filter), mode, sh, sw, int(sx), int(sy), oh, ow, hip.stream())
+    return y, so
+
+
 _op_cache = {}
 
 
@@ -60,13 +93,7 @@ def _filtered_lrelu_op(up, down, padding, gain, slope, clamp, flip_filter):
             if fd is None:
                 fd = torch.ones([1, 1], dtype=torch.float32, device=x.device)
             write_signs = (si is None or si.numel() == 0) and (x.requires_grad or (b is not None and b.requires_grad))
-            y = x + b.reshape(1, -1, 1, 1) if b is not None else x
-            with torch.no_grad():
-                y = _uf.upfirdn2d(y, fu, up=up, padding=[px0, px1, py0, py1], gain=up ** 2, flip_filter=flip_filter).contiguous()
-                if y is x:
-                    y = y.clone()                                    # the activation is in place: never on the caller's tensor
-                so = filtered_lrelu_act_(y, si, sx, sy, gain, slope, clamp, write_signs)
-                y = _uf.upfirdn2d(y, fd, down=down, flip_filter=flip_filter)
+            y, so = _fused(x, fu, fd, b, up, down, (px0, px1, py0, py1), gain, slope, clamp, flip_filter, si, sx, sy, write_signs)
             ctx.save_for_backward(fu, fd, si if (si is not None and si.numel()) else so)
             ctx.x_shape, ctx.y_shape, ctx.s_ofs, ctx.has_b = x.shape, y.shape, (sx, sy), b is not None
             return y
@@ -118,17 +145,4 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=ma
         fu = fu.reshape(1, 1) ** 2 if fu.numel() == 1 else fu
     if fd.ndim == 1:
         fd = fd.reshape(1, 1) ** 2 if fd.numel() == 1 else fd
-    px0, px1, py0, py1 = _parse_padding(padding)
-    n, c, ih, iw = x.shape
-    mid_h = ih * up + py0 + py1 - fu.shape[0] + 1
-    mid_w = iw * up + px0 + px1 - fu.shape[1] + 1
-    oh = (mid_h - fd.shape[0] + down) // down
-    ow = (mid_w - fd.shape[1] + down) // down
-    x = x.contiguous().float()
-    bb = b.contiguous().float() if b is not None else None
-    tmp = torch.empty(n, c, mid_h, mid_w, device=x.device, dtype=torch.float32)
-    y = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32)
-    hip.call('spi_filtered_lrelu', hip.ptr(x), hip.ptr(fu), hip.ptr(fd), hip.ptr(bb), hip.ptr(tmp), hip.ptr(y), n, c, ih, iw,
-             fu.shape[0], fu.shape[1], fd.shape[0], fd.shape[1], int(up), int(down), px0, px1, py0, py1, float(gain), float(slope),
-             float(-1 if clamp is None else clamp), int(flip_filter), oh, ow, hip.stream())
-    return y
+    return _fused(x, fu, fd, b, int(up), int(down), tuple(_parse_padding(padding)), float(gain), float(slope), clamp, bool(flip_filter), None, 0, 0, False)[0]

@@ -121,6 +121,47 @@ def test_filtered_lrelu_gradients_vs_oracle(up, down, pad):
     assert_close(y2, ref, 3e-6, 'filtered_lrelu fwd (fused kernels)')
 
 
+@pytest.mark.parametrize('up,down,fu_t,fd_t,pad,hw', [(2, 2, 12, 12, [10, 10, 10, 10], (36, 40)), (4, 2, 12, 6, [9, 8, 7, 6], (17, 23)),
+                                                      (2, 4, 8, 16, [6, 5, 6, 5], (40, 33)), (1, 1, 1, 1, [0, 0, 0, 0], (19, 21)), (2, 1, 6, 1, [3, 2, 3, 2], (70, 9))])
+def test_filtered_lrelu_single_pass_kernel(up, down, fu_t, fd_t, pad, hw):
+    """`spi_filtered_lrelu_fused` (csrc/flrelu.hip: up-FIR, activation, down-FIR in one launch through LDS, like filtered_lrelu.cu:119-1105) at
+    StyleGAN3-like filter sizes (12 taps, up / down 2 and 4), ragged tiles, asymmetric padding and flip: the forward against the oracle, the sign tensor
+    it writes against the one the stand-alone activation kernel writes on the materialised upsampled tensor, and the gradients (the same launch
+    with up / down swapped, reading the signs) against the oracle's autograd."""
+    from spi_amd.torch_utils.ops import filtered_lrelu as fl, upfirdn2d as uf
+    gen = torch.Generator().manual_seed(up * 100 + down * 10 + fu_t)
+    x = torch.randn(2, 5, *hw, generator=gen, requires_grad=True)
+    b = torch.randn(5, generator=gen, requires_grad=True)
+    k1 = torch.rand(fu_t, generator=gen) + 0.1
+    k2 = torch.rand(fd_t, generator=gen) + 0.1
+    fu = torch.outer(k1, k1.flip(0)) / k1.sum() ** 2 + 0.01 * torch.rand(fu_t, fu_t, generator=gen) / fu_t ** 2       # 2-D, not symmetric
+    fd = torch.outer(k2.flip(0), k2) / k2.sum() ** 2
+    for flip in (False, True):
+        kw = dict(up=up, down=down, padding=pad, gain=1.4, slope=0.2, clamp=0.8, flip_filter=flip)
+        ref = osg.filtered_lrelu(x, fu, fd, b, **kw)
+        dy = torch.randn(ref.shape, generator=gen)
+        gx, gb = torch.autograd.grad(ref, [x, b], dy)
+        xd, bd = x.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+        with torch.no_grad():
+            assert_close(fl.filtered_lrelu(xd, fu.to(DEV), fd.to(DEV), bd, **kw), ref, 3e-6, 'single-pass forward')
+        y = fl.filtered_lrelu(xd, fu.to(DEV), fd.to(DEV), bd, **kw)
+        assert_close(y, ref, 3e-6, 'single-pass forward (writing signs)')
+        ax, ab = torch.autograd.grad(y, [xd, bd], dy.to(DEV))
+        assert_close(ax, gx, 1e-5, 'single-pass dx')
+        assert_close(ab, gb, 1e-5, 'single-pass db')
+        # the sign tensor: fused launch == activation kernel on the materialised upsampled tensor
+        mid = uf.upfirdn2d(xd.detach() + bd.detach().reshape(1, -1, 1, 1), fu.to(DEV), up=up, padding=pad, gain=up ** 2, flip_filter=flip).contiguous()
+        want = fl.filtered_lrelu_act_(mid.clone(), None, 0, 0, 1.4, 0.2, 0.8, write_signs=True)
+        _, got = fl._fused(xd.detach(), fu.to(DEV), fd.to(DEV), bd.detach(), up, down, tuple(pad), 1.4, 0.2, 0.8, flip, None, 0, 0, True)
+        assert got.shape == want.shape
+        # samples under no output's down-filter footprint are never evaluated by the single-pass kernel (their sign is irrelevant: no gradient reaches
+        # them) -- compare where an output depends on the sample
+        need_h = (ref.shape[2] - 1) * down + fd_t
+        need_w = (ref.shape[3] - 1) * down + fd_t
+        wb = (min(need_w, mid.shape[3]) // 4)
+        assert torch.equal(got[:, :, :min(need_h, mid.shape[2]), :wb], want[:, :, :min(need_h, mid.shape[2]), :wb])
+
+
 @pytest.mark.parametrize('inh,pad', [(201, 1), (199, 2), (130, 1), (113, 2)])
 def test_upfirdn2d_tiled_ragged_vs_oracle(inh, pad):
     """LDS-tiled 4x4 FIR (outputs >= 100 px): ragged tile edges, unaligned rows (scalar stores) and the fused tail + gradients."""
