@@ -16,14 +16,11 @@ import torch
 
 def POS(xp, x):
     """least squares: 2D points xp [2,n] ~ s * R[:2] x + t for 3D points x [3,n] -> (t [2,1], s)"""
-    npts = xp.shape[1]
-    A = np.zeros([2 * npts, 8])
-    A[0:2 * npts - 1:2, 0:3] = x.transpose()
-    A[0:2 * npts - 1:2, 3] = 1
-    A[1:2 * npts:2, 4:7] = x.transpose()
-    A[1:2 * npts:2, 7] = 1
-    b = np.reshape(xp.transpose(), [2 * npts, 1])
-    k = np.linalg.lstsq(A, b, rcond=None)[0]
+    n = xp.shape[1]
+    A = np.zeros([2 * n, 8])
+    A[0::2, :3], A[0::2, 3] = x.T, 1                     # x-rows: [X Y Z 1 | 0 0 0 0]
+    A[1::2, 4:7], A[1::2, 7] = x.T, 1                    # y-rows: [0 0 0 0 | X Y Z 1]
+    k = np.linalg.lstsq(A, xp.T.reshape(2 * n, 1), rcond=None)[0]
     s = (np.linalg.norm(k[0:3]) + np.linalg.norm(k[4:7])) / 2
     return np.stack([k[3], k[7]], axis=0), s
 
