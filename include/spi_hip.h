@@ -364,6 +364,12 @@ int spi_contextual_bwd(const float* sim, const float* d_out, int B, int P1, int 
                        const float* row_min, const float* row_sum, const int32_t* row_argmin,
                        const int32_t* col_argmax, float* d_sim, spi_stream_t stream);
 
+/* torchvision.ops.roi_align(x, boxes, output_size = O) with spatial_scale = 1, sampling_ratio = -1, aligned = False (BoxCXLoss,
+ * bbox_cx_loss.py:64-76), ONE box per image: x [N,C,H,W], boxes [N,4] (x1,y1,x2,y2) in device memory -> out [N,C,O,O].
+ * _bwd: dy [N,C,O,O] -> dx [N,C,H,W] (the call zeroes dx). */
+int spi_roi_align_fwd(const float* x, const float* boxes, float* out, int N, int C, int H, int W, int O, spi_stream_t stream);
+int spi_roi_align_bwd(const float* boxes, const float* dy, float* dx, int N, int C, int H, int W, int O, spi_stream_t stream);
+
 /* torch.optim.Adam (no amsgrad, no weight decay) over a list of tensors in one launch.
  *   ptrs: device array of 4*T pointers {param, grad, exp_avg, exp_avg_sq} per tensor; sizes: device int64 [T].
  *   step is the 1-based step count used for bias correction. */

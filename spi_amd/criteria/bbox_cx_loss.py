@@ -3,7 +3,7 @@
 ``BoxCXLoss()(x, y, lm)``: reduce to 256^2, ImageNet-normalise, RoI-align three landmark boxes to
 80x80, VGG19 ``features[:6]`` (MFMA conv kernel), contextual loss between the [n,128,40,40] maps.
 ``roi_align`` is torchvision's op in the reference (not installed here): it is restated from its
-published definition (aligned=False, spatial_scale=1, sampling_ratio=-1) as batched gathers, one box
+published definition (aligned=False, spatial_scale=1, sampling_ratio=-1) as a HIP kernel pair, one box
 per batch element as ``get_bbox`` builds them (:41-61).  The 1600x1600 cosine matrices are plain
 batched GEMMs (``torch.bmm``).
 """
@@ -29,67 +29,38 @@ def get_landmark_bbox(lm, scale=1):
     return boxes
 
 
-def _axis(t, size):
-    valid = ((t >= -1.0) & (t <= size)).float()
-    t = t.clamp(min=0)
-    lo = t.floor().long()
-    edge = lo >= size - 1
-    lo = torch.where(edge, torch.full_like(lo, size - 1), lo)
-    hi = torch.where(edge, lo, lo + 1)
-    t = torch.where(edge, lo.float(), t)
-    return lo, hi, t - lo.float(), valid
+class _RoiAlign(torch.autograd.Function):
+    """x [N,C,H,W], boxes [N,4] float (x1,y1,x2,y2; box i applies to image i) -> [N,C,O,O]: ``torchvision.ops.roi_align`` with spatial_scale = 1,
+    sampling_ratio = -1, aligned = False as one HIP launch each way (csrc/losses.hip: roi_align_kernel; until round 3 ~25 gather / multiply /
+    mean launches per box and direction).  The boxes stay in device memory: no host-side geometry, nothing to synchronise on."""
 
+    @staticmethod
+    def forward(ctx, x, boxes, out_size):
+        from .. import hip
+        x = x.contiguous().float()
+        boxes = boxes.contiguous().float()
+        n, c, h, w = x.shape
+        assert boxes.shape == (n, 4)
+        out = torch.empty(n, c, out_size, out_size, device=x.device)
+        hip.call('spi_roi_align_fwd', hip.ptr(x), hip.ptr(boxes), hip.ptr(out), n, c, h, w, int(out_size), hip.stream())
+        ctx.save_for_backward(boxes)
+        ctx.shape = (n, c, h, w, int(out_size))
+        return out
 
-def roi_plan(boxes, h, w, device, output_size=80):
-    """Sampling geometry of ``roi_align`` for boxes [N,4] (x1,y1,x2,y2), one box per image: a list of per-image index / weight
-    tensors on ``device``.  This is the only host-side part (the sampling grid size depends on the box size); for SPI the
-    landmarks are fixed per image, so the coach builds the plan once per image and the loss itself never synchronises."""
-    out = output_size
-    bx = boxes.detach().float().cpu()
-    plans = []
-    for i in range(bx.shape[0]):
-        x1, y1, x2, y2 = [float(v) for v in bx[i]]
-        rw, rh = max(x2 - x1, 1.0), max(y2 - y1, 1.0)
-        gw, gh = int(math.ceil(rw / out)), int(math.ceil(rh / out))
-        bw, bh = rw / out, rh / out
-        ar = torch.arange(out, dtype=torch.float32).view(-1, 1)
-        xs = (ar * bw + (torch.arange(gw, dtype=torch.float32).view(1, -1) + 0.5) * bw / gw + x1).reshape(-1)
-        ys = (ar * bh + (torch.arange(gh, dtype=torch.float32).view(1, -1) + 0.5) * bh / gh + y1).reshape(-1)
-        key = (x1, y1, x2, y2)
-        if plans and plans[-1]['key'] == key:            # SPI repeats one landmark set over the batch: share the tensors
-            plans.append(plans[-1])
-            continue
-        xl, xh, xf, xv = _axis(xs, w)
-        yl, yh, yf, yv = _axis(ys, h)
-        plans.append(dict(key=key, gw=gw, gh=gh, xl=xl.to(device), xh=xh.to(device), xf=xf.to(device), xv=xv.to(device),
-                          yl=yl.to(device), yh=yh.to(device), yf=yf.to(device), yv=yv.to(device)))
-    return plans
+    @staticmethod
+    def backward(ctx, dy):
+        from .. import hip
+        boxes, = ctx.saved_tensors
+        n, c, h, w, o = ctx.shape
+        dx = torch.empty(n, c, h, w, device=dy.device)
+        hip.call('spi_roi_align_bwd', hip.ptr(boxes), hip.ptr(dy.contiguous().float()), hip.ptr(dx), n, c, h, w, o, hip.stream())
+        return dx, None, None
 
 
 def roi_align(x, boxes, output_size=80, plan=None):
-    """x [N,C,H,W]; boxes [N,4] float (x1,y1,x2,y2), box i applies to image i.  Differentiable wrt x.
-    ``plan`` (from ``roi_plan``) skips the host-side geometry; images that share a plan entry are gathered together."""
-    n, c, h, w = x.shape
-    out = output_size
-    if plan is None:
-        plan = roi_plan(boxes, h, w, x.device, output_size)
-    res, i = [], 0
-    while i < n:
-        pl = plan[i]
-        j = i
-        while j + 1 < n and plan[j + 1] is pl:
-            j += 1
-        img = x[i:j + 1]
-        xf, yf = pl['xf'], pl['yf']
-        # index_select, not img[:, :, idx]: the backward of advanced indexing is a sort-based index_put_, which faulted when the iteration
-        # was replayed from a captured HIP graph; index_select's backward is an atomic index_add_
-        top, bot = img.index_select(2, pl['yl']), img.index_select(2, pl['yh'])
-        val = ((top.index_select(3, pl['xl']) * (1 - xf) + top.index_select(3, pl['xh']) * xf) * (1 - yf).view(1, 1, -1, 1)
-               + (bot.index_select(3, pl['xl']) * (1 - xf) + bot.index_select(3, pl['xh']) * xf) * yf.view(1, 1, -1, 1))
-        val = val * pl['yv'].view(1, 1, -1, 1) * pl['xv'].view(1, 1, 1, -1)
-        res.append(val.reshape(j + 1 - i, c, out, pl['gh'], out, pl['gw']).mean(dim=(3, 5)))
-        i = j + 1
-    return torch.cat(res)
+    """x [N,C,H,W]; boxes [N,4] float (x1,y1,x2,y2), box i applies to image i.  Differentiable wrt x.  (``plan`` is accepted and ignored: the
+    host-side sampling plan of rounds 1-2 is gone with the kernel.)"""
+    return _RoiAlign.apply(x, boxes, int(output_size))
 
 
 def compute_cosine_distance(x, y):
@@ -159,8 +130,8 @@ class BoxCXLoss(torch.nn.Module):
         self.register_buffer('vgg_std', torch.tensor([[[0.229]], [[0.224]], [[0.225]]]))
 
     def plan(self, lm, device):
-        """Host-side box geometry for ``forward(..., plan=)``: build once per image (the landmarks do not change)."""
-        return [roi_plan(box.float(), 256, 256, device) for box in get_landmark_bbox(lm)[:3]]
+        """The three landmark boxes as float tensors on ``device`` for ``forward(..., plan=)``: built once per image (the landmarks do not change)."""
+        return [box.float().to(device) for box in get_landmark_bbox(lm)[:3]]
 
     def forward(self, x, y, lm, plan=None):
         if x.shape[-1] > 256:
@@ -170,18 +141,13 @@ class BoxCXLoss(torch.nn.Module):
         x = (x - self.vgg_mean) / self.vgg_std
         y = (y - self.vgg_mean) / self.vgg_std
         loss = 0
-        if plan is not None and tuple(x.shape[-2:]) != (256, 256):
-            plan = None                                      # the plan is built for the 256^2 working resolution
-        boxes = get_landmark_bbox(lm)[:3] if plan is None else [None] * 3
+        boxes = plan if plan is not None else [b.float() for b in get_landmark_bbox(lm)[:3]]
         # The three boxes (eyes, nose, mouth) go through the VGG head and the contextual loss as ONE batch [3N, ...] instead of three
         # passes of a few hundred tiny launches each; every reduction of the reference (feature mean over the batch of a box, min /
         # sum / max over positions, mean over the batch) keeps its own group.
         n = x.shape[0]
-        cx_in, cy_in = [], []
-        for bi, box in enumerate(boxes):
-            pl = plan[bi] if plan is not None else roi_plan(box.float(), x.shape[-2], x.shape[-1], x.device)
-            cx_in.append(roi_align(x, box, plan=pl))
-            cy_in.append(roi_align(y, box, plan=pl))
+        cx_in = [roi_align(x, box) for box in boxes]
+        cy_in = [roi_align(y, box) for box in boxes]
         nb = len(cx_in)
         if y.requires_grad:
             f = self.vgg_model(torch.cat(cx_in + cy_in))

@@ -66,6 +66,8 @@ _SIGS = {
     'spi_noise_renorm': ([c_p, c_p, c_i, c_p], c_i),
     'spi_lpips_layer_fwd': ([c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
     'spi_lpips_layer_bwd': ([c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_p, c_p], c_i),
+    'spi_roi_align_fwd': ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
+    'spi_roi_align_bwd': ([c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p], c_i),
     'spi_contextual_workspace_bytes': ([c_i, c_i, c_i], c_l),
     'spi_contextual_fwd': ([c_p, c_i, c_i, c_i, c_f] + [c_p] * 7, c_i),
     'spi_contextual_bwd': ([c_p, c_p, c_i, c_i, c_i, c_f] + [c_p] * 6, c_i),

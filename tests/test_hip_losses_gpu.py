@@ -89,6 +89,25 @@ def test_box_cx_vs_oracle():
     assert_close(gg, gref, 5e-3, 'boxcx grad')
 
 
+def test_roi_align_kernel_vs_oracle():
+    """spi_roi_align_fwd / _bwd (csrc/losses.hip) against the oracle's restatement of torchvision.ops.roi_align (aligned=False, sampling_ratio=-1), one
+    box per image: the landmark boxes of the loop, a box hanging over the image on two sides (samples outside [-1, size] contribute 0, the last
+    row / column repeats), a box smaller than a pixel (extent clamped to 1) and one larger than 80 px per side (several samples per bin)."""
+    from spi_amd.criteria.bbox_cx_loss import roi_align
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(5, 3, 64, 96, generator=gen, requires_grad=True)
+    boxes = torch.tensor([[10.0, 12.0, 50.0, 44.0], [-7.5, -3.0, 30.2, 20.9], [60.0, 40.0, 110.0, 80.0], [20.3, 20.3, 20.6, 20.9], [0.0, 0.0, 96.0, 64.0]])
+    for out in (80, 7):
+        ref = olo.roi_align(x, boxes, out)
+        dy = torch.randn(ref.shape, generator=gen)
+        gref, = torch.autograd.grad(ref, x, dy)
+        xd = x.detach().to(DEV).requires_grad_(True)
+        y = roi_align(xd, boxes.to(DEV), out)
+        assert_close(y, ref, 2e-6, f'roi_align forward (out {out})')
+        gx, = torch.autograd.grad(y, xd, dy.to(DEV))
+        assert_close(gx, gref, 1e-5, f'roi_align backward (out {out})')
+
+
 @pytest.mark.parametrize('b,p1,p2,c,bw', [(3, 1600, 1600, 128, 0.5), (2, 70, 130, 16, 0.5), (1, 33, 7000, 8, 0.3), (2, 200, 100, 4, 1.0)])
 def test_contextual_cx_kernels_vs_oracle(b, p1, p2, c, bw):
     """The fused contextual chain (csrc/losses.hip: spi_contextual_fwd / _bwd) against the oracle's step-by-step chain (bbox_cx_loss.py:111-129) on cosine
