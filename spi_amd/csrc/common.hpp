@@ -38,6 +38,8 @@ struct WinoParams {
     const int32_t* seg_flags;     // dgrad: zero-segment map of the gradient operand (or NULL)
     const int32_t* out_flags;     // forward: needed-output map (or NULL)
     int nseg;
+    int ksplit;                   // > 1: the channel reduction is cut into ksplit ranges of slabs (blockIdx.z = n * ksplit + range); partial outputs are
+                                  //      atomically added into a ZEROED out and the epilogue runs afterwards (small layers: too few blocks to fill 256 CUs)
     int64_t u_bs_of() const { return (int64_t)16 * Ci * ocp; }      // floats of one transformed weight set
 };
 int64_t spi_wino_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));

@@ -996,7 +996,26 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
     }
     Wp.seg_flags = P.seg_flags; Wp.out_flags = P.out_flags; Wp.nseg = P.seg_flags ? P.nseg : P.out_nseg;
     const int64_t blocks = (int64_t)Wp.bx * Wp.by * (Wp.ocp / 64) * P.N;
+    // 128 .. 255 blocks (512 channels at 64^2 / N = 1, the 512-channel VGG layers at 32^2 / N = 4, 256 channels at 64^2 / N = 2): half the CUs
+    // would idle -- cut the channel reduction in two ranges of >= 16 slabs; the partial outputs meet through atomics and the epilogue runs as its
+    // own small kernel (0.17 -> 0.13 ms on the first).  Finer splits of smaller layers were measured SLOWER than the split-K implicit GEMM
+    // (32 .. 64 blocks x 4 .. 8 ranges: the zero / weight-transform / epilogue launches and the atomics outweigh the 2.25x fewer MFMAs).
+    Wp.ksplit = (blocks >= 128 && blocks < 256 && P.Ci / 8 >= 32) ? 2 : 1;
     return blocks >= 128 && P.Mo >= 48;
+}
+
+// channel-split Winograd: zero the output first, run the shared epilogue kernel afterwards
+static int wino_conv(WinoParams& Wp, const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, void* ws, hipStream_t st) {
+    if (Wp.ksplit > 1) {
+        int rc = spi_zero_async(out, (int64_t)P.N * P.out_bs, st); if (rc) return rc;
+    }
+    int rc = spi_wino_launch(Wp, in, w, out, ep, ws, st); if (rc) return rc;
+    if (Wp.ksplit > 1 && (ep.bias || ep.noise || ep.act)) {
+        const int64_t total = (int64_t)P.N * P.out_bs;
+        const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(conv_epilogue_kernel, dim3(grid), dim3(256), 0, st, out, total, P.Mo, (int64_t)P.OH * P.OW, ep);
+    }
+    return SPI_OK;
 }
 
 // Winograd F(3x3, 2x2) eligibility of a weight-gradient problem (P = make_forward(d)): 3x3, stride 1, pad 1, exact fp32, rows of at least one
@@ -1014,6 +1033,7 @@ static bool make_wino_wgrad(const spi_conv_desc* d, const IGemmParams& P, WinoPa
         if (T.dy[t] < -1 || T.dy[t] > 1 || T.dx[t] < -1 || T.dx[t] > 1) return false;
         Wp.widx[(T.dy[t] + 1) * 3 + (T.dx[t] + 1)] = T.widx[t];
     }
+    Wp.ksplit = 1;
     Wp.seg_flags = d->dy_seg_flags; Wp.out_flags = nullptr;
     Wp.nseg = d->dy_seg_flags ? (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS) : 0;
     return true;
@@ -1043,7 +1063,7 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     WinoParams Wp;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
-        rc = spi_wino_launch(Wp, x, w, y, ep, d->workspace, as_stream(stream)); if (rc) return rc;
+        rc = wino_conv(Wp, P, x, w, y, ep, d->workspace, as_stream(stream)); if (rc) return rc;
         SPI_LAUNCH_CHECK("spi_conv2d_fwd (winograd)");
         return SPI_OK;
     }
@@ -1060,7 +1080,7 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     WinoParams Wp;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_dgrad: workspace must be 16-byte aligned");
-        rc = spi_wino_launch(Wp, dy, w, dx, ep, d->workspace, as_stream(stream)); if (rc) return rc;
+        rc = wino_conv(Wp, P, dy, w, dx, ep, d->workspace, as_stream(stream)); if (rc) return rc;
         SPI_LAUNCH_CHECK("spi_conv2d_dgrad (winograd)");
         return SPI_OK;
     }

@@ -85,7 +85,8 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l32 = lane & 31;
     const int ocw = wave >> 1, tw = wave & 1;                         // MFMA quadrant: 32 output channels x 32 tiles
-    const int n = blockIdx.z, oc0 = blockIdx.y * WOC;
+    const int ksplit = P.ksplit > 1 ? P.ksplit : 1;
+    const int n = blockIdx.z / ksplit, ks = blockIdx.z - n * ksplit, oc0 = blockIdx.y * WOC;
     const int bxi = blockIdx.x % P.bx, byi = blockIdx.x / P.bx;
     const int oy0 = byi * 16, ox0 = bxi * 16;
     const int64_t HW = (int64_t)P.H * P.W;
@@ -106,6 +107,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
             if (sg <= ((iy * P.W + xhi) >> 4)) any |= fl[sg];
         }
         if (!__syncthreads_or(any)) {
+            if (ksplit > 1) return;                                  // split reduction: out was zeroed by the launcher
             for (int e = tid; e < WOC * 256; e += 256) {
                 const int m = oc0 + (e >> 8), yy = oy0 + ((e >> 4) & 15), xx = ox0 + (e & 15);
                 if (m < P.Mo && yy < P.H && xx < P.W) ob[(int64_t)m * HW + (int64_t)yy * P.W + xx] = 0.f;
@@ -124,6 +126,8 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
     const __amdgpu_buffer_rsrc_t rsI = make_rsrc(in + (int64_t)n * P.in_bs, P.in_bs * 4);
     const int chs4 = __builtin_amdgcn_readfirstlane((int)HW * 4);
     const int nslab = P.Ci / WKC;
+    // this block's range of slabs (the whole reduction unless the layer is split)
+    const int s_beg = (int)((int64_t)nslab * ks / ksplit), s_end = (int)((int64_t)nslab * (ks + 1) / ksplit);
     unsigned voffR[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
@@ -190,7 +194,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
     float* Rs = lds + 4 * WSLAB;
     // prologue: U[0], raw[0], raw[1] -> LDS; V[0] from raw[0]
 #pragma unroll
-    for (int i = 0; i < 11; ++i) { if (i < 8) copy_u(0, 0, i); copy_raw(0, 0, i); copy_raw(1, 1, i); }
+    for (int i = 0; i < 11; ++i) { if (i < 8) copy_u(0, s_beg, i); copy_raw(0, s_beg, i); copy_raw(1, s_beg + 1, i); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #pragma unroll
@@ -200,8 +204,8 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
     __syncthreads();
 
     const int aoff = ((h * 64 + ocw * 32 + l32) << 2), boff = ((h * 64 + tw * 32 + l32) << 2);
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
+    for (int s = s_beg; s < s_end; ++s) {
+        const int buf = (s - s_beg) & 1;
         const float* Ub = Us + buf * WSLAB + aoff;
         const float* Vb = Vs + buf * WSLAB + boff;
         float* Vw = Vs + (buf ^ 1) * WSLAB;
@@ -257,6 +261,24 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         nz[0][0] = ep.noise[pix] * ng;
         if (x1) nz[0][1] = ep.noise[pix + 1] * ng;
         if (y1) { nz[1][0] = ep.noise[pix + P.W] * ng; if (x1) nz[1][1] = ep.noise[pix + P.W + 1] * ng; }
+    }
+    if (ksplit > 1) {                                                 // partial sums of a channel range: no epilogue here, four atomics per tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = oc0 + ocw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= P.Mo) continue;
+            float s0[4], s1[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                s0[a] = acc[a * 4 + 0][r] + acc[a * 4 + 1][r] + acc[a * 4 + 2][r];
+                s1[a] = acc[a * 4 + 1][r] - acc[a * 4 + 2][r] - acc[a * 4 + 3][r];
+            }
+            float* dst = ob + (int64_t)m * HW + pix;
+            atomicAdd(dst, s0[0] + s0[1] + s0[2]);
+            if (x1) atomicAdd(dst + 1, s1[0] + s1[1] + s1[2]);
+            if (y1) { atomicAdd(dst + P.W, s0[1] - s0[2] - s0[3]); if (x1) atomicAdd(dst + P.W + 1, s1[1] - s1[2] - s1[3]); }
+        }
+        return;
     }
     // interior blocks (all 64 channels, all 16 x 16 pixels, even row length): no per-element bounds tests.  The activation is the same
     //   conv_act_gain_clamp as the border blocks and the implicit GEMM: NaN and +-inf propagate identically in every block of a layer,
@@ -605,7 +627,8 @@ int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, c
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { spi_set_error("winograd conv: cannot reserve %zu bytes of LDS: %s", lds_bytes, hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
     }
-    dim3 grid((unsigned)(P.bx * P.by), (unsigned)(P.ocp / WOC), (unsigned)P.N);
+    const int ksplit = P.ksplit > 1 ? P.ksplit : 1;
+    dim3 grid((unsigned)(P.bx * P.by), (unsigned)(P.ocp / WOC), (unsigned)(P.N * ksplit));
     hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), lds_bytes, st, P, in, U, out, ep);
     return SPI_OK;
 }

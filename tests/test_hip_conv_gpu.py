@@ -302,6 +302,9 @@ WINO_CASES = [  # N, I, O, H, W, flip, per_sample, epilogue
     (2, 24, 96, 250, 246, True, True, False),       # ragged edges, 96 channels = one and a half chunks, per-sample weights
     (1, 64, 48, 272, 301, False, False, True),      # odd row length (scalar stores), shared weights, 48 of 64 channel rows
     (4, 8, 64, 128, 128, True, False, False),       # batch sharing one weight set
+    # 128 .. 255 blocks: the channel reduction is split in two ranges that meet through atomics, the epilogue runs as its own kernel (round 3)
+    (2, 256, 256, 64, 64, True, True, True),
+    (2, 256, 256, 60, 52, False, False, False),     # ... ragged tiles, shared weights
 ]
 
 
