@@ -370,7 +370,11 @@ class SynthesisBlock(torch.nn.Module):
         self.num_torgb += 1
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
-        assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim
+        rows = ws if isinstance(ws, (tuple, list)) else None          # SynthesisNetwork hands over the rows of ONE unbind (see there)
+        if rows is None:
+            assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim
+        else:
+            assert len(rows) == self.num_conv + self.num_torgb
         if fused_modconv is None:
             fused_modconv = self.fused_modconv_default
         if fused_modconv == 'inference_only':
@@ -379,9 +383,9 @@ class SynthesisBlock(torch.nn.Module):
         # (global_config.enable_fp16_blocks, `--sr_fp16`): default fp32 everywhere = the reference's CPU path, which is the
         # parity target.  fp16 blocks keep fp32 tensors and round the conv operands to fp16 on their way into the MFMAs.
         f16 = bool(self.use_fp16 and not force_fp32 and global_config.enable_fp16_blocks)
-        w_iter = iter(ws.unbind(dim=1))               # (:432) one unbind -> one stack in the backward instead of a zero-fill + copy per row
+        w_iter = iter(rows if rows is not None else ws.unbind(dim=1))   # (:432) one unbind -> one stack in the backward instead of a zero-fill + copy per row
         if self.in_channels == 0:
-            x = self.const.unsqueeze(0).repeat([ws.shape[0], 1, 1, 1])
+            x = self.const.unsqueeze(0).repeat([(rows[0] if rows is not None else ws).shape[0], 1, 1, 1])
         else:
             x = self.conv0(x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
         x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
@@ -416,9 +420,12 @@ class SynthesisNetwork(torch.nn.Module):
         ws = ws.to(torch.float32)
         x = img = None
         w_idx = 0
+        # the reference narrows ws per block (:509-511) and unbinds inside it: per block a zero-filled [N, num_ws, 512] gradient, a slice copy and an
+        # accumulation in the backward.  One unbind for the whole network gives the same rows and ONE stack in the backward.
+        rows = ws.unbind(dim=1)
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
-            x, img = block(x, img, ws.narrow(1, w_idx, block.num_conv + block.num_torgb), **block_kwargs)
+            x, img = block(x, img, rows[w_idx:w_idx + block.num_conv + block.num_torgb], **block_kwargs)
             w_idx += block.num_conv
         return img
 
