@@ -131,8 +131,11 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
     unsigned voffR[11];
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
+        // LDS image of the raw window: [4 channel pairs][18 rows][18 columns][2 channels of the pair] -- a thread's patch row of BOTH its channels is
+        // two 16-byte reads and the transform runs on (channel 0, channel 1) pairs (v_pk_add_f32) without shuffling registers
         const int slot = (i * 4 + wave) * 64 + lane;
-        const int ch = slot / 324, rem = slot - ch * 324, r = rem / 18, c = rem - r * 18;
+        const int pairq = slot / 648, rem2 = slot - pairq * 648, r = rem2 / 36, c = (rem2 - r * 36) >> 1;
+        const int ch = (pairq >> 1) * 4 + (pairq & 1) + 2 * (slot & 1);      // pair p = wave p's two channels: (0,2) (1,3) (4,6) (5,7)
         const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
         voffR[i] = (slot < WKC * 324 && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? (unsigned)(ch * chs4 + (iy * P.W + ix) * 4) : BUF_OOB;
     }
@@ -156,34 +159,33 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         }
     };
 
-    // ---- transform: tile = lane (8 x 8 tiles), channels k = 2*(jb + q) + hch, q = 0, 1: 4x4 patches from the raw window (8-byte reads)
+    // ---- transform: tile = lane (8 x 8 tiles), channels k = 2*(jb + q) + hch, q = 0, 1: the 4x4 patches of BOTH channels as (q = 0, q = 1) pairs;
+    //      the raw window stores exactly these pairs interleaved (pair index = wave: channels (0,2) (1,3) (4,6) (5,7), see voffR above)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
     const int hch = wave & 1, jb = (wave >> 1) * 2;
     const int ty = lane >> 3, tx = lane & 7;
-    float d[2][16];
-    auto read_patch_row = [&](const float* Rb, int r) {               // row r of both channels' patches
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const float* pr = Rb + (2 * (jb + q) + hch) * 324 + (2 * ty + r) * 18 + 2 * tx;
-            const float2 lo = *reinterpret_cast<const float2*>(pr), hi = *reinterpret_cast<const float2*>(pr + 2);
-            d[q][r * 4 + 0] = lo.x; d[q][r * 4 + 1] = lo.y; d[q][r * 4 + 2] = hi.x; d[q][r * 4 + 3] = hi.y;
-        }
+    f32x2 d2[16];
+    auto read_patch_row = [&](const float* Rb, int r) {               // row r of both channels' patches: two 16-byte reads
+        const float* pr = Rb + ((((jb >> 1) * 2 + hch) * 18 + (2 * ty + r)) * 18 + 2 * tx) * 2;
+        const float4 lo = *reinterpret_cast<const float4*>(pr), hi = *reinterpret_cast<const float4*>(pr + 4);
+        d2[r * 4 + 0] = f32x2{lo.x, lo.y}; d2[r * 4 + 1] = f32x2{lo.z, lo.w}; d2[r * 4 + 2] = f32x2{hi.x, hi.y}; d2[r * 4 + 3] = f32x2{hi.z, hi.w};
     };
-    // B^T d B: row group a (4 of the 16 frequencies) of channel q's patch ...
-    float vt[2][4];
-    auto transform_rows = [&](int a, int q) {
-        float t[4];
+    // B^T d B: row group a (4 of the 16 frequencies) of both channels' patches ...
+    f32x2 vt2[4];
+    auto transform_rows = [&](int a, int) {
+        f32x2 t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            t[c] = a == 0 ? d[q][0 + c] - d[q][8 + c] : a == 1 ? d[q][4 + c] + d[q][8 + c] : a == 2 ? d[q][8 + c] - d[q][4 + c] : d[q][4 + c] - d[q][12 + c];
-        vt[q][0] = t[0] - t[2]; vt[q][1] = t[1] + t[2]; vt[q][2] = t[2] - t[1]; vt[q][3] = t[1] - t[3];
+            t[c] = a == 0 ? d2[0 + c] - d2[8 + c] : a == 1 ? d2[4 + c] + d2[8 + c] : a == 2 ? d2[8 + c] - d2[4 + c] : d2[4 + c] - d2[12 + c];
+        vt2[0] = t[0] - t[2]; vt2[1] = t[1] + t[2]; vt2[2] = t[2] - t[1]; vt2[3] = t[1] - t[3];
     };
     // ... and the two channels of a frequency written as one 8-byte store
     auto store_rows = [&](float* Vb, int a) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-            *reinterpret_cast<float2*>(Vb + ((((a * 4 + b) * 2 + hch) * 64 + lane) << 2) + jb) = make_float2(vt[0][b], vt[1][b]);
+            *reinterpret_cast<f32x2*>(Vb + ((((a * 4 + b) * 2 + hch) * 64 + lane) << 2) + jb) = vt2[b];
     };
-    auto transform_store = [&](float* Vb, int a) { transform_rows(a, 0); transform_rows(a, 1); store_rows(Vb, a); };
+    auto transform_store = [&](float* Vb, int a) { transform_rows(a, 0); store_rows(Vb, a); };
 
     f32x16 acc[16];
 #pragma unroll
@@ -240,7 +242,7 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
             if ((m & 3) == 2 && (m >> 2) < 4) read_patch_row(Rn, m >> 2);
             if (m >= 24 && m < 40) {
                 const int a = (m - 24) >> 2, ph = (m - 24) & 3;
-                if (ph < 2) transform_rows(a, ph);
+                if (ph == 0) transform_rows(a, 0);
                 else if (ph == 2) store_rows(Vw, a);
             }
             __builtin_amdgcn_sched_barrier(0);
