@@ -170,14 +170,17 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         const float4 lo = *reinterpret_cast<const float4*>(pr), hi = *reinterpret_cast<const float4*>(pr + 4);
         d2[r * 4 + 0] = f32x2{lo.x, lo.y}; d2[r * 4 + 1] = f32x2{lo.z, lo.w}; d2[r * 4 + 2] = f32x2{hi.x, hi.y}; d2[r * 4 + 3] = f32x2{hi.z, hi.w};
     };
-    // B^T d B: row group a (4 of the 16 frequencies) of both channels' patches ...
+    // B^T d B: row group a (4 of the 16 frequencies) of both channels' patches: 8 packed adds (v_pk_add_f32 spelled out -- left to itself the
+    // compiler scalarises about half of these vector adds again) ...
+    auto pk_add = [](f32x2 x, f32x2 y) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto pk_sub = [](f32x2 x, f32x2 y) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
     f32x2 vt2[4];
     auto transform_rows = [&](int a, int) {
         f32x2 t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            t[c] = a == 0 ? d2[0 + c] - d2[8 + c] : a == 1 ? d2[4 + c] + d2[8 + c] : a == 2 ? d2[8 + c] - d2[4 + c] : d2[4 + c] - d2[12 + c];
-        vt2[0] = t[0] - t[2]; vt2[1] = t[1] + t[2]; vt2[2] = t[2] - t[1]; vt2[3] = t[1] - t[3];
+            t[c] = a == 0 ? pk_sub(d2[0 + c], d2[8 + c]) : a == 1 ? pk_add(d2[4 + c], d2[8 + c]) : a == 2 ? pk_sub(d2[8 + c], d2[4 + c]) : pk_sub(d2[4 + c], d2[12 + c]);
+        vt2[0] = pk_sub(t[0], t[2]); vt2[1] = pk_add(t[1], t[2]); vt2[2] = pk_sub(t[2], t[1]); vt2[3] = pk_sub(t[1], t[3]);
     };
     // ... and the two channels of a frequency written as one 8-byte store
     auto store_rows = [&](float* Vb, int a) {
