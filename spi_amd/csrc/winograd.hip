@@ -438,8 +438,9 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
     };
 
     // ---- operands: raw patch of (channel l32 of the quadrant, tile 2 p + h) -> 16 frequencies, in registers
-    float rx[16], rd[4];
-    float opa[2][16], opb[2][16];
+    typedef float f32x2w __attribute__((ext_vector_type(2)));
+    f32x2w rx2[8], rd2[2];                                            // raw patch rows as (column 0, column 1) / (column 2, column 3) pairs
+    f32x2w opa[2][8], opb[2][8];                                      // operand f = 4 a + b lives in pair [2 a + (b >> 1)], half b & 1
     const float* xrow[4]; const float* drow[2];
     auto set_rows = [&](int ty) {                                     // ring rows of tile row ty: input rows 2 ty - 1 .. 2 ty + 2, gradient rows 2 ty, 2 ty + 1
         const int xs = (2 * ty) % GXR, ds = (2 * ty) % GDR;
@@ -449,33 +450,40 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
         for (int k = 0; k < 2; ++k) drow[k] = lds + (GXR + ds + k) * GROW + (ocw * 32 + l32) * GPX + 2 * h;
     };
     auto read_x = [&](int p, int k) {                                 // row k of the input patch of tile pair p
-        const float2 lo = *reinterpret_cast<const float2*>(xrow[k] + 4 * p), hi = *reinterpret_cast<const float2*>(xrow[k] + 4 * p + 2);
-        rx[k * 4 + 0] = lo.x; rx[k * 4 + 1] = lo.y; rx[k * 4 + 2] = hi.x; rx[k * 4 + 3] = hi.y;
+        rx2[k * 2 + 0] = *reinterpret_cast<const f32x2w*>(xrow[k] + 4 * p);
+        rx2[k * 2 + 1] = *reinterpret_cast<const f32x2w*>(xrow[k] + 4 * p + 2);
     };
-    auto read_d = [&](int p, int k) {
-        const float2 v = *reinterpret_cast<const float2*>(drow[k] + 4 * p);
-        rd[k * 2 + 0] = v.x; rd[k * 2 + 1] = v.y;
+    auto read_d = [&](int p, int k) { rd2[k] = *reinterpret_cast<const f32x2w*>(drow[k] + 4 * p); };
+    // packed adds with half selects, spelled out (the compiler scalarises vector expressions of this shape and adds register moves).  Volatile: they
+    // stay in the micro-slot they are written in (LLVM would sink pure adds to their use, in front of the NEXT pair's MFMAs).
+    auto pk_add = [](f32x2w x, f32x2w y) { f32x2w r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    auto pk_sub = [](f32x2w x, f32x2w y) { f32x2w r; asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    // (x.lo - y.lo, x.hi + y.lo)
+    auto pk_mlo_plo = [](f32x2w x, f32x2w y) { f32x2w r; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    // (x.lo - y.hi, x.hi - y.hi)
+    auto pk_sub_hi = [](f32x2w x, f32x2w y) { f32x2w r; asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
+    // (x.lo + x.hi, x.lo - x.hi)
+    auto pk_sum_diff = [](f32x2w x) { f32x2w r; asm volatile("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x)); return r; };
+    // B^T X B, row group a (4 of the 16 frequencies): rows x0 - x2, x1 + x2, x2 - x1, x3 - x1 on both column pairs, then the same along the columns
+    auto xform_x = [&](f32x2w (&o)[8], int a) {
+        const int r0 = a == 0 ? 0 : a == 1 ? 1 : a == 2 ? 2 : 3, r1 = a == 0 ? 2 : a == 1 ? 2 : 1;
+        const f32x2w tl = a == 1 ? pk_add(rx2[r0 * 2], rx2[r1 * 2]) : pk_sub(rx2[r0 * 2], rx2[r1 * 2]);
+        const f32x2w th = a == 1 ? pk_add(rx2[r0 * 2 + 1], rx2[r1 * 2 + 1]) : pk_sub(rx2[r0 * 2 + 1], rx2[r1 * 2 + 1]);
+        o[a * 2 + 0] = pk_mlo_plo(tl, th);                            // t0 - t2, t1 + t2
+        o[a * 2 + 1] = pk_sub_hi(th, tl);                             // t2 - t1, t3 - t1
     };
-    // B^T X B, row group a (4 of the 16 frequencies)
-    auto xform_x = [&](float (&o)[16], int a) {
-        float t[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-            t[c] = a == 0 ? rx[0 + c] - rx[8 + c] : a == 1 ? rx[4 + c] + rx[8 + c] : a == 2 ? rx[8 + c] - rx[4 + c] : rx[12 + c] - rx[4 + c];
-        o[a * 4 + 0] = t[0] - t[2]; o[a * 4 + 1] = t[1] + t[2]; o[a * 4 + 2] = t[2] - t[1]; o[a * 4 + 3] = t[3] - t[1];
-        // pinned: without a side effect LLVM sinks these adds to their use, i.e. in front of the NEXT pair's MFMAs (a dependent VALU op + s_nop
-        // before each) and keeps the raw patch alive until then
-        asm volatile("" : "+v"(o[a * 4 + 0]), "+v"(o[a * 4 + 1]), "+v"(o[a * 4 + 2]), "+v"(o[a * 4 + 3]));
-    };
-    // G' dY G'^T (the halves of G live in the output transform)
-    auto xform_d = [&](float (&o)[16]) {
-        const float u[4][2] = {{rd[0], rd[1]}, {rd[0] + rd[2], rd[1] + rd[3]}, {rd[0] - rd[2], rd[1] - rd[3]}, {rd[2], rd[3]}};
+    // G' dY G'^T (the halves of G live in the output transform): rows d0, d0 + d1, d0 - d1, d1; columns u0, u0 + u1, u0 - u1, u1
+    auto xform_d = [&](f32x2w (&o)[8]) {
+        const f32x2w u[4] = {rd2[0], pk_add(rd2[0], rd2[1]), pk_sub(rd2[0], rd2[1]), rd2[1]};
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            o[a * 4 + 0] = u[a][0]; o[a * 4 + 1] = u[a][0] + u[a][1]; o[a * 4 + 2] = u[a][0] - u[a][1]; o[a * 4 + 3] = u[a][1];
-            asm volatile("" : "+v"(o[a * 4 + 0]), "+v"(o[a * 4 + 1]), "+v"(o[a * 4 + 2]), "+v"(o[a * 4 + 3]));
+            o[a * 2 + 0] = u[a];                                      // (b = 0, b = 3)   -- rows 0 and 3 are copies of the raw pairs (the raw registers are re-read next)
+            o[a * 2 + 1] = pk_sum_diff(u[a]);                         // (b = 1, b = 2)
         }
     };
+    // operand of frequency f = 4 a + b out of the pair arrays
+    auto fa = [](const f32x2w (&o)[8], int f) { const int a = f >> 2, b = f & 3; return b == 0 ? o[a * 2].x : b == 3 ? o[a * 2].y : b == 1 ? o[a * 2 + 1].x : o[a * 2 + 1].y; };
+    auto fb = [](const f32x2w (&o)[8], int f) { const int a = f >> 2, b = f & 3; return (b & 1) ? o[a * 2 + (b >> 1)].y : o[a * 2 + (b >> 1)].x; };
 
     f32x16 acc[16];
 #pragma unroll
@@ -539,13 +547,13 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
         // body: after the block's last tile row the same work runs once more on rows nobody reads (transfers of rows outside the image are zeros).
 #pragma unroll
         for (int p = 0; p < 8; ++p) {
-            float (&ca)[16] = opa[p & 1];
-            float (&cb)[16] = opb[p & 1];
-            float (&na)[16] = opa[(p + 1) & 1];
-            float (&nb)[16] = opb[(p + 1) & 1];
+            f32x2w (&ca)[8] = opa[p & 1];
+            f32x2w (&cb)[8] = opb[p & 1];
+            f32x2w (&na)[8] = opa[(p + 1) & 1];
+            f32x2w (&nb)[8] = opb[(p + 1) & 1];
 #pragma unroll
             for (int f = 0; f < 16; ++f) {
-                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[f], cb[f], acc[f], 0, 0, 0);
+                acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa(ca, f), fb(cb, f), acc[f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (p < 7) {
                     if (f < 4) read_x(p + 1, f);
