@@ -121,6 +121,7 @@ __device__ __forceinline__ int64_t out_row(const DecodeArgs& a, int64_t g) {
     return ray * a.out_S + a.out_off + (g - ray * a.S);
 }
 
+constexpr float THIRD = 1.f / 3.f;        // the mean over the three planes (renderer.py:62-64)
 struct Corner { int x0, y0; float wx0, wx1, wy0, wy1; };
 
 __device__ __forceinline__ Corner make_corner(float gx, float gy, int W, int H) {
@@ -187,7 +188,8 @@ __device__ __forceinline__ float4 gather_point(__amdgpu_buffer_rsrc_t rs, int n,
         acc.z += v[4 * pl].z * w[4 * pl] + v[4 * pl + 1].z * w[4 * pl + 1] + v[4 * pl + 2].z * w[4 * pl + 2] + v[4 * pl + 3].z * w[4 * pl + 3];
         acc.w += v[4 * pl].w * w[4 * pl] + v[4 * pl + 1].w * w[4 * pl + 1] + v[4 * pl + 2].w * w[4 * pl + 2] + v[4 * pl + 3].w * w[4 * pl + 3];
     }
-    acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+    // (x * (1/3), not x / 3: an IEEE division is ~10 VALU instructions per channel; the two differ by at most one ulp of the plane mean)
+    acc.x *= THIRD; acc.y *= THIRD; acc.z *= THIRD; acc.w *= THIRD;
     return acc;
 }
 
@@ -230,7 +232,7 @@ __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, i
             acc.z += v[4 * pl].z * w[4 * pl] + v[4 * pl + 1].z * w[4 * pl + 1] + v[4 * pl + 2].z * w[4 * pl + 2] + v[4 * pl + 3].z * w[4 * pl + 3];
             acc.w += v[4 * pl].w * w[4 * pl] + v[4 * pl + 1].w * w[4 * pl + 1] + v[4 * pl + 2].w * w[4 * pl + 2] + v[4 * pl + 3].w * w[4 * pl + 3];
         }
-        acc.x /= 3.f; acc.y /= 3.f; acc.z /= 3.f; acc.w /= 3.f;
+        acc.x *= THIRD; acc.y *= THIRD; acc.z *= THIRD; acc.w *= THIRD;
         if (g >= total) acc = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
     }
@@ -414,7 +416,7 @@ __global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const floa
         float acc = 0.f;
 #pragma unroll
         for (int j = 0; j < DEC_HID; ++j) acc = fmaf(wr[j], dp[j], acc);
-        grow[i] = acc / 3.f;
+        grow[i] = acc * THIRD;
     }
     __syncthreads();
     // scatter-add into the channels-last plane gradient: 8 lanes per point, one float4 of channels each
@@ -917,7 +919,7 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
             }
         // this tile's feature rows are dead now (the weight gradients are done with them): d_feat takes their place
 #pragma unroll
-        for (int r = 0; r < 16; ++r) frow[rowmap(r, hh_)] = dF[r] / 3.f;           // the plane mean contributes the 1/3
+        for (int r = 0; r < 16; ++r) frow[rowmap(r, hh_)] = dF[r] * THIRD;           // the plane mean contributes the 1/3
     }
     }
     // ---- hand-over to plane_scatter_kernel: this tile's 256 d_feat rows (contiguous: 32 KB; rows of padding points are zero).  The
