@@ -762,9 +762,12 @@ __global__ void __launch_bounds__(1024) lpips_fwd_kernel(const float* __restrict
     for (int c = cg; c < C; c += LP_CG) { const float va = a[c * HW], vb = b[c * HW]; sa = fmaf(va, va, sa); sb = fmaf(vb, vb, sb); }
     sa = lp_cross(sa, red, px, cg); sb = lp_cross(sb, red, px, cg);
     const float na = sqrtf(sa) + 1e-10f, nb = sqrtf(sb) + 1e-10f;
+    // x / (|x| + eps) as x * (1 / (|x| + eps)): two divisions per PIXEL instead of two per element (an IEEE division is ~10 VALU instructions; the
+    // results differ by at most an ulp per operand)
+    const float ina = 1.f / na, inb = 1.f / nb;
     float val = 0.f;
 #pragma unroll 8
-    for (int c = cg; c < C; c += LP_CG) { const float d = a[c * HW] / na - b[c * HW] / nb; val = fmaf(lin[c], d * d, val); }
+    for (int c = cg; c < C; c += LP_CG) { const float d = a[c * HW] * ina - b[c * HW] * inb; val = fmaf(lin[c], d * d, val); }
     val = wave_sum(ok ? val : 0.f);
     __syncthreads();
     if (px == 0) red[0][cg] = val;                             // same-address global atomics serialise (~10 ns each): one per block
@@ -792,16 +795,17 @@ __global__ void __launch_bounds__(1024) lpips_bwd_kernel(const float* __restrict
     sa = lp_cross(sa, red, px, cg); sb = lp_cross(sb, red, px, cg);
     const float ra = sqrtf(sa), na = ra + 1e-10f, nb = sqrtf(sb) + 1e-10f;
     const float gsc = d_out[n] / (float)HW;
+    const float ina = 1.f / na, inb = 1.f / nb;
     float dot = 0.f;        // sum_c 2 lin_c (a_c - b_c) fx_c
 #pragma unroll 8
-    for (int c = cg; c < C; c += LP_CG) { const float va = a[c * HW]; const float d = va / na - b[c * HW] / nb; dot = fmaf(2.f * lin[c] * d, va, dot); }
+    for (int c = cg; c < C; c += LP_CG) { const float va = a[c * HW]; const float d = va * ina - b[c * HW] * inb; dot = fmaf(2.f * lin[c] * d, va, dot); }
     dot = lp_cross(dot, red, px, cg);
     const float k2 = (ra > 0.f) ? dot / (ra * na * na) : 0.f;
     if (!ok) return;
 #pragma unroll 8
     for (int c = cg; c < C; c += LP_CG) {
-        const float va = a[c * HW]; const float d = va / na - b[c * HW] / nb;
-        o[c * HW] = gsc * (2.f * lin[c] * d / na - va * k2);
+        const float va = a[c * HW]; const float d = va * ina - b[c * HW] * inb;
+        o[c * HW] = gsc * (2.f * lin[c] * d * ina - va * k2);
     }
 }
 

@@ -115,6 +115,64 @@ __device__ __forceinline__ void point_xyz(const DecodeArgs& a, int64_t g, int& n
     x *= a.scale; y *= a.scale; z *= a.scale;
 }
 
+// Index arithmetic of a 256-point tile WITHOUT per-point 64-bit divisions (there is no integer divide instruction: `g / a.P`, `p / a.S` and
+// out_row's `g / a.S` cost ~25 VALU + SALU instructions each, 25 of them per point and tile in the forward kernel = 11 % of its instructions).
+// The tile's first point is divided once (block-uniform); a point s in 0..255 of the tile is then  ray = ray0 + q,  sample k = t - q S  with
+// t = k0 + s < S + 256 and q = t / S taken as (t * m) >> 20, m = 2^20 / S + 1 (exact while t * S < 2^20: S <= 256 here), and the
+// sample index n advances when ray0's offset inside its image wraps -- at most once per tile when an image holds >= 512 rays (P >= 512 in
+// the explicit-coordinate mode).  Anything else (tiny launches) takes the general path.
+struct TileIndex {
+    bool fast;
+    int64_t ray0;        // ray (ray mode) of the tile's first point
+    int k0, m;           // its sample index; the multiplier for / S
+    int n0; int64_t r0, rpi;     // its image, the ray's (point's) offset inside the image, rays (points) per image
+};
+__device__ __forceinline__ TileIndex tile_index(const DecodeArgs& a, int64_t base) {
+    TileIndex t;
+    const bool ray_mode = a.ray_o != nullptr;
+    t.rpi = ray_mode ? a.P / a.S : a.P;
+    t.fast = t.rpi >= 512 && (!ray_mode || (a.S >= 1 && a.S <= 256 && a.P % a.S == 0));
+    if (!t.fast) return t;
+    const int S = ray_mode ? a.S : 1;
+    t.ray0 = base / S;                                   // block-uniform: once per tile
+    t.k0 = (int)(base - t.ray0 * S);
+    t.m = (int)((1u << 20) / (unsigned)S) + 1;
+    t.n0 = (int)(t.ray0 / t.rpi);
+    t.r0 = t.ray0 - (int64_t)t.n0 * t.rpi;
+    return t;
+}
+// point s (0..255) of the tile -> image n, ray (ray mode: global ray index; coordinate mode: global point index), sample k
+__device__ __forceinline__ void tile_point(const DecodeArgs& a, const TileIndex& t, int64_t base, int s, int& n, int64_t& ray, int& k) {
+    if (t.fast) {
+        const int S = a.ray_o != nullptr ? a.S : 1;
+        const int tt = t.k0 + s;
+        const int q = a.ray_o != nullptr ? (int)(((unsigned)tt * (unsigned)t.m) >> 20) : tt;
+        k = tt - q * S;
+        ray = t.ray0 + q;
+        n = t.n0 + ((t.r0 + q >= t.rpi) ? 1 : 0);
+    } else {
+        const int64_t g = base + s;
+        n = (int)(g / a.P);
+        const int64_t p = g - (int64_t)n * a.P;
+        if (a.ray_o != nullptr) { ray = (int64_t)n * (a.P / a.S) + p / a.S; k = (int)(p % a.S); } else { ray = g; k = 0; }
+    }
+}
+__device__ __forceinline__ void point_xyz_at(const DecodeArgs& a, int64_t g, int n_, int64_t ray, float& x, float& y, float& z) {
+    if (a.ray_o == nullptr) {
+        const float* c = a.coords + g * 3;
+        x = c[0]; y = c[1]; z = c[2];
+    } else {
+        const float t = a.depths[g];
+        const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
+        x = o[0] + t * d[0]; y = o[1] + t * d[1]; z = o[2] + t * d[2];
+    }
+    x *= a.scale; y *= a.scale; z *= a.scale;
+    (void)n_;
+}
+__device__ __forceinline__ int64_t out_row_at(const DecodeArgs& a, int64_t g, int64_t ray, int k) {
+    return a.out_S == 0 ? g : ray * a.out_S + a.out_off + k;
+}
+
 __device__ __forceinline__ int64_t out_row(const DecodeArgs& a, int64_t g) {
     if (a.out_S == 0) return g;
     const int64_t ray = g / a.S;
@@ -201,8 +259,15 @@ __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, i
     const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
     const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
     const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);          // host: < 2 GiB
+    const TileIndex ti = tile_index(a, base);
+    const int last = (int)min((int64_t)DT - 1, total - 1 - base);      // the tail tile clamps to its last real point
     int n_next; float xn, yn, zn;
-    point_xyz(a, min(base + grp, total - 1), n_next, xn, yn, zn);
+    {
+        int64_t ray; int k;
+        const int sc = min(grp, last);
+        tile_point(a, ti, base, sc, n_next, ray, k);
+        point_xyz_at(a, base + sc, n_next, ray, xn, yn, zn);
+    }
 #pragma unroll
     for (int pass = 0; pass < DT / 32; ++pass) {
         const int s = pass * 32 + grp;
@@ -222,7 +287,12 @@ __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, i
         f32x4_t v[12];
         buf_load12_f32x4_nowait(rs, o, v);
         // ... and the next pass's coordinates behind them
-        if (pass + 1 < DT / 32) point_xyz(a, min(g + 32, total - 1), n_next, xn, yn, zn);
+        if (pass + 1 < DT / 32) {
+            int64_t ray; int k;
+            const int sc = min(s + 32, last);
+            tile_point(a, ti, base, sc, n_next, ray, k);
+            point_xyz_at(a, base + sc, n_next, ray, xn, yn, zn);
+        }
         buf_wait_gathers(v);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -323,6 +393,7 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
     gather_tile(a, base, total, feat);
     __syncthreads();
     const int t = threadIdx.x;
+    const TileIndex ti_out = tile_index(a, base);
     float* frow = feat + t * FS;
     float h[DEC_HID];
     layer1_forward(w1t, b1, frow, h);
@@ -336,7 +407,13 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
 #pragma unroll
         for (int j = 0; j < DEC_HID / 2; ++j) acc2 = __builtin_elementwise_fma(wr[j], f32x2_t{h[2 * j], h[2 * j + 1]}, acc2);
         const float acc = acc2.x + acc2.y;
-        if (o == 0) { if (base + t < total) sigma[out_row(a, base + t)] = acc; }
+        if (o == 0) {
+            if (base + t < total) {
+                int nn; int64_t ray; int k;
+                tile_point(a, ti_out, base, t, nn, ray, k);
+                sigma[out_row_at(a, base + t, ray, k)] = acc;
+            }
+        }
         else frow[o - 1] = sigmoid_fast(acc) * 1.002f - 0.001f;
     }
     if (!rgb) return;
@@ -346,9 +423,12 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
     for (int it = 0; it < 8; ++it) {
         const int e = it * DT + t;                 // float4 index within the tile
         const int s = e >> 3, q = e & 7;
-        if (base + s < total)
+        if (base + s < total) {
+            int nn; int64_t ray; int k;
+            tile_point(a, ti_out, base, s, nn, ray, k);
             __builtin_nontemporal_store(*reinterpret_cast<const f32x4_t*>(feat + s * FS + q * 4),
-                                        reinterpret_cast<f32x4_t*>(rgb + out_row(a, base + s) * DEC_IN + q * 4));    // 400 MB per image, read back once
+                                        reinterpret_cast<f32x4_t*>(rgb + out_row_at(a, base + s, ray, k) * DEC_IN + q * 4));    // 400 MB per image, read back once
+        }
     }
 }
 
