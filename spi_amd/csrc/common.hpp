@@ -161,36 +161,51 @@ __device__ __forceinline__ float softplus_fast(float x) {
 }
 __device__ __forceinline__ float sigmoid_fast(float x) { return __builtin_amdgcn_rcpf(1.f + exp_fast(-x)); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+// Cross-lane arithmetic on the DPP path (data-parallel primitives: the lane permutation is a modifier of the VALU instruction itself,
+// ~1 issue slot), not through `__shfl*` -- hipcc lowers those to `ds_bpermute_b32`, a round trip through the LDS crossbar of >= 64 cycles
+// of latency each, and the scans / reductions below are dependent chains of six of them.  CTRL: quad_perm 0x00-0xff, row_shr:n 0x110+n,
+// row_ror:n 0x120+n, wave_shr:1 0x138, row_mirror 0x140, row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143 (GFX9 encodings).
+// Lanes without a source lane, and rows / banks masked out, receive `old`.  All 64 lanes must be active.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float lane_bcast(float v, int src_lane) {          // value of one lane, as a wave-uniform (SGPR) operand
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+// sum over each aligned group of 8 lanes, in every lane of the group
+__device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f32<0xB1>(0.f, v);            // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(0.f, v);            // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(0.f, v);           // row_half_mirror: the other quad of the 8
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = group8_sum(v);
+    v += dpp_f32<0x140>(0.f, v);           // row_mirror: row (16-lane) totals in every lane
+    v += dpp_f32<0x142, 0xa>(0.f, v);      // rows 1, 3 += lane 15 of rows 0, 2
+    v += dpp_f32<0x143, 0xc>(0.f, v);      // rows 2, 3 += lane 31
+    return lane_bcast(v, 63);
 }
 __device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
-    return v;
+    v = fminf(v, dpp_f32<0xB1>(v, v)); v = fminf(v, dpp_f32<0x4E>(v, v)); v = fminf(v, dpp_f32<0x141>(v, v)); v = fminf(v, dpp_f32<0x140>(v, v));
+    v = fminf(v, dpp_f32<0x142, 0xa>(v, v)); v = fminf(v, dpp_f32<0x143, 0xc>(v, v));
+    return lane_bcast(v, 63);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    v = fmaxf(v, dpp_f32<0xB1>(v, v)); v = fmaxf(v, dpp_f32<0x4E>(v, v)); v = fmaxf(v, dpp_f32<0x141>(v, v)); v = fmaxf(v, dpp_f32<0x140>(v, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xa>(v, v)); v = fmaxf(v, dpp_f32<0x143, 0xc>(v, v));
+    return lane_bcast(v, 63);
+}
+// inclusive product / sum scans across the 64 lanes of a wave: Hillis-Steele inside each row of 16 (row_shr 1, 2, 4, 8), then the rows chained
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    v *= dpp_f32<0x111>(1.f, v); v *= dpp_f32<0x112>(1.f, v); v *= dpp_f32<0x114>(1.f, v); v *= dpp_f32<0x118>(1.f, v);
+    v *= dpp_f32<0x142, 0xa>(1.f, v); v *= dpp_f32<0x143, 0xc>(1.f, v);
     return v;
 }
-// inclusive product / sum scans across the 64 lanes of a wave
-__device__ __forceinline__ float wave_scan_mul(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        float t = __shfl_up(v, o, WAVE);
-        if (lane >= o) v *= t;
-    }
-    return v;
-}
-__device__ __forceinline__ float wave_scan_add(float v, int lane) {
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        float t = __shfl_up(v, o, WAVE);
-        if (lane >= o) v += t;
-    }
+__device__ __forceinline__ float wave_scan_add(float v) {
+    v += dpp_f32<0x111>(0.f, v); v += dpp_f32<0x112>(0.f, v); v += dpp_f32<0x114>(0.f, v); v += dpp_f32<0x118>(0.f, v);
+    v += dpp_f32<0x142, 0xa>(0.f, v); v += dpp_f32<0x143, 0xc>(0.f, v);
     return v;
 }
 #endif

@@ -1376,46 +1376,54 @@ __global__ void minmax_kernel(const float* __restrict__ x, int64_t n, float* __r
 }
 
 // ------------------------------------------------------------------------------------------------
-// MipRayMarcher2 (ray_marcher.py:25-57).  One wave64 per ray, 4 rays per block.
+// MipRayMarcher2 (ray_marcher.py:25-57).  Forward: one wave64 per ray, 4 rays per block; backward: up to 8 rays per wave.
 //   scalars per interval live one-per-lane (S <= 256 -> up to 4 chunks); transmittance is an
-//   exclusive product scan done with wave shuffles; colour rows are read 8 rows (1 KB) per
-//   wave-instruction, 8 lanes x float4 per 128-B row, and reduced across the row groups by xor-shuffles.
+//   exclusive product scan on the DPP path (common.hpp); colour rows are read 8 rows (1 KB) per
+//   wave-instruction, 8 lanes x float4 per 128-B row, and reduced across the row groups by DPP adds / xor-shuffles.
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXS = 256;
 constexpr int RM_WAVES = 4;
+constexpr int RM_RPW = 8;               // backward: rays per wave -- their eight 128-B gradient rows are ONE 1 KB wave-instruction
 
-struct MarchLds { float sig[MAXS]; float dep[MAXS]; float w[MAXS]; float q[MAXS]; int row[MAXS]; };
-struct MarchLdsFwd : MarchLds { float sraw[MAXS]; };          // + the ray's densities in storage order (forward)
+struct MarchLds { float sig[MAXS]; float dep[MAXS]; float w[MAXS]; float q[MAXS]; int row[MAXS]; float sraw[MAXS]; };   // sraw: the ray's densities in storage order
 
-__device__ __forceinline__ int64_t row_of(const int32_t* perm, int64_t r, int S, int S_store, int k) {
-    return r * S_store + (perm ? perm[r * S + k] : k);
-}
-
-// Stage the ray's sort permutation, densities and depths in LDS (chunk c, lane l <-> sample k = c*64 + l).
+// First round trip of a ray: its sort permutation, depths and densities (the densities in STORAGE order, coalesced, in the same round
+// trip as the permutation, which is applied from LDS afterwards -- gathering them through perm from global memory was a second,
+// dependent round trip: final march 0.75 -> 0.80 of the HBM roofline, and the depth-only marches read nothing else).  All loads are
+// unconditional on clamped indices (guarded loads compile to one exec-masked region each with a wait in between), addressed as a
+// wave-uniform row base + a 32-bit lane offset (the 64-bit per-lane address arithmetic was ~400 of the kernel's VALU instructions).
 template <int NCH>
-__device__ __forceinline__ void march_load(MarchLds& L, const float* __restrict__ densities, const float* __restrict__ depths,
-                                           const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane) {
-    // Unconditional loads on clamped indices, in two waves: all permutation entries + depths first, then the densities they
-    // point to.  (Guarded loads compile to one exec-masked region each with a wait in between: 2 * NCH serialised round trips
-    // at the head of every ray.)
-    int pk[NCH]; float dp[NCH], sg[NCH];
+struct MarchRow { int pk[NCH]; float dp[NCH]; float sr[MAXS / 64]; };
+
+template <int NCH>
+__device__ __forceinline__ void march_fetch(MarchRow<NCH>& P, const float* __restrict__ densities, const float* __restrict__ depths,
+                                            const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane) {
+    const float* dep_r = depths + r * S;
+    const float* den_r = densities + r * S_store;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-        const int k = min(c * 64 + lane, S - 1);
-        pk[c] = perm ? perm[r * S + k] : k;                       // row of sample k inside the ray's S_store rows
-        dp[c] = depths[r * S + k];
+        const unsigned k = (unsigned)min(c * 64 + lane, S - 1);
+        P.pk[c] = perm ? (perm + r * S)[k] : (int)k;              // row of sample k inside the ray's S_store rows
+        P.dp[c] = dep_r[k];
     }
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) sg[c] = densities[r * S_store + pk[c]];
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int k = c * 64 + lane;
-        if (k < S) { L.row[k] = pk[c]; L.sig[k] = sg[c]; L.dep[k] = dp[c]; }
-    }
-    __builtin_amdgcn_wave_barrier();
+    for (int c = 0; c < MAXS / 64; ++c) P.sr[c] = den_r[(unsigned)min(c * 64 + lane, S_store - 1)];
 }
 
-// alpha / transmittance for every interval of the ray, one interval per lane and chunk.
+// ... into LDS (chunk c, lane l <-> sample k = c*64 + l; every index written is < MAXS, entries past S hold clamped duplicates) and the
+// sorted densities back out of it.
+template <int NCH>
+__device__ __forceinline__ void march_stage(MarchLds& L, const MarchRow<NCH>& P, int lane, float (&sg)[NCH]) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { L.row[c * 64 + lane] = P.pk[c]; L.dep[c * 64 + lane] = P.dp[c]; }
+#pragma unroll
+    for (int c = 0; c < MAXS / 64; ++c) L.sraw[c * 64 + lane] = P.sr[c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) sg[c] = L.sraw[P.pk[c]];
+}
+
+// alpha / transmittance for every interval of the ray, one interval per lane and chunk (exclusive product scan on the DPP path).
 template <int NCH>
 __device__ __forceinline__ void march_scan(const MarchLds& L, int S, int lane, float (&alpha)[NCH], float (&trans)[NCH],
                                            float (&delta)[NCH], float (&smid)[NCH]) {
@@ -1430,22 +1438,12 @@ __device__ __forceinline__ void march_scan(const MarchLds& L, int S, int lane, f
             a = 1.f - expf(-softplus_f(sm - 1.f) * dl);
             om = 1.f - a + 1e-10f;
         }
-        const float incl = wave_scan_mul(om, lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (lane == 0) excl = 1.f;
+        const float incl = wave_scan_mul(om);
+        const float excl = dpp_f32<0x138>(1.f, incl);               // wave_shr:1, lane 0 keeps 1
         alpha[c] = a; delta[c] = dl; smid[c] = sm;
         trans[c] = carry * excl;
-        carry *= __shfl(incl, 63, 64);
+        carry *= lane_bcast(incl, 63);
     }
-}
-
-template <int NCH>
-__device__ __forceinline__ void march_scalars(MarchLds& L, const float* __restrict__ densities, const float* __restrict__ depths,
-                                              const int32_t* __restrict__ perm, int64_t r, int S, int S_store, int lane,
-                                              float (&alpha)[NCH], float (&trans)[NCH], float (&delta)[NCH],
-                                              float (&smid)[NCH]) {
-    march_load<NCH>(L, densities, depths, perm, r, S, S_store, lane);
-    march_scan<NCH>(L, S, lane, alpha, trans, delta, smid);
 }
 
 template <int NCH>
@@ -1453,54 +1451,32 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
         const int32_t* __restrict__ perm, const float* __restrict__ clamp2, int64_t R, int S, int S_store, int white_back,
         float* __restrict__ rgb, float* __restrict__ depth_out, float* __restrict__ weights, float* __restrict__ wsum_out) {
-    __shared__ MarchLdsFwd lds[RM_WAVES];
+    __shared__ MarchLds lds[RM_WAVES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
+    const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * RM_WAVES + wave));     // wave-uniform: row bases live in SGPRs
     if (r >= R) return;
-    MarchLdsFwd& L = lds[wave];
-    // Round trip 1: the ray's sort permutation and depths.  Round trip 2: the densities they point to AND all colour rows of
-    // the ray (NCH*8 float4 per lane, 8 rows = 1 KB per wave-instruction), requested together so that the ~24 KB stream is in
-    // flight while the densities arrive and the scans and exponentials run.  All loads are unconditional on clamped indices.
+    MarchLds& L = lds[wave];
+    // Round trip 1: march_fetch.  Round trip 2: all colour rows of the ray (NCH*8 float4 per lane, 8 rows = 1 KB per
+    // wave-instruction), requested together so that the ~24 KB stream is in flight while the scans and exponentials run.
     const int sub = lane & 7, rg = lane >> 3;
     float4 creg[NCH * 8];
     {
-        int pk[NCH]; float dp[NCH], sg[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int k = min(c * 64 + lane, S - 1);
-            pk[c] = perm ? perm[r * S + k] : k;
-            dp[c] = depths[r * S + k];
-        }
-        // the ray's densities in STORAGE order, coalesced, in the same round trip as the permutation; the permutation is applied from LDS
-        // (gathering them through perm from global memory was a second, dependent round trip: final march 0.75 -> 0.80 of the HBM roofline,
-        // and the depth-only marches read nothing else)
-        float sr[MAXS / 64];
-#pragma unroll
-        for (int c = 0; c < MAXS / 64; ++c) sr[c] = densities[r * S_store + min(c * 64 + lane, S_store - 1)];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int k = c * 64 + lane;
-            if (k < S) { L.row[k] = pk[c]; L.dep[k] = dp[c]; }
-        }
-#pragma unroll
-        for (int c = 0; c < MAXS / 64; ++c) { const int k = c * 64 + lane; if (k < S_store) L.sraw[k] = sr[c]; }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) sg[c] = L.sraw[pk[c]];
+        MarchRow<NCH> P;
+        march_fetch<NCH>(P, densities, depths, perm, r, S, S_store, lane);
+        float sg[NCH];
+        march_stage<NCH>(L, P, lane, sg);
         if (rgb != nullptr) {
+            const float* col_r = colors + r * S_store * 32;
 #pragma unroll
             for (int it = 0; it < NCH * 8; ++it) {
                 const int k = min(it * 8 + rg, S - 1);
                 // read once, never again: non-temporal (keeps the 400 MB colour stream from evicting what the next kernels reuse)
-                const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4));
+                const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(col_r + (unsigned)(L.row[k] * 32 + sub * 4)));
                 creg[it] = make_float4(cv.x, cv.y, cv.z, cv.w);
             }
         }
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int k = c * 64 + lane;
-            if (k < S) L.sig[k] = sg[c];
-        }
+        for (int c = 0; c < NCH; ++c) L.sig[c * 64 + lane] = sg[c];
         __builtin_amdgcn_wave_barrier();
     }
     float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
@@ -1513,9 +1489,9 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
         if (k < S - 1) {
             wsum += w;
             dnum += w * ((L.dep[k] + L.dep[k + 1]) / 2.f);
-            if (weights) weights[r * (S - 1) + k] = w;
+            if (weights) (weights + r * (S - 1))[(unsigned)k] = w;
         }
-        if (k < S) L.w[k] = (k < S - 1) ? w : 0.f;
+        L.w[k] = (k < S - 1) ? w : 0.f;
     }
     wsum = wave_sum(wsum); dnum = wave_sum(dnum);
     if (lane == 0) {
@@ -1538,8 +1514,10 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
         acc.x = fmaf(v, creg[it].x, acc.x); acc.y = fmaf(v, creg[it].y, acc.y);
         acc.z = fmaf(v, creg[it].z, acc.z); acc.w = fmaf(v, creg[it].w, acc.w);
     }
+    // across the 8 row groups (lanes with the same sub): row_ror:8 pairs lane i with i ^ 8 inside a row of 16; 16 and 32 cross rows
+    acc.x += dpp_f32<0x128>(0.f, acc.x); acc.y += dpp_f32<0x128>(0.f, acc.y); acc.z += dpp_f32<0x128>(0.f, acc.z); acc.w += dpp_f32<0x128>(0.f, acc.w);
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
+    for (int o = 16; o < 64; o <<= 1) {
         acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
         acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
     }
@@ -1551,158 +1529,186 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
     }
 }
 
+// Backward.  One wave owns up to RM_RPW = 8 rays and walks its live ones: a ray whose incoming gradient is exactly zero
+// contributes exactly zero everywhere downstream, so it is only flagged (its d_colors / d_color_scale / d_densities rows are NOT
+// written and must not be read -- spi_triplane_decode_bwd_sorted takes the same flags).  SPI's masked pseudo-view losses leave
+// 65-90 % of the rays of those views in this state; the 128-B gradient rows of a wave's rays are ONE wave-instruction (8 lanes x
+// float4 per row), so a dead ray costs an eighth of a load and a few scalar bit operations (round 2: one wave, one dependent flag
+// round trip and one store per ray -- 60 us per 49 000 dead rays, and the flag round trip sat at the head of every live ray too).
+// The rays of wave g are g, g + W, g + 2W, ... (W = waves of the launch): live regions of an image are contiguous, and the stride
+// spreads them evenly over the waves (8 CONSECUTIVE rays per wave: 138 us for 16 384 live of 65 536 rays; strided: 127-133 us;
+// all 16 384 live rays of a dense launch: 100 us).  While a ray's colour rows stream in, the first round trip of the wave's NEXT
+// live ray is already issued.  The colour rows are consumed as they arrive (q_k = <d_rgb, c_k> needs nothing from the scans)
+// through a ring of RM_RING row groups: 32 registers instead of 96 for the 24 KB of a ray, so three waves share a SIMD.
+// What bounds it (tools/bench_march.py, tools/pmc_march_bwd.sh): NOT the memory system -- the launch takes the same ~100 us with the
+// colour loads replaced by constants, at 2, 3 or 4 waves per SIMD, with 4 to 24 KB in flight per wave, with and without a
+// cross-ray double buffer; a ray-shaped cold non-temporal read of the same 430 MB runs at 6.5 TB/s = 66 us (tools/ubench/read_bw).
+// The ~1 800 instructions per ray issue at one per ~7 cycles per SIMD (VALU 35 % busy; 36 % of the wave cycles in s_waitcnt).
+constexpr int RM_RING = 8;
 template <int NCH>
-__global__ void __launch_bounds__(64 * RM_WAVES) raymarch_bwd_kernel(
+__global__ void __launch_bounds__(64 * RM_WAVES) __attribute__((amdgpu_waves_per_eu(NCH <= 3 ? 3 : 2, NCH <= 3 ? 3 : 2))) raymarch_bwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
         const int32_t* __restrict__ perm, const float* __restrict__ clamp2, const float* __restrict__ d_rgb,
-        const float* __restrict__ d_depth, const float* __restrict__ d_weights, int64_t R, int S, int S_store, int white_back,
+        const float* __restrict__ d_depth, const float* __restrict__ d_weights, int64_t R, int S, int S_store, int white_back, int rpw,
         float* __restrict__ d_colors, float* __restrict__ d_color_scale, float* __restrict__ d_densities, int32_t* __restrict__ ray_active) {
     __shared__ MarchLds lds[RM_WAVES];
+    constexpr int NIT = NCH * 8, RING = RM_RING < NIT ? RM_RING : NIT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * RM_WAVES + wave;
-    if (r >= R) return;
-    if (ray_active) {
-        // A ray whose incoming gradient is exactly zero contributes exactly zero everywhere downstream: it is only flagged
-        // (its d_colors / d_color_scale / d_densities rows are NOT written and must not be read -- spi_triplane_decode_bwd_sorted
-        // takes the same flags).  SPI's masked pseudo-view losses leave 65-90 % of the rays of those views in this state.
-        bool nz = d_rgb && lane < 32 && d_rgb[r * 32 + lane] != 0.f;
-        if (d_depth && lane == 32) nz = d_depth[r] != 0.f;
-        const bool any = __any(nz) || d_weights != nullptr;
-        if (lane == 0) ray_active[r] = any ? 1 : 0;
-        if (!any) return;
-    }
-    MarchLds& L = lds[wave];
-    // Same memory schedule as the forward: round trip 1 = permutation + depths, round trip 2 = densities AND every colour row of
-    // the ray (NCH*8 float4 per lane) requested together, in flight while the scans run.  (Until round 2 the colour rows were
-    // fetched 4 row groups at a time AFTER the scans: 0.37 ms per 16 384 rays = 0.29 of the HBM roofline.)
+    const int64_t gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * RM_WAVES + wave));      // wave-uniform: row bases live in SGPRs
+    const int64_t W = (int64_t)gridDim.x * RM_WAVES;
+    if (gw >= R) return;
     const int sub = lane & 7, rg = lane >> 3;
-    float4 creg[NCH * 8];
-    const float4 g4 = d_rgb ? *reinterpret_cast<const float4*>(d_rgb + r * 32 + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    uint64_t live;                                  // bit 8*j: ray gw + j*W is to be marched
+    float ddep_lane = 0.f;                          // d_depth of ray gw + rg*W (lanes 8*rg .. 8*rg+7)
     {
-        int pk[NCH]; float dp[NCH], sg[NCH];
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int k = min(c * 64 + lane, S - 1);
-            pk[c] = perm ? perm[r * S + k] : k;
-            dp[c] = depths[r * S + k];
-        }
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int k = c * 64 + lane;
-            if (k < S) { L.row[k] = pk[c]; L.dep[k] = dp[c]; }
-        }
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int c = 0; c < NCH; ++c) sg[c] = densities[r * S_store + pk[c]];
-        if (d_rgb != nullptr) {
-#pragma unroll
-            for (int it = 0; it < NCH * 8; ++it) {
-                const int k = min(it * 8 + rg, S - 1);
-                const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(colors + (r * S_store + L.row[k]) * 32 + sub * 4));   // last use of the colour rows
-                creg[it] = make_float4(cv.x, cv.y, cv.z, cv.w);
+        const int64_t rr = gw + rg * W;
+        const bool valid = rg < rpw && rr < R;
+        const int64_t rc = valid ? rr : gw;
+        if (d_depth) ddep_lane = d_depth[rc];
+        bool nz = true;
+        if (ray_active && !d_weights) {
+            nz = ddep_lane != 0.f;
+            if (d_rgb) {
+                const float4 g = *reinterpret_cast<const float4*>(d_rgb + rc * 32 + sub * 4);
+                nz = nz || g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f;
             }
         }
+        uint64_t m = __ballot(nz && valid);
+        m |= m >> 4; m |= m >> 2; m |= m >> 1;
+        live = m & 0x0101010101010101ull;
+        if (ray_active && sub == 0 && valid) ray_active[rr] = (int)((live >> (8 * rg)) & 1);
+    }
+    if (live == 0) return;
+    MarchLds& L = lds[wave];
+    int j = __builtin_ctzll(live) >> 3;
+    MarchRow<NCH> P;
+    march_fetch<NCH>(P, densities, depths, perm, gw + j * W, S, S_store, lane);
+#pragma nounroll
+    while (true) {
+        const int64_t r = gw + j * W;
+        const uint64_t rest = live & (~0xffull << (8 * j));            // live rays after j
+        const int jn = rest ? (__builtin_ctzll(rest) >> 3) : -1;
+        // Same memory schedule as the forward: round trip 1 = march_fetch (already in flight / arrived), round trip 2 = the colour
+        // rows of the ray, the first RING row groups (8 rows = 1 KB per wave-instruction) requested before the scans run.
+        float4 ring[RING];
+        float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* col_r = colors + r * S_store * 32;
+        auto cload = [&](int it) {
+            const int k = min(it * 8 + rg, S - 1);
+            const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(col_r + (unsigned)(L.row[k] * 32 + sub * 4)));   // last use of the colour rows
+            return make_float4(cv.x, cv.y, cv.z, cv.w);
+        };
+        {
+            float sg[NCH];
+            march_stage<NCH>(L, P, lane, sg);
+            if (d_rgb != nullptr) {
+                g4 = *reinterpret_cast<const float4*>(d_rgb + r * 32 + sub * 4);
+#pragma unroll
+                for (int it = 0; it < RING; ++it) ring[it] = cload(it);
+            }
+            if (jn >= 0) march_fetch<NCH>(P, densities, depths, perm, gw + jn * W, S, S_store, lane);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) L.sig[c * 64 + lane] = sg[c];
+            __builtin_amdgcn_wave_barrier();
+        }
+        float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
+        march_scan<NCH>(L, S, lane, alpha, trans, delta, smid);
+        float wsum = 0.f, dnum = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int k = c * 64 + lane;
-            if (k < S) L.sig[k] = sg[c];
+            const float w = alpha[c] * trans[c];
+            if (k < S - 1) { wsum += w; dnum += w * ((L.dep[k] + L.dep[k + 1]) / 2.f); }
+            L.w[k] = (k < S - 1) ? w : 0.f;
         }
+        wsum = wave_sum(wsum); dnum = wave_sum(dnum);
         __builtin_amdgcn_wave_barrier();
-    }
-    float alpha[NCH], trans[NCH], delta[NCH], smid[NCH];
-    march_scan<NCH>(L, S, lane, alpha, trans, delta, smid);
-    float wsum = 0.f, dnum = 0.f;
+        // q_k = <d_rgb, c_k>.  The colour-row gradient is d_rgb * (w_{k-1} + w_k): a per-ray vector times a per-sample scalar.
+        // d_color_scale != NULL: only that scalar is written (4 B per sample; the decoder backward rebuilds the row from d_rgb),
+        // which removes the [R,S,32] gradient tensor -- 403 MB written here and read again there per 128^2 x 192 image.
+        if (!d_rgb) {                     // only the depth map is differentiated (SPI's depth branch): no colour traffic at all
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int k = c * 64 + lane;
-        const float w = alpha[c] * trans[c];
-        if (k < S - 1) { wsum += w; dnum += w * ((L.dep[k] + L.dep[k + 1]) / 2.f); }
-        if (k < S) L.w[k] = (k < S - 1) ? w : 0.f;
-    }
-    wsum = wave_sum(wsum); dnum = wave_sum(dnum);
-    __builtin_amdgcn_wave_barrier();
-    // q_k = <d_rgb, c_k>.  The colour-row gradient is d_rgb * (w_{k-1} + w_k): a per-ray vector times a per-sample scalar.
-    // d_color_scale != NULL: only that scalar is written (4 B per sample; the decoder backward rebuilds the row from d_rgb),
-    // which removes the [R,S,32] gradient tensor -- 403 MB written here and read again there per 128^2 x 192 image.
-    if (!d_rgb) {                     // only the depth map is differentiated (SPI's depth branch): no colour traffic at all
+            for (int c = 0; c < NCH; ++c) L.q[c * 64 + lane] = 0.f;
+        } else {
+            float* dcol_r = d_colors ? d_colors + r * S_store * 32 : nullptr;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) if (c * 64 + lane < S) L.q[c * 64 + lane] = 0.f;
-    } else {
-#pragma unroll
-        for (int it = 0; it < NCH * 8; ++it) {
-            const int k = it * 8 + rg;
-            float part = g4.x * creg[it].x + g4.y * creg[it].y + g4.z * creg[it].z + g4.w * creg[it].w;
-            part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64); part += __shfl_xor(part, 4, 64);
-            if (k < S) {
-                if (sub == 0) L.q[k] = part;
-                if (d_colors) {
+            for (int it = 0; it < NIT; ++it) {
+                const int k = it * 8 + rg;
+                const float4 c4 = ring[it % RING];
+                const float part = group8_sum(g4.x * c4.x + g4.y * c4.y + g4.z * c4.z + g4.w * c4.w);
+                if (it + RING < NIT) { ring[it % RING] = cload(it + RING); asm volatile("" ::: "memory"); }      // (the fence keeps the compiler from hoisting every load to the top again)
+                L.q[k] = part;                                           // (the 8 lanes of a row group write the same value)
+                if (d_colors && k < S) {
                     const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
                     const f32x4_t o = {g4.x * v, g4.y * v, g4.z * v, g4.w * v};
-                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(d_colors + (r * S_store + L.row[k]) * 32 + sub * 4));
+                    __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(dcol_r + (unsigned)(L.row[k] * 32 + sub * 4)));
+                }
+            }
+            if (d_color_scale) {
+                float* dcs_r = d_color_scale + r * S_store;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    const int k = c * 64 + lane;
+                    if (k < S) dcs_r[(unsigned)L.row[k]] = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
                 }
             }
         }
-        if (d_color_scale) {
+        __builtin_amdgcn_wave_barrier();
+        // dL/dw_k
+        float depth_scale = 0.f, D = 0.f;
+        if (d_depth) {
+            D = dnum / wsum;
+            const bool ok = (D == D) && (D >= clamp2[0]) && (D <= clamp2[1]) && (fabsf(D) != INFINITY);
+            depth_scale = ok ? lane_bcast(ddep_lane, 8 * j) / wsum : 0.f;      // empty rays: the reference yields NaN here; we give 0
+            if (!ok) D = 0.f;
+        }
+        float gsum = 0.f;
+        if (white_back) gsum = -2.f * wave_sum(rg == 0 ? (g4.x + g4.y + g4.z + g4.w) : 0.f);
+        float gw_[NCH];                   // g_k * w_k
+        float g[NCH];
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                const int k = c * 64 + lane;
-                if (k < S) d_color_scale[r * S_store + L.row[k]] = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            float gk = 0.f;
+            if (k < S - 1) {
+                gk = L.q[k] + L.q[k + 1] + depth_scale * ((L.dep[k] + L.dep[k + 1]) / 2.f - D) + gsum;
+                if (d_weights) gk += (d_weights + r * (S - 1))[(unsigned)k];
             }
+            g[c] = gk;
+            gw_[c] = gk * alpha[c] * trans[c];
         }
-    }
-    __builtin_amdgcn_wave_barrier();
-    // dL/dw_k
-    float depth_scale = 0.f, D = 0.f;
-    if (d_depth) {
-        D = dnum / wsum;
-        const bool ok = (D == D) && (D >= clamp2[0]) && (D <= clamp2[1]) && (fabsf(D) != INFINITY);
-        depth_scale = ok ? d_depth[r] / wsum : 0.f;      // empty rays: the reference yields NaN here; we give 0
-        if (!ok) D = 0.f;
-    }
-    float gsum = 0.f;
-    if (white_back) gsum = -2.f * wave_sum(rg == 0 ? (g4.x + g4.y + g4.z + g4.w) : 0.f);
-    float gw[NCH];                    // g_k * w_k
-    float g[NCH];
+        // suffix (exclusive) sums of g_m w_m over m > k
+        float total = 0.f;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int k = c * 64 + lane;
-        float gk = 0.f;
-        if (k < S - 1) {
-            gk = L.q[k] + L.q[k + 1] + depth_scale * ((L.dep[k] + L.dep[k + 1]) / 2.f - D) + gsum;
-            if (d_weights) gk += d_weights[r * (S - 1) + k];
+        for (int c = 0; c < NCH; ++c) total += gw_[c];
+        total = wave_sum(total);
+        __builtin_amdgcn_wave_barrier();                                   // every read of q above precedes its reuse below
+        float before = 0.f;               // sum over earlier chunks
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            const float incl = wave_scan_add(gw_[c]) + before;              // sum_{m <= k}
+            const float suffix = total - incl;                              // sum_{m > k}
+            before = lane_bcast(incl, 63);
+            float ds = 0.f;
+            if (k < S - 1) {
+                const float om = 1.f - alpha[c] + 1e-10f;
+                const float da = g[c] * trans[c] - suffix / om;
+                const float dsh = da * delta[c] * (1.f - alpha[c]);             // d alpha / d sigma_hat = delta * exp(-sigma_hat delta)
+                ds = dsh * sigmoid_f(smid[c] - 1.f) * 0.5f;                     // softplus'(x-1) and the midpoint's 1/2
+            }
+            L.q[k] = ds;                                                        // reuse q: contribution of interval k
         }
-        g[c] = gk;
-        gw[c] = gk * alpha[c] * trans[c];
-    }
-    // suffix (exclusive) sums of g_m w_m over m > k
-    float total = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        float* dden_r = d_densities + r * S_store;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) total += gw[c];
-    total = wave_sum(total);
-    float before = 0.f;               // sum over earlier chunks
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int k = c * 64 + lane;
-        const float incl = wave_scan_add(gw[c], lane) + before;     // sum_{m <= k}
-        const float suffix = total - incl;                          // sum_{m > k}
-        before += __shfl(incl - before, 63, 64);
-        float ds = 0.f;
-        if (k < S - 1) {
-            const float om = 1.f - alpha[c] + 1e-10f;
-            const float da = g[c] * trans[c] - suffix / om;
-            const float dsh = da * delta[c] * (1.f - alpha[c]);             // d alpha / d sigma_hat = delta * exp(-sigma_hat delta)
-            ds = dsh * sigmoid_f(smid[c] - 1.f) * 0.5f;                     // softplus'(x-1) and the midpoint's 1/2
+        for (int c = 0; c < NCH; ++c) {
+            const int k = c * 64 + lane;
+            if (k < S) dden_r[(unsigned)L.row[k]] = (k < S - 1 ? L.q[k] : 0.f) + (k > 0 ? L.q[k - 1] : 0.f);
         }
-        if (k < S) L.q[k] = ds;                                             // reuse q: contribution of interval k
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-        const int k = c * 64 + lane;
-        if (k < S) {
-            const float v = (k < S - 1 ? L.q[k] : 0.f) + (k > 0 ? L.q[k - 1] : 0.f);
-            d_densities[r * S_store + L.row[k]] = v;
-        }
+        if (jn < 0) break;
+        j = jn;
+        __builtin_amdgcn_wave_barrier();                                   // the next ray's staging overwrites this ray's LDS rows
     }
 }
 
@@ -1745,9 +1751,9 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
 #pragma unroll
     for (int c = 0; c < (MAXS + 63) / 64; ++c) {
         const int j = c * 64 + lane;
-        const float incl = wave_scan_add(pv[c] / tot, lane) + carry;
+        const float incl = wave_scan_add(pv[c] / tot) + carry;
         if (j < NP) cdf[j + 1] = incl;
-        carry = __shfl(incl, 63, 64);
+        carry = lane_bcast(incl, 63);
     }
     if (lane == 0) cdf[0] = 0.f;
     __builtin_amdgcn_wave_barrier();
@@ -2045,10 +2051,12 @@ int spi_raymarch_bwd(const float* colors, const float* densities, const float* d
     SPI_REQUIRE(d_depth == nullptr || clamp2 != nullptr, "spi_raymarch_bwd: d_depth given without clamp range");
     SPI_REQUIRE(d_rgb == nullptr || d_colors != nullptr || d_color_scale != nullptr,
                 "spi_raymarch_bwd: d_rgb given without a d_colors or d_color_scale output");
-    dim3 grid((unsigned)ceil_div64(R, RM_WAVES)), block(64 * RM_WAVES);
+    // rays per wave: 8 (one wave-instruction of gradient rows) unless that leaves fewer than 2 048 waves (256 CUs x 4 SIMDs x 2)
+    const int rpw = (int)std::min<int64_t>(RM_RPW, std::max<int64_t>(1, R / 2048));
+    dim3 grid((unsigned)ceil_div64(ceil_div64(R, rpw), RM_WAVES)), block(64 * RM_WAVES);
     const int nch = (S + 63) / 64;
 #define LAUNCH_BWD(NCH) hipLaunchKernelGGL(raymarch_bwd_kernel<NCH>, grid, block, 0, as_stream(stream), colors, densities, \
-                                          depths, perm, clamp2, d_rgb, d_depth, d_weights, R, S, S_store, white_back, d_colors, d_color_scale, d_densities, ray_active)
+                                          depths, perm, clamp2, d_rgb, d_depth, d_weights, R, S, S_store, white_back, rpw, d_colors, d_color_scale, d_densities, ray_active)
     switch (nch) { case 1: LAUNCH_BWD(1); break; case 2: LAUNCH_BWD(2); break; case 3: LAUNCH_BWD(3); break; default: LAUNCH_BWD(4); }
 #undef LAUNCH_BWD
     SPI_LAUNCH_CHECK("spi_raymarch_bwd");

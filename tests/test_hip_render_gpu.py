@@ -81,6 +81,59 @@ def test_raymarch_sizes_vs_oracle(S):
     assert_close(gcb, gca, 2e-5, 'grad colors'); assert_close(gdb, gda, 2e-5, 'grad densities')
 
 
+@pytest.mark.parametrize('R,S,depth_only', [(1003, 192, False), (1003, 192, True), (61, 65, False), (5, 7, False)])
+def test_raymarch_bwd_flags_and_live_rays_through_the_abi(R, S, depth_only):
+    """One wave of the backward owns 8 consecutive rays and walks the live ones: flags, untouched rows of dead rays and the live rays'
+    gradients are those of a launch without flags (every ray marched), for ragged ray counts, dead / live runs and lone live rays."""
+    from spi_amd import hip
+    gen = torch.Generator().manual_seed(R * 1000 + S)
+    sc = S // 2
+    col = torch.rand(R, S, 32, generator=gen).to(DEV); den = (torch.randn(R, S, generator=gen) * 3 + 1).to(DEV)
+    dc = torch.sort(torch.rand(R, sc, generator=gen) + 2.25, 1)[0].to(DEV).contiguous()
+    df = torch.sort(torch.rand(R, S - sc, generator=gen) + 2.25, 1)[0].to(DEV).contiguous()
+    dep = torch.empty(R, S, device=DEV); perm = torch.empty(R, S, device=DEV, dtype=torch.int32)
+    hip.call('spi_merge_sort_depths', hip.ptr(dc), hip.ptr(df), R, sc, S - sc, hip.ptr(dep), hip.ptr(perm), hip.stream())
+    cl = torch.tensor([2.25, 3.3], device=DEV)
+    live = torch.rand(R, generator=gen) < 0.3
+    live[R // 3: R // 3 + 40] = True                         # a run of live rays across several waves
+    live[R // 2: R // 2 + 100] = False                       # ... and of dead ones
+    live[-1] = True                                          # the last ray of the ragged tail
+    d_rgb = torch.randn(R, 32, generator=gen) * live[:, None]
+    d_rgb[live.nonzero()[0, 0]] = 0.; d_rgb[live.nonzero()[0, 0], 31] = 1e-30      # live through one tiny component of the last channel quad
+    d_dep = torch.randn(R, generator=gen) * live
+    if not depth_only:
+        only_depth = (~live).nonzero()[:3, 0]                # rays that are live through their depth gradient alone
+        d_dep[only_depth] = 0.5; live[only_depth] = True
+    d_rgb, d_dep = d_rgb.to(DEV), d_dep.to(DEV)
+    out = {}
+    for flags in (False, True):
+        d_cs = torch.full((R, S), 7.5, device=DEV); d_sig = torch.full((R, S), 7.5, device=DEV)
+        act = torch.full((R,), -3, device=DEV, dtype=torch.int32)
+        hip.call('spi_raymarch_bwd', None if depth_only else hip.ptr(col), hip.ptr(den), hip.ptr(dep), hip.ptr(perm), hip.ptr(cl),
+                 None if depth_only else hip.ptr(d_rgb), hip.ptr(d_dep), None, R, S, S, 32, 1, None, None if depth_only else hip.ptr(d_cs), hip.ptr(d_sig),
+                 hip.ptr(act) if flags else None, hip.stream())
+        out[flags] = (d_cs, d_sig, act)
+    torch.cuda.synchronize()
+    (cs0, sig0, _), (cs1, sig1, act) = out[False], out[True]
+    lv = live.to(DEV)
+    assert torch.equal(act, lv.int()), 'flags'
+    assert (sig1[~lv] == 7.5).all() and (cs1[~lv] == 7.5).all(), 'rows of dead rays must stay unwritten'
+    assert torch.equal(sig1[lv], sig0[lv]) and (depth_only or torch.equal(cs1[lv], cs0[lv])), 'live rays: same arithmetic with and without flags'
+    assert (sig0[~lv] == 0).all(), 'a dead ray marched anyway has an exactly-zero density gradient'
+    # and against the oracle's autograd on the live rays
+    k = lv.nonzero()[:64, 0]
+    idx = perm[k].long()
+    cr = torch.gather(col[k], 1, idx[:, :, None].expand(-1, -1, 32)).cpu()[None].requires_grad_(True)
+    dr = torch.gather(den[k], 1, idx).cpu()[None, :, :, None].requires_grad_(True)
+    a, b, _ = orr.ray_march(cr, dr, dep[k].cpu()[None, :, :, None], white_back=True)
+    heads = [b] if depth_only else [a, b]
+    gs = [d_dep[k].cpu()[None, :, None]] if depth_only else [d_rgb[k].cpu()[None], d_dep[k].cpu()[None, :, None]]
+    gden = torch.autograd.grad(heads, [dr], gs)[0][0, :, :, 0]
+    finite = torch.isfinite(gden).all(1)
+    got = torch.gather(sig1[k], 1, idx).cpu()
+    assert_close(got[finite], gden[finite], 3e-5, 'density gradient of live rays vs the oracle')
+
+
 def test_gather_decode_golden_fwd_bwd(golden):
     from spi_amd.training.volumetric_rendering.renderer import ImportanceRenderer
     g = golden('renderer')
@@ -104,9 +157,9 @@ def test_importance_golden(golden):
     n, m, s = dep.shape
     fine = torch.empty(n, m, 20, device=DEV)
     hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(w), hip.ptr(u), n * m, s, 20, hip.ptr(fine), 0, hip.stream())
-    assert (fine.cpu() - g['is_fine'][..., 0]).abs().max() < 2e-6                 # draw order, as the reference returns them
+    assert (fine.cpu() - g['is_fine'][..., 0]).abs().max() < 3e-6                 # draw order, as the reference returns them (the inverse CDF amplifies the rounding of the cumulative sums: parallel scan here, sequential cumsum there)
     hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(w), hip.ptr(u), n * m, s, 20, hip.ptr(fine), 1, hip.stream())
-    assert (fine.cpu() - torch.sort(g['is_fine'][..., 0], dim=-1)[0]).abs().max() < 2e-6     # ascending variant: same multiset
+    assert (fine.cpu() - torch.sort(g['is_fine'][..., 0], dim=-1)[0]).abs().max() < 3e-6     # ascending variant: same multiset
 
 
 def test_merge_sort_matches_torch_sort():
