@@ -1384,6 +1384,7 @@ __global__ void minmax_kernel(const float* __restrict__ x, int64_t n, float* __r
 constexpr int MAXS = 256;
 constexpr int RM_WAVES = 4;
 constexpr int RM_RPW = 8;               // backward: rays per wave -- their eight 128-B gradient rows are ONE 1 KB wave-instruction
+constexpr int RM_RING = 8;              // colour row groups (8 rows = 1 KB per wave-instruction) a wave keeps in flight
 
 struct MarchLds { float sig[MAXS]; float dep[MAXS]; float w[MAXS]; float q[MAXS]; int row[MAXS]; float sraw[MAXS]; };   // sraw: the ray's densities in storage order
 
@@ -1443,37 +1444,42 @@ __device__ __forceinline__ void march_scan(const MarchLds& L, int S, int lane, f
         alpha[c] = a; delta[c] = dl; smid[c] = sm;
         trans[c] = carry * excl;
         carry *= lane_bcast(incl, 63);
+        __builtin_amdgcn_sched_barrier(0);          // one chunk's exponentials at a time: interleaved, the three chunks' temporaries cost ~40 registers
     }
 }
 
+// (RM_RING row groups in flight: 66 registers, six waves per SIMD -- the depth-only marches, which are all arithmetic, went from 84 to 69 us
+// per 65 536 rays with the occupancy; the composite is the same 86 us at 3 to 6 waves per SIMD and 4 to 24 KB in flight per wave)
 template <int NCH>
-__global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
+__global__ void __launch_bounds__(64 * RM_WAVES) __attribute__((amdgpu_waves_per_eu(6, 6))) raymarch_fwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
         const int32_t* __restrict__ perm, const float* __restrict__ clamp2, int64_t R, int S, int S_store, int white_back,
         float* __restrict__ rgb, float* __restrict__ depth_out, float* __restrict__ weights, float* __restrict__ wsum_out) {
     __shared__ MarchLds lds[RM_WAVES];
+    constexpr int NIT = NCH * 8, RING = RM_RING < NIT ? RM_RING : NIT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * RM_WAVES + wave));     // wave-uniform: row bases live in SGPRs
     if (r >= R) return;
     MarchLds& L = lds[wave];
-    // Round trip 1: march_fetch.  Round trip 2: all colour rows of the ray (NCH*8 float4 per lane, 8 rows = 1 KB per
-    // wave-instruction), requested together so that the ~24 KB stream is in flight while the scans and exponentials run.
+    // Round trip 1: march_fetch.  Round trip 2: the colour rows of the ray (8 rows = 1 KB per wave-instruction): the first RING row
+    // groups are requested before the scans and exponentials run, the rest stream through the ring while the composite accumulates.
     const int sub = lane & 7, rg = lane >> 3;
-    float4 creg[NCH * 8];
+    float4 ring[RING];
+    const float* col_r = colors + r * S_store * 32;
+    auto cload = [&](int it) {
+        const int k = min(it * 8 + rg, S - 1);
+        // read once, never again: non-temporal (keeps the 400 MB colour stream from evicting what the next kernels reuse)
+        const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(col_r + (unsigned)(L.row[k] * 32 + sub * 4)));
+        return make_float4(cv.x, cv.y, cv.z, cv.w);
+    };
     {
         MarchRow<NCH> P;
         march_fetch<NCH>(P, densities, depths, perm, r, S, S_store, lane);
         float sg[NCH];
         march_stage<NCH>(L, P, lane, sg);
         if (rgb != nullptr) {
-            const float* col_r = colors + r * S_store * 32;
 #pragma unroll
-            for (int it = 0; it < NCH * 8; ++it) {
-                const int k = min(it * 8 + rg, S - 1);
-                // read once, never again: non-temporal (keeps the 400 MB colour stream from evicting what the next kernels reuse)
-                const f32x4_t cv = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(col_r + (unsigned)(L.row[k] * 32 + sub * 4)));
-                creg[it] = make_float4(cv.x, cv.y, cv.z, cv.w);
-            }
+            for (int it = 0; it < RING; ++it) ring[it] = cload(it);
         }
 #pragma unroll
         for (int c = 0; c < NCH; ++c) L.sig[c * 64 + lane] = sg[c];
@@ -1508,11 +1514,18 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
     // sum_k w_k (c_k + c_{k+1})/2  ==  sum_k c_k * (w_{k-1} + w_k)/2
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int it = 0; it < NCH * 8; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int k = it * 8 + rg;
         const float v = (k < S) ? 0.5f * ((k > 0 ? L.w[k - 1] : 0.f) + L.w[k]) : 0.f;
-        acc.x = fmaf(v, creg[it].x, acc.x); acc.y = fmaf(v, creg[it].y, acc.y);
-        acc.z = fmaf(v, creg[it].z, acc.z); acc.w = fmaf(v, creg[it].w, acc.w);
+        const float4 c4 = ring[it % RING];
+        acc.x = fmaf(v, c4.x, acc.x); acc.y = fmaf(v, c4.y, acc.y);
+        acc.z = fmaf(v, c4.z, acc.z); acc.w = fmaf(v, c4.w, acc.w);
+        if (it + RING < NIT) {
+            // the fence keeps the compiler from hoisting every load to the top again, and pins the accumulation in front of the refill
+            // (a sunk FMA keeps its ring slot alive: all 24 row groups ended up in registers of their own)
+            asm volatile("" : "+v"(acc.x), "+v"(acc.y), "+v"(acc.z), "+v"(acc.w) :: "memory");
+            ring[it % RING] = cload(it + RING);
+        }
     }
     // across the 8 row groups (lanes with the same sub): row_ror:8 pairs lane i with i ^ 8 inside a row of 16; 16 and 32 cross rows
     acc.x += dpp_f32<0x128>(0.f, acc.x); acc.y += dpp_f32<0x128>(0.f, acc.y); acc.z += dpp_f32<0x128>(0.f, acc.z); acc.w += dpp_f32<0x128>(0.f, acc.w);
@@ -1544,7 +1557,6 @@ __global__ void __launch_bounds__(64 * RM_WAVES) raymarch_fwd_kernel(
 // colour loads replaced by constants, at 2, 3 or 4 waves per SIMD, with 4 to 24 KB in flight per wave, with and without a
 // cross-ray double buffer; a ray-shaped cold non-temporal read of the same 430 MB runs at 6.5 TB/s = 66 us (tools/ubench/read_bw).
 // The ~1 800 instructions per ray issue at one per ~7 cycles per SIMD (VALU 35 % busy; 36 % of the wave cycles in s_waitcnt).
-constexpr int RM_RING = 8;
 template <int NCH>
 __global__ void __launch_bounds__(64 * RM_WAVES) __attribute__((amdgpu_waves_per_eu(NCH <= 3 ? 3 : 2, NCH <= 3 ? 3 : 2))) raymarch_bwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,
@@ -1636,8 +1648,8 @@ __global__ void __launch_bounds__(64 * RM_WAVES) __attribute__((amdgpu_waves_per
                 const int k = it * 8 + rg;
                 const float4 c4 = ring[it % RING];
                 const float part = group8_sum(g4.x * c4.x + g4.y * c4.y + g4.z * c4.z + g4.w * c4.w);
-                if (it + RING < NIT) { ring[it % RING] = cload(it + RING); asm volatile("" ::: "memory"); }      // (the fence keeps the compiler from hoisting every load to the top again)
                 L.q[k] = part;                                           // (the 8 lanes of a row group write the same value)
+                if (it + RING < NIT) { asm volatile("" ::: "memory"); ring[it % RING] = cload(it + RING); }      // (the fence keeps the compiler from hoisting every load to the top again)
                 if (d_colors && k < S) {
                     const float v = (k > 0 ? L.w[k - 1] : 0.f) + L.w[k];
                     const f32x4_t o = {g4.x * v, g4.y * v, g4.z * v, g4.w * v};
