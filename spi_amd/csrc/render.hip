@@ -1553,10 +1553,13 @@ __global__ void __launch_bounds__(64 * RM_WAVES) __attribute__((amdgpu_waves_per
 // all 16 384 live rays of a dense launch: 100 us).  While a ray's colour rows stream in, the first round trip of the wave's NEXT
 // live ray is already issued.  The colour rows are consumed as they arrive (q_k = <d_rgb, c_k> needs nothing from the scans)
 // through a ring of RM_RING row groups: 32 registers instead of 96 for the 24 KB of a ray, so three waves share a SIMD.
-// What bounds it (tools/bench_march.py, tools/pmc_march_bwd.sh): NOT the memory system -- the launch takes the same ~100 us with the
-// colour loads replaced by constants, at 2, 3 or 4 waves per SIMD, with 4 to 24 KB in flight per wave, with and without a
-// cross-ray double buffer; a ray-shaped cold non-temporal read of the same 430 MB runs at 6.5 TB/s = 66 us (tools/ubench/read_bw).
-// The ~1 800 instructions per ray issue at one per ~7 cycles per SIMD (VALU 35 % busy; 36 % of the wave cycles in s_waitcnt).
+// Where a ray's ~29 000 cycles go (s_memtime stamps per section, dense launch): colour loop 45 % (waiting for memory), staging + issue
+// 22 %, suffix sums + stores 21 %, scans 12 %; 92 us per 16 384 rays against the 68 us a ray-shaped non-temporal read of the same 430 MB
+// takes (tools/ubench/read_bw).  Measured no better on top of this form: 2 / 3 / 4 waves per SIMD, rings of 4 to 24 row groups, and a
+// cross-ray double buffer that keeps the ring full through the arithmetic phases (89.6 us dense, but 138 against 128 us masked).
+// gfx9 notes from that work: loads and stores share ONE in-order counter, and a load in flight across a loop's back edge, or issued
+// inside a branch, is awaited with vmcnt(0) -- keep the count of what is in flight static; `const __restrict__` loads are hoisted across
+// asm("" ::: "memory") fences unless an address operand passes through a volatile asm.
 template <int NCH>
 __global__ void __launch_bounds__(64 * RM_WAVES) __attribute__((amdgpu_waves_per_eu(NCH <= 3 ? 3 : 2, NCH <= 3 ? 3 : 2))) raymarch_bwd_kernel(
         const float* __restrict__ colors, const float* __restrict__ densities, const float* __restrict__ depths,

@@ -37,9 +37,14 @@ def timeit(fn):
         fn()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-    flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    flush = torch.zeros(128 << 20, dtype=torch.int32, device=dev)
     for a, b in ev:
-        flush.zero_()                                   # the 256 MB MALL / L2 do not serve the next launch
+        # the 256 MB MALL / L2 must not serve the next launch.  DIRTY=1 flushes by writing instead of reading: every line the timed kernel allocates then
+        # evicts a dirty one, which costs the kernels with allocating accesses 10-15 % (plain loads of a cold 430 MB: 3.5 instead of ~6 TB/s)
+        if os.environ.get('DIRTY'):
+            flush.zero_()
+        else:
+            flush.max()
         a.record(); fn(); b.record()
     torch.cuda.synchronize()
     ts = sorted(a.elapsed_time(b) for a, b in ev)
