@@ -203,6 +203,15 @@ __device__ __forceinline__ float wave_scan_mul(float v) {
     v *= dpp_f32<0x142, 0xa>(1.f, v); v *= dpp_f32<0x143, 0xc>(1.f, v);
     return v;
 }
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_i32(int old, int src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, BANK_MASK, false); }
+__device__ __forceinline__ int wave_scan_add(int v) {
+    v += dpp_i32<0x111>(0, v); v += dpp_i32<0x112>(0, v); v += dpp_i32<0x114>(0, v); v += dpp_i32<0x118>(0, v);
+    v += dpp_i32<0x142, 0xa>(0, v); v += dpp_i32<0x143, 0xc>(0, v);
+    return v;
+}
+// sum over each aligned group of 4 lanes (a quad), in every lane of it
+__device__ __forceinline__ float quad_sum(float v) { v += dpp_f32<0xB1>(0.f, v); v += dpp_f32<0x4E>(0.f, v); return v; }
 __device__ __forceinline__ float wave_scan_add(float v) {
     v += dpp_f32<0x111>(0.f, v); v += dpp_f32<0x112>(0.f, v); v += dpp_f32<0x114>(0.f, v); v += dpp_f32<0x118>(0.f, v);
     v += dpp_f32<0x142, 0xa>(0.f, v); v += dpp_f32<0x143, 0xc>(0.f, v);

@@ -21,12 +21,6 @@ constexpr int CX_ROWS = 32;       // rows per block (4 waves x 8 rows)
 constexpr int CX_THREADS = 256;
 constexpr int CX_CACHE_COLS = 4096;  // widest row whose weights are cached in LDS between the passes (4 strips + column maxima = 96 KB)
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
 // rel and w of one element, written once so that forward and backward round identically
 __device__ __forceinline__ float cx_weight(float sim, float m, float inv_bw, float& d, bool& clamped) {
     d = 1.f - sim;

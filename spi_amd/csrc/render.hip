@@ -678,9 +678,7 @@ __global__ void __launch_bounds__(256) bin_points_kernel(const float* __restrict
     int loc[PER], sum = 0;
 #pragma unroll
     for (int i = 0; i < PER; ++i) { loc[i] = sum; sum += cnt[t * PER + i]; }
-    int incl = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    const int incl = wave_scan_add(sum);
     if (lane == 63) wsum_s[wave] = incl;
     __syncthreads();
     int base = incl - sum;
@@ -1334,9 +1332,9 @@ __global__ void __launch_bounds__(256) decoder_wgrad_kernel(const float* __restr
     }
     // row sums: the 4 threads sharing a row (tid & 3) combine, then one atomic per row
 #pragma unroll
-    for (int q = 0; q < 3; ++q) { bsum[q] += __shfl_xor(bsum[q], 1, 64); bsum[q] += __shfl_xor(bsum[q], 2, 64); }
-    sigacc += __shfl_xor(sigacc, 1, 64); sigacc += __shfl_xor(sigacc, 2, 64);
-    sigsum += __shfl_xor(sigsum, 1, 64); sigsum += __shfl_xor(sigsum, 2, 64);
+    for (int q = 0; q < 3; ++q) bsum[q] = quad_sum(bsum[q]);
+    sigacc = quad_sum(sigacc);
+    sigsum = quad_sum(sigsum);
     if ((tid & 3) == 0) {
         atomicAdd(db1 + r0, bsum[0]);                                  // q = 0: dpre row r0
         if (r0 < 32) atomicAdd(db2 + 1 + r0, bsum[1]);                 // q = 1: lcol 64..95 are dy_rgb rows (r0 < 32); 96..127 are f rows (no sum needed)
