@@ -125,7 +125,7 @@ int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, f
 int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream);
 
 /* MipRayMarcher2.run_forward, ray_marcher.py:25-57.  One launch = R rays of S sorted samples.
- *   colors [R,S_store,C] (C = 32), densities [R,S_store] with S_store >= S rows kept per ray;
+ *   colors [R,S_store,C] (C = 32), densities [R,S_store] with S <= S_store <= 256 rows kept per ray;
  *   depths [R,S] sorted; perm (optional, int32 [R,S]): sample k of ray r is row perm[r,k] of
  *   colors/densities (identity if NULL) -- this folds unify_samples' three gathers
  *   (renderer.py:157-167) into the march.

@@ -2037,7 +2037,7 @@ int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream) {
 int spi_raymarch_fwd(const float* colors, const float* densities, const float* depths, const int32_t* perm,
                      const float* clamp2, int64_t R, int S, int S_store, int C, int white_back, float* rgb, float* depth,
                      float* weights, float* wsum, spi_stream_t stream) {
-    SPI_REQUIRE(S_store >= S, "spi_raymarch_fwd: S_store must be >= S");
+    SPI_REQUIRE(S_store >= S && S_store <= MAXS, "spi_raymarch_fwd: need S <= S_store <= %d (the ray's rows are staged in LDS), got S_store = %d", MAXS, S_store);
     SPI_REQUIRE(densities && depths && R > 0, "spi_raymarch_fwd: null tensor");
     SPI_REQUIRE(S >= 2 && S <= MAXS, "spi_raymarch_fwd: need 2 <= S <= %d, got %d", MAXS, S);
     SPI_REQUIRE(C == 32, "spi_raymarch_fwd: only C = 32 feature channels are supported, got %d", C);
@@ -2057,7 +2057,7 @@ int spi_raymarch_bwd(const float* colors, const float* densities, const float* d
                      const float* clamp2, const float* d_rgb, const float* d_depth, const float* d_weights, int64_t R,
                      int S, int S_store, int C, int white_back, float* d_colors, float* d_color_scale, float* d_densities,
                      int32_t* ray_active, spi_stream_t stream) {
-    SPI_REQUIRE(S_store >= S, "spi_raymarch_bwd: S_store must be >= S");
+    SPI_REQUIRE(S_store >= S && S_store <= MAXS, "spi_raymarch_bwd: need S <= S_store <= %d (the ray's rows are staged in LDS), got S_store = %d", MAXS, S_store);
     SPI_REQUIRE(densities && depths && d_densities && R > 0 && (d_rgb == nullptr || colors != nullptr), "spi_raymarch_bwd: null tensor");
     SPI_REQUIRE(S >= 2 && S <= MAXS, "spi_raymarch_bwd: need 2 <= S <= %d, got %d", MAXS, S);
     SPI_REQUIRE(C == 32, "spi_raymarch_bwd: only C = 32 feature channels are supported, got %d", C);

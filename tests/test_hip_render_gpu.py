@@ -134,6 +134,36 @@ def test_raymarch_bwd_flags_and_live_rays_through_the_abi(R, S, depth_only):
     assert_close(got[finite], gden[finite], 3e-5, 'density gradient of live rays vs the oracle')
 
 
+def test_raymarch_subset_of_stored_rows_through_perm():
+    """S of S_store stored rows per ray are marched (perm picks them, sorted by depth): same results as on the compacted arrays; the rows that
+    are not picked keep their contents in the gradient outputs."""
+    from spi_amd import hip
+    gen = torch.Generator().manual_seed(11)
+    R, S, SS = 77, 100, 160
+    col = torch.rand(R, SS, 32, generator=gen).to(DEV); den = (torch.randn(R, SS, generator=gen) * 3 + 1).to(DEV)
+    pick = torch.stack([torch.randperm(SS, generator=gen)[:S] for _ in range(R)]).to(DEV)                 # rows marched, in depth order
+    dep = torch.sort(torch.rand(R, S, generator=gen) + 2.25, 1)[0].to(DEV).contiguous()
+    perm = pick.int().contiguous()
+    cl = torch.tensor([2.25, 3.3], device=DEV)
+    colc = torch.gather(col, 1, pick[:, :, None].expand(-1, -1, 32)).contiguous(); denc = torch.gather(den, 1, pick).contiguous()
+    d_rgb = torch.randn(R, 32, generator=gen).to(DEV); d_dep = torch.randn(R, generator=gen).to(DEV)
+    res = []
+    for c, d, pm, ss in ((col, den, perm, SS), (colc, denc, None, S)):
+        rgb = torch.empty(R, 32, device=DEV); depth = torch.empty(R, device=DEV); w = torch.empty(R, S - 1, device=DEV)
+        hip.call('spi_raymarch_fwd', hip.ptr(c), hip.ptr(d), hip.ptr(dep), hip.ptr(pm), hip.ptr(cl), R, S, ss, 32, 1, hip.ptr(rgb), hip.ptr(depth), hip.ptr(w), None, hip.stream())
+        d_cs = torch.full((R, ss), 7.5, device=DEV); d_sig = torch.full((R, ss), 7.5, device=DEV)
+        hip.call('spi_raymarch_bwd', hip.ptr(c), hip.ptr(d), hip.ptr(dep), hip.ptr(pm), hip.ptr(cl), hip.ptr(d_rgb), hip.ptr(d_dep), None, R, S, ss, 32, 1,
+                 None, hip.ptr(d_cs), hip.ptr(d_sig), None, hip.stream())
+        res.append((rgb, depth, w, d_cs, d_sig))
+    (rgb0, dp0, w0, cs0, sg0), (rgb1, dp1, w1, cs1, sg1) = res
+    assert torch.equal(rgb0, rgb1) and torch.equal(dp0, dp1) and torch.equal(w0, w1)
+    assert torch.equal(torch.gather(cs0, 1, pick), cs1) and torch.equal(torch.gather(sg0, 1, pick), sg1)
+    rest = torch.ones(R, SS, dtype=torch.bool, device=DEV).scatter_(1, pick, False)
+    assert (cs0[rest] == 7.5).all() and (sg0[rest] == 7.5).all()
+    with pytest.raises(RuntimeError):
+        hip.call('spi_raymarch_fwd', hip.ptr(col), hip.ptr(den), hip.ptr(dep), hip.ptr(perm), hip.ptr(cl), R, S, 300, 32, 1, hip.ptr(rgb0), None, None, None, hip.stream())
+
+
 def test_gather_decode_golden_fwd_bwd(golden):
     from spi_amd.training.volumetric_rendering.renderer import ImportanceRenderer
     g = golden('renderer')
