@@ -27,9 +27,10 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 5   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 6   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
-                             * 4: + spi_sample_from_planes_fwd / _bwd (additive) */
+                             * 4: + spi_sample_from_planes_fwd / _bwd (additive)
+                             * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -375,6 +376,13 @@ int spi_roi_align_bwd(const float* boxes, const float* dy, float* dx, int N, int
  *   step is the 1-based step count used for bias correction. */
 int spi_adam_multi(void* const* ptrs, const int64_t* sizes, int T, int64_t max_size, float lr, float beta1,
                    float beta2, float eps, int step, spi_stream_t stream);
+
+/* Affine (style) layers at inversion batch sizes: FullyConnectedLayer with activation 'linear', networks_stylegan2.py:95-127, as matrix-vector
+ * products (N <= 8 rows).  y [N,O] = b [O] (NULL = 0) + gain * x [N,I] W[O,I]^T; in_features I a multiple of 4. */
+int spi_affine_fwd(const float* x, const float* w, const float* b, float gain, float* y, int N, int I, int O, spi_stream_t stream);
+/* g [N,O] -> dx [N,I] = gain * g W and / or dw [O,I] = gain * g^T x in one pass over the [O,I] index space (either output may be NULL;
+ * w is read for dx only, x for dw only).  The bias gradient is the column sum of g (caller's). */
+int spi_affine_bwd(const float* g, const float* x, const float* w, float gain, float* dx, float* dw, int N, int I, int O, spi_stream_t stream);
 /* spi_adam_multi predicated on a DEVICE byte: *skip != 0 -> nothing is written.  The reference tests `loss_lpips <= threshold` on the
  * host before optimizer.step() (rot_bbox_cx_coach.py:148-151); a loop that enqueues iterations ahead of that read leaves the decision in
  * device memory and lets this launch honour it, so the parameters end exactly where the reference's break leaves them. */

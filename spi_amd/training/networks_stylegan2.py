@@ -203,24 +203,44 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
 
 
 class _LinearGain(torch.autograd.Function):
-    """y = bias + gain * x W^T as ONE library GEMM each way.  torch's own addmm backward scales the weight gradient with a separate [out, in]
-    elementwise launch and materialises the broadcast bias gradient through a fill; with 29 affine layers per generator pass that was 58 of the
-    ~5 us launches of every stage-2 iteration (SPI_TORCH_PROFILE=shapes).  Here the gain rides as the GEMMs' alpha in both directions."""
+    """y = bias + gain * x W^T.  At inversion batch sizes (<= 8 rows: one image, or the four pseudo-views) these are matrix-VECTOR products: a
+    library GEMM runs them on one workgroup (18 us forward, 2 x 7.5 us backward; 29 affine layers per generator pass = 2 % of the step's GPU
+    time), `spi_affine_fwd / _bwd` read W once with the whole chip and produce dx and dW in one pass.  Larger batches keep the library GEMM,
+    with the gain riding as alpha in both directions (torch's own addmm backward scales the weight gradient with a separate [out, in]
+    elementwise launch and materialises the broadcast bias gradient through a fill)."""
+
+    @staticmethod
+    def _small(x, weight):
+        return x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and x.dim() == 2 and 1 <= x.shape[0] <= 8 and x.shape[1] % 4 == 0
 
     @staticmethod
     def forward(ctx, x, weight, bias, gain):
-        ctx.save_for_backward(x, weight)
         ctx.gain = float(gain)
+        if _LinearGain._small(x, weight):
+            x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+            ctx.save_for_backward(x, weight)
+            y = torch.empty(x.shape[0], weight.shape[0], device=x.device, dtype=torch.float32)
+            hip.call('spi_affine_fwd', hip.ptr(x), hip.ptr(weight), hip.ptr(bias), ctx.gain, hip.ptr(y), x.shape[0], x.shape[1], weight.shape[0], hip.stream())
+            return y
+        ctx.save_for_backward(x, weight)
         return torch.addmm(bias.unsqueeze(0), x, weight.t(), alpha=ctx.gain)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.addmm(g.new_empty(x.shape), g, weight, beta=0, alpha=ctx.gain)            # beta = 0: the input tensor is ignored
-        if ctx.needs_input_grad[1]:
-            dw = torch.addmm(g.new_empty(weight.shape), g.t(), x, beta=0, alpha=ctx.gain)
+        if _LinearGain._small(x, weight) and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]):
+            g = g.contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+            if ctx.needs_input_grad[1]:
+                dw = torch.empty_like(weight)
+            hip.call('spi_affine_bwd', hip.ptr(g), hip.ptr(x), hip.ptr(weight), ctx.gain, hip.ptr(dx), hip.ptr(dw), x.shape[0], x.shape[1], weight.shape[0], hip.stream())
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = torch.addmm(g.new_empty(x.shape), g, weight, beta=0, alpha=ctx.gain)            # beta = 0: the input tensor is ignored
+            if ctx.needs_input_grad[1]:
+                dw = torch.addmm(g.new_empty(weight.shape), g.t(), x, beta=0, alpha=ctx.gain)
         if ctx.needs_input_grad[2]:
             db = g[0] if g.shape[0] == 1 else g.sum(0)
         return dx, dw, db, None

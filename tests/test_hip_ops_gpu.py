@@ -228,3 +228,31 @@ def test_filtered_lrelu_act_sign_tensor_modes():
     y = x.clone().to(DEV)
     so = filtered_lrelu_act_(y, None, 0, 0, gain, slope, None, write_signs=True)
     assert int(((so.cpu().long() >> 1) & 0x55).sum()) == 0
+
+
+@pytest.mark.parametrize('n,i,o', [(1, 512, 512), (4, 512, 256), (8, 512, 32), (1, 512, 3), (3, 24, 7), (4, 516, 70)])
+def test_affine_layer_matrix_vector_kernels(n, i, o):
+    """FullyConnectedLayer (activation linear) at inversion batch sizes runs on spi_affine_fwd / _bwd: forward, dx, dW and db against fp64
+    (networks_stylegan2.py:95-127: y = x (W * weight_gain)^T + b * bias_gain); nine rows fall back to the library GEMM with the same results."""
+    from spi_amd.training.networks_stylegan2 import FullyConnectedLayer
+    gen = torch.Generator().manual_seed(n * 1000 + i + o)
+    fc = FullyConnectedLayer(i, o, bias_init=1).to(DEV)
+    with torch.no_grad():
+        fc.weight.copy_(torch.randn(o, i, generator=gen)); fc.bias.copy_(torch.randn(o, generator=gen))
+    for rows in (n, 9):
+        x = torch.randn(rows, i, generator=gen).to(DEV).requires_grad_(True)
+        gy = torch.randn(rows, o, generator=gen).to(DEV)
+        y = fc(x)
+        dx, dw, db = torch.autograd.grad(y, [x, fc.weight, fc.bias], gy)
+        xr = x.detach().double().cpu().requires_grad_(True); wr = fc.weight.detach().double().cpu().requires_grad_(True); br = fc.bias.detach().double().cpu().requires_grad_(True)
+        yr = xr @ (wr * fc.weight_gain).t() + br * fc.bias_gain
+        dxr, dwr, dbr = torch.autograd.grad(yr, [xr, wr, br], gy.double().cpu())
+        assert_close(y, yr.float(), 2e-6, f'affine y rows={rows}'); assert_close(dx, dxr.float(), 2e-6, 'affine dx')
+        assert_close(dw, dwr.float(), 2e-6, 'affine dW'); assert_close(db, dbr.float(), 2e-6, 'affine db')
+    # frozen weights (stage 1): only dx is asked for
+    x = torch.randn(n, i, generator=gen).to(DEV).requires_grad_(True)
+    fc.requires_grad_(False)
+    (dx,) = torch.autograd.grad(fc(x).square().sum(), [x])
+    xr = x.detach().double().cpu().requires_grad_(True)
+    (dxr,) = torch.autograd.grad((xr @ (fc.weight.double().cpu() * fc.weight_gain).t() + fc.bias.double().cpu() * fc.bias_gain).square().sum(), [xr])
+    assert_close(dx, dxr.float(), 3e-6, 'affine dx (frozen)')
