@@ -380,7 +380,7 @@ int spi_adam_multi(void* const* ptrs, const int64_t* sizes, int T, int64_t max_s
 /* Affine (style) layers at inversion batch sizes: FullyConnectedLayer with activation 'linear', networks_stylegan2.py:95-127, as matrix-vector
  * products (N <= 8 rows).  y [N,O] = b [O] (NULL = 0) + gain * x [N,I] W[O,I]^T; in_features I a multiple of 4. */
 int spi_affine_fwd(const float* x, const float* w, const float* b, float gain, float* y, int N, int I, int O, spi_stream_t stream);
-/* g [N,O] -> dx [N,I] = gain * g W and / or dw [O,I] = gain * g^T x in one pass over the [O,I] index space (either output may be NULL;
+/* g [N,O] -> dx [N,I] = gain * g W and / or dw [O,I] = gain * g^T x in one launch (either output may be NULL;
  * w is read for dx only, x for dw only).  The bias gradient is the column sum of g (caller's). */
 int spi_affine_bwd(const float* g, const float* x, const float* w, float gain, float* dx, float* dw, int N, int I, int O, spi_stream_t stream);
 /* spi_adam_multi predicated on a DEVICE byte: *skip != 0 -> nothing is written.  The reference tests `loss_lpips <= threshold` on the

@@ -639,9 +639,8 @@ __global__ void rotate_warp_kernel(const float* __restrict__ tgt_cam, const floa
 // A library GEMM runs these [1..4, 512] x [512, O] products on ONE workgroup (18 us forward, 2 x 7.5 us backward, 29 layers per generator
 // pass: 2 % of the step's GPU time); they are matrix-VECTOR products bound by reading W once.
 //   forward : one wave per output row o, lanes stride over i with float4 loads, DPP wave sums          (O/4 blocks)
-//   backward: one 1024-thread block per 64 columns i; wave w walks rows o = w, w+16, ...: reads W[o, i] once for
-//             dx[n,i] = gain * sum_o g[n,o] W[o,i]   (reduced over the 16 waves through LDS)   and writes
-//             dW[o,i] = gain * sum_n g[n,o] x[n,i]   in the same pass                                   (I/64 blocks)
+//   backward: ONE launch with two kinds of blocks (affine_bwd_kernel): 64-column blocks for dx = gain * g W (W read once, 16 waves reduced
+//             through LDS) and elementwise blocks for the outer product dW = gain * g^T x
 // ------------------------------------------------------------------------------------------------
 constexpr int AFF_NMAX = 8;
 
@@ -675,29 +674,48 @@ __global__ void __launch_bounds__(256) affine_fwd_kernel(const float* __restrict
 }
 
 __global__ void __launch_bounds__(1024) affine_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ w,
-                                                          float gain, float* __restrict__ dx, float* __restrict__ dw, int N, int I, int O) {
+                                                          float gain, float* __restrict__ dx, float* __restrict__ dw, int N, int I, int O, int dx_blocks) {
+    // Two kinds of blocks in ONE launch (neither gradient needs the other's operand):
+    //   blockIdx.x <  dx_blocks: dx[n, c] = gain * sum_o g[n,o] W[o,c] for 64 columns c; wave w walks rows o = w, w + 16, ... 8 at a time with
+    //                            their loads issued together (a 512-row W is two round trips per wave), the 16 waves reduce through LDS
+    //   blockIdx.x >= dx_blocks: dW[o, i] = gain * sum_n g[n,o] x[n,i], four elements per thread (a pure outer product: 4 I O bytes written)
     __shared__ float red[16][AFF_NMAX][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;                    // column of W
-    const bool ok = c < I;
-    const int cc = ok ? c : I - 1;
-    float xv[AFF_NMAX], acc[AFF_NMAX];
-#pragma unroll
-    for (int n = 0; n < AFF_NMAX; ++n) { xv[n] = (n < N && dw) ? x[(int64_t)n * I + cc] : 0.f; acc[n] = 0.f; }
-    for (int o = wave; o < O; o += 16) {
-        const float wv = dx ? w[(int64_t)o * I + cc] : 0.f;
-        float dwv = 0.f;
+    if ((int)blockIdx.x >= dx_blocks) {
+        const int64_t e = ((int64_t)(blockIdx.x - dx_blocks) * 1024 + threadIdx.x) * 4;
+        if (e >= (int64_t)O * I) return;
+        const int o = (int)(e / I), i = (int)(e - (int64_t)o * I);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int n = 0; n < AFF_NMAX; ++n) {
             if (n < N) {
-                const float gv = g[(int64_t)n * O + o];      // wave-uniform address: one scalar load
-                acc[n] = fmaf(gv, wv, acc[n]);
-                dwv = fmaf(gv, xv[n], dwv);
+                const float gv = g[(int64_t)n * O + o];
+                const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)n * I + i);
+                acc.x = fmaf(gv, xv.x, acc.x); acc.y = fmaf(gv, xv.y, acc.y); acc.z = fmaf(gv, xv.z, acc.z); acc.w = fmaf(gv, xv.w, acc.w);
             }
         }
-        if (dw && ok) dw[(int64_t)o * I + c] = gain * dwv;
+        *reinterpret_cast<float4*>(dw + e) = make_float4(gain * acc.x, gain * acc.y, gain * acc.z, gain * acc.w);
+        return;
     }
-    if (!dx) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const int cc = min(c, I - 1);
+    float acc[AFF_NMAX];
+#pragma unroll
+    for (int n = 0; n < AFF_NMAX; ++n) acc[n] = 0.f;
+    for (int o0 = wave; o0 < O; o0 += 16 * 8) {
+        float wv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv[k] = w[(int64_t)min(o0 + 16 * k, O - 1) * I + cc];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int o = o0 + 16 * k;
+            if (o < O) {                                         // wave-uniform
+#pragma unroll
+                for (int n = 0; n < AFF_NMAX; ++n)
+                    if (n < N) acc[n] = fmaf(g[(int64_t)n * O + o], wv[k], acc[n]);      // g: wave-uniform address, one scalar load
+            }
+        }
+    }
 #pragma unroll
     for (int n = 0; n < AFF_NMAX; ++n) red[wave][n][lane] = acc[n];
     __syncthreads();
@@ -1387,8 +1405,10 @@ int spi_affine_fwd(const float* x, const float* w, const float* b, float gain, f
 }
 
 int spi_affine_bwd(const float* g, const float* x, const float* w, float gain, float* dx, float* dw, int N, int I, int O, spi_stream_t stream) {
-    SPI_REQUIRE(g && (dx || dw) && (!dx || w) && (!dw || x) && N >= 1 && N <= AFF_NMAX && I >= 1 && O >= 1, "spi_affine_bwd: bad argument (1 <= N <= %d; got N = %d, I = %d, O = %d)", AFF_NMAX, N, I, O);
-    hipLaunchKernelGGL(affine_bwd_kernel, dim3((unsigned)((I + 63) / 64)), dim3(1024), 0, as_stream(stream), g, x, w, gain, dx, dw, N, I, O);
+    SPI_REQUIRE(g && (dx || dw) && (!dx || w) && (!dw || x) && N >= 1 && N <= AFF_NMAX && I >= 4 && I % 4 == 0 && O >= 1, "spi_affine_bwd: need 1 <= N <= %d rows, in_features a multiple of 4 (got N = %d, I = %d, O = %d)", AFF_NMAX, N, I, O);
+    const int dx_blocks = dx ? (I + 63) / 64 : 0;
+    const int dw_blocks = dw ? (int)ceil_div64((int64_t)O * I, 4096) : 0;
+    hipLaunchKernelGGL(affine_bwd_kernel, dim3((unsigned)(dx_blocks + dw_blocks)), dim3(1024), 0, as_stream(stream), g, x, w, gain, dx, dw, N, I, O, dx_blocks);
     SPI_LAUNCH_CHECK("spi_affine_bwd");
     return SPI_OK;
 }
