@@ -1108,7 +1108,10 @@ int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, floa
     // channel splits: enough blocks (~1024) to fill 256 CUs.  With the per-pixel sums every split adds ONE atomic per pixel address (HW * splits
     // atomics in all, each address touched `splits` times over the whole kernel: no hot spot) -- capped at 16.  (Until round 2 the cap was
     // 128 / gx, i.e. 128-256 blocks on the 256^2 / 512^2 layers: 1.3-2.8 TB/s against 4.1-5.6 without the sums.)
-    int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? 16 : 1024)));
+    // Round 3: the cap follows the plane size -- 16 from 128^2 up, up to 64 on the 4^2 ... 64^2 layers, whose single column of 16 blocks
+    // took 24 us for 2 MB (224 launches of the profiled run).
+    const int64_t pix_cap = std::min<int64_t>(64, std::max<int64_t>(16, 262144 / HW));
+    int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? pix_cap : 1024)));
     const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
     splits = (C + cchunk - 1) / cchunk;
     if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
