@@ -623,6 +623,7 @@ __global__ void decoder_partial_reduce_kernel(const float* __restrict__ part, in
 //   order[patch][pos] = ray-in-patch << 8 | sorted sample index (S <= 256), count[patch] = live points.
 // ------------------------------------------------------------------------------------------------
 constexpr int NBIN = 64;
+constexpr int MAXBINS_S = 256;          // samples per ray the binning handles (the order entries keep the sample index in 8 bits)
 
 __device__ __forceinline__ int patch_ray(int patch, int rl, int ray_w, int patch2d) {
     if (patch2d) {
@@ -643,19 +644,36 @@ __global__ void __launch_bounds__(256) bin_points_kernel(const float* __restrict
     __shared__ int8_t live[64];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = blockIdx.x / patches, patch = blockIdx.x - n * patches;
+    bool mine = false;
     if (t < 64) {
         const int m = patch_ray(patch, t, ray_w, patch2d);
-        live[t] = (m < M) && (!ray_active || ray_active[(int64_t)n * M + m] != 0);
+        mine = (m < M) && (!ray_active || ray_active[(int64_t)n * M + m] != 0);
+        live[t] = mine;
     }
     for (int i = t; i < NBIN * 64; i += 256) { cnt[i] = 0; first[i] = 0x7fffffff; }
-    __syncthreads();
-    const int total = 64 * S;
+    if (!__syncthreads_or(mine)) {                // a patch of dead rays (most of a masked pseudo-view): nothing to order
+        if (t == 0) count[blockIdx.x] = 0;
+        return;
+    }
+    // The patch's 64 x S depths live in REGISTERS for all three passes (range, counts, ranks): wave w owns rays 16w .. 16w+15, lane l the samples
+    // l, l + 64, ... of each -- every load a coalesced 256-B row piece, all of them in flight together, the ray index wave-uniform.  (Until
+    // round 3 each pass re-read the depths through a flat p -> (p / S, p % S) loop: three times 48 dependent round trips, 95 us per image.)
+    constexpr int RW = 16, KC = MAXBINS_S / 64;
+    float dv[RW][KC];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int m = min(patch_ray(patch, wave * RW + r, ray_w, patch2d), M - 1);
+        const float* row = depths + ((int64_t)n * M + m) * S;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) dv[r][c] = (c * 64 < S) ? row[min(c * 64 + lane, S - 1)] : 0.f;
+    }
     float lo = INFINITY, hi = -INFINITY;
-    for (int p = t; p < total; p += 256) {
-        const int rl = p / S, k = p - rl * S;
-        if (!live[rl]) continue;
-        const float d = depths[((int64_t)n * M + patch_ray(patch, rl, ray_w, patch2d)) * S + k];
-        lo = fminf(lo, d); hi = fmaxf(hi, d);
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        if (!live[wave * RW + r]) continue;       // wave-uniform
+#pragma unroll
+        for (int c = 0; c < KC; ++c)
+            if (c * 64 + lane < S) { lo = fminf(lo, dv[r][c]); hi = fmaxf(hi, dv[r][c]); }
     }
     lo = wave_min(lo); hi = wave_max(hi);
     if (lane == 0) { red[0][wave] = lo; red[1][wave] = hi; }
@@ -664,13 +682,19 @@ __global__ void __launch_bounds__(256) bin_points_kernel(const float* __restrict
     hi = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
     const float inv = hi > lo ? (float)NBIN / (hi - lo) : 0.f;
     auto bin_of = [&](float d) { return min(max((int)((d - lo) * inv), 0), NBIN - 1); };
-    for (int p = t; p < total; p += 256) {
-        const int rl = p / S, k = p - rl * S;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int rl = wave * RW + r;
         if (!live[rl]) continue;
-        const float d = depths[((int64_t)n * M + patch_ray(patch, rl, ray_w, patch2d)) * S + k];
-        const int b = bin_of(d);
-        atomicAdd(&cnt[b * 64 + rl], 1);
-        atomicMin(&first[b * 64 + rl], k);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = c * 64 + lane;
+            if (k < S) {
+                const int b = bin_of(dv[r][c]);
+                atomicAdd(&cnt[b * 64 + rl], 1);
+                atomicMin(&first[b * 64 + rl], k);
+            }
+        }
     }
     __syncthreads();
     // exclusive prefix over the NBIN * 64 counts in (bin, ray) order: 16 consecutive entries per thread
@@ -687,13 +711,19 @@ __global__ void __launch_bounds__(256) bin_points_kernel(const float* __restrict
     for (int i = 0; i < PER; ++i) cnt[t * PER + i] = base + loc[i];
     if (t == 255) count[blockIdx.x] = base + sum;
     __syncthreads();
-    uint16_t* out = order + (int64_t)blockIdx.x * total;
-    for (int p = t; p < total; p += 256) {
-        const int rl = p / S, k = p - rl * S;
+    uint16_t* out = order + (int64_t)blockIdx.x * 64 * S;
+#pragma unroll
+    for (int r = 0; r < RW; ++r) {
+        const int rl = wave * RW + r;
         if (!live[rl]) continue;
-        const float d = depths[((int64_t)n * M + patch_ray(patch, rl, ray_w, patch2d)) * S + k];
-        const int e = bin_of(d) * 64 + rl;
-        out[cnt[e] + k - first[e]] = (uint16_t)((rl << 8) | k);
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            const int k = c * 64 + lane;
+            if (k < S) {
+                const int e = bin_of(dv[r][c]) * 64 + rl;
+                out[cnt[e] + k - first[e]] = (uint16_t)((rl << 8) | k);
+            }
+        }
     }
 }
 
