@@ -27,10 +27,10 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 6   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 7   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive)
-                             * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd (additive) */
+                             * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -125,6 +125,12 @@ int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, f
 /* min / max over a depth tensor (ray_marcher.py:50 clamps to the GLOBAL range).  out[2] = {min,max}. */
 int spi_minmax(const float* x, int64_t n, float* out2, spi_stream_t stream);
 
+
+/* The OSG decoder's parameters (FC 32 -> 64: w1 [64,32], b1 [64]; FC 64 -> 33: w2 [33,64], b2 [33]) times their FullyConnectedLayer gains
+ * (networks_stylegan2.py:114-127) in one launch.  transpose_w1 = 1 writes w1 as [32,64] (the operand layout of the decode kernels),
+ * 0 keeps [64,32] (scaling the gradients on the way back). */
+int spi_decoder_gains(const float* w1, const float* b1, const float* w2, const float* b2, float g_w1, float g_b1, float g_w2, float g_b2,
+                      float* o_w1, float* o_b1, float* o_w2, float* o_b2, int transpose_w1, spi_stream_t stream);
 /* MipRayMarcher2.run_forward, ray_marcher.py:25-57.  One launch = R rays of S sorted samples.
  *   colors [R,S_store,C] (C = 32), densities [R,S_store] with S <= S_store <= 256 rows kept per ray;
  *   depths [R,S] sorted; perm (optional, int32 [R,S]): sample k of ray r is row perm[r,k] of

@@ -1875,6 +1875,24 @@ __global__ void __launch_bounds__(256) merge_sort_kernel(const float* __restrict
 // ================================================================================================
 // C ABI
 // ================================================================================================
+// The OSG decoder's four parameter tensors times their FullyConnectedLayer gains (networks_stylegan2.py:114-127 folds `weight_gain` /
+// `bias_gain` into every forward) in ONE launch: w1 [64,32] -> transposed [32,64] (forward operands) or as stored (gradients), b1 [64],
+// w2 [33,64], b2 [33].  Four `mul`s + a transposing copy per render forward and four per backward were 9 of the ~5 us ATen launches.
+__global__ void __launch_bounds__(256) decoder_gains_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                            const float* __restrict__ b2, float g_w1, float g_b1, float g_w2, float g_b2,
+                                                            float* __restrict__ o_w1, float* __restrict__ o_b1, float* __restrict__ o_w2,
+                                                            float* __restrict__ o_b2, int transpose_w1) {
+    constexpr int N1 = DEC_HID * DEC_IN, N2 = DEC_HID, N3 = DEC_OUT * DEC_HID, N4 = DEC_OUT;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < N1 + N2 + N3 + N4; e += gridDim.x * 256) {
+        if (e < N1) {
+            const int j = e / DEC_IN, i = e - j * DEC_IN;                    // w1[j][i]
+            o_w1[transpose_w1 ? i * DEC_HID + j : e] = w1[e] * g_w1;
+        } else if (e < N1 + N2) o_b1[e - N1] = b1[e - N1] * g_b1;
+        else if (e < N1 + N2 + N3) o_w2[e - N1 - N2] = w2[e - N1 - N2] * g_w2;
+        else o_b2[e - N1 - N2 - N3] = b2[e - N1 - N2 - N3] * g_b2;
+    }
+}
+
 static int g_spi_debug = 0;
 extern "C" {
 
@@ -2123,6 +2141,14 @@ int spi_merge_sort_depths(const float* coarse, const float* fine, int64_t R, int
     hipLaunchKernelGGL(merge_sort_kernel, dim3((unsigned)ceil_div64(R, 4)), dim3(256), 0, as_stream(stream), coarse, fine, R, Sc,
                        Sf, sorted, perm);
     SPI_LAUNCH_CHECK("spi_merge_sort_depths");
+    return SPI_OK;
+}
+
+int spi_decoder_gains(const float* w1, const float* b1, const float* w2, const float* b2, float g_w1, float g_b1, float g_w2, float g_b2,
+                      float* o_w1, float* o_b1, float* o_w2, float* o_b2, int transpose_w1, spi_stream_t stream) {
+    SPI_REQUIRE(w1 && b1 && w2 && b2 && o_w1 && o_b1 && o_w2 && o_b2, "spi_decoder_gains: null tensor");
+    hipLaunchKernelGGL(decoder_gains_kernel, dim3(17), dim3(256), 0, as_stream(stream), w1, b1, w2, b2, g_w1, g_b1, g_w2, g_b2, o_w1, o_b1, o_w2, o_b2, transpose_w1);
+    SPI_LAUNCH_CHECK("spi_decoder_gains");
     return SPI_OK;
 }
 

@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
-ABI_VERSION = 6          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
+ABI_VERSION = 7          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -73,6 +73,7 @@ _SIGS = {
     'spi_contextual_bwd': ([c_p, c_p, c_i, c_i, c_i, c_f] + [c_p] * 6, c_i),
     'spi_adam_multi': ([c_p, c_p, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p], c_i),
     'spi_adam_multi_pred': ([c_p, c_p, c_i, c_l, c_f, c_f, c_f, c_f, c_i, c_p, c_p], c_i),
+    'spi_decoder_gains': ([c_p] * 4 + [c_f] * 4 + [c_p] * 4 + [c_i, c_p], c_i),
     'spi_affine_fwd': ([c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p], c_i),
     'spi_affine_bwd': ([c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p], c_i),
     'spi_adam_multi_dev': ([c_p, c_p, c_i, c_l, c_p, c_f, c_f, c_f, c_p], c_i),

@@ -45,6 +45,16 @@ def _timed(events):
     return events is not None and not torch.cuda.is_current_stream_capturing()      # (a captured step cannot hold timing events)
 
 
+def _scaled_decoder(w1, b1, w2, b2, gains, transpose_w1):
+    """(w1 * g, b1 * g, w2 * g, b2 * g) in one launch; w1 comes back transposed ([32,64], the kernels' operand layout) if asked."""
+    w1, b1, w2, b2 = (t.detach().contiguous().float() for t in (w1, b1, w2, b2))
+    flat = torch.empty(64 * 32 + 64 + 33 * 64 + 33, device=w1.device, dtype=torch.float32)
+    o1, ob1, o2, ob2 = flat[:2048].view(32, 64) if transpose_w1 else flat[:2048].view(64, 32), flat[2048:2112], flat[2112:4224].view(33, 64), flat[4224:]
+    hip.call('spi_decoder_gains', hip.ptr(w1), hip.ptr(b1), hip.ptr(w2), hip.ptr(b2), *[float(g) for g in gains], hip.ptr(o1), hip.ptr(ob1), hip.ptr(o2), hip.ptr(ob2),
+             int(transpose_w1), hip.stream())
+    return o1, ob1, o2, ob2
+
+
 def decoder_tensors(decoder):
     """(w1t [32,64], b1 [64], w2 [33,64], b2 [33]) with the FullyConnectedLayer gains folded in."""
     l0, l2 = decoder.net[0], decoder.net[2]
@@ -141,9 +151,7 @@ class _Render(torch.autograd.Function):
         s = sc + sf
         r = n * m
         dev = planes.device
-        wg1, bg1, wg2, bg2 = gains
-        dec = ((w1.detach() * wg1).t().contiguous(), (b1.detach() * bg1).contiguous(), (w2.detach() * wg2).contiguous(),
-               (b2.detach() * bg2).contiguous())
+        dec = _scaled_decoder(w1, b1, w2, b2, gains, True)
         planes_nhwc = planes_to_nhwc(planes.detach())
         ray_o = ray_o.detach().contiguous().float()
         ray_d = ray_d.detach().contiguous().float()
@@ -278,8 +286,7 @@ class _Render(torch.autograd.Function):
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
         if want_w:
-            wg1, bg1, wg2, bg2 = gains
-            gw1, gb1, gw2, gb2 = gw[0] * wg1, gw[1] * bg1, gw[2] * wg2, gw[3] * bg2
+            gw1, gb1, gw2, gb2 = _scaled_decoder(*gw, gains, False)
         return g_planes, gw1, gb1, gw2, gb2, None, None, None, None, None, None
 
 
@@ -287,9 +294,7 @@ class _RunModel(torch.autograd.Function):
     """sample_from_planes + decoder at explicit coordinates (ImportanceRenderer.run_model)."""
     @staticmethod
     def forward(ctx, planes, w1, b1, w2, b2, gains, coords, box_warp):
-        wg1, bg1, wg2, bg2 = gains
-        dec = ((w1.detach() * wg1).t().contiguous(), (b1.detach() * bg1).contiguous(), (w2.detach() * wg2).contiguous(),
-               (b2.detach() * bg2).contiguous())
+        dec = _scaled_decoder(w1, b1, w2, b2, gains, True)
         planes_nhwc = planes_to_nhwc(planes.detach())
         coords = coords.detach().contiguous().float()
         rgb, sigma = _decode_fwd(planes_nhwc, dec, coords=coords, box_warp=box_warp)
@@ -311,8 +316,7 @@ class _RunModel(torch.autograd.Function):
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
         if want_w:
-            wg1, bg1, wg2, bg2 = gains
-            gw1, gb1, gw2, gb2 = gw[0] * wg1, gw[1] * bg1, gw[2] * wg2, gw[3] * bg2
+            gw1, gb1, gw2, gb2 = _scaled_decoder(*gw, gains, False)
         return g_planes, gw1, gb1, gw2, gb2, None, None, None
 
 
