@@ -65,14 +65,15 @@ def _rotation(yaw, pitch):
 
 def sample_surrounding_camera(middle_camera, batch_size, yaw_range, pitch_range, rand):
     ry, rp = rand
-    y = (ry.reshape(batch_size) * 2 - 1) * yaw_range + 0.0
-    p = (rp.reshape(batch_size) * 2 - 1) * pitch_range + 0.0
+    y = (ry.reshape(batch_size, 1) * 2 - 1) * yaw_range + 0.0
+    p = (rp.reshape(batch_size, 1) * 2 - 1) * pitch_range + 0.0
+    # float64 rotations rounded to fp32, then ONE batched product with rows 0-2 of the pose (:203-208; the batched product's summation order
+    # is what the reference's result carries -- a per-sample `@` differs in the last bit)
+    rot = torch.stack([torch.from_numpy(_rotation(float(y[b]), float(p[b]))) for b in range(batch_size)]).float()
     out = middle_camera.reshape(1, 25).repeat(batch_size, 1).clone()
-    for b in range(batch_size):
-        rot = torch.from_numpy(_rotation(float(y[b]), float(p[b]))).float()
-        ext = out[b, :16].reshape(4, 4).clone()
-        ext[:3] = rot @ ext[:3]
-        out[b, :16] = ext.reshape(16)
+    ext = out[:, :16].reshape(batch_size, 4, 4).clone()
+    ext[:, :3] = torch.bmm(rot, ext[:, :3])
+    out[:, :16] = ext.reshape(batch_size, 16)
     return out
 
 

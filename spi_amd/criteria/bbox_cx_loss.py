@@ -38,9 +38,9 @@ class _RoiAlign(torch.autograd.Function):
     def forward(ctx, x, boxes, out_size):
         from .. import hip
         x = x.contiguous().float()
-        boxes = boxes.contiguous().float()
+        boxes = boxes.to(x.device).contiguous().float()          # landmarks may live on the host (the reference moves them, bbox_cx_loss.py:46)
         n, c, h, w = x.shape
-        assert boxes.shape == (n, 4)
+        assert boxes.shape == (n, 4), f'one box per batch element: boxes {tuple(boxes.shape)} for a batch of {n}'
         out = torch.empty(n, c, out_size, out_size, device=x.device)
         hip.call('spi_roi_align_fwd', hip.ptr(x), hip.ptr(boxes), hip.ptr(out), n, c, h, w, int(out_size), hip.stream())
         ctx.save_for_backward(boxes)
@@ -57,9 +57,8 @@ class _RoiAlign(torch.autograd.Function):
         return dx, None, None
 
 
-def roi_align(x, boxes, output_size=80, plan=None):
-    """x [N,C,H,W]; boxes [N,4] float (x1,y1,x2,y2), box i applies to image i.  Differentiable wrt x.  (``plan`` is accepted and ignored: the
-    host-side sampling plan of rounds 1-2 is gone with the kernel.)"""
+def roi_align(x, boxes, output_size=80):
+    """x [N,C,H,W]; boxes [N,4] float (x1,y1,x2,y2), box i applies to image i (host or device tensor).  Differentiable wrt x."""
     return _RoiAlign.apply(x, boxes, int(output_size))
 
 

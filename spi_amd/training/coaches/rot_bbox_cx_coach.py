@@ -57,7 +57,20 @@ class RotBboxCoach(BaseCoach):
         ctx['target_feats'] = self.lpips_loss.features(image)
         ctx['box_plan'] = self.box_cx_loss.plan(ctx['lm'].repeat(self.rot_bs, 1, 1), dev)      # host-side RoI geometry, once per image
         self.original_G._last_planes = None                      # per-image backbone cache of the frozen generator (depth branch)
+        ctx['generation'] = self._next_generation()              # identity of this image's constants for the graph cache (ids / pointers get recycled)
         return ctx
+
+    def _next_generation(self):
+        self._generation = getattr(self, '_generation', 0) + 1
+        return self._generation
+
+    def reset_pipeline(self):
+        """Start of an image's loop: no early stop is pending, the sticky stop byte is clear (a stop belongs to ONE image's loop)."""
+        self._late_stop = None
+        g2 = getattr(self, '_g2', None)
+        if g2:
+            g2['pending'].clear()
+            g2['stop'].zero_()
 
     def _side_streams(self):
         if getattr(self, '_streams', None) is None:
@@ -104,10 +117,11 @@ class RotBboxCoach(BaseCoach):
         """Wait for the early-stop bytes of all but the newest `keep` replays in flight.  -> (iteration, losses) of the FIRST one that had it set."""
         pend = self._g2.get('pending') if getattr(self, '_g2', None) else None
         while pend and len(pend) > keep:
-            it, ev, host, losses = pend.popleft()
+            it, ev, host, losses, steps_before = pend.popleft()
             ev.synchronize()
             if bool(host[0]):
-                pend.clear()                                     # everything launched after it was speculative
+                pend.clear()                                     # everything launched after it was speculative:
+                self.optimizer.step_count = steps_before         # their predicated Adam launches changed nothing and do not count as steps
                 return it, losses
         return None
 
@@ -122,13 +136,19 @@ class RotBboxCoach(BaseCoach):
 
     def _graph_train_step(self, i, ctx, w_pivot, rng):
         import collections
-        key = (id(ctx), w_pivot.data_ptr(), id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold),    # (the threshold is baked in,
+        if 'generation' not in ctx:                             # a hand-built ctx (tests): give it an identity once
+            ctx['generation'] = self._next_generation()
+        if ctx.get('pivot_ptr') != w_pivot.data_ptr():          # a new pivot for the same image constants is a new set of baked-in addresses
+            ctx['pivot_ptr'], ctx['pivot_generation'] = w_pivot.data_ptr(), self._next_generation()
+        key = (ctx['generation'], ctx['pivot_generation'], id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold),    # (the threshold is baked in,
                global_config.conv_precision, global_config.conv_winograd, global_config.enable_fp16_blocks, global_config.exploit_sparsity)   # and so is the arithmetic)
         if getattr(self, '_g2_key', None) != key:
             self._g2_key = key
             self._g2 = dict(stop=torch.zeros(1, device=self.device, dtype=torch.uint8), pending=collections.deque(),
                             host=[torch.zeros(1, dtype=torch.uint8).pin_memory() for _ in range(self.GRAPH_LAG + 1)])
             self._late_stop = None
+        if self._late_stop is not None:                         # the loop was told to stop and called again: nothing runs, nothing is counted
+            return True, self._late_stop[1]
         st = self._g2.setdefault('branch' if i % self.rot_bs == 0 else 'plain', dict(eager=0, graph=None))
         if st['graph'] is None:
             late = self._resolve_pending(0)                      # eager iterations and captures start from a drained pipeline
@@ -157,6 +177,7 @@ class RotBboxCoach(BaseCoach):
         if late is not None:
             self._late_stop = late
             return True, late[1]
+        steps_before = self.optimizer.step_count
         st['graph'].replay()
         losses = {k: v.clone() for k, v in st['losses'].items()}  # the graph's outputs are overwritten by the next replay
         self.optimizer.step(skip=self._g2['stop'])               # predicated on the device: a stop of THIS iteration (or an earlier one) freezes it
@@ -164,7 +185,7 @@ class RotBboxCoach(BaseCoach):
         host.copy_(self._g2['stop'], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        self._g2['pending'].append((i, ev, host, losses))
+        self._g2['pending'].append((i, ev, host, losses, steps_before))
         return False, losses
 
     def train_step(self, i, ctx, w_pivot, rng=None):
@@ -332,6 +353,7 @@ class RotBboxCoach(BaseCoach):
         iters = completed = 0
         losses = {}
         log_images_counter = 0
+        self.reset_pipeline()
         from ...torch_utils.misc import quiet_gc
         with quiet_gc():
             for i in range(hyperparameters.G_1_step):
