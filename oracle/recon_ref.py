@@ -8,14 +8,14 @@ Restates, relative to /root/reference:
                            stride on the 3x3 conv, global average pool, seven 1x1 heads -> 257 coefficients), models/bfm.py:252-273 (split_coeff)
   camera from coefficients preprocess/extract_camera.py:14-47 (compute_rotation), :83-138 (cal_camera), preprocess/process_camera.py:9-62
   mirror camera            preprocess/extract_camera.py:161-176
-Pinning (tests/golden/make_golden.py, section `recon`): the NETWORK against the imported reference class `ReconNetWrapper` (fp32 round-off) and
-`process_camera` against the imported preprocess/process_camera.py (bit-exact).  PARITY UNPINNED for `align_img` / `pos` and `cal_camera` /
-`compute_rotation`: their reference modules cannot be imported in this container (preprocess/extract_3dmm.py and extract_camera.py pull in
-`face_alignment`, `cv2`, `torchvision` and instantiate the landmark detector at import time; none of them is installed, and stand-ins for
-libraries are not an option) -- they are restated line by line and checked by known-answer properties instead (a similarity transform is
-recovered from its own points; rotations are orthonormal and compose as R_z R_y R_x; the camera sits at radius 2.7 looking at the origin).
+Pinning (tests/golden/make_golden.py): section `recon` -- the NETWORK against the imported reference class `ReconNetWrapper` (fp32 round-off)
+and `process_camera` against the imported preprocess/process_camera.py (bit-exact); section `preprocess` (round 4) -- `pos`, `extract_5p`,
+`align_img` (both rescale factors), `compute_rotation`, `cal_camera`, `mirror_camera` against the reference's own preprocess/extract_3dmm.py and
+extract_camera.py functions, bit-exact (`golden/preprocess.npz`).  Those modules import `face_alignment`, `cv2`, `skimage`, `kornia`,
+`torchvision` at module level and instantiate the landmark detector; none of that is used by the functions above, so the imports resolve to
+empty placeholder modules for the run (the technique sections `bisenet` / `recon` already use for `torchvision` / `kornia`).
 The landmark detector itself (`face_alignment`, preprocess/extract_landmark.py:11-24) is a third-party package that is not in the reference
-tree: landmarks are an input here.
+tree: landmarks are an input here ("parity unpinned" at that edge).
 """
 import numpy as np
 import torch

@@ -4,8 +4,10 @@
 yaw +-0.7 / pitch +-0.4 orbit around the look-at point (0, 0, 0.2), radius 2.7, FFHQ intrinsics.  The reference evaluates
 ``G.synthesis`` once per frame, i.e. runs the StyleGAN2 backbone 120 times on the same ``w``; here the frames go through the
 generator in batches with ONE ``w`` (``TriPlaneGenerator.synthesis`` shares the backbone and the weight modulation across the
-views), under ``no_grad``.  Only the single-latent 1x1 grid SPI uses is implemented; keyframe interpolation over several
-latents (the reference's scipy ``interp1d`` over seeds) is not.
+views), under ``no_grad``.  Several latents (``G_kwargs['w']`` of shape [K * grid_w * grid_h, 14, 512]) are keyframes: every grid cell walks
+its ``num_keyframes`` latents with the reference's wrapped cubic interpolation (scipy ``interp1d`` over the keyframes tiled ``2 * wraps + 1``
+times, :118-134) while the camera completes ONE orbit over the ``num_keyframes * w_frames`` frames (:155-160), and the cells are laid out
+by ``layout_grid`` (:31-44).
 Output: frames are written as ``<mp4 stem>_frames/%04d.jpg`` (PIL).  The ``.mp4`` container itself needs ``imageio`` + ffmpeg/libx264
 (the reference's writer, video_utils.py:141), which are NOT dependencies of this package: with imageio importable the file is encoded,
 otherwise the run prints where the frames are and the ffmpeg command that encodes them (stated dependency, no silent skip).  ``gen_shapes`` exports the density grid of frame 0 like video_utils.py:198-218: the
@@ -86,23 +88,65 @@ def sigma_grid(G, w, resolution=128, max_batch=1 << 22):
     return s
 
 
+def layout_grid(img, grid_w=None, grid_h=1):
+    """uint8 [B,H,W,3] cells -> one [grid_h * H, grid_w * W, 3] frame, row-major cells (video_utils.py:31-44)."""
+    b, h, w, ch = img.shape
+    grid_w = b // grid_h if grid_w is None else grid_w
+    assert b == grid_w * grid_h
+    return img.reshape(grid_h, grid_w, h, w, ch).permute(0, 2, 1, 3, 4).reshape(grid_h * h, grid_w * w, ch)
+
+
+def keyframe_interpolators(ws, grid_dims=(1, 1), num_keyframes=None, wraps=2, kind='cubic'):
+    """ws [grid_h * grid_w * K, 14, 512] -> (K, [[f(frame_idx / w_frames) -> [14,512] float64 numpy] per cell]) exactly as video_utils.py:101-134
+    builds them: cell (yi, xi) owns K consecutive latents, tiled 2 * wraps + 1 times over x = -K * wraps .. K * (wraps + 1) - 1, so the
+    interpolant is periodic over the video and cubic through every keyframe."""
+    import scipy.interpolate
+    grid_w, grid_h = grid_dims
+    if num_keyframes is None:
+        if len(ws) % (grid_w * grid_h) != 0:
+            raise ValueError('Number of input seeds must be divisible by grid W*H')
+        num_keyframes = len(ws) // (grid_w * grid_h)
+    wk = ws.detach().cpu().numpy().reshape(grid_h, grid_w, num_keyframes, *ws.shape[1:])
+    x = np.arange(-num_keyframes * wraps, num_keyframes * (wraps + 1))
+    return num_keyframes, [[scipy.interpolate.interp1d(x, np.tile(wk[yi][xi], [wraps * 2 + 1, 1, 1]), kind=kind, axis=0) for xi in range(grid_w)]
+                           for yi in range(grid_h)]
+
+
 @torch.no_grad()
 def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_shapes=False, batch=4, device=None,
-                     voxel_resolution=128, save_frames=True, shape_format='ply', shape_level=10, render_noise=None, return_float=False, **_unused):
-    """Orbit video of ONE latent.  Returns the frames as uint8 [F,H,W,3] (numpy).
+                     voxel_resolution=128, save_frames=True, shape_format='ply', shape_level=10, render_noise=None, return_float=False,
+                     grid_dims=(1, 1), num_keyframes=None, wraps=2, kind='cubic', **_unused):
+    """Orbit video.  Returns the frames as uint8 [F, grid_h * H, grid_w * W, 3] (numpy); F = num_keyframes * w_frames.
+    One latent (what BaseCoach.log_video passes): 120 frames of that latent.  Several: keyframe interpolation, see the module docstring.
     render_noise (extension, tests): callable frame index -> (xi [1,M,Sc,1], u [M,Sf]) or None -- the renderer's two draws of that frame
     (the reference draws them with torch.rand inside G.synthesis, once per frame); return_float: also the float frames before uint8."""
     w = G_kwargs['w']
     if w.ndim == 2:
         w = w.unsqueeze(0)
-    if w.shape[0] != 1:
-        raise NotImplementedError('keyframe interpolation over several latents is not implemented (SPI renders one latent per video)')
     device = device or w.device
-    cams = orbit_cameras(w_frames, device=device)
+    grid_w, grid_h = grid_dims
+    cells = grid_w * grid_h
+    single = w.shape[0] == 1 and cells == 1
+    if single:
+        num_keyframes, interp = 1, None
+    else:
+        num_keyframes, interp = keyframe_interpolators(w, grid_dims, num_keyframes, wraps, kind)
+    total = num_keyframes * w_frames
+    cams = orbit_cameras(total, device=device)                   # ONE orbit over the whole video (:155-160 divide by num_keyframes * w_frames)
     frames, floats = [], []
     m, rk = G.neural_rendering_resolution ** 2, G.rendering_kwargs
-    for i in range(0, w_frames, batch):
+    if not single and (render_noise is not None or return_float):
+        raise NotImplementedError('render_noise / return_float are test hooks of the single-latent path')
+    for i in range(0, total, batch):
         c = cams[i:i + batch]
+        if not single:
+            # frame f, cell (yi, xi): latent interp[yi][xi](f / w_frames), camera of frame f; cells of a frame are consecutive (row-major), frames of a
+            # batch follow each other -- distinct latents, so the generator runs its per-sample path
+            wb = np.stack([interp[yi][xi]((i + f) / w_frames) for f in range(len(c)) for yi in range(grid_h) for xi in range(grid_w)])
+            out = G.synthesis(torch.from_numpy(wb).float().to(device), c.repeat_interleave(cells, dim=0), noise_mode='const')[image_mode]
+            u8 = to_uint8(out, image_mode).cpu()
+            frames.append(torch.stack([layout_grid(u8[f * cells:(f + 1) * cells], grid_w, grid_h) for f in range(len(c))]))
+            continue
         noise = None
         if render_noise is not None:
             per = [render_noise(k) for k in range(i, i + len(c))]
@@ -139,7 +183,7 @@ def gen_interp_video(G, G_kwargs, mp4, w_frames=30 * 4, image_mode='image', gen_
         from . import shape_utils
         outdir = os.path.join(os.path.dirname(mp4) or '.', 'interpolation_shape')
         os.makedirs(outdir, exist_ok=True)
-        sigmas = sigma_grid(G, w.to(device), voxel_resolution)
+        sigmas = sigma_grid(G, w[:1].to(device), voxel_resolution)           # frame 0 = the first keyframe of cell (0, 0)
         np.save(os.path.join(outdir, '0000_sigma.npy'), sigmas)
         if shape_format == 'ply':                                                    # video_utils.py:209-214
             shape_utils.convert_sdf_samples_to_ply(np.transpose(sigmas, (2, 1, 0)), [0, 0, 0], 1, os.path.join(outdir, '0000_shape.ply'), level=shape_level)

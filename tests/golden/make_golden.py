@@ -1151,9 +1151,164 @@ def sec_pti():
     print(f"    early stop: reference broke in iteration 0 with {len(ref2['draws'])} draws made and no optimiser step")
     save('trajectory_pti', **out)
 
+
+class StubGenerator:
+    """a generator whose "image" is a cheap deterministic function of (w, c): what gen_interp_video feeds the generator per frame and cell
+    is the pinned quantity of sec_interp_video, not the rendering (that is golden/orbit_frames.npz)"""
+    neural_rendering_resolution = 8
+    rendering_kwargs = dict(depth_resolution=2, depth_resolution_importance=2, box_warp=1)
+
+    def __init__(self):
+        self.calls = []
+
+    def synthesis(self, ws, c, noise_mode='const', **kw):
+        self.calls.append((ws.detach().clone().float(), c.detach().clone().float()))
+        n = ws.shape[0]
+        base = ws.reshape(n, -1)[:, :192].reshape(n, 3, 8, 8).float()
+        img = torch.tanh(base + c[:, :16].sum(dim=1).view(n, 1, 1, 1) * 0.05 + c[:, 3].view(n, 1, 1, 1))
+        return {'image': img, 'image_depth': img[:, :1] + 2.5, 'image_raw': img}
+
+
+def sec_interp_video():
+    """SURVEY 8f-1 / VERDICT r03 missing #5: the reference's own gen_interp_video (spi/utils/video_utils.py:74-230) over SEVERAL latents -- keyframe
+    interpolation (scipy interp1d over the tiled keyframes), one camera orbit over num_keyframes * w_frames frames, layout_grid -- driven with a stub
+    generator and a placeholder imageio writer that keeps the frames (imageio / mrcfile are import-time dependencies of that module only)."""
+    import types
+    reference_loss_env()
+    captured = []
+
+    class Writer:
+        def append_data(self, f):
+            captured.append(np.asarray(f).copy())
+
+        def close(self):
+            pass
+    sys.modules['imageio'].get_writer = lambda *a, **k: Writer()
+    import spi.utils.video_utils as rvu
+    rvu.tqdm = lambda x, **k: x
+    out = {}
+    g = torch.Generator().manual_seed(81)
+    for tag, (nk, gw, gh, wf) in dict(k3=(3, 1, 1, 5), grid=(2, 2, 1, 4), one=(1, 1, 1, 6)).items():
+        ws = torch.randn(nk * gw * gh, 14, 16, generator=g)
+        G = StubGenerator()
+        captured.clear()
+        rvu.gen_interp_video(G, {'w': ws}, mp4='/tmp/unused.mp4', w_frames=wf, grid_dims=(gw, gh), device=torch.device('cpu'))
+        calls = G.calls[1:]                                       # (the first call is the reference's warm-up, :113)
+        assert len(calls) == nk * wf * gw * gh and len(captured) == nk * wf
+        out.update({f'{tag}_ws': ws, f'{tag}_w_per_call': torch.cat([a for a, _ in calls]), f'{tag}_c_per_call': torch.cat([b for _, b in calls]),
+                    f'{tag}_frames': np.stack(captured), f'{tag}_cfg': np.array([nk, gw, gh, wf])})
+        print(f'    {tag}: {nk} keyframes, grid {gw}x{gh}, {wf} frames per keyframe -> {len(captured)} frames of shape {captured[0].shape}')
+    save('interp_video', **out)
+
+
+def preprocess_inputs():
+    """synthetic photo + 68 landmarks (image coordinates, y down) + a 5 x 3 stand-in for the BFM's standard landmarks (similarity_Lm3D_all.mat
+    is not available offline); shared with the tests through this function's recipe (seeded numpy)"""
+    from PIL import Image
+    rng = np.random.default_rng(7)
+    base = rng.random((30, 28, 3))
+    photo = Image.fromarray((base * 255).astype(np.uint8)).resize((280, 300), resample=Image.BICUBIC)          # W 280, H 300, smooth
+    a = np.linspace(0, 2 * np.pi, 68, endpoint=False)
+    lm = np.stack([140 + 55 * np.cos(a) + 3 * np.sin(5 * a), 150 + 65 * np.sin(a) + 2 * np.cos(7 * a)], axis=1)
+    lm3d = np.array([[-0.31, 0.29, 0.05], [0.31, 0.30, 0.04], [0.0, 0.02, 0.35], [-0.25, -0.33, 0.07], [0.24, -0.34, 0.06]])
+    return photo, lm, lm3d
+
+
+def sec_preprocess():
+    """SURVEY 8f-4 / VERDICT r03 missing #4: the crop + camera producer's own arithmetic, executed from the reference:
+    preprocess/extract_3dmm.py POS / extract_5p / resize_n_crop_img / align_img / Extract3dmm.image_transform (:16-138),
+    preprocess/extract_camera.py compute_rotation / CameraExtractor.crop / cal_camera / flip_yaw / _cal_mirror_c (:14-176).
+    Import-time obstacles, none of them arithmetic: `face_alignment`, `cv2`, `skimage`, `kornia`, `torchvision` are imported at module level
+    (placeholders; the detector instantiated by extract_landmark.py:10 is a placeholder call) and Deep3DFaceRecon's util/preprocess.py:12 names
+    `np.VisibleDeprecationWarning`, which numpy 2 removed (aliased).  One run-time obstacle: align_img builds `np.array([w0, h0, s, t[0], t[1]])`
+    from scalars and shape-(1,) arrays (:98) -- a ragged array, an error since numpy 1.24 -- so that module sees a numpy proxy whose `array`
+    takes the first element of such entries (the five numbers that are meant); every other numpy call is forwarded untouched."""
+    import types
+    import tempfile
+
+    class Lazy(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            m = Lazy(self.__name__ + '.' + k)
+            setattr(self, k, m)
+            return m
+
+        def __call__(self, *a, **k):
+            return Lazy('called')
+    reference_loss_env()
+    for name in ('face_alignment', 'cv2', 'skimage', 'skimage.transform', 'kornia', 'kornia.geometry'):
+        sys.modules[name] = Lazy(name)
+    sys.modules['torchvision'] = Lazy('torchvision')
+    if not hasattr(np, 'VisibleDeprecationWarning'):
+        np.VisibleDeprecationWarning = DeprecationWarning
+    import preprocess.extract_3dmm as e3
+    import preprocess.extract_camera as ec
+    from PIL import Image
+
+    class NpProxy:
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        @staticmethod
+        def array(obj, *a, **k):
+            try:
+                return np.array(obj, *a, **k)
+            except ValueError:
+                return np.array([float(np.ravel(v)[0]) for v in obj], *a, **k)
+    e3.np = NpProxy()
+    from oracle import recon_ref as orr2
+    photo, lm, lm3d = preprocess_inputs()
+    out = dict(photo=np.array(photo), lm=lm, lm3d=lm3d)
+    lm_up = lm.copy()
+    lm_up[:, -1] = photo.size[1] - 1 - lm_up[:, -1]
+    # POS / extract_5p
+    lm5 = e3.extract_5p(lm_up)
+    t, sc = e3.POS(lm5.transpose(), lm3d.transpose())
+    out.update(lm5=lm5, pos_t=np.ravel(t), pos_s=np.array(sc))
+    to, so = orr2.pos(lm5.transpose(), lm3d.transpose())
+    print('    pin POS: max|ref-oracle| t %.3e  s %.3e' % (np.abs(np.ravel(t) - np.ravel(to)).max(), abs(sc - so)))
+    # align_img at both rescale factors the pipeline uses (466.285 for the regressor, 300 for the training crop)
+    for tag, rf in (('a466', 466.285), ('a300', 300)):
+        tp, im_low, lm_new, _, im_high = e3.align_img(photo, lm_up.copy(), lm3d, rescale_factor=rf)
+        tpo, im_low_o, lm_new_o, im_high_o = orr2.align_img(photo, lm_up.copy(), lm3d, rescale_factor=rf)
+        print(f'    pin align_img[{rf}]: trans_params %.3e  landmarks %.3e  224^2 image %d  1024^2 image %d grey levels' % (
+            np.abs(tp - tpo).max(), np.abs(lm_new - lm_new_o).max(), np.abs(np.array(im_low).astype(int) - np.array(im_low_o).astype(int)).max(),
+            np.abs(np.array(im_high).astype(int) - np.array(im_high_o).astype(int)).max()))
+        out.update({tag + '_tp': tp, tag + '_lm': lm_new, tag + '_low': np.array(im_low), tag + '_high_sub': np.array(im_high)[::8, ::8],
+                    tag + '_high_sum': np.array(im_high).astype(np.int64).sum()})
+    # Extract3dmm.image_transform (flips the caller's landmarks in place, :134) and CameraExtractor.crop on dummy instances (no checkpoints)
+    ex = object.__new__(e3.Extract3dmm)
+    ex.lm3d_std = lm3d
+    lm_arg = lm.copy()
+    img_t, lm_t = ex.image_transform(photo, lm_arg)
+    out.update(it_img=img_t, it_lm=lm_t, it_lm_after=lm_arg)
+    tmp = tempfile.mkdtemp()
+    cex = object.__new__(ec.CameraExtractor)
+    cex.lm3d_std, cex.crop_outdir, cex.c_outdir, cex.mode = lm3d, tmp, tmp, 'png'
+    cex.crop(photo, lm_arg, 'x')                                      # (sees the flipped landmarks, as in __extract :142-146)
+    crop = np.array(Image.open(os.path.join(tmp, 'x.png')))
+    out.update(crop_sub=crop[::4, ::4], crop_sum=crop.astype(np.int64).sum(), crop_shape=np.array(crop.shape))
+    # rotation / camera
+    ang = torch.tensor([[0.3, -0.5, 0.2], [0.1, 0.2, -0.3]])
+    R = ec.compute_rotation(ang)
+    print('    pin compute_rotation: %.3e' % (R - orr2.compute_rotation(ang)).abs().max().item())
+    coeff = {'angle': ang[:1].clone(), 'trans': torch.tensor([[0.1, -0.2, 0.3]])}
+    cam = cex.cal_camera(coeff)
+    camo = orr2.cal_camera(ang[:1].clone(), torch.tensor([0.1, -0.2, 0.3]))
+    print('    pin cal_camera: pose %.3e  intrinsics %.3e' % (np.abs(np.array(cam['pose']) - np.array(camo['pose'])).max(),
+                                                            np.abs(np.array(cam['intrinsics']) - np.array(camo['intrinsics'])).max()))
+    from preprocess.process_camera import process_camera
+    c25 = process_camera(cam['pose'], cam['intrinsics'])
+    c25m = cex._cal_mirror_c(c25)
+    print('    pin _cal_mirror_c: %.3e' % np.abs(c25m - orr2.mirror_camera(c25)).max())
+    out.update(rot_ang=ang, rot=R, cam_pose=np.array(cam['pose']), cam_K=np.array(cam['intrinsics']), cam_angle=np.array(cam['angle']),
+               cam_trans_after=coeff['trans'], c25=c25, c25_mirror=c25m)
+    save('preprocess', **out)
+
 SECTIONS = dict(manifest=sec_manifest, ops=sec_ops, renderer=sec_renderer, renderer_options=sec_renderer_options, synthesis=sec_synthesis,
                 geometry=sec_geometry, schedule=sec_schedule, trajectory=sec_trajectory, trajectory_sg=sec_trajectory_sg,
-                tv=sec_tv, orbit=sec_orbit, orbit_frames=sec_orbit_frames, bisenet=sec_bisenet, recon=sec_recon, losses=sec_losses, stage2=sec_stage2, pti=sec_pti)
+                tv=sec_tv, orbit=sec_orbit, orbit_frames=sec_orbit_frames, bisenet=sec_bisenet, recon=sec_recon, losses=sec_losses, stage2=sec_stage2, pti=sec_pti, interp_video=sec_interp_video, preprocess=sec_preprocess)
 
 if __name__ == '__main__':
     todo = sys.argv[1:] or list(SECTIONS)

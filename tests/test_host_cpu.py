@@ -301,6 +301,43 @@ def test_orbit_cameras_geometry():
     assert torch.allclose(s[0, 1], torch.tensor([-0.5 + (1 / 16) / 3, -0.5 + (1 / 4) / 3, -0.5 + 1 / 3]))
 
 
+def test_gen_interp_video_keyframes_vs_reference_golden(golden, tmp_path):
+    """Several latents (VERDICT r03 missing #5): what the reference's gen_interp_video (spi/utils/video_utils.py:74-230) hands its generator per
+    frame and grid cell -- the cubically interpolated keyframe latent and the camera of ONE orbit over num_keyframes * w_frames frames -- and the
+    frames its writer receives after layout_grid, for 3 keyframes, a 2 x 1 grid of 2 keyframes each and the single-latent case
+    (golden/interp_video.npz: the reference's function driven with a stub generator).  The product batches the calls; same rows, same order."""
+    from spi_amd.utils import video_utils as vu
+    from conftest import assert_close
+
+    class Stub:                                                  # the same cheap (w, c) -> image map the fixture was made with
+        neural_rendering_resolution = 8
+        rendering_kwargs = dict(depth_resolution=2, depth_resolution_importance=2, box_warp=1)
+
+        def __init__(self):
+            self.ws, self.cs = [], []
+
+        def synthesis(self, ws, c, noise_mode='const', render_noise=None, **kw):
+            n = c.shape[0]
+            ws = ws.expand(n, *ws.shape[1:]) if ws.shape[0] == 1 else ws       # the single-latent path passes ONE w with n cameras
+            self.ws.append(ws.clone().float()); self.cs.append(c.clone().float())
+            base = ws.reshape(n, -1)[:, :192].reshape(n, 3, 8, 8).float()
+            img = torch.tanh(base + c[:, :16].sum(dim=1).view(n, 1, 1, 1) * 0.05 + c[:, 3].view(n, 1, 1, 1))
+            return {'image': img, 'image_depth': img[:, :1] + 2.5, 'image_raw': img}
+    g = golden('interp_video')
+    for tag in ('k3', 'grid', 'one'):
+        nk, gw, gh, wf = (int(v) for v in g[tag + '_cfg'])
+        G = Stub()
+        frames = vu.gen_interp_video(G, {'w': g[tag + '_ws']}, mp4=str(tmp_path / f'{tag}.mp4'), w_frames=wf, grid_dims=(gw, gh), batch=3,
+                                     device=torch.device('cpu'), save_frames=False)
+        assert_close(torch.cat(G.ws), g[tag + '_w_per_call'], 1e-6, f'{tag}: latent per frame and cell')
+        assert torch.equal(torch.cat(G.cs), g[tag + '_c_per_call']), f'{tag}: camera per frame and cell'
+        ref = g[tag + '_frames'].numpy()
+        assert frames.shape == ref.shape == (nk * wf, gh * 8, gw * 8, 3)
+        assert np.abs(frames.astype(int) - ref.astype(int)).max() <= 1, tag          # uint8 after an fp32 tanh: at most one grey level
+    with pytest.raises(ValueError):
+        vu.gen_interp_video(Stub(), {'w': torch.zeros(3, 14, 16)}, mp4=str(tmp_path / 'x.mp4'), grid_dims=(2, 1), save_frames=False)
+
+
 REF = '/root/reference'
 
 
@@ -545,6 +582,52 @@ def test_crop_camera_producer_arithmetic(golden):
     assert np.allclose(np.array(front['pose'])[:3, 3], [0, 0.006, 2.7 + 0.161], atol=1e-6) and np.allclose(np.array(front['pose'])[:3, :3], np.diag([1, -1, -1]))
     c25 = pc.process_camera(front['pose'], front['intrinsics'])
     assert np.allclose(ce._cal_mirror_c(c25), orr2.mirror_camera(c25)) and np.allclose(ce._cal_mirror_c(ce._cal_mirror_c(c25)), c25)
+
+
+def test_preprocess_alignment_and_camera_vs_reference_golden(golden, tmp_path):
+    """SURVEY 8f-4 (VERDICT r03 missing #4): the crop + camera producer against the REFERENCE's own functions -- preprocess/extract_3dmm.py POS /
+    extract_5p / align_img / Extract3dmm.image_transform and preprocess/extract_camera.py compute_rotation / CameraExtractor.crop / cal_camera /
+    _cal_mirror_c, executed by tests/golden/make_golden.py `preprocess` -- product AND oracle, bit-exact (numpy / PIL on both sides)."""
+    from PIL import Image
+    from oracle import recon_ref as orr2
+    from spi_amd.preprocess import extract_3dmm as e3, process_camera as pc
+    from spi_amd.preprocess.extract_camera import CameraExtractor, compute_rotation
+    g = golden('preprocess')
+    photo = Image.fromarray(g['photo'].numpy())
+    lm, lm3d = g['lm'].numpy(), g['lm3d'].numpy()
+    lm_up = lm.copy()
+    lm_up[:, -1] = photo.size[1] - 1 - lm_up[:, -1]
+    for five, pos in ((e3.extract_5p, e3.POS), (orr2.extract_5p, orr2.pos)):
+        lm5 = five(lm_up)
+        t, s = pos(lm5.transpose(), lm3d.transpose())
+        assert np.array_equal(lm5, g['lm5'].numpy()) and np.array_equal(np.ravel(t), g['pos_t'].numpy()) and float(s) == float(g['pos_s'])
+    for tag, rf in (('a466', 466.285), ('a300', 300)):
+        tp, low, lm_new, _, high = e3.align_img(photo, lm_up.copy(), lm3d, rescale_factor=rf)
+        tpo, low_o, lm_new_o, high_o = orr2.align_img(photo, lm_up.copy(), lm3d, rescale_factor=rf)
+        for a, b, c, d in ((tp, low, lm_new, high), (tpo, low_o, lm_new_o, high_o)):
+            assert np.array_equal(a, g[tag + '_tp'].numpy()) and np.array_equal(c, g[tag + '_lm'].numpy())
+            assert np.array_equal(np.array(b), g[tag + '_low'].numpy())
+            assert np.array_equal(np.array(d)[::8, ::8], g[tag + '_high_sub'].numpy()) and np.array(d).astype(np.int64).sum() == int(g[tag + '_high_sum'])
+    ex = e3.Extract3dmm.__new__(e3.Extract3dmm)
+    ex.lm3d_std = lm3d
+    img_t, lm_t = ex.image_transform(photo, lm.copy())
+    assert torch.equal(img_t, g['it_img']) and torch.equal(lm_t, g['it_lm'])
+    assert np.array_equal(lm_up, g['it_lm_after'].numpy())          # the reference flips the CALLER's landmarks in place (:134); the product flips a copy and hands crop() the flipped ones
+    ce = CameraExtractor.__new__(CameraExtractor)
+    ce.lm3d_std, ce.crop_outdir, ce.c_outdir, ce.mode = lm3d, str(tmp_path), str(tmp_path), 'png'
+    ce.crop(photo, lm_up.copy(), 'x')
+    crop = np.array(Image.open(tmp_path / 'x.png'))
+    assert list(crop.shape) == g['crop_shape'].tolist() and np.array_equal(crop[::4, ::4], g['crop_sub'].numpy()) and crop.astype(np.int64).sum() == int(g['crop_sum'])
+    ang = g['rot_ang']
+    assert torch.equal(compute_rotation(ang), g['rot']) and torch.equal(orr2.compute_rotation(ang), g['rot'])
+    cam = ce.cal_camera({'angle': ang[:1].clone(), 'trans': torch.tensor([[0.1, -0.2, 0.3]])})
+    camo = orr2.cal_camera(ang[:1].clone(), torch.tensor([0.1, -0.2, 0.3]))
+    for c in (cam, camo):
+        assert np.array_equal(np.array(c['pose']), g['cam_pose'].numpy()) and np.array_equal(np.array(c['intrinsics']), g['cam_K'].numpy())
+        assert np.allclose(np.array(c['angle']), g['cam_angle'].numpy(), rtol=0, atol=0)
+    c25 = pc.process_camera(cam['pose'], cam['intrinsics'])
+    assert np.array_equal(c25, g['c25'].numpy()) and np.array_equal(ce._cal_mirror_c(c25), g['c25_mirror'].numpy())
+    assert np.array_equal(orr2.mirror_camera(c25), g['c25_mirror'].numpy())
 
 
 def test_tracing_helpers_mirror_the_reference_decorator():
