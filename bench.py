@@ -15,6 +15,10 @@ with the stage-2 part a whole number of 4-iteration super-cycles so the every-4t
 NOT depend on how K happened to split: it is the rate of the configuration's exact 500:1000 mix computed from the two per-stage rates
 measured inside the timed region (max over ranks per stage), value = 3 / (1 / r_stage1 + 2 / r_stage2); `ms_per_step` = 1000 / value per
 GPU, and the raw K-step wall time is reported beside it (`timed_region`).
+Extra keys of the line, none of them `value`: `sustained` (>= 300 more steps of the same loops in one window of several seconds), `alt`
+(split-bf16 convolutions), `dense` (no data-driven skipping), `cfg4` (BASELINE configs[4]: 128+128 samples, fp16 super-resolution) and `pti`
+(BASELINE configs[2]: `sg` + `pti`) -- the last two are separate bench.py processes (`--depth 128 --sr-fp16`, `--workload pti`) started after
+the benchmark line has been measured (single-GPU default runs only; `--no-legs` skips them).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -59,6 +63,14 @@ def parse():
                     help='after the timed region, time the same K steps once more with this conv arithmetic and report it as `alt` (never as `value`)')
     ap.add_argument('--no-dense-leg', action='store_true', help='skip the extra `dense` measurement (stage 2 once more without the data-driven skipping)')
     ap.add_argument('--only', choices=('stage1', 'stage2'), default=None, help='profiling aid, NOT the benchmark configuration: all K steps from one stage')
+    ap.add_argument('--workload', choices=('spi', 'pti'), default='spi',
+                    help="spi (default) = BASELINE configs[1] (or configs[4] with --depth 128 --sr-fp16): 'mir' stage 1 + RotBbox stage 2; "
+                         "pti = BASELINE configs[2], the PTI baseline: first_inv_type=sg (W projector) + G_1_type=pti (SingleIDCoach)")
+    ap.add_argument('--sustained', type=int, default=300,
+                    help='after the K timed steps, time this many more steps (1:2 stage mix, whole super-cycles) and report them as `sustained` beside '
+                         '`value` (0 = skip): a sub-second window can sit on a boost clock, a 7-second one cannot')
+    ap.add_argument('--no-legs', action='store_true', help='skip the `cfg4` (128+128 samples, fp16 super-resolution) and `pti` (configs[2]) legs, which '
+                                                           'run as child processes of a default single-GPU run after the benchmark line is measured')
     ap.add_argument('--dry-run', action='store_true', help='plumbing self-test without a GPU: launcher, rendezvous (gloo), barrier and the statistics '
                                                            'all-reduces run as in a real run, the timed steps are replaced by a sleep; prints no metric')
     return ap.parse_args()
@@ -205,6 +217,29 @@ def conv_roofline(dev, f16, prec=0):
     return out
 
 
+def child_leg(extra, steps, warmup, timeout=600):
+    """Run this script once more as a child process with another configuration and return the fields of its JSON line that a leg reports.
+    The child is a complete, independent bench.py run (own process, own warm-up, own barrier + sync bracketing); it runs AFTER the parent's
+    measurements, on the same GPU."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--steps', str(steps), '--warmup', str(warmup), '--no-cpu-baseline', '--alt-conv-precision', 'none',
+           '--no-dense-leg', '--no-legs', '--sustained', '0'] + list(extra)
+    env = dict(os.environ, SPI_BENCH_POOL_GIB='8')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+        if r.returncode != 0 or not line:
+            return {'error': f'rc {r.returncode}: ' + (r.stderr or '')[-400:]}
+        j = json.loads(line[-1])
+        return {k: j.get(k) for k in ('value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'stages', 'timed_region') if k in j} | {
+            'workload': j['config']['workload'], 'command': 'python bench.py ' + ' '.join(cmd[2:]),
+            'note': 'a separate bench.py process run after the benchmark line was measured; NOT the benchmark value'}
+    except Exception as e:                                       # noqa: BLE001
+        return {'error': repr(e)}
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` from a bare shell: spawn one rank per GPU (the reference's analogue: one `--dataset_block i/N` process per
     GPU, images_dataset.py:149-158), relay their output, and never let a dead rank hang the others: the first non-zero exit kills the rest."""
@@ -268,6 +303,20 @@ def gather_rank_devices(sdist, rank, world, local, dev):
     return [{'rank': r, 'device_index': int(slots[4 * r]), 'pci': '%04x:%02x:%02x' % tuple(int(v) for v in slots[4 * r + 1:4 * r + 4])} for r in range(world)]
 
 
+def gather_affinity(sdist, rank, world, affinity, dev):
+    """One sum-reduce of a per-CPU occupancy vector: how many ranks hold each host CPU after pin_rank_affinity (an entry > 1 = shared core)."""
+    ncpu = os.cpu_count() or 1
+    held = sorted(affinity) if affinity is not None else sorted(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else []
+    vec = [0.0] * (ncpu + world)
+    for c in held:
+        if c < ncpu:
+            vec[c] = 1.0
+    vec[ncpu + rank] = float(len(held))
+    vec = sdist.reduce_stats(vec, device=dev)
+    return {'pinned': affinity is not None, 'cpus_per_rank': [int(v) for v in vec[ncpu:]], 'max_ranks_on_one_cpu': int(max(vec[:ncpu]) if ncpu else 0),
+            'disjoint': bool(world == 1 or max(vec[:ncpu]) <= 1.0)}
+
+
 def process_group_info(world):
     import torch.distributed as td
     if world > 1 and td.is_available() and td.is_initialized():
@@ -288,12 +337,14 @@ def dry_run(args, sdist, rank, world):
         ok = 0.0
     dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, time.perf_counter() - t0, ok, None)
     devices = gather_rank_devices(sdist, rank, world, int(os.environ.get('LOCAL_RANK', rank)), None)
+    affinity = sdist.pin_rank_affinity(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    affinity_report = gather_affinity(sdist, rank, world, affinity, None)
     from spi_amd.configs import global_config
     from spi_amd.training.projectors.common import graph_policy, capture_mode
     if rank == 0:
         print(json.dumps({'dry_run': True, 'n_gpus': world, 'steps': args.steps, 'seconds_max_over_ranks': dt,
                           'ranks': {'launched': world, 'completed': int(sum(rank_ok)), 'per_rank_seconds': rank_s, 'devices': devices,
-                                    'process_group': process_group_info(world)},
+                                    'process_group': process_group_info(world), 'cpu_affinity': affinity_report},
                           'stage1_hip_graph_policy': graph_policy(global_config.stage1_hip_graph), 'graph_capture_mode': capture_mode()}), flush=True)
     sdist.shutdown()
     if int(sum(rank_ok)) != world:
@@ -312,8 +363,10 @@ def main():
         return dry_run(args, sdist, rank, world)
     if not torch.cuda.is_available():
         raise RuntimeError('bench.py needs an MI355X (the HIP path has no CPU fallback)')
-    torch.cuda.set_device(local)
-    dev = torch.device(f'cuda:{local}')
+    dev_index = sdist.device_index(local)                        # HIP_VISIBLE_DEVICES honoured
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f'cuda:{dev_index}')
+    affinity = sdist.pin_rank_affinity(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     from spi_amd import hip
     hip.lib()                                                    # fail loudly if libspi_hip.so is missing
     from spi_amd.configs import hyperparameters, paths_config, global_config
@@ -334,8 +387,9 @@ def main():
     tmp = tempfile.mkdtemp(prefix='spi_bench_')
     for k in ('checkpoints_dir', 'embedding_base_dir', 'experiments_output_dir', 'images_output_dir', 'mirror_images_output_dir'):
         setattr(paths_config, k, f'{tmp}/{k}/')
-    hyperparameters.first_inv_type, hyperparameters.first_inv_steps = 'mir', 500
-    hyperparameters.G_1_type, hyperparameters.G_1_step = 'RotBbox', 1000
+    pti = args.workload == 'pti'
+    hyperparameters.first_inv_type, hyperparameters.first_inv_steps = ('sg' if pti else 'mir'), 500
+    hyperparameters.G_1_type, hyperparameters.G_1_step = ('pti' if pti else 'RotBbox'), 1000
     hyperparameters.pt_rot_lambda, hyperparameters.pt_mirror_rot_lambda, hyperparameters.pt_depth_lambda, hyperparameters.pt_tv_lambda = 0.1, 0.05, 1.0, 0.0
     hyperparameters.LPIPS_value_threshold = -1.0                 # random weights: never early-stop inside the timed region
 
@@ -343,14 +397,29 @@ def main():
     G = TriPlaneGenerator(**ffhq512_kwargs(narrow=args.narrow, depth_resolution=args.depth, depth_resolution_importance=args.depth))
     G = G.eval().requires_grad_(False).to(dev)
     G.neural_rendering_resolution = 128
-    with contextlib.redirect_stdout(sys.stderr):                 # the coach announces its name like the reference does; stdout carries the JSON line only
-        coach = RotBboxCoach(None, False, G=G, synthetic=True)
     d = SyntheticDataset(world)[rank]                            # one independent image per rank
     data = {k: (v[None] if torch.is_tensor(v) else v) for k, v in d.items()}
-    ctx = coach.prepare_image(data)
-    cameras, dist_fn = mirror_setup(ctx['image'], ctx['camera'], coach.lpips_loss, dev)
-    proj = Projection(coach.G, cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=500, w_avg_samples=600, device=dev)
-    w_pivot = proj.w_opt.detach().clone()
+    with contextlib.redirect_stdout(sys.stderr):                 # the coach announces its name like the reference does; stdout carries the JSON line only
+        if pti:
+            from spi_amd.training.coaches.pti_coach import SingleIDCoach
+            from spi_amd.training.projectors.w_projector import sg_distance
+            coach = SingleIDCoach(None, False, G=G, synthetic=True)
+        else:
+            coach = RotBboxCoach(None, False, G=G, synthetic=True)
+    if pti:
+        # BASELINE configs[2]: stage 1 = the W projector (`sg`: one w for all 14 layers, feature distance of the vgg16 extractor), stage 2 = PTI
+        image = data['img'].to(dev).float()
+        camera = torch.as_tensor(data['c']).to(dev).float().reshape(-1, 25)
+        proj = Projection(coach.G, camera, sg_distance(image, coach._sg_vgg16(), dev), w_mode='w', initial_w=None, num_steps=500, w_avg_samples=600, device=dev)
+        w_pivot = proj.w_opt.detach().repeat([1, coach.G.backbone.mapping.num_ws, 1]).clone()
+        target_feats = coach.lpips_loss.features(image)
+        stage2_step = lambda i: coach.train_step(image, camera, w_pivot, target_feats)
+    else:
+        ctx = coach.prepare_image(data)
+        cameras, dist_fn = mirror_setup(ctx['image'], ctx['camera'], coach.lpips_loss, dev)
+        proj = Projection(coach.G, cameras, dist_fn, w_mode='w+', initial_w=None, num_steps=500, w_avg_samples=600, device=dev)
+        w_pivot = proj.w_opt.detach().clone()
+        stage2_step = lambda i: coach.train_step(i, ctx, w_pivot)
     # set-up, not warm-up: the projector replays its step from a HIP graph that it captures on its second call (one eager step first); a
     # real run pays for that once in 500 steps, so it is built here and neither the W warm-up steps nor the K timed steps contain it
     graph_build_steps = 0
@@ -365,15 +434,7 @@ def main():
     # One large block allocated and released here stays in torch's cache and is carved up on demand -- what a long-running inversion service
     # does once at start-up (288 GB of HBM per GPU).  (The one-off pause that was actually measured inside the timed region turned out to be
     # Python's garbage collector, see below; this is the precaution against the other source.)
-    pool_gib = 0
-    try:
-        free_b, _total_b = torch.cuda.mem_get_info(dev)
-        pool_gib = int(min(24, free_b / 2 ** 30 * 0.25))
-        if pool_gib > 0:
-            _pool = torch.empty(pool_gib << 30, dtype=torch.uint8, device=dev)
-            del _pool
-    except Exception:                                            # noqa: BLE001  (a failed reservation only loses the protection)
-        pool_gib = 0
+    pool_gib = sdist.reserve_allocator_pool(dev, int(os.environ.get('SPI_BENCH_POOL_GIB', '24')))      # (the same call run_inversion.run makes)
 
     marks = {}
 
@@ -388,7 +449,8 @@ def main():
         tb = time.perf_counter()
         per_iter = [] if os.environ.get('SPI_BENCH_ITER_TIMES') else None      # debugging aid (synchronises every iteration: NOT for the benchmark value)
         for i in range(n2):
-            coach.train_step(s2_base + i, ctx, w_pivot)
+            if stage2_step(s2_base + i)[0]:                      # (a stopped loop runs no further iterations -- timing them would time nothing)
+                raise RuntimeError('the stage-2 loop early-stopped inside a timed run (LPIPS <= threshold): not a valid measurement')
             if per_iter is not None:
                 torch.cuda.synchronize()
                 per_iter.append(round((time.perf_counter() - tb) * 1e3, 2))
@@ -462,6 +524,7 @@ def main():
     n_ok = int(sum(rank_ok))
     rank_devices = gather_rank_devices(sdist, rank, world, local, dev)
     graph_ranks = int(sdist.reduce_stats([1.0 if getattr(proj, '_graph', None) is not None else 0.0], device=dev)[0])
+    affinity_report = gather_affinity(sdist, rank, world, affinity, dev)
     # per-stage wall time, max over ranks: the two rates `value` is computed from
     st_s = sdist.reduce_stats([marks.get('stage1_s', 0.0), marks.get('stage2_s', 0.0)], device=dev, op='max')
 
@@ -472,22 +535,51 @@ def main():
         return n_ok * (k1 + k2) / max(t1 + t2, 1e-12)
     value = mix_value(st_s[0], st_s[1])
     main_stage_s = list(st_s)
+    step1_next, step2_next = 25 + w1 + k1, ((w2 + 3) // 4) * 4 + ((k2 + 3) // 4) * 4      # where later legs continue the two loops
+    sustained = None
+    if args.sustained > 0 and ok and k1 and k2 and not os.environ.get('SPI_TORCH_PROFILE'):
+        # the same loops for >= 300 more steps in ONE window of several seconds (the K-step window above is < 1 s): stage 1 : stage 2 = 1 : 2,
+        # stage 2 in whole super-cycles.  Reported beside `value`; `value` stays the K-step measurement the driver asked for.
+        n2s = max(4, int(round(args.sustained * 2 / 3 / 4)) * 4)
+        n1s = max(1, n2s // 2)
+        main_marks = dict(marks)
+        sus_err = None
+        sdist.barrier(); torch.cuda.synchronize()
+        ts = time.perf_counter()
+        try:
+            run(n1s, n2s, step1_next, step2_next)
+        except Exception as e:                                    # noqa: BLE001
+            sus_err = repr(e)
+        torch.cuda.synchronize(); sdist.barrier()
+        dts = sdist.reduce_stats([time.perf_counter() - ts], device=dev, op='max')[0]
+        bad = sdist.reduce_stats([0.0 if sus_err is None else 1.0], device=dev)[0]
+        s_s = sdist.reduce_stats([marks.get('stage1_s', 0.0), marks.get('stage2_s', 0.0)], device=dev, op='max')
+        step1_next, step2_next = step1_next + n1s, step2_next + n2s
+        if bad:
+            sustained = {'error': sus_err or 'failed on another rank'}
+        else:
+            sv = n_ok * 3.0 / (s_s[0] / n1s + 2.0 * s_s[1] / n2s)
+            sustained = {'value': sv, 'unit': 'iters/s', 'ms_per_step': 1e3 * max(n_ok, 1) / sv, 'steps': n1s + n2s, 'timed_steps': {'stage1': n1s, 'stage2': n2s},
+                         'seconds_max_over_ranks': dts, 'stage1_iters_per_s_per_gpu': n1s / s_s[0], 'stage2_iters_per_s_per_gpu': n2s / s_s[1],
+                         'note': 'same definition as `value` (exact 1:2 mix of the per-stage rates, max over ranks), measured over one window of several seconds '
+                                 'right after the K timed steps, barrier + synchronize on both sides'}
+        marks.clear(); marks.update(main_marks)
     alt = None
-    if args.alt_conv_precision != 'none' and args.alt_conv_precision != args.conv_precision and ok and not os.environ.get('SPI_TORCH_PROFILE'):
+    if args.alt_conv_precision != 'none' and args.alt_conv_precision != args.conv_precision and ok and not pti and not os.environ.get('SPI_TORCH_PROFILE'):
         # the same K steps once more with the split-bf16 convolutions (opt-in arithmetic; reported beside the benchmark value, never as it).
         # A failure here must not cost the benchmark line: the collectives below run on every rank either way.
         global_config.conv_precision = {'bf16x6': 3, 'bf16x3': 2}[args.alt_conv_precision]
         main_marks = dict(marks)
         alt_err = None
         try:
-            run(2 if k1 else 0, min(w2, 4), 25 + w1 + k1, ((w2 + k2 + 3) // 4) * 4)      # (2 stage-1 steps: the projector re-captures its graph for this arithmetic)
+            run(2 if k1 else 0, min(w2, 4), step1_next, step2_next)      # (2 stage-1 steps: the projector re-captures its graph for this arithmetic)
         except Exception as e:                                    # noqa: BLE001
             alt_err = repr(e)
         sdist.barrier(); torch.cuda.synchronize()
         ta = time.perf_counter()
         try:
             if alt_err is None:
-                run(k1, k2, 25 + w1 + k1 + 2, ((w2 + k2 + 7) // 4) * 4)
+                run(k1, k2, step1_next + 2, step2_next + 4)
         except Exception as e:                                    # noqa: BLE001
             alt_err = repr(e)
         torch.cuda.synchronize(); sdist.barrier()
@@ -504,13 +596,13 @@ def main():
         marks.clear(); marks.update(main_marks)
         global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
     dense_leg = None
-    if not args.dense and not args.no_dense_leg and ok and k2 and not os.environ.get('SPI_TORCH_PROFILE'):
+    if not args.dense and not args.no_dense_leg and ok and k2 and not pti and not os.environ.get('SPI_TORCH_PROFILE'):
         # the dense bound of the same step: the stage-2 iterations once more with the data-driven skipping of exactly-zero gradients /
         # unneeded SR tiles switched off (stage 1 has no masked branch: its rate is the main run's).  Reported beside `value`, never as it.
         global_config.exploit_sparsity = False
         main_marks = dict(marks)
         dense_err = None
-        base2 = ((w2 + 2 * k2 + 15) // 4) * 4
+        base2 = step2_next + ((k2 + 11) // 4) * 4
         try:
             run(0, 4, 0, base2)                                   # one untimed super-cycle (allocator / workspace shapes of the dense branches)
             sdist.barrier(); torch.cuda.synchronize()
@@ -551,16 +643,19 @@ def main():
             'ranks': {'launched': world, 'completed': n_ok, 'backend': 'rccl (torch.distributed nccl)' if world > 1 else 'none (single process)',
                       'collectives': 'barrier + 2 all-reduces of <= %d fp64 (timing / done-flags); no data-path collective' % (2 * world),
                       'per_rank_iters_per_s': [args.steps / t if t > 0 else None for t in rank_s], 'devices': rank_devices,
-                      'process_group': process_group_info(world), 'ranks_replaying_stage1_graph': graph_ranks},
-            'stages': {'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
-                       'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
-                       'note': 'rank 0; stage 2 amortises the every-4th-iteration rot / mirror-rot / depth branches over whole super-cycles'},
+                      'process_group': process_group_info(world), 'ranks_replaying_stage1_graph': graph_ranks, 'cpu_affinity': affinity_report},
+            'stages': ({'stage1_sg_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
+                        'stage2_pti_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None, 'note': 'rank 0'} if pti else
+                       {'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
+                        'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
+                        'note': 'rank 0; stage 2 amortises the every-4th-iteration rot / mirror-rot / depth branches over whole super-cycles'}),
             'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': ('f32+f16sr' if args.sr_fp16 else 'f32') + ('' if args.conv_precision == 'f32' else f' (convolutions: fp32 operands split {args.conv_precision}, fp32 accumulate)'), 'data': 'synthetic (seeded 512^2 image / camera / mask / landmarks; '
             'random-init weights of the ffhqrebalanced512-128 architecture)',
-            'config': {'workload': ('configs[4]' if (args.depth == 128 and args.sr_fp16) else 'configs[1]') +
-                                   ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, '
-                                   f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else ''), 'step_mix': {'value_mix': 'stage1:stage2 = 1:2 exact (500:1000), computed from the per-stage rates' if (k1 and k2) else 'single stage', 'timed_steps': {'stage1_mir': k1, 'stage2_rotbbox': k2}},
+            'config': {'workload': (('configs[2]: PTI baseline, 1 image per GPU, first_inv_type=sg (500) + G_1_type=pti (1000), 512^2, ' if pti else
+                                    ('configs[4]' if (args.depth == 128 and args.sr_fp16) else 'configs[1]') +
+                                    ': 1 image per GPU, first_inv_type=mir (500) + G_1_type=RotBbox (1000), 512^2, ') +
+                                   f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else '')), 'step_mix': {'value_mix': 'stage1:stage2 = 1:2 exact (500:1000), computed from the per-stage rates' if (k1 and k2) else 'single stage', 'timed_steps': {'stage1_mir': k1, 'stage2_rotbbox': k2}},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
                        'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph),
@@ -623,6 +718,8 @@ def main():
                                           'note': 'algorithmic FLOPs of the decoder backward per live point / call time (gather, MLP on the matrix cores, plane-gradient scatter '
                                                   'all inside the call); the scatter is LDS-atomic / flush bound, see DESIGN.md 3'}
         out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16), global_config.conv_precision)
+        if sustained is not None:
+            out['sustained'] = sustained
         if alt is not None:
             out['alt'] = alt
         if dense_leg is not None:
@@ -632,6 +729,14 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, 1 if k1 else 0, 2 if k2 else 0)
             except Exception as e:                                # noqa: BLE001  (a host-side failure must not lose the GPU measurement)
                 out['cpu_baseline'] = {'error': repr(e)}
+        default_cfg = (not pti and args.depth == 96 and not args.sr_fp16 and not args.narrow and not args.dense and args.only is None
+                       and args.conv_precision == 'f32' and not args.no_winograd)
+        if world == 1 and not args.no_legs and default_cfg and ok:
+            # BASELINE configs[4] and configs[2] measured the same way, each as its own bench.py process (VERDICT r03 missing #3)
+            del proj, coach
+            torch.cuda.empty_cache()
+            out['cfg4'] = child_leg(['--depth', '128', '--sr-fp16'], args.steps, args.warmup)
+            out['pti'] = child_leg(['--workload', 'pti'], args.steps, args.warmup)
         print(json.dumps(out), flush=True)
     sdist.shutdown()                                             # ranks leave together (rank 0 is still timing its roofline lines)
     if n_ok != world:

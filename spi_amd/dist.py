@@ -26,6 +26,99 @@ def init_from_env(backend=None, timeout_s=900):
     return rank, world, local
 
 
+def device_index(local_rank):
+    """Index of this rank's GPU among the VISIBLE devices.  `HIP_VISIBLE_DEVICES` / `ROCR_VISIBLE_DEVICES` are honoured by the runtime itself
+    (indices are relative to the visible set); a launcher that shows every rank exactly one device (HIP_VISIBLE_DEVICES=<rank>) makes that
+    device index 0 for everybody.  (The reference overwrites CUDA_VISIBLE_DEVICES with '0', run_inversion.py:109 -- one process per job.)"""
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return local_rank % n if n else 0
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        a, _, b = part.partition('-')
+        cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def _gpu_numa_cpus(index):
+    """host CPUs of the NUMA node the GPU with this visible index hangs off (sysfs), or None"""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        bdf = '%04x:%02x:%02x.0' % (getattr(p, 'pci_domain_id', 0), p.pci_bus_id, p.pci_device_id)
+        node = int(open(f'/sys/bus/pci/devices/{bdf}/numa_node').read())
+        if node < 0:
+            return None
+        return _parse_cpulist(open(f'/sys/devices/system/node/node{node}/cpulist').read())
+    except Exception:                                            # noqa: BLE001  (no sysfs, no GPU: fall back to an even split)
+        return None
+
+
+def plan_affinity(local_world, allowed, numa_cpus=None):
+    """Disjoint CPU sets for the `local_world` ranks of this host -> list of sorted lists.  Ranks whose GPUs share a NUMA node split THAT node's
+    CPUs (numa_cpus[r] = set or None); ranks without NUMA information split what is left evenly.  Pure function (tested on CPU)."""
+    allowed = sorted(allowed)
+    numa_cpus = numa_cpus or [None] * local_world
+    groups = {}
+    for r in range(local_world):
+        key = tuple(sorted(numa_cpus[r] & set(allowed))) if numa_cpus[r] else None
+        groups.setdefault(key if key else None, []).append(r)
+    plan = [None] * local_world
+    taken = set()
+    for key, ranks in groups.items():
+        if key is None:
+            continue
+        per = max(1, len(key) // len(ranks))
+        for j, r in enumerate(ranks):
+            plan[r] = list(key[j * per:(j + 1) * per]) or [key[j % len(key)]]
+            taken.update(plan[r])
+    rest = [c for c in allowed if c not in taken] or allowed
+    ranks = groups.get(None, [])
+    if ranks:
+        per = max(1, len(rest) // len(ranks))
+        for j, r in enumerate(ranks):
+            plan[r] = rest[j * per:(j + 1) * per] or [rest[j % len(rest)]]
+    return plan
+
+
+def pin_rank_affinity(local_rank, local_world):
+    """One process per GPU on one host: give every rank its own host cores, next to its GPU.  An eager stage-2 iteration needs ~25 ms of
+    single-thread launch work per ~25 ms of GPU time, so ranks that share cores (or sit on the far socket) lose throughput to each other;
+    8 ranks with one all-core OpenMP pool each would also oversubscribe the host.  No-op for a single-rank run, on platforms without
+    sched_setaffinity, and when SPI_PIN_AFFINITY=0.  -> the CPU list this rank now holds (or None)."""
+    if local_world <= 1 or os.environ.get('SPI_PIN_AFFINITY', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    allowed = os.sched_getaffinity(0)
+    numa = [_gpu_numa_cpus(device_index(r)) for r in range(local_world)] if torch.cuda.is_available() else None
+    mine = plan_affinity(local_world, allowed, numa)[local_rank]
+    try:
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), int(os.environ.get('OMP_NUM_THREADS', len(mine))))))
+    except OSError:
+        return None
+    return mine
+
+
+def reserve_allocator_pool(device, gib=None):
+    """Start-up step of a long-running inversion process: allocate and release one large block so that it stays in torch's caching allocator
+    and later requests are carved out of it.  The workspace sizes of the masked pseudo-view branches depend on each iteration's random cameras;
+    without the pool a later iteration can ask for a block size the allocator has not seen, and a first-time hipMalloc of GBs is a host-side
+    stall in the middle of the loop (288 GB of HBM per GPU: 24 GiB is < 10 %).  -> GiB reserved."""
+    gib = int(os.environ.get('SPI_POOL_GIB', '24')) if gib is None else gib
+    try:
+        free_b, _ = torch.cuda.mem_get_info(device)
+        gib = int(min(gib, free_b / 2 ** 30 * 0.25))
+        if gib > 0:
+            block = torch.empty(gib << 30, dtype=torch.uint8, device=device)
+            del block
+        return max(gib, 0)
+    except Exception:                                            # noqa: BLE001  (a failed reservation only loses the protection)
+        return 0
+
+
 def shard_indices(n_items, rank, world_size, mode='block'):
     """Indices of the items this rank owns.  'block' reproduces the reference's contiguous blocks
     (block = n // world + 1); 'stride' is round-robin."""

@@ -99,8 +99,11 @@ def run(argv=None):
     args = parse_args(argv)
     use_wandb = not args.not_use_wandb
     rank, world, local = sdist.init_from_env()
-    global_config.device = f'cuda:{local}'
-    torch.cuda.set_device(local)
+    dev_index = sdist.device_index(local)                         # HIP_VISIBLE_DEVICES honoured (the reference pins CUDA_VISIBLE_DEVICES='0', :109)
+    global_config.device = f'cuda:{dev_index}'
+    torch.cuda.set_device(dev_index)
+    sdist.pin_rank_affinity(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))      # own host cores per rank, next to its GPU
+    sdist.reserve_allocator_pool(global_config.device)           # the measured path of bench.py: pool reserved once; the loops freeze the GC (quiet_gc)
     _, loader = build_dataset(args, rank, world)
     G = load_utils.load_eg3d(device=global_config.device, synthetic=args.synthetic > 0)
     from .training.coaches.pti_coach import SingleIDCoach

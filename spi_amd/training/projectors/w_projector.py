@@ -11,14 +11,9 @@ from ...configs import global_config
 from .common import run_projection
 
 
-def project(G, target, camera, vgg16, *, num_steps=1000, w_avg_samples=10000, initial_learning_rate=0.01,
-            initial_noise_factor=0.05, lr_rampdown_length=0.25, lr_rampup_length=0.05, noise_ramp_length=0.75,
-            regularize_noise_weight=1e5, verbose=False, device, use_wandb=False, initial_w=None, image_log_step=global_config.log_snapshot,
-            w_name='', rng=None, log=None):
-    """Signature of w_projector.py:9-29 (``vgg16`` positional; ``use_wandb`` / ``image_log_step`` accepted, they only gate logging
-    there) plus the two test hooks ``rng`` (draw source) and ``log`` (per-step losses)."""
-    assert target.shape[1:] == (G.img_channels, G.img_resolution, G.img_resolution)
-
+def sg_distance(target, vgg16, device):
+    """-> dist_fn(images) of the W projector: squared difference of the extractor's feature vectors on 256^2 area-downsampled 0..255 images
+    (:48-51,81-87); the fixed target's features are computed once."""
     def prep(img):
         img = (img + 1) * (255 / 2)
         if img.shape[2] > 256:
@@ -30,6 +25,18 @@ def project(G, target, camera, vgg16, *, num_steps=1000, w_avg_samples=10000, in
 
     def dist_fn(images):
         return (target_features - vgg16(prep(images), resize_images=False, return_lpips=True)).square().sum()
+    return dist_fn
+
+
+def project(G, target, camera, vgg16, *, num_steps=1000, w_avg_samples=10000, initial_learning_rate=0.01,
+            initial_noise_factor=0.05, lr_rampdown_length=0.25, lr_rampup_length=0.05, noise_ramp_length=0.75,
+            regularize_noise_weight=1e5, verbose=False, device, use_wandb=False, initial_w=None, image_log_step=global_config.log_snapshot,
+            w_name='', rng=None, log=None):
+    """Signature of w_projector.py:9-29 (``vgg16`` positional; ``use_wandb`` / ``image_log_step`` accepted, they only gate logging
+    there) plus the two test hooks ``rng`` (draw source) and ``log`` (per-step losses)."""
+    assert target.shape[1:] == (G.img_channels, G.img_resolution, G.img_resolution)
+
+    dist_fn = sg_distance(target, vgg16, device)
 
     sched = dict(initial_learning_rate=initial_learning_rate, initial_noise_factor=initial_noise_factor,
                  lr_rampdown_length=lr_rampdown_length, lr_rampup_length=lr_rampup_length, noise_ramp_length=noise_ramp_length)

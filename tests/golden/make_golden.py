@@ -961,12 +961,12 @@ def sec_losses():
     for i in range(3):
         assert torch.equal(bb[i].float(), mine[i]), i
     print('    pin get_landmark_bbox: mouth / l_eye / r_eye boxes bit-equal;', [b.tolist()[3] for b in bb[:3]])
-    for tag, (x, y, l) in li.boxcx_cases().items():
+    for tag, (x, m, y, l) in li.boxcx_cases().items():
         xr = x.clone().requires_grad_(True)
-        val = bx(xr, y, l)
+        val = bx(xr * m if m is not None else xr, y, l)
         gx, = torch.autograd.grad(val, xr)
         xo = x.clone().requires_grad_(True)
-        vo = olo.box_cx_loss(W19, xo, y, l)
+        vo = olo.box_cx_loss(W19, xo * m if m is not None else xo, y, l)
         go, = torch.autograd.grad(vo, xo)
         diff(f'BoxCX[{tag}] value', val, vo)
         diff(f'BoxCX[{tag}] d/dx', gx, go)

@@ -45,12 +45,16 @@ def lpips_cases():
 
 
 def boxcx_cases():
-    """tag -> (x, y, lm)"""
+    """tag -> (x, mask or None, y, lm): x is the differentiated input, multiplied by the mask before the loss when there is one -- the way the
+    mirror-rot branch feeds it (`flip_gen_image * flip_warp_mask`, rot_bbox_cx_coach.py:127).  Inside a masked-out region every feature
+    vector is identical, so the contextual loss's max / min run into EXACT ties there; which tied index receives the gradient differs
+    between implementations (torch CPU: the first; the HIP kernels: their reduction order), but tied positions have fully masked receptive
+    fields, so the difference is multiplied by the mask's zeros on its way to x -- differentiating through the mask is the meaningful test."""
     from spi_amd.data.images_dataset import synthetic_landmarks
     m4 = blob_mask(913, 4)
     xb, yb = smooth_img(909, 4, 40), smooth_img(910, 4, 40)
     yb = 0.7 * yb + 0.3 * xb                                        # correlated, like a render against its warped target
-    return dict(bx4=(xb * m4, yb, landmarks(911, 4)), bx1=(xb[:1].clone(), yb[:1].clone(), synthetic_landmarks()[None]))
+    return dict(bx4=(xb, m4, yb * m4, landmarks(911, 4)), bx1=(xb[:1].clone(), None, yb[:1].clone(), synthetic_landmarks()[None]))
 
 
 def grad_sub(g):

@@ -50,7 +50,10 @@ def test_lpips_vs_reference_golden(golden):
         out2 = net(xg * m.to(DEV) if m is not None else xg, y_feats=net.features(y.to(DEV)))
         assert abs(out2.item() - out.item()) <= 1e-6 * abs(ref)
     for i, f in enumerate(net.features(li.lpips_cases()['lp64'][0].to(DEV))):
-        assert_close(f, g[f'lp64_feat{i}'], 1e-4, f'LPIPS tap {i}')
+        # the product caches the RAW relu taps and normalises inside spi_lpips_layer_fwd; the reference's BaseNet.forward returns them
+        # channel-normalised (networks.py:53-63, utils.py:6-8)
+        fn = f / (torch.sqrt(torch.sum(f ** 2, dim=1, keepdim=True)) + 1e-10)
+        assert_close(fn, g[f'lp64_feat{i}'], 1e-4, f'LPIPS tap {i}')
 
 
 def test_box_cx_vs_reference_golden(golden):
@@ -62,13 +65,14 @@ def test_box_cx_vs_reference_golden(golden):
     boxes = get_landmark_bbox(li.landmarks(911, 4))
     for i in range(4):
         assert torch.equal(boxes[i].cpu().long(), g[f'bx_box{i}'].long()), f'landmark box {i}'
-    for tag, (x, y, lm) in li.boxcx_cases().items():
-        xg = x.to(DEV).requires_grad_(True)
+    for tag, (x, m, y, lm) in li.boxcx_cases().items():
+        xl = x.to(DEV).requires_grad_(True)
+        xg = xl * m.to(DEV) if m is not None else xl             # through the mask, like the mirror-rot branch (see loss_inputs.boxcx_cases)
         out = net(xg, y.to(DEV), lm.to(DEV))
         ref = g[tag + '_val'].item()
         assert abs(out.item() - ref) <= 1e-3 * abs(ref), (tag, out.item(), ref)
-        _grad_check(torch.autograd.grad(out, xg)[0], g, tag, 2e-3, 5e-3)
-        out_cpu_lm = net(xg, y.to(DEV), lm)                                                  # landmarks on the host: same number
+        _grad_check(torch.autograd.grad(out, xl)[0], g, tag, 2e-3, 5e-3)
+        out_cpu_lm = net(xg.detach(), y.to(DEV), lm)                                                  # landmarks on the host: same number
         assert abs(out_cpu_lm.item() - out.item()) <= 1e-6 * abs(ref)
 
 

@@ -190,6 +190,11 @@ def test_bench_self_launches_two_ranks_and_survives_a_failing_rank():
     assert line['stage1_hip_graph_policy'] is True and line['graph_capture_mode'] == 'thread_local'
     assert len(line['ranks']['per_rank_seconds']) == 2 and line['ranks']['per_rank_seconds'][1] > line['ranks']['per_rank_seconds'][0] > 0
     assert line['seconds_max_over_ranks'] >= line['ranks']['per_rank_seconds'][1]
+    # every rank holds its own host cores (an eager stage-2 iteration is ~25 ms of single-thread launch work per ~25 ms of GPU
+    # time: ranks that share cores starve each other) -- the two ranks' CPU sets are disjoint and both are non-empty
+    aff = line['ranks']['cpu_affinity']
+    if len(os.sched_getaffinity(0)) >= 2:
+        assert aff['pinned'] and aff['disjoint'] and aff['max_ranks_on_one_cpu'] == 1 and all(n >= 1 for n in aff['cpus_per_rank']), aff
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=dict(env, SPI_BENCH_FAIL_RANK='1'),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 3
@@ -199,6 +204,26 @@ def test_bench_self_launches_two_ranks_and_survives_a_failing_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run'], env=dict(env, WORLD_SIZE='1', RANK='0'),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr + r.stdout
+
+
+def test_affinity_plan_is_disjoint_and_numa_aware():
+    """spi_amd/dist.plan_affinity: ranks whose GPUs hang off the same NUMA node split that node's CPUs, ranks without NUMA information split the
+    rest; never an empty set, never a shared CPU while there are enough CPUs."""
+    from spi_amd.dist import plan_affinity, _parse_cpulist, device_index
+    assert _parse_cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+    allowed = range(64)
+    node0, node1 = set(range(0, 32)), set(range(32, 64))
+    plan = plan_affinity(8, allowed, [node0] * 4 + [node1] * 4)
+    assert [len(p) for p in plan] == [8] * 8 and all(set(p) <= (node0 if r < 4 else node1) for r, p in enumerate(plan))
+    flat = [c for p in plan for c in p]
+    assert len(flat) == len(set(flat)) == 64
+    plan = plan_affinity(3, range(8))                            # no NUMA information: an even split of what the process may use
+    assert [len(p) for p in plan] == [2, 2, 2] and len({c for p in plan for c in p}) == 6
+    plan = plan_affinity(4, [5, 9], None)                        # fewer CPUs than ranks: still one CPU each (shared by necessity)
+    assert all(len(p) == 1 for p in plan)
+    plan = plan_affinity(2, range(16), [set(range(8)), None])
+    assert plan[0] == list(range(8)) and plan[1] == list(range(8, 16))
+    assert device_index(3) == 0                                  # no GPU here: index 0 (with GPUs: local rank modulo the VISIBLE devices)
 
 
 def test_pretrained_weight_files_are_required_unless_synthetic(tmp_path):

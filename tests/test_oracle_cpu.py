@@ -353,10 +353,10 @@ def test_oracle_lpips_and_boxcx_vs_reference_golden(golden):
     boxes = olo.landmark_boxes(li.landmarks(911, 4))
     for i in range(3):
         assert torch.equal(boxes[i], g[f'bx_box{i}'].float()), f'landmark box {i}'
-    for tag, (x, y, lm) in li.boxcx_cases().items():
+    for tag, (x, m, y, lm) in li.boxcx_cases().items():
         assert x.double().sum().item() == g[tag + '_x_sum'].item() and torch.equal(lm, g[tag + '_lm'])
         xr = x.clone().requires_grad_(True)
-        val = olo.box_cx_loss(W19, xr, y, lm)
+        val = olo.box_cx_loss(W19, xr * m if m is not None else xr, y, lm)
         assert_close(val, g[tag + '_val'], 1e-6, f'BoxCX[{tag}]')
         _full_grad_check(torch.autograd.grad(val, xr)[0], g, tag, 1e-6)
     fx = g['cx_fx'].clone().requires_grad_(True)
