@@ -21,6 +21,22 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-ato
          '-Wno-pass-failed', '-I' + os.path.join(ROOT, 'include'), '-I' + HERE]
 
 
+# The sources carry inline asm for LDS-DMA loads and for raw_buffer_load_b64 / b128 (the builtins of this compiler mis-handle them, see
+# render.hip / winograd.hip) and rely on its register allocation for the 512-register Winograd kernels: they were written against and
+# verified with ROCm 7.2's hipcc.  Another compiler may build something that runs differently, so it must be asked for explicitly.
+HIPCC_SERIES = '7.2'
+
+
+def check_compiler(hipcc):
+    """-> the compiler's 'HIP version' string; raises unless it is the series the kernels were verified with (SPI_ALLOW_ANY_HIPCC=1 overrides)."""
+    out = subprocess.run([hipcc, '--version'], capture_output=True, text=True).stdout
+    ver = next((ln.split(':', 1)[1].strip() for ln in out.splitlines() if ln.startswith('HIP version')), '')
+    if not ver.startswith(HIPCC_SERIES + '.') and os.environ.get('SPI_ALLOW_ANY_HIPCC') != '1':
+        raise RuntimeError(f'{hipcc} reports HIP version {ver or "?"}; the kernels are verified with {HIPCC_SERIES}.x '
+                           '(set SPI_ALLOW_ANY_HIPCC=1 to build with another compiler and re-run the GPU tests)')
+    return ver
+
+
 def _digest():
     h = hashlib.sha256(' '.join(FLAGS).encode())
     for name in SOURCES + ['common.hpp', os.path.join(ROOT, 'include', 'spi_hip.h')]:
@@ -34,6 +50,9 @@ def build(force=False, verbose=True):
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
         return LIB
+    ver = check_compiler(hipcc)
+    if verbose:
+        print(f'[spi_amd build] hipcc: HIP version {ver}', flush=True)
     objs = []
     procs = []
     for src in SOURCES:

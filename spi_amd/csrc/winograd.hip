@@ -24,6 +24,20 @@
 // The output transform (A^T M A), noise / bias / activation epilogue and the 2x2 stores run on the accumulators in registers.
 #include "common.hpp"
 
+// LDS-DMA loads take their LDS destination from M0.  M0 is a register the compiler manages itself (LDS instruction bounds, other DMA
+// builtins): an inline-asm statement that names it as a clobber is flagged by hipcc ("reserved register ... undefined behaviour"), because the
+// compiler may keep a value of its own in M0 across the statement.  So M0 is SAVED and RESTORED inside the same statement (two extra
+// scalar moves per transfer, off the vector issue port): whatever the compiler had there is intact when the statement ends.
+#define SPI_LDS_DMA_GLOBAL_X4(dst, voff, sbase)                                                                                   \
+    do { unsigned m0_keep_;                                                                                                      \
+         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"                \
+                      : "=&s"(m0_keep_) : "s"(dst), "v"(voff), "s"(sbase) : "memory"); } while (0)
+#define SPI_LDS_DMA_BUFFER_X1(dst, voff, rsrc, soff)                                                                              \
+    do { unsigned m0_keep_;                                                                                                      \
+         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"        \
+                      : "=&s"(m0_keep_) : "s"(dst), "v"(voff), "s"(rsrc), "s"(soff) : "memory"); } while (0)
+
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int WKC = 8;                 // input channels per slab
@@ -148,14 +162,14 @@ __global__ void __launch_bounds__(256, 1) wino_conv_kernel(WinoParams P, const f
         s = min(s, nslab - 1);
         const char* src = Ubase + (int64_t)s * 32 * P.ocp * 16;
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * WSLAB + (((i * 4 + wave) * 64) << 2)) * 4));
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(uvoff[i]), "s"(src) : "memory", "m0");
+        SPI_LDS_DMA_GLOBAL_X4(dst, uvoff[i], src);
     };
     auto copy_raw = [&](int rbuf, int s, int i) {                     // wave transfer i (0..10) of the raw window of slab s
         s = min(s, nslab - 1);
         const int soff = __builtin_amdgcn_readfirstlane(s * WKC * chs4);
         if (i < 10 || wave == 0) {                                   // 41 wave transfers: the last round is wave 0's alone
             const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((4 * WSLAB + rbuf * WRAW + (i * 4 + wave) * 64) * 4));
-            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(dst), "v"(voffR[i]), "s"(rsI), "s"(soff) : "memory", "m0");
+            SPI_LDS_DMA_BUFFER_X1(dst, voffR[i], rsI, soff);
         }
     };
 
@@ -433,8 +447,8 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
         const unsigned vo = rok ? (kind ? patD[i] : patX[i]) : BUF_OOB;
         const int soff = __builtin_amdgcn_readfirstlane(rok ? y * P.W * 4 : 0);
         const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(((kind ? GXR * GROW : 0) + (slot0 + r) * GROW + q * 64) * 4));
-        if (kind) asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rsD), "s"(soff) : "memory", "m0");
-        else      asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(dst), "v"(vo), "s"(rsX), "s"(soff) : "memory", "m0");
+        if (kind) SPI_LDS_DMA_BUFFER_X1(dst, vo, rsD, soff);
+        else      SPI_LDS_DMA_BUFFER_X1(dst, vo, rsX, soff);
     };
 
     // ---- operands: raw patch of (channel l32 of the quadrant, tile 2 p + h) -> 16 frequencies, in registers
