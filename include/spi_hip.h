@@ -27,10 +27,11 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 7   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 8   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive)
-                             * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive) */
+                             * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive)
+                             * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -221,6 +222,21 @@ int spi_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int in
                   int pady1, int flip, float gain, int outH, int outW,
                   const float* noise, const float* noise_gain, const float* bias, int act, float alpha,
                   float act_gain, float clamp, spi_stream_t stream);
+
+/* The same two plugin entry points with the tensor type as an argument, as the reference instantiates them (bias_act.cpp:81 and
+ * upfirdn2d.cpp:67 dispatch over half / float / double; its fp16 super-resolution blocks call them with half tensors in channels_last
+ * layout, networks_stylegan2.py:423-436).  dtype: SPI_DTYPE_F32 or SPI_DTYPE_F16 (every tensor argument of the call has that type, the
+ * FIR filter `f` stays float32 as in upfirdn2d.cpp:27); half tensors are computed in fp32 and rounded once at the store, like
+ * InternalType<half> in bias_act.cu:14-16.  Anything else returns SPI_ERR_UNSUPPORTED (-2): the caller falls back to its own path, the
+ * contract filtered_lrelu's rc = -1 has in the reference.
+ * spi_upfirdn2d_t takes element strides {n, c, h, w} of x and y (NULL = dense NCHW): dense NCHW and channels_last are accepted, in any
+ * combination, like the plugin's "non-overlapping and dense" rule (upfirdn2d.cpp:23).  No fused epilogue on this entry point. */
+enum { SPI_DTYPE_F32 = 0, SPI_DTYPE_F16 = 1 };
+int spi_bias_act_t(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y, int64_t n, int sizeB,
+                   int64_t stepB, int grad, int act, float alpha, float gain, float clamp, int dtype, spi_stream_t stream);
+int spi_upfirdn2d_t(const void* x, const float* f, void* y, int N, int C, int inH, int inW, const int64_t* x_strides,
+                    const int64_t* y_strides, int fH, int fW, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
+                    int pady1, int flip, float gain, int outH, int outW, int dtype, spi_stream_t stream);
 
 /* filtered_lrelu.cpp:20 `filtered_lrelu(x,fu,fd,b,si,up,down,px0,px1,py0,py1,sx,sy,gain,slope,clamp,flip,writeSigns)`
  * forward without sign tensors: bias -> up-FIR(gain up^2) -> lrelu*gain, clamp -> down-FIR.

@@ -124,6 +124,69 @@ __global__ void bias_act_kernel(const float* __restrict__ x, const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// Typed plugin boundary (spi_bias_act_t / spi_upfirdn2d_t): the reference's plugins are instantiated for half / float / double
+// (bias_act.cpp:81, upfirdn2d.cpp:67 AT_DISPATCH_FLOATING_TYPES_AND_HALF) and upfirdn2d takes any dense strides (channels_last for the
+// fp16 super-resolution blocks, upfirdn2d.cpp:42 suggest_memory_format).  Like there, the arithmetic is fp32 for half tensors
+// (InternalType<half> = float, bias_act.cu:14-16): one rounding, at the store.  fp64 is not offered (no caller on this path: -2).
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Vec4;
+template <> struct Vec4<float> { typedef float4 type; };
+typedef _Float16 spi_half4 __attribute__((ext_vector_type(4)));
+template <> struct Vec4<_Float16> { typedef spi_half4 type; };
+__device__ __forceinline__ float4 to_f4(const float4& v) { return v; }
+__device__ __forceinline__ float4 to_f4(const spi_half4& v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+template <typename T> __device__ __forceinline__ typename Vec4<T>::type from_f4(const float4& v);
+template <> __device__ __forceinline__ float4 from_f4<float>(const float4& v) { return v; }
+template <> __device__ __forceinline__ spi_half4 from_f4<_Float16>(const float4& v) {
+    spi_half4 o; o.x = (_Float16)v.x; o.y = (_Float16)v.y; o.z = (_Float16)v.z; o.w = (_Float16)v.w; return o;      // round-to-nearest-even, once
+}
+
+template <typename T, bool VEC>
+__global__ void bias_act_t_kernel(const T* __restrict__ x, const T* __restrict__ b, const T* __restrict__ xref, const T* __restrict__ yref,
+                                  const T* __restrict__ dy, T* __restrict__ y, int64_t n, int sizeB, int64_t stepB, ActParams p) {
+    typedef typename Vec4<T>::type V;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (VEC) {      // n % 4 == 0, stepB % 4 == 0, pointers aligned to 4 elements
+        const int64_t n4 = n >> 2;
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n4; g += stride) {
+            float4 xa = to_f4(reinterpret_cast<const V*>(x)[g]);
+            const float bv = b ? (float)b[((g << 2) / stepB) % sizeB] : 0.f;
+            float4 xr = xref ? to_f4(reinterpret_cast<const V*>(xref)[g]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 yr = yref ? to_f4(reinterpret_cast<const V*>(yref)[g]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 dv = dy ? to_f4(reinterpret_cast<const V*>(dy)[g]) : make_float4(1.f, 1.f, 1.f, 1.f);
+            if (p.grad == 0) { xa.x += bv; xa.y += bv; xa.z += bv; xa.w += bv; }
+            else { xr.x += bv; xr.y += bv; xr.z += bv; xr.w += bv; }
+            float4 o;
+            o.x = act_apply(p, xa.x, xr.x, yr.x, dv.x); o.y = act_apply(p, xa.y, xr.y, yr.y, dv.y);
+            o.z = act_apply(p, xa.z, xr.z, yr.z, dv.z); o.w = act_apply(p, xa.w, xr.w, yr.w, dv.w);
+            reinterpret_cast<V*>(y)[g] = from_f4<T>(o);
+        }
+    } else {
+        for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n; g += stride) {
+            const float bv = b ? (float)b[(g / stepB) % sizeB] : 0.f;
+            float xa = (float)x[g], xr = xref ? (float)xref[g] : 0.f;
+            if (p.grad == 0) xa += bv; else xr += bv;
+            y[g] = (T)act_apply(p, xa, xr, yref ? (float)yref[g] : 0.f, dy ? (float)dy[g] : 1.f);
+        }
+    }
+}
+
+template <typename T>
+static int launch_bias_act_t(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y, int64_t n, int sizeB,
+                             int64_t stepB, const ActParams& p, spi_stream_t stream) {
+    const uintptr_t al = 4 * sizeof(T) - 1;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)xref | (uintptr_t)yref | (uintptr_t)dy) & al) == 0;
+    const bool vec = aligned && (n % 4 == 0) && (b == nullptr || stepB % 4 == 0);
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(vec ? n / 4 : n, 256), 256 * 16);
+    if (vec) hipLaunchKernelGGL((bias_act_t_kernel<T, true>), dim3(grid), dim3(256), 0, as_stream(stream), (const T*)x, (const T*)b, (const T*)xref,
+                                (const T*)yref, (const T*)dy, (T*)y, n, sizeB, stepB, p);
+    else hipLaunchKernelGGL((bias_act_t_kernel<T, false>), dim3(grid), dim3(256), 0, as_stream(stream), (const T*)x, (const T*)b, (const T*)xref,
+                            (const T*)yref, (const T*)dy, (T*)y, n, sizeB, stepB, p);
+    SPI_LAUNCH_CHECK("spi_bias_act_t");
+    return SPI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Layer-tail backward: activation gradient + bias gradient (sum over n, hw) + noise gradient
 // (sum over n, c) in one pass.  Block = 256 threads x PX consecutive pixels; blockIdx.y picks a chunk
 // of channels.  Per channel the block adds 4 wave-partials to d_bias[c]; the per-pixel sums stay in
@@ -334,6 +397,42 @@ __global__ void __launch_bounds__(256) upfirdn2d_kernel(const float* __restrict_
         if (noise) acc += noise[rem] * ng;
         if (ap.act != 0) acc = act_apply(ap, acc + (bias ? bias[c] : 0.f), 0.f, 0.f, 1.f);
         y[g] = acc;
+    }
+}
+
+struct Strides4 { int64_t n, c, h, w; };
+
+// generic upfirdn2d over arbitrary dense strides (NCHW or channels_last), typed I/O, fp32 taps and accumulation.  The thread index runs over
+// the OUTPUT in its own memory order (the stride with |w| == 1 fastest for NCHW, c fastest for channels_last), so stores stay coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256) upfirdn2d_t_kernel(const T* __restrict__ x, const float* __restrict__ f, T* __restrict__ y, UpfirdnParams p,
+                                                          Strides4 xs, Strides4 ys, int c_fastest) {
+    __shared__ float sf[MAX_TAPS];
+    for (int i = threadIdx.x; i < p.fH * p.fW; i += blockDim.x) {
+        const int ty = i / p.fW, tx = i % p.fW;
+        sf[i] = (p.flip ? f[ty * p.fW + tx] : f[(p.fH - 1 - ty) * p.fW + (p.fW - 1 - tx)]) * p.gain;
+    }
+    __syncthreads();
+    const int64_t total = (int64_t)p.N * p.C * p.outH * p.outW;
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+        int n, c, oy, ox;
+        if (c_fastest) { c = (int)(g % p.C); int64_t r = g / p.C; ox = (int)(r % p.outW); r /= p.outW; oy = (int)(r % p.outH); n = (int)(r / p.outH); }
+        else { ox = (int)(g % p.outW); int64_t r = g / p.outW; oy = (int)(r % p.outH); r /= p.outH; c = (int)(r % p.C); n = (int)(r / p.C); }
+        const T* xp = x + n * xs.n + c * xs.c;
+        const int by = oy * p.downy - p.pady0, bx = ox * p.downx - p.padx0;
+        int ty0 = (-by) % p.upy; if (ty0 < 0) ty0 += p.upy;
+        int tx0 = (-bx) % p.upx; if (tx0 < 0) tx0 += p.upx;
+        float acc = 0.f;
+        for (int ty = ty0; ty < p.fH; ty += p.upy) {
+            const int iy = (by + ty) / p.upy;
+            if (by + ty < 0 || iy >= p.inH) continue;
+            for (int tx = tx0; tx < p.fW; tx += p.upx) {
+                const int ix = (bx + tx) / p.upx;
+                if (bx + tx < 0 || ix >= p.inW) continue;
+                acc = fmaf(sf[ty * p.fW + tx], (float)xp[iy * xs.h + ix * xs.w], acc);
+            }
+        }
+        y[n * ys.n + c * ys.c + oy * ys.h + ox * ys.w] = (T)acc;
     }
 }
 
@@ -1165,6 +1264,50 @@ int spi_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int in
     UpfirdnParams p{N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, pady0, flip, outH, outW, gain};
     ActParams ap{act, 0, alpha, act_gain, clamp};
     return launch_upfirdn(x, f, y, p, nullptr, noise, noise_gain, bias, ap, stream);
+}
+
+int spi_bias_act_t(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y, int64_t n, int sizeB,
+                   int64_t stepB, int grad, int act, float alpha, float gain, float clamp, int dtype, spi_stream_t stream) {
+    if (dtype == SPI_DTYPE_F32)
+        return spi_bias_act((const float*)x, (const float*)b, (const float*)xref, (const float*)yref, (const float*)dy, (float*)y, n, sizeB, stepB,
+                            grad, act, alpha, gain, clamp, stream);
+    if (dtype != SPI_DTYPE_F16) { spi_set_error("spi_bias_act_t: dtype %d (0 = fp32, 1 = fp16; fp64 has no kernel in this build)", dtype); return SPI_ERR_UNSUPPORTED; }
+    SPI_REQUIRE(x && y && n > 0, "spi_bias_act_t: null tensor or empty");
+    SPI_REQUIRE(act >= SPI_ACT_LINEAR && act <= SPI_ACT_SWISH, "spi_bias_act_t: unknown activation %d", act);
+    SPI_REQUIRE(grad >= 0 && grad <= 2, "spi_bias_act_t: grad must be 0, 1 or 2");
+    SPI_REQUIRE(b == nullptr || (sizeB > 0 && stepB > 0), "spi_bias_act_t: bias given without sizeB/stepB");
+    ActParams p{act, grad, alpha, gain, clamp};
+    return launch_bias_act_t<_Float16>(x, b, xref, yref, dy, y, n, sizeB, stepB, p, stream);
+}
+
+int spi_upfirdn2d_t(const void* x, const float* f, void* y, int N, int C, int inH, int inW, const int64_t* x_strides, const int64_t* y_strides,
+                    int fH, int fW, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain,
+                    int outH, int outW, int dtype, spi_stream_t stream) {
+    SPI_REQUIRE(x && f && y, "spi_upfirdn2d_t: null tensor");
+    SPI_REQUIRE(N > 0 && C > 0 && inH > 0 && inW > 0 && fH > 0 && fW > 0 && fH * fW <= MAX_TAPS, "spi_upfirdn2d_t: bad sizes");
+    SPI_REQUIRE(upx >= 1 && upy >= 1 && downx >= 1 && downy >= 1, "spi_upfirdn2d_t: bad up/down factors");
+    const int eh = (inH * upy + pady0 + pady1 - fH + downy) / downy, ew = (inW * upx + padx0 + padx1 - fW + downx) / downx;
+    SPI_REQUIRE(outH == eh && outW == ew && outH > 0 && outW > 0, "spi_upfirdn2d_t: output size must be %dx%d, got %dx%d", eh, ew, outH, outW);
+    if (dtype != SPI_DTYPE_F32 && dtype != SPI_DTYPE_F16) { spi_set_error("spi_upfirdn2d_t: dtype %d (0 = fp32, 1 = fp16)", dtype); return SPI_ERR_UNSUPPORTED; }
+    const Strides4 xs = x_strides ? Strides4{x_strides[0], x_strides[1], x_strides[2], x_strides[3]} : Strides4{(int64_t)C * inH * inW, (int64_t)inH * inW, inW, 1};
+    const Strides4 ys = y_strides ? Strides4{y_strides[0], y_strides[1], y_strides[2], y_strides[3]} : Strides4{(int64_t)C * outH * outW, (int64_t)outH * outW, outW, 1};
+    const bool dense_nchw = xs.w == 1 && xs.h == inW && xs.c == (int64_t)inH * inW && xs.n == xs.c * C && ys.w == 1 && ys.h == outW && ys.c == (int64_t)outH * outW && ys.n == ys.c * C;
+    if (dtype == SPI_DTYPE_F32 && dense_nchw)            // the tuned fp32 kernels of the loop
+        return spi_upfirdn2d((const float*)x, f, (float*)y, N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, outH,
+                             outW, nullptr, nullptr, nullptr, 0, 0.f, 1.f, -1.f, stream);
+    // both tensors must be dense in SOME permutation with non-overlapping elements: the two layouts the reference produces
+    const bool cl_x = xs.c == 1 && xs.w == C && xs.h == (int64_t)inW * C && xs.n == (int64_t)inH * inW * C;
+    const bool cl_y = ys.c == 1 && ys.w == C && ys.h == (int64_t)outW * C && ys.n == (int64_t)outH * outW * C;
+    const bool nchw_x = xs.w == 1 && xs.h == inW && xs.c == (int64_t)inH * inW && xs.n == xs.c * C;
+    const bool nchw_y = ys.w == 1 && ys.h == outW && ys.c == (int64_t)outH * outW && ys.n == ys.c * C;
+    SPI_REQUIRE((cl_x || nchw_x) && (cl_y || nchw_y), "spi_upfirdn2d_t: tensors must be dense NCHW or channels_last (upfirdn2d.cpp:23 'non-overlapping and dense')");
+    UpfirdnParams p{N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, pady0, flip, outH, outW, gain};
+    const int64_t total = (int64_t)N * C * outH * outW;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div64(total, 256), 256 * 32);
+    if (dtype == SPI_DTYPE_F16) hipLaunchKernelGGL(upfirdn2d_t_kernel<_Float16>, dim3(grid), dim3(256), 0, as_stream(stream), (const _Float16*)x, f, (_Float16*)y, p, xs, ys, cl_y ? 1 : 0);
+    else hipLaunchKernelGGL(upfirdn2d_t_kernel<float>, dim3(grid), dim3(256), 0, as_stream(stream), (const float*)x, f, (float*)y, p, xs, ys, cl_y ? 1 : 0);
+    SPI_LAUNCH_CHECK("spi_upfirdn2d_t");
+    return SPI_OK;
 }
 
 int spi_filtered_lrelu(const float* x, const float* fu, const float* fd, const float* b, float* tmp, float* y, int N, int C,

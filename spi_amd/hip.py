@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
-ABI_VERSION = 7          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
+ABI_VERSION = 8          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -49,6 +49,8 @@ _SIGS = {
     'spi_seg_flags': ([c_p, c_p, c_i, c_i, c_l, c_p], c_i),
     'spi_bias_act': ([c_p] * 6 + [c_l, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_p], c_i),
     'spi_upfirdn2d': ([c_p] * 3 + [c_i] * 15 + [c_f, c_i, c_i] + [c_p] * 3 + [c_i, c_f, c_f, c_f, c_p], c_i),
+    'spi_bias_act_t': ([c_p] * 6 + [c_l, c_i, c_l, c_i, c_i, c_f, c_f, c_f, c_i, c_p], c_i),
+    'spi_upfirdn2d_t': ([c_p] * 3 + [c_i] * 4 + [c_p, c_p] + [c_i] * 11 + [c_f, c_i, c_i, c_i, c_p], c_i),
     'spi_filtered_lrelu': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f, c_i, c_i, c_i, c_p], c_i),
     'spi_filtered_lrelu_fused': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f] + [c_i] * 8 + [c_p], c_i),
     'spi_filtered_lrelu_act': ([c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_p], c_i),
@@ -102,6 +104,17 @@ def lib():
 
 
 _PTR_DTYPES = (torch.float32, torch.int32, torch.int64, torch.uint8)
+DTYPE_IDS = {torch.float32: 0, torch.float16: 1}          # SPI_DTYPE_* of the typed plugin entry points (spi_bias_act_t, spi_upfirdn2d_t)
+
+
+def ptr_any(t):
+    """Device pointer of a GPU tensor of any dtype / dense layout for the typed entry points (the caller passes dtype and strides)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('spi_amd kernels need GPU tensors (no CPU fallback); got a %s tensor' % t.device.type)
+    return t.data_ptr()
+
 
 
 def ptr(t):

@@ -29,6 +29,10 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
     if b is not None:
         for d in x.shape[dim + 1:]:
             step_b *= d
+    if x.dtype == torch.float16:        # the reference's plugin is instantiated for half too (bias_act.cpp:81): fp32 arithmetic, one rounding at the store
+        hip.call('spi_bias_act_t', hip.ptr_any(x), hip.ptr_any(b), hip.ptr_any(xref), hip.ptr_any(yref), hip.ptr_any(dy), hip.ptr_any(y), x.numel(),
+                 size_b, step_b, grad, act_id, alpha, gain, clamp, hip.DTYPE_IDS[x.dtype], hip.stream())
+        return y
     hip.call('spi_bias_act', hip.ptr(x), hip.ptr(b), hip.ptr(xref), hip.ptr(yref), hip.ptr(dy), hip.ptr(y), x.numel(), size_b,
              step_b, grad, act_id, alpha, gain, clamp, hip.stream())
     return y
@@ -73,8 +77,9 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b, dim, act_id, alpha, gain, clamp, ref):
-        x = x.contiguous().float()
-        bb = b.contiguous().float() if b is not None else None
+        dt = torch.float16 if x.dtype == torch.float16 else torch.float32          # half stays half (b follows x, bias_act.py:146-148 of the reference)
+        x = x.contiguous().to(dt)
+        bb = b.contiguous().to(dt) if b is not None else None
         y = _launch(x, bb, None, None, None, 0, dim, act_id, alpha, gain, clamp)
         # the clamp mask needs the output for every activation (the reference's plugin drops it for
         # 'linear' and so ignores the clamp in that backward; its CPU path -- our oracle -- does not)
@@ -87,7 +92,8 @@ class _BiasAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, b, y = ctx.saved_tensors
         dim, act_id, alpha, gain, clamp, has_b = ctx.cfg
-        dy = dy.contiguous().float()
+        ref_t = y if y is not None else x
+        dy = dy.contiguous().to(ref_t.dtype if ref_t is not None else (torch.float16 if dy.dtype == torch.float16 else torch.float32))
         dx = dy
         if act_id != 1 or gain != 1 or clamp >= 0:
             dx = _launch(dy, b, x, y, None, 1, dim, act_id, alpha, gain, clamp)

@@ -75,8 +75,43 @@ def _launch(x, f2d, up, down, pad, flip, gain, epilogue=None):
     return y
 
 
+def _launch_typed(x, f2d, up, down, pad, flip, gain):
+    """fp16 and / or channels_last tensors (the reference's use_fp16 blocks hand the plugin half tensors in channels_last layout,
+    networks_stylegan2.py:423-436): spi_upfirdn2d_t with the dtype and both stride sets; the output keeps x's dtype and memory format
+    (upfirdn2d.cpp:42 suggest_memory_format)."""
+    n, c, ih, iw = x.shape
+    fh, fw = f2d.shape
+    upx, upy = up
+    dx, dy = down
+    px0, px1, py0, py1 = pad
+    oh = (ih * upy + py0 + py1 - fh + dy) // dy
+    ow = (iw * upx + px0 + px1 - fw + dx) // dx
+    assert oh >= 1 and ow >= 1
+    cl = x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous()
+    if not (cl or x.is_contiguous()):
+        x = x.contiguous()
+    y = torch.empty(n, c, oh, ow, device=x.device, dtype=x.dtype, memory_format=torch.channels_last if cl else torch.contiguous_format)
+    import ctypes
+    xs = (ctypes.c_int64 * 4)(*x.stride())
+    ys = (ctypes.c_int64 * 4)(*y.stride())
+    hip.call('spi_upfirdn2d_t', hip.ptr_any(x), hip.ptr(f2d), hip.ptr_any(y), n, c, ih, iw, ctypes.cast(xs, ctypes.c_void_p), ctypes.cast(ys, ctypes.c_void_p),
+             fh, fw, upx, upy, dx, dy, px0, px1, py0, py1, int(flip), float(gain), oh, ow, hip.DTYPE_IDS[x.dtype], hip.stream())
+    return y
+
+
 def _run(x, f, up, down, pad, flip, gain):
     """Non-differentiable core; handles None / separable filters like the reference (upfirdn2d.py:240-250)."""
+    typed = x.dtype == torch.float16 or (x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
+    if typed:
+        if f is None:
+            f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+        f = f.to(x.device).float().contiguous()
+        if f.ndim == 1 and f.shape[0] == 1:
+            f = f.square().unsqueeze(0)
+        if f.ndim == 2:
+            return _launch_typed(x, f, up, down, pad, flip, gain)
+        y = _launch_typed(x, f.unsqueeze(0).contiguous(), (up[0], 1), (down[0], 1), (pad[0], pad[1], 0, 0), flip, 1.0)
+        return _launch_typed(y, f.unsqueeze(1).contiguous(), (1, up[1]), (1, down[1]), (0, 0, pad[2], pad[3]), flip, gain)
     x = x.contiguous().float()
     if f is None:
         f = torch.ones([1, 1], dtype=torch.float32, device=x.device)

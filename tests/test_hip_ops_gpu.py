@@ -256,3 +256,93 @@ def test_affine_layer_matrix_vector_kernels(n, i, o):
     xr = x.detach().double().cpu().requires_grad_(True)
     (dxr,) = torch.autograd.grad((xr @ (fc.weight.double().cpu() * fc.weight_gain).t() + fc.bias.double().cpu() * fc.bias_gain).square().sum(), [xr])
     assert_close(dx, dxr.float(), 3e-6, 'affine dx (frozen)')
+
+
+# ---- the typed plugin boundary (round 4): fp16 tensors and channels_last strides, as the reference's plugins are instantiated ----------------
+def _half_ulps(a, b):
+    """largest difference of two fp16 tensors in units of b's ulp (0 = bit-equal)"""
+    a, b = a.detach().cpu().float(), b.detach().cpu().float()
+    ulp = torch.maximum(b.abs(), torch.full_like(b, 2.0 ** -14)).log2().floor().exp2() * 2.0 ** -10
+    return ((a - b).abs() / ulp).max().item()
+
+
+def test_bias_act_fp16_golden_cases(golden):
+    """bias_act.cpp:81 dispatches the plugin over half / float / double; half tensors are computed in fp32 and rounded once at the store
+    (bias_act.cu:14-16 InternalType).  The 11 golden activation / clamp cases with fp16 x, b, dy: the result must be the fp32 oracle of the
+    fp16-rounded inputs, rounded to fp16 (<= 1 fp16 ulp: transcendental functions differ in the last fp32 bit); outputs stay fp16."""
+    from spi_amd.torch_utils.ops import bias_act
+    g = golden('ops')
+    cases = json.loads(str(g.z['ba_cases'][0]))
+    x16, b16, dy16 = g['ba_x'].half(), g['ba_b'].half(), g['ba_dy'].half()
+    for i, (act, alpha, gain, clamp) in enumerate(cases):
+        x = x16.to(DEV).requires_grad_(True)
+        b = b16.to(DEV).requires_grad_(True)
+        y = bias_act.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        assert y.dtype == torch.float16
+        xr, br = x16.float().requires_grad_(True), b16.float().requires_grad_(True)
+        yr = osg.bias_act(xr, br, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        assert _half_ulps(y, yr.half()) <= 1.0, (act, clamp, _half_ulps(y, yr.half()))
+        gx, gb = torch.autograd.grad(y, [x, b], dy16.to(DEV))
+        assert gx.dtype == torch.float16
+        # the backward reads the SAVED fp16 output (the reference plugin's yref): its oracle is the fp32 formula on that rounded tensor
+        gxr, gbr = torch.autograd.grad(yr, [xr, br], dy16.float())
+        assert_close(gx, gxr, 4e-3, f'fp16 bias_act {act} dx')
+        assert_close(gb, gbr, 4e-3, f'fp16 bias_act {act} db')
+    # odd sizes take the scalar kernel, multiples of 4 the 8-byte vector kernel: same numbers
+    xo = torch.randn(3, 5, 7, generator=torch.Generator().manual_seed(3)).half()
+    bo = torch.randn(5, generator=torch.Generator().manual_seed(4)).half()
+    y = bias_act.bias_act(xo.to(DEV), bo.to(DEV), act='lrelu', clamp=0.9)
+    assert _half_ulps(y, osg.bias_act(xo.float(), bo.float(), act='lrelu', clamp=0.9).half()) <= 1.0
+
+
+def test_upfirdn2d_fp16_and_channels_last(golden):
+    """upfirdn2d.cpp:67 dispatches over half / float / double and keeps the input's memory format (:42): the six golden pad / up / down cases
+    with (a) fp16 NCHW, (b) fp32 channels_last, (c) fp16 channels_last -- what the reference's fp16 super-resolution blocks hand the plugin."""
+    from spi_amd.torch_utils.ops import upfirdn2d
+    g = golden('ops')
+    f = g['fir'].to(DEV)
+    cases = json.loads(str(g.z['uf_cases'][0]))
+    for i, kw in enumerate(cases):
+        x32 = g['uf_x']
+        ref = g[f'uf_y{i}']
+        xcl = x32.to(DEV).contiguous(memory_format=torch.channels_last)
+        ycl = upfirdn2d.upfirdn2d(xcl, f, **kw)
+        assert ycl.dtype == torch.float32 and ycl.is_contiguous(memory_format=torch.channels_last)
+        assert_close(ycl, ref, 2e-6, f'upfirdn2d[{i}] fp32 channels_last')
+        x16 = x32.half()
+        ref16 = osg.upfirdn2d(x16.float(), g['fir'], **kw).half()
+        for tag, xin in (('nchw', x16.to(DEV)), ('channels_last', x16.to(DEV).contiguous(memory_format=torch.channels_last))):
+            xin = xin.requires_grad_(True)
+            y = upfirdn2d.upfirdn2d(xin, f, **kw)
+            assert y.dtype == torch.float16 and y.shape == ref.shape
+            assert y.is_contiguous(memory_format=torch.channels_last) == (tag == 'channels_last')
+            assert _half_ulps(y, ref16) <= 1.0, (i, tag, _half_ulps(y, ref16))
+            gx, = torch.autograd.grad(y, xin, g[f'uf_dy{i}'].half().to(DEV))
+            assert gx.dtype == torch.float16
+            assert_close(gx, g[f'uf_gx{i}'], 3e-3, f'upfirdn2d[{i}] fp16 {tag} dx')
+
+
+def test_typed_entry_points_through_the_c_abi():
+    """spi_bias_act_t / spi_upfirdn2d_t called directly: dtype 0 forwards to the fp32 kernels, dtype 1 is fp16, anything else returns
+    SPI_ERR_UNSUPPORTED (-2) with a message -- the caller's cue to fall back, like filtered_lrelu's rc = -1 in the reference."""
+    import ctypes
+    from spi_amd import hip
+    x = torch.randn(2, 4, 6, 6, device=DEV)
+    b = torch.randn(4, device=DEV)
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    hip.call('spi_bias_act', hip.ptr(x), hip.ptr(b), None, None, None, hip.ptr(y0), x.numel(), 4, 36, 0, 3, 0.2, 1.4142, -1.0, hip.stream())
+    hip.call('spi_bias_act_t', hip.ptr(x), hip.ptr(b), None, None, None, hip.ptr(y1), x.numel(), 4, 36, 0, 3, 0.2, 1.4142, -1.0, 0, hip.stream())
+    assert torch.equal(y0, y1)
+    xh, bh, yh = x.half(), b.half(), torch.empty_like(x, dtype=torch.float16)
+    hip.call('spi_bias_act_t', xh.data_ptr(), bh.data_ptr(), None, None, None, yh.data_ptr(), x.numel(), 4, 36, 0, 3, 0.2, 1.4142, -1.0, 1, hip.stream())
+    assert _half_ulps(yh, osg.bias_act(xh.float().cpu(), bh.float().cpu(), act='lrelu', gain=1.4142).half()) <= 1.0
+    rc = hip.lib().spi_bias_act_t(hip.ptr(x), None, None, None, None, hip.ptr(y1), x.numel(), 0, 0, 0, 3, 0.2, 1.0, -1.0, 2, hip.stream())
+    assert rc == -2 and b'dtype 2' in hip.lib().spi_last_error()
+    f = torch.tensor([[1., 2.], [3., 4.]], device=DEV) / 10
+    yo = torch.empty(2, 4, 5, 5, device=DEV)
+    rc = hip.lib().spi_upfirdn2d_t(hip.ptr(x), hip.ptr(f), hip.ptr(yo), 2, 4, 6, 6, None, None, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, 5, 5, 7, hip.stream())
+    assert rc == -2
+    bad = (ctypes.c_int64 * 4)(144, 36, 12, 2)                     # overlapping / non-dense strides are refused, like the plugin (upfirdn2d.cpp:23)
+    rc = hip.lib().spi_upfirdn2d_t(hip.ptr(x), hip.ptr(f), hip.ptr(yo), 2, 4, 6, 6, ctypes.cast(bad, ctypes.c_void_p), None, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0,
+                                   5, 5, 0, hip.stream())
+    assert rc == -1 and b'dense' in hip.lib().spi_last_error()
