@@ -460,7 +460,10 @@ def main():
         marks['stage2_s'] = time.perf_counter() - tb
         marks['stage2_ms_per_step'] = marks['stage2_s'] / max(n2, 1) * 1e3
 
-    setup_iters = int(os.environ.get('SPI_BENCH_SETUP_ITERS', '0'))
+    # set-up, not warm-up (like the stage-1 graph above): the stage-2 loop captures one HIP graph per iteration kind on the SECOND occurrence of
+    # that kind (plain: iteration 2, with branches: iteration 4).  A real 1000-iteration run pays the two captures once; here they are built
+    # before the W warm-up steps, so neither the warm-up nor the K timed steps contain a capture.
+    setup_iters = int(os.environ.get('SPI_BENCH_SETUP_ITERS', '8' if (global_config.stage2_hip_graph and not pti and args.only != 'stage1') else '0'))
     if setup_iters:
         run(0, setup_iters, 0, 400)
     w1, w2 = split_steps(args.warmup)
@@ -572,14 +575,15 @@ def main():
         main_marks = dict(marks)
         alt_err = None
         try:
-            run(2 if k1 else 0, min(w2, 4), step1_next, step2_next)      # (2 stage-1 steps: the projector re-captures its graph for this arithmetic)
+            leg_warm = 8 if global_config.stage2_hip_graph else 4   # (both stage-2 graphs are re-captured for another arithmetic: second occurrence of each kind)
+            run(2 if k1 else 0, leg_warm if k2 else 0, step1_next, step2_next)      # (2 stage-1 steps: the projector re-captures its graph for this arithmetic)
         except Exception as e:                                    # noqa: BLE001
             alt_err = repr(e)
         sdist.barrier(); torch.cuda.synchronize()
         ta = time.perf_counter()
         try:
             if alt_err is None:
-                run(k1, k2, step1_next + 2, step2_next + 4)
+                run(k1, k2, step1_next + 2, step2_next + leg_warm)
         except Exception as e:                                    # noqa: BLE001
             alt_err = repr(e)
         torch.cuda.synchronize(); sdist.barrier()
@@ -604,9 +608,10 @@ def main():
         dense_err = None
         base2 = step2_next + ((k2 + 11) // 4) * 4
         try:
-            run(0, 4, 0, base2)                                   # one untimed super-cycle (allocator / workspace shapes of the dense branches)
+            leg_warm = 8 if global_config.stage2_hip_graph else 4
+            run(0, leg_warm, 0, base2)                            # untimed super-cycle(s): allocator / workspace shapes of the dense branches, graph re-capture
             sdist.barrier(); torch.cuda.synchronize()
-            run(0, k2, 0, base2 + 4)
+            run(0, k2, 0, base2 + leg_warm)
         except Exception as e:                                    # noqa: BLE001
             dense_err = repr(e)
         torch.cuda.synchronize(); sdist.barrier()
@@ -658,7 +663,8 @@ def main():
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else '')), 'step_mix': {'value_mix': 'stage1:stage2 = 1:2 exact (500:1000), computed from the per-stage rates' if (k1 and k2) else 'single stage', 'timed_steps': {'stage1_mir': k1, 'stage2_rotbbox': k2}},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
-                       'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph),
+                       'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph and not pti and getattr(coach, '_g2', None) is not None and not getattr(coach, '_graph_failed', False)),
+                       'stage2_graph_build_iterations_before_warmup': setup_iters,
                        'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
                                    if global_config.conv_winograd and global_config.conv_precision in (0, 3) else 'implicit GEMM'),
                        'sparsity': 'dense (every ray / gradient segment / SR tile processed; NOT the benchmark configuration)' if args.dense else

@@ -49,13 +49,15 @@ conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
 stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'
 
 # stage 2: the same for the RotBbox iteration (rot_bbox_cx_coach.py): one graph for the plain iteration, one for the iteration with the
-# rot / mirror-rot / depth branches.  OPT-IN (SPI_STAGE2_GRAPH=1).  It replays correctly at full size since round 3 (BoxCX uses amin / amax:
+# rot / mirror-rot / depth branches.  ON by default since round 4 (SPI_STAGE2_GRAPH=0 switches it off).  It replays correctly at full size since round 3 (BoxCX uses amin / amax:
 # the index scatter of torch.min's backward faulted under replay; test_stage2_hip_graph_replay_equals_eager_iterations_full_size) and the
 # replays are PIPELINED: the early-stop comparison is ORed into a sticky device byte, the Adam launch is predicated on it, and the host
 # reads the byte of iteration i - 2 when it launches iteration i.  Measured: 35.8 vs 35.4 it/s eager in steady state, 38.8 vs 39.3 over a
 # whole 1 500-iteration job with its two captures (the first version, which read the flag after every replay, ran 33.0 vs 35.0) -- the
-# iteration is GPU-bound, so eager stays the default and the graph buys host time (one graph launch instead of ~25 ms of enqueue work).
-stage2_hip_graph = os.environ.get('SPI_STAGE2_GRAPH', '0') == '1'
+# iteration is GPU-bound: the graph buys HOST time (one graph launch instead of ~25 ms of single-thread enqueue work per iteration), which is
+# what eight ranks sharing one host's cores need (dist.pin_rank_affinity), and a little throughput (round 4: 45.46 vs 45.31 it/s over 300 steps).
+# Draw sources that are not the device generator (tests replaying recorded draws) and concurrent_branches keep the eager iteration.
+stage2_hip_graph = os.environ.get('SPI_STAGE2_GRAPH', '1') != '0'
 
 # host side: freeze Python's garbage collector state around the optimisation loops (torch_utils/misc.quiet_gc): a full collection over the
 # whole heap costs 50-80 ms = two or three iterations whenever it strikes inside a loop.

@@ -68,9 +68,10 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 // -------------------------------------------------------------------------------------------------
 //   AMF (needs BUF): the A-tile loader runs its lanes along m instead of k -- for the dgrad of tap-major
 //   weights (m = input channel is the contiguous axis) that turns 16 scattered 4-byte reads into one line.
-//   F16 (needs BUF, no SPLITK): operands are rounded to fp16 when they are staged in LDS ([k/4][m][4] halves, one 8-byte
-//   fragment per lane) and multiplied on v_mfma_f32_32x32x8_f16 with fp32 accumulation -- the precision of the reference's
-//   `use_fp16` super-resolution blocks (superresolution.py:271), at 16x the fp32 matrix rate.
+//   F16 (needs BUF, no SPLITK): operands are rounded to fp16 (nearest even) when they are staged in LDS -- [k/8][m][8] halves, one 16-byte
+//   fragment per lane, the same cell layout as a split-bf16 piece -- and a K = 16 slab is ONE gfx950 v_mfma_f32_32x32x16_f16 per 32 x 32 tile
+//   with fp32 accumulation (round 3 issued two CDNA3-style v_mfma_f32_32x32x8_f16 per slab: half the matrix rate, twice the fragment reads):
+//   the precision of the reference's `use_fp16` super-resolution blocks (superresolution.py:271), at 16x the fp32 matrix rate.
 //   PREC 2 / 3 (needs BUF, no SPLITK): "split bf16" -- every fp32 operand is cut into 2 / 3 bf16 pieces when it is staged in LDS
 //   (x = c0 + c1 [+ c2] exactly up to 2^-16 / 2^-24 relative: truncating splits, each residual is exact) and the product is the sum of
 //   the 3 / 6 significant piece products on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: c0*c0 + c0*c1 + c1*c0 [+ c0*c2 + c2*c0 +
@@ -78,6 +79,7 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 //   matrix rate is 16x the fp32 one: 3 / 6 MFMAs of K = 16 replace 8 of K = 2 (64 cycles each) -- 5.3x / 2.7x less matrix-pipe time
 //   at an error of ~2^-16 / ~2^-23 per product.  LDS layout per piece: [k/8][m][8 bf16] = one 16-byte fragment per lane.
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 constexpr int prec_pieces(int prec) { return prec == 3 ? 3 : 2; }
 constexpr int prec_lds_factor(int prec) { return prec == 3 ? 3 : 2; }          // LDS halves per element / 1  (fp32 = 2 halves)
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
             if (j == 0) store_split_run<NS, A_PER>(As[buf], LDA, a_m, a_k, S.ra);
         } else if constexpr (F16) {
             const int k = AMF ? a_k + j * A_KSTEP : a_k, m = AMF ? a_m : a_m + j * A_MSTEP;
-            reinterpret_cast<_Float16*>(As[buf])[((k >> 2) * LDA + m) * 4 + (k & 3)] = (_Float16)S.ra[j];
+            reinterpret_cast<_Float16*>(As[buf])[((k >> 3) * LDA + m) * 8 + (k & 7)] = (_Float16)S.ra[j];
         } else if (AMF) As[buf][(a_k + j * A_KSTEP) * LDA + a_m] = S.ra[j];
         else As[buf][a_k * LDA + a_m + j * A_MSTEP] = (BUF || ((S.am >> j) & 1u)) ? S.ra[j] : 0.f;
     };
@@ -358,7 +360,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
             if (j == 0) store_split_run<NS, B_PER>(Bs[buf], LDB, b_p, b_k, S.rb);
         } else if constexpr (F16) {
             const int k = b_k + j * B_KSTEP;
-            reinterpret_cast<_Float16*>(Bs[buf])[((k >> 2) * LDB + b_p) * 4 + (k & 3)] = (_Float16)S.rb[j];
+            reinterpret_cast<_Float16*>(Bs[buf])[((k >> 3) * LDB + b_p) * 8 + (k & 7)] = (_Float16)S.rb[j];
         } else Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? S.rb[j] : 0.f;
     };
 
@@ -418,9 +420,34 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
             __syncthreads();
             return;
         }
-        constexpr int NK = F16 ? BK / 8 : BK / 2;
-        // one body for both operand types: FragT = float (one k per lane half) or 4 halves (k = 4*half .. 4*half+3)
-        using FragT = typename std::conditional<F16, half4_t, float>::type;
+        if constexpr (F16) {
+            // one K = 16 MFMA per tile and slab: lane half fk holds k = 8 fk .. 8 fk + 7 of its row / pixel (one 16-byte LDS read per fragment)
+            static_assert(BK == 16, "one v_mfma_f32_32x32x16_f16 per slab");
+            const half8_t* Ab = reinterpret_cast<const half8_t*>(As[buf]) + fk * LDA + wm * TM * 32 + fr;
+            const half8_t* Bb = reinterpret_cast<const half8_t*>(Bs[buf]) + fk * LDB + wn * TN * 32 + fr;
+            half8_t af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) load_a(L, q2, j);              // slab s+2 requested behind the MFMAs
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) load_b(L, q2, j);
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) store_a(W, buf ^ 1, j);         // slab s+1 rounded and written to the other buffer
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) store_b(W, buf ^ 1, j);
+            __syncthreads();
+            return;
+        }
+        constexpr int NK = BK / 2;
+        using FragT = float;
         const FragT* Ab = reinterpret_cast<const FragT*>(As[buf]) + wm * TM * 32 + fr;
         const FragT* Bb = reinterpret_cast<const FragT*>(Bs[buf]) + wn * TN * 32 + fr;
         // fragments are read one MFMA group ahead (two register sets), so the lgkmcnt wait in front of a
@@ -441,10 +468,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kk < NK / 2) {               // first half of the MFMA groups: request slab s+2
 #pragma unroll
@@ -646,7 +670,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
             unsigned short* base = reinterpret_cast<unsigned short*>(As[buf]) + (((l_p >> 3) * LDA + l_r + q * ROWSTEP) << 3) + (l_p & 7);
 #pragma unroll
             for (int z = 0; z < NS; ++z) base[z * 2 * LDA * 8] = c[z];
-        } else if constexpr (F16) reinterpret_cast<_Float16*>(As[buf])[((l_p >> 2) * LDA + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.ra[q];
+        } else if constexpr (F16) reinterpret_cast<_Float16*>(As[buf])[((l_p >> 3) * LDA + l_r + q * ROWSTEP) * 8 + (l_p & 7)] = (_Float16)S.ra[q];
         else As[buf][l_p * LDA + l_r + q * ROWSTEP] = S.ra[q];
     };
     auto store_b = [&](const Stage& S, int buf, int q) {
@@ -656,7 +680,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
             unsigned short* base = reinterpret_cast<unsigned short*>(Bs[buf]) + (((l_p >> 3) * LDB + l_r + q * ROWSTEP) << 3) + (l_p & 7);
 #pragma unroll
             for (int z = 0; z < NS; ++z) base[z * 2 * LDB * 8] = c[z];
-        } else if constexpr (F16) reinterpret_cast<_Float16*>(Bs[buf])[((l_p >> 2) * LDB + l_r + q * ROWSTEP) * 4 + (l_p & 3)] = (_Float16)S.rb[q];
+        } else if constexpr (F16) reinterpret_cast<_Float16*>(Bs[buf])[((l_p >> 3) * LDB + l_r + q * ROWSTEP) * 8 + (l_p & 7)] = (_Float16)S.rb[q];
         else Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = S.rb[q];
     };
 
@@ -756,8 +780,30 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
             __syncthreads();
             return;
         }
-        constexpr int NK = F16 ? BK / 8 : BK / 2;
-        using FragT = typename std::conditional<F16, half4_t, float>::type;
+        if constexpr (F16) {
+            static_assert(BK == 16, "one v_mfma_f32_32x32x16_f16 per slab");
+            const half8_t* Ab = reinterpret_cast<const half8_t*>(As[buf]) + fk * LDA + wm * TM * 32 + fr;
+            const half8_t* Bb = reinterpret_cast<const half8_t*>(Bs[buf]) + fk * LDB + wn * TN * 32 + fr;
+            half8_t af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_all(L, slab_pk(s + 2));
+#pragma unroll
+            for (int q = 0; q < A_PER; ++q) store_a(W, buf ^ 1, q);
+#pragma unroll
+            for (int q = 0; q < B_PER; ++q) store_b(W, buf ^ 1, q);
+            __syncthreads();
+            return;
+        }
+        constexpr int NK = BK / 2;
+        using FragT = float;
         const FragT* Ab = reinterpret_cast<const FragT*>(As[buf]) + wm * TM * 32 + fr;
         const FragT* Bb = reinterpret_cast<const FragT*>(Bs[buf]) + wn * TN * 32 + fr;
         FragT af[2][TM], bf[2][TN];
@@ -776,10 +822,7 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (kk == 0) load_all(L, slab_pk(s + 2));           // slab s+2 (beyond pend: every element out of range -> zeros)
             if (kk >= NK / 2) {
