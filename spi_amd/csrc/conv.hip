@@ -1044,7 +1044,9 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
     // would idle -- cut the channel reduction in two ranges of >= 16 slabs; the partial outputs meet through atomics and the epilogue runs as its
     // own small kernel (0.17 -> 0.13 ms on the first).  Finer splits of smaller layers were measured SLOWER than the split-K implicit GEMM
     // (32 .. 64 blocks x 4 .. 8 ranges: the zero / weight-transform / epilogue launches and the atomics outweigh the 2.25x fewer MFMAs).
-    Wp.ksplit = (blocks >= 128 && blocks < 256 && P.Ci / 8 >= 32) ? 2 : 1;
+    // (not with a needed-output map: the split's separate epilogue pass would write act(bias + noise) into the tiles the kernel skipped, where
+    //  the unsplit path leaves exact zeros -- the contract of out_seg_flags must not depend on the block count)
+    Wp.ksplit = (blocks >= 128 && blocks < 256 && P.Ci / 8 >= 32 && !P.out_flags) ? 2 : 1;
     return blocks >= 128 && P.Mo >= 48;
 }
 

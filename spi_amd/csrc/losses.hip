@@ -83,21 +83,24 @@ __global__ void __launch_bounds__(CX_THREADS) cx_rows_kernel(const float* __rest
     for (int j = threadIdx.x; j < P2; j += CX_THREADS) pb[j] = colmax[j];
 }
 
-// maximum over the row blocks, and the mean over the columns: out[b] += sum over this block's 256 columns / P2   (out zeroed by the caller)
+// maximum over the row blocks, and the mean over the columns.  ONE block per batch element walks all P2 columns and reduces in a fixed
+// order, so out[b] has the same bits on every run (round 3 split the columns over ceil(P2 / 256) blocks that finished with a float
+// atomicAdd each: the loss's last bits depended on which block arrived first, which made graph-vs-eager comparisons of the stage-2 loss
+// flaky -- ADVICE r03).  The work is P2 * nblk 8-byte reads per element: microseconds.
 __global__ void __launch_bounds__(CX_THREADS) cx_cols_kernel(const unsigned long long* __restrict__ part, int nblk, int P2, int32_t* __restrict__ col_argmax,
                                                             float* __restrict__ out) {
     __shared__ float red[CX_THREADS / 64];
-    const int b = blockIdx.y, j = blockIdx.x * CX_THREADS + threadIdx.x;
+    const int b = blockIdx.y;
     const unsigned long long* pb = part + (int64_t)b * nblk * P2;
     float s = 0.f;
-    if (j < P2) {
+    for (int j = threadIdx.x; j < P2; j += CX_THREADS) {
         unsigned long long best = 0ull;
         for (int k = 0; k < nblk; ++k) {
             unsigned long long v = pb[(int64_t)k * P2 + j];
             best = v > best ? v : best;
         }
         col_argmax[(int64_t)b * P2 + j] = (int32_t)(0xffffffffu - (unsigned)(best & 0xffffffffull));
-        s = __uint_as_float((unsigned)(best >> 32));
+        s += __uint_as_float((unsigned)(best >> 32));
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -105,7 +108,7 @@ __global__ void __launch_bounds__(CX_THREADS) cx_cols_kernel(const unsigned long
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int k = 0; k < CX_THREADS / 64; ++k) t += red[k];
-        atomicAdd(out + b, t / (float)P2);
+        out[b] += t / (float)P2;                             // (out is zeroed by the caller: the contract of round 3 is kept)
     }
 }
 
@@ -177,7 +180,7 @@ extern "C" int spi_contextual_fwd(const float* sim, int B, int P1, int P2, float
         hipLaunchKernelGGL(cx_rows_kernel<false>, dim3(nblk, B), dim3(CX_THREADS), lds, as_stream(stream), sim, P1, P2, 1.f / band_width, row_min, row_sum,
                            row_argmin, (unsigned long long*)workspace);
     SPI_LAUNCH_CHECK("spi_contextual_fwd");
-    hipLaunchKernelGGL(cx_cols_kernel, dim3((unsigned)ceil_div64(P2, CX_THREADS), B), dim3(CX_THREADS), 0, as_stream(stream), (const unsigned long long*)workspace, nblk, P2, col_argmax, out);
+    hipLaunchKernelGGL(cx_cols_kernel, dim3(1, B), dim3(CX_THREADS), 0, as_stream(stream), (const unsigned long long*)workspace, nblk, P2, col_argmax, out);
     SPI_LAUNCH_CHECK("spi_contextual_fwd");
     return SPI_OK;
 }

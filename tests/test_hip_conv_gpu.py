@@ -297,6 +297,25 @@ def test_conv_forward_needed_output_region(n, i, o, h, k, transposed):
         assert torch.equal(conv2d_mfma.conv2d(x, w, **kw), dense)
 
 
+def test_needed_output_with_channel_split_sized_winograd_layer():
+    """a 512-channel 64^2 layer at N = 1 is the one Winograd problem that runs channel-split (128..255 blocks); its separate epilogue
+    pass wrote act(bias) into the tiles the kernel had skipped.  With an output map the split is not taken: skipped tiles hold exact zeros,
+    needed pixels equal the dense forward bit for bit, with the fused bias + lrelu epilogue on."""
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(77)
+    x = torch.randn(1, 512, 64, 64, generator=gen).to(DEV)
+    w = (torch.randn(512, 512, 3, 3, generator=gen) / (512 * 9) ** 0.5).to(DEV)
+    b = torch.randn(512, generator=gen).to(DEV)
+    kw = dict(padding=1, flip=True, bias=b, act='lrelu', sparse_grad=True)
+    dense = conv2d_mfma.conv2d(x, w, **kw)
+    m = torch.zeros(1, 1, 64, 64, device=DEV)
+    m[:, :, 8:24, 16:48] = 1
+    with conv2d_mfma.needed_output({(64, 64): conv2d_mfma.seg_flags(m)}):
+        y = conv2d_mfma.conv2d(x, w, **kw)
+    assert torch.equal(y * m, dense * m)
+    assert float(y[:, :, 40:, :].abs().max()) == 0              # rows far from the flagged box: exact zeros, not act(bias)
+
+
 WINO_CASES = [  # N, I, O, H, W, flip, per_sample, epilogue
     (1, 16, 64, 256, 256, True, True, True),        # interior fast path (even sizes, whole channel chunks) with the fused epilogue
     (2, 24, 96, 250, 246, True, True, False),       # ragged edges, 96 channels = one and a half chunks, per-sample weights
