@@ -280,9 +280,11 @@ def test_stage1_hip_graph_replay_equals_eager_steps_full_size():
     print(f'full-size stage-1 graph vs eager over 26 steps: worst loss difference {worst:.2e}, w+ {e_w:.2e}, noise maps', [f'{e:.1e}' for e in e_n])
     assert worst <= 1e-5, (worst, runs[True][1], runs[False][1])                    # observed 1.3e-7
     # w+: Adam divides every coordinate's step by its own sqrt(v); a coordinate whose gradient is small takes a visibly different step when
-    # the atomics of the split-K / scatter kernels sum in another order (observed 1.1e-4 of max|w| after 26 steps, on run-to-run noise of
-    # 1e-7 in the loss) -- 3e-4 bounds that; the graph itself adds nothing (the noise maps below agree to 3e-7)
-    assert e_w <= 3e-4, e_w
+    # the atomics of the split-K / scatter kernels sum in another order.  That is RUN-TO-RUN noise of the eager path itself, amplified over 26
+    # Adam steps: 17 runs of this test on MI355X boxes (round 4) gave 3.1e-5 ... 3.5e-4 of max|w| on loss differences of 0 ... 1.3e-7 -- the
+    # round-3 bound of 3e-4 sat inside that range and failed about one run in eight.  1e-3 bounds it; the graph itself adds nothing (the
+    # per-step losses above agree to 1e-7 and the noise maps below to 3e-7, both far from any chaotic amplification)
+    assert e_w <= 1e-3, e_w
     assert max(e_n) <= 1e-4, e_n
 
 
