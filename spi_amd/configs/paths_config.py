@@ -6,6 +6,8 @@ VGG16_PATH = 'checkpoints/vgg16-397923af.pth'      # torchvision vgg16 state_dic
 VGG19_PATH = 'checkpoints/vgg19-dcbb9e9c.pth'      # torchvision vgg19 state_dict (the reference: torchvision vgg19(pretrained=True))
 BISENET_PATH = 'checkpoints/bisenet.pth'
 VGG_PATH = 'checkpoints/vgg16.pt'
+SFD_PATH = 'checkpoints/s3fd-619a316812.pth'       # face_alignment's S3FD detector weights (the pip package downloads them; extract_landmark.py:10)
+FAN_PATH = 'checkpoints/2DFAN4-11f355bf06.pth.tar'  # face_alignment's 2D-FAN-4 weights
 
 root = 'test/output/'
 checkpoints_dir = root + 'checkpoints/'

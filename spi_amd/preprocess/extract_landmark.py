@@ -1,9 +1,10 @@
 """68 facial landmarks per crop (mirror of preprocess/extract_landmark.py:15-40).
 
 The reference's detector is the third-party ``face_alignment`` package (an S3FD face detector + a 4-stack hourglass network with downloaded
-weights, extract_landmark.py:11): neither its source nor its weights are in the reference tree, so the detector is an INJECTED callable
-``landmark_fn(PIL RGB image) -> float [68, 2]`` (x, y in image coordinates).  With `face_alignment` installed,
-``face_alignment_detector()`` builds exactly the reference's callable."""
+weights, extract_landmark.py:11); neither its source nor its weights are in the reference tree.  ``face_alignment_detector()`` returns, in this
+order: the pip package if it is importable (exactly the reference's callable); else this package's own restatement of the same two networks
+on the MI355X conv kernels (``third_part/face_alignment``: S3FD + 2D-FAN-4, state-dict compatible with the package's downloaded weights, which
+``paths_config.SFD_PATH`` / ``FAN_PATH`` must point to).  Any ``landmark_fn(PIL RGB image) -> float [68, 2]`` can be injected instead."""
 import glob
 import os
 
@@ -16,11 +17,12 @@ def face_alignment_detector():
     """The reference's detector, if the package is importable (it is not a dependency of this package)."""
     try:
         import face_alignment
-    except ImportError as e:
-        raise RuntimeError('no landmark detector: the reference uses the third-party `face_alignment` package (extract_landmark.py:11); '
-                           'install it or pass landmark_fn(image) -> [68, 2]') from e
-    kind = getattr(face_alignment.LandmarksType, 'TWO_D', None) or face_alignment.LandmarksType._2D
-    det = face_alignment.FaceAlignment(kind)
+        kind = getattr(face_alignment.LandmarksType, 'TWO_D', None) or face_alignment.LandmarksType._2D
+        det = face_alignment.FaceAlignment(kind)
+    except ImportError:
+        from ..third_part import face_alignment as own            # S3FD + 2D-FAN-4 on the HIP convs; raises FileNotFoundError without the weight files
+        from ..configs import global_config
+        det = own.FaceAlignment(own.LandmarksType._2D, device=global_config.device)
 
     def fn(image):
         lm = det.get_landmarks_from_image(np.array(image))

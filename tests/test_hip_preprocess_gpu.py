@@ -158,3 +158,67 @@ def test_camera_extractor_end_to_end_vs_oracle(tmp_path):
     ex.cal_mirror_c(str(tmp_path / 'face.png'))
     cm_ = np.load(tmp_path / 'c' / 'face_m.npy')
     assert np.allclose(cm_, orr2.mirror_camera(cam)) and np.array_equal(np.array(Image.open(tmp_path / 'crop' / 'face_m.png')), np.array(crop)[:, ::-1])
+
+
+# ---- landmark producer (round 4): S3FD + 2D-FAN-4 on the HIP convs, the one call the reference makes into the `face_alignment` package ----------
+def _fa_nets():
+    from spi_amd.third_part import face_alignment as own
+    from spi_amd.third_part.face_alignment.api import synthetic_state_dict
+    from spi_amd.third_part.face_alignment.fan import FAN
+    from spi_amd.third_part.face_alignment.sfd import s3fd
+    fan_sd, sfd_sd = synthetic_state_dict(FAN(4), 11), synthetic_state_dict(s3fd(), 12)
+    fa = own.FaceAlignment(own.LandmarksType._2D, device=DEV, fan_state_dict=fan_sd, sfd_state_dict=sfd_sd)
+    return fa, fan_sd, sfd_sd
+
+
+@pytest.mark.timeout(900)
+def test_fan_and_s3fd_networks_vs_oracle():
+    """The two networks of the landmark producer on seeded weights, HIP convs against the CPU oracle's functional restatement
+    (oracle/face_alignment_ref.py): all four FAN heat-map stacks and the twelve S3FD head outputs."""
+    from oracle import face_alignment_ref as ofr
+    fa, fan_sd, sfd_sd = _fa_nets()
+    g = torch.Generator().manual_seed(5)
+    x = F.interpolate(torch.rand(2, 3, 32, 32, generator=g), size=(256, 256), mode='bicubic', align_corners=False).clamp(0, 1)
+    hip_out = fa.face_alignment_net(x.to(DEV))
+    ref_out = ofr.fan_forward(fan_sd, x)
+    assert len(hip_out) == 4 and hip_out[-1].shape == (2, 68, 64, 64)
+    for i, (a, b) in enumerate(zip(hip_out, ref_out)):
+        assert_close(a, b, 2e-4, f'FAN stack {i} heat maps')
+    img = (torch.rand(1, 3, 160, 128, generator=g) * 255 - 115)
+    hip_o = fa.face_detector(img.to(DEV))
+    ref_o = ofr.s3fd_forward(sfd_sd, img)
+    assert len(hip_o) == 12
+    for i, (a, b) in enumerate(zip(hip_o, ref_o)):
+        assert a.shape == b.shape
+        assert_close(a, b, 2e-4, f'S3FD head output {i}')
+
+
+@pytest.mark.timeout(900)
+def test_landmark_pipeline_vs_oracle():
+    """get_landmarks_from_image end to end on seeded weights: detection boxes (softmax, anchors, decoding, NMS, thresholds) and, for a given
+    face box, the crop -> FAN -> heat-map decoding -> image coordinates chain, HIP against the oracle; then the preprocess entry point
+    (extract_landmark.get_landmark) with the built-in detector injected."""
+    from oracle import face_alignment_ref as ofr
+    from spi_amd.third_part.face_alignment.sfd import detect
+    from spi_amd.preprocess import extract_landmark as el
+    fa, fan_sd, sfd_sd = _fa_nets()
+    g = torch.Generator().manual_seed(6)
+    photo = (F.interpolate(torch.rand(1, 3, 20, 16, generator=g), size=(160, 128), mode='bicubic', align_corners=False).clamp(0, 1)[0].permute(1, 2, 0) * 255).to(torch.uint8).numpy()
+    d_hip, d_ref = detect(fa.face_detector, photo, DEV), ofr.detect(sfd_sd, photo)
+    # random weights: scores sit near 0.5, so a box can fall on either side of a threshold; the bulk must coincide
+    assert abs(len(d_hip) - len(d_ref)) <= max(2, len(d_ref) // 20), (len(d_hip), len(d_ref))
+    matched = 0
+    for b in d_ref:
+        j = np.abs(d_hip[:, :4] - b[:4]).max(axis=1).argmin() if len(d_hip) else None
+        matched += int(j is not None and np.abs(d_hip[j] - b).max() < 1e-2)
+    assert len(d_ref) == 0 or matched >= 0.9 * len(d_ref), (matched, len(d_ref))
+    box = np.array([30.0, 40.0, 100.0, 130.0, 0.9])
+    lm_hip = fa.get_landmarks_from_image(photo, detected_faces=[box])[0]
+    lm_ref = ofr.landmarks_from_face(fan_sd, photo, box)
+    assert lm_hip.shape == (68, 2)
+    # an arg-max over a random-weight heat map can tie within round-off: the landmarks must coincide except for isolated flips
+    same = np.abs(lm_hip - lm_ref).max(axis=1) < 1e-3
+    assert same.mean() >= 0.95, (same.mean(), np.abs(lm_hip - lm_ref).max())
+    from PIL import Image
+    lm = el.get_landmark(Image.fromarray(photo), landmark_fn=lambda im: fa.get_landmarks_from_image(np.array(im), detected_faces=[box])[0])
+    assert lm.shape == (68, 2) and lm.dtype == np.float32 and np.array_equal(lm, lm_hip)

@@ -684,3 +684,40 @@ def test_tracing_helpers_mirror_the_reference_decorator():
         assert 'silent' not in {e.name for e in prof.function_events}
     finally:
         misc.enable_tracing(old)
+
+
+def test_landmark_crop_transform_and_heatmap_decoding_known_answers():
+    """Host logic of the landmark producer (third_part/face_alignment/api.py, the `face_alignment` package's published crop / decoding rules):
+    the crop transform and its inverse, a crop that lies inside the image reproduces its pixels, a heat-map peak maps back to the image point it
+    was rendered from (quarter-pixel rule included), product == oracle on the decoding, NMS keeps the best of overlapping boxes."""
+    import numpy as np
+    from spi_amd.third_part.face_alignment import api
+    from spi_amd.third_part.face_alignment.sfd import nms
+    from oracle import face_alignment_ref as ofr
+    center, scale = [140.0, 150.0], 1.28                         # crop side 200 * 1.28 = 256 px: the crop is a pure translation
+    p = api.transform([10, 20], center, scale, 256)
+    assert np.allclose(api.transform(p, center, scale, 256, invert=True), [10, 20])
+    assert np.allclose(api.transform(center, center, scale, 256), [128, 128])
+    rng = np.random.default_rng(0)
+    img = (rng.random((320, 300, 3)) * 255).astype(np.uint8)
+    c = api.crop(img, center, scale)
+    assert c.shape == (3, 256, 256)
+    ul = api.transform([1, 1], center, scale, 256, True).astype(np.int64)
+    br = api.transform([256, 256], center, scale, 256, True).astype(np.int64)
+    assert tuple(ul) == (13, 23) and tuple(br) == (268, 278)    # the package's crop is (br - ul) = 255 px wide before it is resized to 256
+    patch = torch.from_numpy(img[ul[1]:br[1], ul[0]:br[0]].astype(np.float32)).permute(2, 0, 1)[None]
+    assert torch.equal(c, torch.nn.functional.interpolate(patch, size=(256, 256), mode='bilinear', align_corners=False)[0])
+    edge = api.crop(img, [5.0, 8.0], scale)                      # a crop hanging over the top-left corner: zeros outside the image
+    assert float(edge[:, :100, :100].abs().max()) == 0 and float(edge[:, 200:, 200:].abs().min()) >= 0 and float(edge.abs().max()) > 0
+    hm = torch.zeros(68, 64, 64)
+    truth = []
+    for k in range(68):
+        px, py = 3 + (k * 7) % 58, 2 + (k * 5) % 60
+        hm[k, py, px] = 1.0
+        hm[k, py, px + 1] = 0.6                                  # larger right neighbour: + 0.25 px in x
+        hm[k, py - 1, px] = 0.3                                  # larger upper neighbour: - 0.25 px in y
+        truth.append(api.transform([px + 1 + 0.25 - 0.5, py + 1 - 0.25 - 0.5], center, scale, 64, True))
+    pts = api.get_preds_fromhm(hm, center, scale)
+    assert np.allclose(pts, np.array(truth), atol=1e-4)
+    dets = np.array([[10, 10, 60, 60, 0.9], [12, 12, 62, 62, 0.8], [100, 100, 150, 150, 0.7], [11, 9, 59, 61, 0.95]], dtype=np.float32)
+    assert nms(dets, 0.3) == [3, 2] == ofr.nms(dets, 0.3)
