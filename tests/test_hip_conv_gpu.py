@@ -312,7 +312,8 @@ def test_needed_output_with_channel_split_sized_winograd_layer():
     m[:, :, 8:24, 16:48] = 1
     with conv2d_mfma.needed_output({(64, 64): conv2d_mfma.seg_flags(m)}):
         y = conv2d_mfma.conv2d(x, w, **kw)
-    assert torch.equal(y * m, dense * m)
+    # (the dense forward of this layer IS channel-split -- two partial sums meeting through atomics -- so the two runs differ by fp32 round-off)
+    assert_close(y * m, dense * m, 1e-6, 'needed pixels of the unsplit region forward vs the channel-split dense forward')
     assert float(y[:, :, 40:, :].abs().max()) == 0              # rows far from the flagged box: exact zeros, not act(bias)
 
 

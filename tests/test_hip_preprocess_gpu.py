@@ -3,6 +3,7 @@ own network (tests/golden/bisenet.npz, third_part/bisenet on seeded weights) and
 import json
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -209,8 +210,9 @@ def test_landmark_pipeline_vs_oracle():
     assert abs(len(d_hip) - len(d_ref)) <= max(2, len(d_ref) // 20), (len(d_hip), len(d_ref))
     matched = 0
     for b in d_ref:
-        j = np.abs(d_hip[:, :4] - b[:4]).max(axis=1).argmin() if len(d_hip) else None
-        matched += int(j is not None and np.abs(d_hip[j] - b).max() < 1e-2)
+        tol = 1e-3 * np.maximum(1.0, np.abs(b))                   # (seeded weights: exp(loc) makes some boxes 1e4 pixels wide -- relative tolerance)
+        j = (np.abs(d_hip[:, :4] - b[:4]) / tol[:4]).max(axis=1).argmin() if len(d_hip) else None
+        matched += int(j is not None and bool((np.abs(d_hip[j] - b) <= tol).all()))
     assert len(d_ref) == 0 or matched >= 0.9 * len(d_ref), (matched, len(d_ref))
     box = np.array([30.0, 40.0, 100.0, 130.0, 0.9])
     lm_hip = fa.get_landmarks_from_image(photo, detected_faces=[box])[0]
