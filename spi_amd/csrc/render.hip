@@ -1112,6 +1112,13 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
     //    each = 93 % of the SIMD's time; a 64-lane variant with one point per wave-instruction and weights prepared once per point
     //    needed as many -- the per-tile set-up outweighs the shorter loop -- and ran slower).
     __shared__ __attribute__((aligned(16))) double pwin[WIN * WIN * DEC_IN];        // the persistent window: cell ((y & 15) << 4 | (x & 15)), 32 channels each
+    // Round 4: what a point contributes to this plane -- its four corner weights and its four window cells -- is prepared ONCE by the lane that owns
+    // the point and handed to the half-wave that scatters it through a 20-byte LDS record (one broadcast ds_read_b128 + ds_read_b32 per point)
+    // instead of three v_readlane pairs + selects and ~15 instructions of weight / cell arithmetic repeated by all 32 lanes for every point
+    // (the loop was VALU-issue bound: profiles/r04a_bench_render.txt, the scatter costs 0.5 ms of its 0.69 even without its atomics).
+    // A half-wave only ever reads the records its own wave wrote (LDS operations of one wave execute in order): no barrier.
+    __shared__ __attribute__((aligned(16))) float tabw[SCT / 32][16][4];          // per half-wave, per point: w00 w01 w10 w11
+    __shared__ unsigned tabc[SCT / 32][16];                                       // cells c00 | c01 << 8 | c10 << 16 | c11 << 24, or PC_SKIP / PC_SLOW
     const int t = threadIdx.x;
     const int hw = t >> 5, ch = t & 31;
     const bool upper = (t & 32) != 0;
@@ -1226,41 +1233,60 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
         // fast path: all four corners inside the image AND inside the window -> no per-corner tests in the loop
         const bool fast = vin && lxo >= 0 && lxo + 1 < WIN && lyo >= 0 && lyo + 1 < WIN &&
                           c.x0 >= 0 && c.x0 + 1 < a.W && c.y0 >= 0 && c.y0 + 1 < a.H;
-        const int my_base = fast ? (((c.y0 & (WIN - 1)) << 4) | (c.x0 & (WIN - 1))) : (vin ? CELL_SLOW : CELL_SKIP);       // the cell of corner (x0, y0)
+        const int my_base = ((c.y0 & (WIN - 1)) << 4) | (c.x0 & (WIN - 1));          // the cell of corner (x0, y0)
         const int my_xy = ((c.x0 + 0x4000) & 0xffff) | ((c.y0 + 0x4000) << 16);
         const float my_wx = c.wx1, my_wy = c.wy1;
-        // ---- a half-wave (32 lanes = the 32 channels of one texel row) per point: four ds_add_f64 of 32 consecutive doubles
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int base = half_bcast(my_base, j, upper);
-            if (base == CELL_SKIP) continue;
-            const float fx1 = half_bcast(my_wx, j, upper), fy1 = half_bcast(my_wy, j, upper);
+        {
+            const float fx1 = my_wx, fy1 = my_wy;
             const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;      // == (floor+1) - x up to 1 ulp; the forward uses the same pair through make_corner
-            const float dvj = dv[j];
-            if (base >= 0) {
-                if (a.dbg & 32) continue;
-                const int c01 = (base & ~(WIN - 1)) | ((base + 1) & (WIN - 1));            // x + 1, wrapped inside the row
-                const int c10 = (base + WIN) & (WIN * WIN - 1), c11 = (c01 + WIN) & (WIN * WIN - 1);     // y + 1, wrapped
-                // the product in fp32 (what grid_sample's backward forms too), the SUM in fp64
-                atomicAdd(pwin + base * DEC_IN + ch, (double)(dvj * (fx0 * fy0)));
-                atomicAdd(pwin + c01 * DEC_IN + ch, (double)(dvj * (fx1 * fy0)));
-                atomicAdd(pwin + c10 * DEC_IN + ch, (double)(dvj * (fx0 * fy1)));
-                atomicAdd(pwin + c11 * DEC_IN + ch, (double)(dvj * (fx1 * fy1)));
-                continue;
+            const int c01 = (my_base & ~(WIN - 1)) | ((my_base + 1) & (WIN - 1));            // x + 1, wrapped inside the row
+            const int c10 = (my_base + WIN) & (WIN * WIN - 1), c11 = (c01 + WIN) & (WIN * WIN - 1);     // y + 1, wrapped
+            if ((t & 16) == 0) {                               // lanes 0..15 of the half-wave own its 16 points (lanes 16..31 mirror them)
+                // points that are skipped (padding, outside the plane) or take the slow path below get ZERO weights on cell 0: the main loop has
+                // no branch (a branch on a value that has just been read from LDS costs the LDS latency per point -- measured, first version)
+                *reinterpret_cast<float4*>(&tabw[hw][t & 15][0]) = fast ? make_float4(fx0 * fy0, fx1 * fy0, fx0 * fy1, fx1 * fy1) : make_float4(0.f, 0.f, 0.f, 0.f);
+                tabc[hw][t & 15] = fast ? ((unsigned)my_base | ((unsigned)c01 << 8) | ((unsigned)c10 << 16) | ((unsigned)c11 << 24)) : 0u;
             }
-            if (a.dbg & 16) continue;
-            const int pk = half_bcast(my_xy, j, upper);
-            const int x0 = (pk & 0xffff) - 0x4000, y0 = (pk >> 16) - 0x4000;
+            asm volatile("" ::: "memory");
+        }
+        const unsigned long long slow_all = __ballot(vin && !fast && (t & 16) == 0);     // bits 0..15: lower half-wave's points, 32..47: upper's
+        char* const wch = reinterpret_cast<char*>(pwin) + ch * 8;                 // this lane's channel inside a cell (256 B per cell)
+        // ---- a half-wave (32 lanes = the 32 channels of one texel row) per point: four ds_add_f64 of 32 consecutive doubles, straight-line code
+        if (!(a.dbg & 32)) {
 #pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int cx = qq & 1, cy = qq >> 1;
-                const int xx = x0 + cx, yy = y0 + cy;
-                if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
-                const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
-                if (xx >= ox && xx < ox + WIN && yy >= oy && yy < oy + WIN) {
-                    if (!(a.dbg & 32)) atomicAdd(pwin + (((yy & (WIN - 1)) << 4) | (xx & (WIN - 1))) * DEC_IN + ch, (double)(dvj * wq));
-                } else if (!(a.dbg & 128)) {
-                    atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dvj * wq);                    // rare: straight to HBM
+            for (int j = 0; j < 16; ++j) {
+                const unsigned pc = tabc[hw][j];
+                const float4 w = *reinterpret_cast<const float4*>(&tabw[hw][j][0]);
+                const float dvj = dv[j];
+                // the product in fp32 (what grid_sample's backward forms too), the SUM in fp64
+                atomicAdd(reinterpret_cast<double*>(wch + ((pc & 0xffu) << 8)), (double)(dvj * w.x));
+                atomicAdd(reinterpret_cast<double*>(wch + (pc & 0xff00u)), (double)(dvj * w.y));
+                atomicAdd(reinterpret_cast<double*>(wch + ((pc >> 8) & 0xff00u)), (double)(dvj * w.z));
+                atomicAdd(reinterpret_cast<double*>(wch + ((pc >> 16) & 0xff00u)), (double)(dvj * w.w));
+            }
+        }
+        // ---- rare: points with a corner outside the window or outside the plane image, corner by corner (wave-uniform test first)
+        if (slow_all != 0ull && !(a.dbg & 16)) {
+            const unsigned mine = (unsigned)(upper ? (slow_all >> 32) : slow_all) & 0xffffu;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float fx1 = half_bcast(my_wx, j, upper), fy1 = half_bcast(my_wy, j, upper);
+                const int pk = half_bcast(my_xy, j, upper);
+                if (!((mine >> j) & 1u)) continue;
+                const float fx0 = 1.f - fx1, fy0 = 1.f - fy1;
+                const float dvj = dv[j];
+                const int x0 = (pk & 0xffff) - 0x4000, y0 = (pk >> 16) - 0x4000;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int cx = qq & 1, cy = qq >> 1;
+                    const int xx = x0 + cx, yy = y0 + cy;
+                    if (xx < 0 || xx >= a.W || yy < 0 || yy >= a.H) continue;
+                    const float wq = (cx ? fx1 : fx0) * (cy ? fy1 : fy0);
+                    if (xx >= ox && xx < ox + WIN && yy >= oy && yy < oy + WIN) {
+                        if (!(a.dbg & 32)) atomicAdd(pwin + (((yy & (WIN - 1)) << 4) | (xx & (WIN - 1))) * DEC_IN + ch, (double)(dvj * wq));
+                    } else if (!(a.dbg & 128)) {
+                        atomicAdd(gplane + ((int64_t)yy * a.W + xx) * DEC_IN + ch, dvj * wq);                    // rare: straight to HBM
+                    }
                 }
             }
         }
