@@ -81,8 +81,32 @@ __device__ __forceinline__ float epilogue_act(const Epilogue& e, float v) {
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-constexpr int prec_pieces(int prec) { return prec == 3 ? 3 : 2; }
-constexpr int prec_lds_factor(int prec) { return prec == 3 ? 3 : 2; }          // LDS halves per element / 1  (fp32 = 2 halves)
+constexpr int prec_pieces(int prec) { return prec == 3 ? 3 : (prec == 4 ? 1 : 2); }
+constexpr int prec_lds_factor(int prec) { return prec == 3 ? 3 : (prec == 4 ? 1 : 2); }          // LDS halves per element / 1  (fp32 = 2 halves)
+
+// PREC 4 (forward / dgrad, round 4): the fp16 mode of PREC 1 staged like the split-bf16 modes -- every thread owns a RUN of consecutive ks of one row
+// / pixel, rounds it to fp16 (nearest even: two v_cvt_f16_f32 + a pack per pair) and writes it as ONE packed LDS store of up to 16 bytes, where
+// PREC 1 writes every element with its own 2-byte store (the fp16 kernels are staging-bound: 0.13 of the fp16 matrix peak).  Needs the
+// channel-contiguous weight layouts the split modes need; other layouts keep PREC 1.
+template <int PER>
+__device__ __forceinline__ void store_f16_run(float* lds, int LD, int row, int k0, const float (&v)[PER]) {
+    static_assert(PER == 2 || PER == 4 || PER == 8 || PER == 16, "run length");
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    unsigned pk[PER / 2];
+#pragma unroll
+    for (int i = 0; i < PER / 2; ++i) {
+        const half2_t h = {(_Float16)v[2 * i], (_Float16)v[2 * i + 1]};
+        pk[i] = __builtin_bit_cast(unsigned, h);
+    }
+    unsigned* d = reinterpret_cast<unsigned*>(lds) + ((((k0 >> 3) * LD + row) << 3) + (k0 & 7)) / 2;
+    if (PER == 2) d[0] = pk[0];
+    else if (PER == 4) *reinterpret_cast<uint2*>(d) = make_uint2(pk[0], pk[1]);
+    else if (PER == 8) *reinterpret_cast<uint4*>(d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    else {
+        *reinterpret_cast<uint4*>(d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4*>(d + LD * 4) = make_uint4(pk[4 % (PER / 2)], pk[5 % (PER / 2)], pk[6 % (PER / 2)], pk[7 % (PER / 2)]);
+    }
+}
 
 // x -> up to three bf16 pieces (bit patterns), truncating: x == f(c0) + f(c1) + f(c2) + O(2^-24 |x|)
 template <int NS>
@@ -160,7 +184,8 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     static_assert(NT >= BN && NT % BK == 0 && NT % BN == 0 && A_PER >= 1 && B_PER >= 1, "tile/threads mismatch");
     static_assert(!AMF || (BUF && NT % BM == 0), "m-fast A loads need the buffer path");
     constexpr bool F16 = (PREC == 1);
-    constexpr bool SPL = (PREC >= 2);
+    constexpr bool F16R = (PREC == 4);                                 // fp16, run-staged (see store_f16_run)
+    constexpr bool SPL = (PREC >= 2);                                  // run-staged operands: the split-bf16 modes and F16R
     constexpr int NS = prec_pieces(PREC);
     static_assert(PREC == 0 || (BUF && !SPLITK), "fp16 / split-bf16 operands: buffer path, no split-K");
     constexpr int A_KSTEP = AMF ? NT / BM : 0; // AMF: k rows covered per pass (m fastest)
@@ -347,7 +372,9 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         for (int j = 0; j < B_PER; ++j) load_b(S, q, j);
     };
     auto store_a = [&](const Stage& S, int buf, int j) {
-        if constexpr (SPL) {
+        if constexpr (F16R) {
+            if (j == 0) store_f16_run<A_PER>(As[buf], LDA, a_m, a_k, S.ra);
+        } else if constexpr (SPL) {
             if (j == 0) store_split_run<NS, A_PER>(As[buf], LDA, a_m, a_k, S.ra);
         } else if constexpr (F16) {
             const int k = AMF ? a_k + j * A_KSTEP : a_k, m = AMF ? a_m : a_m + j * A_MSTEP;
@@ -356,7 +383,9 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         else As[buf][a_k * LDA + a_m + j * A_MSTEP] = (BUF || ((S.am >> j) & 1u)) ? S.ra[j] : 0.f;
     };
     auto store_b = [&](const Stage& S, int buf, int j) {
-        if constexpr (SPL) {
+        if constexpr (F16R) {
+            if (j == 0) store_f16_run<B_PER>(Bs[buf], LDB, b_p, b_k, S.rb);
+        } else if constexpr (SPL) {
             if (j == 0) store_split_run<NS, B_PER>(Bs[buf], LDB, b_p, b_k, S.rb);
         } else if constexpr (F16) {
             const int k = b_k + j * B_KSTEP;
@@ -377,6 +406,35 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     auto step = [&](int s, int buf, Stage& L, const Stage& W) {
         L.am = L.bm = 0;
         const SlabAddr q2 = slab_setup(s + 2);
+        if constexpr (F16R) {
+            static_assert(BK == 16, "one v_mfma_f32_32x32x16_f16 per slab");
+            const half8_t* Ab = reinterpret_cast<const half8_t*>(As[buf]) + fk * LDA + wm * TM * 32 + fr;
+            const half8_t* Bb = reinterpret_cast<const half8_t*>(Bs[buf]) + fk * LDB + wn * TN * 32 + fr;
+            half8_t af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ab[i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Bb[j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (i == 0) {                                    // slab s+2 requested behind the first tile row
+#pragma unroll
+                    for (int j = 0; j < A_PER; ++j) load_a(L, q2, j);
+#pragma unroll
+                    for (int j = 0; j < B_PER; ++j) load_b(L, q2, j);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < A_PER; ++j) store_a(W, buf ^ 1, j);       // slab s+1: rounded, packed, written to the other buffer
+#pragma unroll
+            for (int j = 0; j < B_PER; ++j) store_b(W, buf ^ 1, j);
+            __syncthreads();
+            return;
+        }
         if constexpr (SPL) {
             // one K = 16 step per slab: all piece fragments of the wave's tiles (16 B each), then per tile NS*(NS+1)/2 MFMAs.  The loads
             // of slab s+2 are issued behind the first tile row, slab s+1 is split and written to the other LDS buffer behind the last.
@@ -972,7 +1030,8 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
     } else if (prec && buf && (prec == 1 || P.wsm == 1 || P.wsc == 1)) {      // split-bf16 without channels-innermost weights: exact fp32 below
 #define SPI_IG_PREC(PR) do { if (P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true, PR>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); \
                              else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, false, PR>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); } while (0)
-        if (prec == 1) SPI_IG_PREC(1); else if (prec == 2) SPI_IG_PREC(2); else SPI_IG_PREC(3);
+        if (prec == 1) { if (P.wsm == 1 || P.wsc == 1) SPI_IG_PREC(4); else SPI_IG_PREC(1); }        // fp16: run-staged when the weights are channel-contiguous
+        else if (prec == 2) SPI_IG_PREC(2); else SPI_IG_PREC(3);
 #undef SPI_IG_PREC
     } else {
         if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
@@ -996,6 +1055,9 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     // 2-piece split-bf16: the matrix pipe is 5.3x faster, so the per-slab staging work (splitting, LDS stores) weighs more: a 128 x 256
     // tile halves the A-operand work per MFMA (measured: +10..20 % at 256 channels; the 3-piece mode loses a third with it -- registers)
     if (f16 == 2 && cfg == 1 && blocks(128, 256) >= 512) cfg = 5;
+    // fp16 operands: the matrix pipe is 16x faster than fp32's, the kernel is bound by moving fp32 operands from L2 into registers (64 B / clk / CU:
+    // a 128 x 128 tile loads 16 KB per K = 16 slab for 128 matrix-pipe cycles per wave) -- the 128 x 256 tile loads 1.5x the bytes for 2x the MFMAs
+    if (f16 == 1 && cfg == 1 && blocks(128, 256) >= 512 && (P.wsm == 1 || P.wsc == 1)) cfg = 5;
     static const int bm_of[6] = {32, 128, 64, 32, 64, 128}, bn_of[6] = {128, 128, 64, 32, 256, 256};
     const int64_t nb = blocks(bm_of[cfg], bn_of[cfg]);
     int nsplit = 1;
