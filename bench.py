@@ -151,8 +151,7 @@ def cpu_baseline(depth, narrow, mode='sample', k1=8, k2=16):
         full = os.path.join(ROOT, 'profiles', 'cpu_baseline_full.json')
         if os.path.exists(full):
             rec = json.load(open(full))
-            rec.pop('gpu_value_same_run_iters_per_s', None)       # (a GPU number of the day the file was recorded; the line above it is the live one)
-            res['full_protocol_recorded'] = rec
+            res['full_protocol_recorded'] = rec                   # (recorded once per round by `bench.py --cpu-baseline full`, with that process's own GPU value beside it)
     res['sample'] += f'; 512^2, {depth}+{depth} samples, torch {torch.__version__} CPU fp32, {cores} threads of {ncpu}'
     return res
 
@@ -483,10 +482,6 @@ def main():
         import gc
         gc.collect()
         gc.freeze()
-    rmod.MARCH_EVENTS = []                                       # HIP events around every final-march launch in the timed region
-    rmod.MARCH_BWD_EVENTS = []                                   # ... and around every march-backward launch
-    rmod.DECODE_FWD_EVENTS = []                                  # ... every tri-plane gather + decoder forward launch
-    rmod.DECODE_BWD_EVENTS = []                                  # ... every tiled decoder-backward call
     sdist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     if os.environ.get('SPI_TORCH_PROFILE'):                      # debugging aid: per-op device time / launch counts per stage (stderr)
@@ -519,10 +514,6 @@ def main():
             ok = 0.0
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0                           # this rank's own K steps
-    events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
-    bwd_events, rmod.MARCH_BWD_EVENTS = rmod.MARCH_BWD_EVENTS, None
-    dfwd_events, rmod.DECODE_FWD_EVENTS = rmod.DECODE_FWD_EVENTS, None
-    dbwd_events, rmod.DECODE_BWD_EVENTS = rmod.DECODE_BWD_EVENTS, None
     dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, dt_rank, ok, dev)
     n_ok = int(sum(rank_ok))
     rank_devices = gather_rank_devices(sdist, rank, world, local, dev)
@@ -567,6 +558,34 @@ def main():
                          'note': 'same definition as `value` (exact 1:2 mix of the per-stage rates, max over ranks), measured over one window of several seconds '
                                  'right after the K timed steps, barrier + synchronize on both sides'}
         marks.clear(); marks.update(main_marks)
+    # ---- roofline instrumentation.  Both stages of the timed region are HIP-graph replays (round 4: stage 2 too), and a replayed launch cannot be
+    # bracketed by HIP events.  So the SAME steps run once more right here, eagerly enqueued (graphs switched off for this pass only), with HIP events
+    # on the launch stream around every march / decoder launch: same kernels, same shapes, same process, straight after the timed region.
+    events = bwd_events = dfwd_events = dbwd_events = None
+    if ok and not os.environ.get('SPI_TORCH_PROFILE'):
+        g1, g2 = global_config.stage1_hip_graph, global_config.stage2_hip_graph
+        main_marks = dict(marks)
+        try:
+            if hasattr(coach, 'drain_pipeline'):
+                coach.drain_pipeline()
+            torch.cuda.synchronize()
+            global_config.stage1_hip_graph = global_config.stage2_hip_graph = False
+            rmod.MARCH_EVENTS, rmod.MARCH_BWD_EVENTS, rmod.DECODE_FWD_EVENTS, rmod.DECODE_BWD_EVENTS = [], [], [], []
+            n2i = min(((k2 + 3) // 4) * 4, 8) if k2 else 0
+            run(min(k1, 4), n2i, step1_next, step2_next)
+            torch.cuda.synchronize()
+            step1_next, step2_next = step1_next + min(k1, 4), step2_next + n2i
+        except Exception:                                        # noqa: BLE001  (instrumentation must not cost the benchmark line)
+            import traceback
+            traceback.print_exc()
+        finally:
+            events, rmod.MARCH_EVENTS = rmod.MARCH_EVENTS, None
+            bwd_events, rmod.MARCH_BWD_EVENTS = rmod.MARCH_BWD_EVENTS, None
+            dfwd_events, rmod.DECODE_FWD_EVENTS = rmod.DECODE_FWD_EVENTS, None
+            dbwd_events, rmod.DECODE_BWD_EVENTS = rmod.DECODE_BWD_EVENTS, None
+            global_config.stage1_hip_graph, global_config.stage2_hip_graph = g1, g2
+            marks.clear(); marks.update(main_marks)
+    events = events or []
     alt = None
     if args.alt_conv_precision != 'none' and args.alt_conv_precision != args.conv_precision and ok and not pti and not os.environ.get('SPI_TORCH_PROFILE'):
         # the same K steps once more with the split-bf16 convolutions (opt-in arithmetic; reported beside the benchmark value, never as it).
@@ -673,8 +692,9 @@ def main():
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'launches': len(march_ms), 'avg_launch_us': (sum(march_ms) / max(len(march_ms), 1)) * 1e3,
                          'bytes_per_ray': per_ray, 'rays_per_launch': (sum(march_rays) / max(len(march_rays), 1)),
-                         'note': ('HIP events around every eagerly enqueued launch of the timed region; stage-1 steps replayed from the captured HIP graph '
-                                  'carry no events' if global_config.stage1_hip_graph else 'HIP events around every launch of the timed region')},
+                         'note': 'HIP events on the launch stream around every final-march launch of an eagerly enqueued repeat of the timed steps, run in this '
+                                 'process right after the timed region (the timed steps themselves are HIP-graph replays, which cannot carry events); '
+                                 'stage 1 (N = 2) and stage 2 (N = 1 main view, N = 4 pseudo-view branches) launches'},
         }
         # second HBM line: the march BACKWARD.  Algorithmic bytes per ACTIVE ray: read S*(C+2)*4 (colours, density, depth)
         # + (C+1)*4 incoming gradients, write S*2*4 (density gradient + colour-gradient scale; the [R,S,C] colour gradient is never
@@ -733,6 +753,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, 1 if k1 else 0, 2 if k2 else 0)
+                if args.cpu_baseline == 'full':
+                    # the once-per-round record (profiles/cpu_baseline_full.json): the full CPU protocol with the GPU value of THIS process beside it
+                    rec = dict(out['cpu_baseline'], gpu_value_same_process_iters_per_s=value,
+                               gpu_sustained_same_process_iters_per_s=(sustained or {}).get('value'), command='python bench.py ' + ' '.join(sys.argv[1:]))
+                    os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+                    with open(os.path.join(ROOT, 'gpurun_out', 'cpu_baseline_full.json'), 'w') as f:
+                        json.dump(rec, f, indent=1)
             except Exception as e:                                # noqa: BLE001  (a host-side failure must not lose the GPU measurement)
                 out['cpu_baseline'] = {'error': repr(e)}
         default_cfg = (not pti and args.depth == 96 and not args.sr_fp16 and not args.narrow and not args.dense and args.only is None

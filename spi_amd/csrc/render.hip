@@ -252,47 +252,52 @@ __device__ __forceinline__ float4 gather_point(__amdgpu_buffer_rsrc_t rs, int n,
 }
 
 // Phase A shared by forward and backward: feat[s][0..31] = mean over planes of the bilinear samples.
-// Software-pipelined over the 8 passes of a tile: the coordinates of pass p + 1 (depth / ray loads) are requested right behind the twelve
-// corner gathers of pass p, so a pass costs ONE memory round trip instead of two (coordinates, then gathers).  All loads are unconditional
-// on a clamped point index -- a guarded load would sit in an exec-masked region that hipcc closes with s_waitcnt vmcnt(0).
-__device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, int64_t total, float* feat) {
-    const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
-    const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
-    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);          // host: < 2 GiB
-    const TileIndex ti = tile_index(a, base);
-    const int last = (int)min((int64_t)DT - 1, total - 1 - base);      // the tail tile clamps to its last real point
-    int n_next; float xn, yn, zn;
-    {
-        int64_t ray; int k;
-        const int sc = min(grp, last);
-        tile_point(a, ti, base, sc, n_next, ray, k);
-        point_xyz_at(a, base + sc, n_next, ray, xn, yn, zn);
+// Round 4: the kernel is VALU-issue bound, and the gather's ADDRESS ARITHMETIC was almost half of its vector instructions: the 8 lanes that
+// fetch one point's twelve corner rows each recomputed the point's position, three plane projections, twelve corner offsets and twelve
+// bilinear weights (~250 instructions per pass, 8 passes per tile) -- the same numbers in 8 lanes.  Now a PRE-PASS with one point per lane
+// (64 points per wave-instruction instead of 8) writes the point's 12 offsets + 12 weights into columns 0..23 of the point's OWN feature row
+// (the row is dead until the point has been gathered; no extra LDS), and a gather pass reads its point's record back with six broadcast
+// ds_read_b128, adds its 16-byte piece offset and issues the twelve loads: ~50 instructions per pass.  The record of pass p + 1 is read before
+// pass p waits for its gathers, so the LDS latency hides behind them.  Same offsets, weights and summation order: bit-identical features.
+// (The eight lanes of a point sit in one wave, whose LDS operations execute in order: their record reads precede their feature writes.)
+// the point's gather record: 12 corner offsets (piece 0 of each texel row; out-of-plane corners / invalid points -> out of range = zeros from the
+// buffer load) + 12 bilinear weights -> columns 0..23 of its feature row
+__device__ __forceinline__ void write_gather_record(float* frow, int n, float x, float y, float z, int W, int H, unsigned plane_bytes, bool valid) {
+    uint4* rec = reinterpret_cast<uint4*>(frow);                     // (row stride 144 B: 16-byte aligned)
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        float gx, gy;
+        plane_uv(pl, x, y, z, gx, gy);
+        const CornerOff c = corner_offsets(make_corner(gx, gy, W, H), W, H, (unsigned)(n * 3 + pl) * plane_bytes, 0);
+        rec[pl] = valid ? make_uint4(c.o00, c.o01, c.o10, c.o11) : make_uint4(BUF_OOB, BUF_OOB, BUF_OOB, BUF_OOB);
+        reinterpret_cast<float4*>(rec)[3 + pl] = make_float4(c.w00, c.w01, c.w10, c.w11);
     }
+}
+
+// the eight gather passes of a 256-point tile over records written by write_gather_record (block-wide barrier in between): 8 lanes per point,
+// one 16-byte piece of the 32 channels each; feat[s][0..31] = plane mean of the bilinear samples.  `zero_from`: points s >= zero_from get zeros.
+__device__ __forceinline__ void gather_from_records(float* feat, __amdgpu_buffer_rsrc_t rs, int zero_from) {
+    const int sub = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const unsigned sub16 = (unsigned)sub * 16u;
+    uint4 ro[3]; float4 rw[3];
+    auto read_record = [&](int s) {
+        const uint4* rec = reinterpret_cast<const uint4*>(feat + s * FS);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) { ro[pl] = rec[pl]; rw[pl] = reinterpret_cast<const float4*>(rec)[3 + pl]; }
+    };
+    read_record(grp);
 #pragma unroll
     for (int pass = 0; pass < DT / 32; ++pass) {
         const int s = pass * 32 + grp;
-        const int64_t g = base + s;
-        const int n = n_next;
-        const float x = xn, y = yn, z = zn;
-        // twelve corner rows of this pass in flight ...
         unsigned o[12]; float w[12];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-            float gx, gy;
-            plane_uv(pl, x, y, z, gx, gy);
-            const CornerOff k = corner_offsets(make_corner(gx, gy, a.W, a.H), a.W, a.H, (unsigned)(n * 3 + pl) * plane_bytes, sub);
-            o[4 * pl] = k.o00; o[4 * pl + 1] = k.o01; o[4 * pl + 2] = k.o10; o[4 * pl + 3] = k.o11;
-            w[4 * pl] = k.w00; w[4 * pl + 1] = k.w01; w[4 * pl + 2] = k.w10; w[4 * pl + 3] = k.w11;
+            o[4 * pl] = ro[pl].x + sub16; o[4 * pl + 1] = ro[pl].y + sub16; o[4 * pl + 2] = ro[pl].z + sub16; o[4 * pl + 3] = ro[pl].w + sub16;      // (out of range stays out of range)
+            w[4 * pl] = rw[pl].x; w[4 * pl + 1] = rw[pl].y; w[4 * pl + 2] = rw[pl].z; w[4 * pl + 3] = rw[pl].w;
         }
         f32x4_t v[12];
         buf_load12_f32x4_nowait(rs, o, v);
-        // ... and the next pass's coordinates behind them
-        if (pass + 1 < DT / 32) {
-            int64_t ray; int k;
-            const int sc = min(s + 32, last);
-            tile_point(a, ti, base, sc, n_next, ray, k);
-            point_xyz_at(a, base + sc, n_next, ray, xn, yn, zn);
-        }
+        if (pass + 1 < DT / 32) read_record(s + 32);             // the next pass's record, while this pass's gathers are in flight (its row is still a record)
         buf_wait_gathers(v);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -303,9 +308,26 @@ __device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, i
             acc.w += v[4 * pl].w * w[4 * pl] + v[4 * pl + 1].w * w[4 * pl + 1] + v[4 * pl + 2].w * w[4 * pl + 2] + v[4 * pl + 3].w * w[4 * pl + 3];
         }
         acc.x *= THIRD; acc.y *= THIRD; acc.z *= THIRD; acc.w *= THIRD;
-        if (g >= total) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s >= zero_from) acc = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
     }
+}
+
+__device__ __forceinline__ void gather_tile(const DecodeArgs& a, int64_t base, int64_t total, float* feat) {
+    const int t = threadIdx.x;
+    const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);          // host: < 2 GiB
+    const int last = (int)min((int64_t)DT - 1, total - 1 - base);      // the tail tile clamps to its last real point
+    {
+        const TileIndex ti = tile_index(a, base);
+        int n; int64_t ray; int k; float x, y, z;
+        const int sc = min(t, last);
+        tile_point(a, ti, base, sc, n, ray, k);
+        point_xyz_at(a, base + sc, n, ray, x, y, z);
+        write_gather_record(feat + t * FS, n, x, y, z, a.W, a.H, plane_bytes, true);
+    }
+    __syncthreads();
+    gather_from_records(feat, rs, last + 1);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -838,29 +860,18 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     const int row = valid ? (int)(ray * a.S + raw.prow) : -1;
     const float x = valid ? (raw.o0 + raw.dpt * raw.d0) * a.scale : 0.f, y = valid ? (raw.o1 + raw.dpt * raw.d1) * a.scale : 0.f,
                 z = valid ? (raw.o2 + raw.dpt * raw.d2) * a.scale : 0.f;
-    s_x[t] = x; s_y[t] = y; s_z[t] = z; s_row[t] = row;
+    s_row[t] = row;
+    // ---- phase A: gather features.  This thread's point -> its gather record (round 4, see gather_tile: the corner arithmetic once per point instead
+    //      of once per lane of the 8-lane gather group); padding points get out-of-range offsets (zeros), no branch around the loads
+    const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
+    if (!(a.dbg & 64)) write_gather_record(feat + t * FS, n, x, y, z, a.W, a.H, plane_bytes, valid);
     // the point's gradient scalars: requested now (clamped row), stored to its LDS row after the gather phase
     const int64_t rowc = ray * a.S + raw.prow;
     const float g_sigma = d_sigma[rowc];
     const float g_scale = (RGB && d_rgb_scale) ? d_rgb_scale[rowc] : 0.f;
     __syncthreads();
-    // ---- phase A: gather features, 8 lanes per point
-    {
-    const int sub = t & 7, grp = t >> 3;
-    const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
-    const __amdgpu_buffer_rsrc_t rs_planes = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);  // host: < 2 GiB
-#pragma unroll 2
-    for (int pass = 0; pass < DT / 32; ++pass) {
-        const int s = pass * 32 + grp;
-        const int64_t prow = s_row[s];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (prow >= 0) {
-            const float qx = s_x[s], qy = s_y[s], qz = s_z[s];
-            if (!(a.dbg & 64)) acc = gather_point(rs_planes, n, qx, qy, qz, a.W, a.H, plane_bytes, sub);
-        }
-        *reinterpret_cast<float4*>(feat + s * FS + sub * 4) = acc;
-    }
-    }
+    if (!(a.dbg & 64)) gather_from_records(feat, make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes), DT);       // (host: < 2 GiB)
+    else for (int pass = 0; pass < DT / 32; ++pass) *reinterpret_cast<float4*>(feat + (pass * 32 + (t >> 3)) * FS + (t & 7) * 4) = make_float4(0.f, 0.f, 0.f, 0.f);      // (tools/bench_render.py only)
     feat[t * FS + 32] = valid ? g_sigma : 0.f;                 // columns 32..34 of the point's LDS row: d_sigma | its ray | its colour-gradient scale
     if (RGB && d_rgb_scale) {
         feat[t * FS + 33] = __int_as_float(valid ? n * a.M + m : 0);
