@@ -970,16 +970,13 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         if (WGRAD) {
             f32x16_t Y2;                                           // orientation 2: dY[1 + q_][point rowmap(r, hh_)]
             if (RGB) {
+                // Round 4: the same 32 x 32 block of dY as Y1, transposed through the wave's LDS tile like H1 / dpre1 below.  Until round 3 it was
+                // rebuilt from global memory in this orientation: 32 more loads of the gradient / colour rows per lane with 64-bit address
+                // arithmetic, selects and the sigmoid derivative again -- ~400 of the phase's ~1500 vector instructions (ISA count), all of them
+                // stealing matrix-pipe cycles from the fp32 MFMAs around them.  Same values bit for bit.
+                transpose(Y1, Y2);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int p2 = pbase + rowmap(r, hh_);
-                    const int prow2 = s_row[p2];
-                    const int64_t grow2 = d_rgb_scale ? (int64_t)__float_as_int(feat[p2 * FS + 33]) : (int64_t)max(prow2, 0);
-                    const float dv = d_rgb[grow2 * DEC_IN + q_] * (d_rgb_scale ? feat[p2 * FS + 34] : 1.f);
-                    const float sg2 = (colors[(int64_t)max(prow2, 0) * DEC_IN + q_] + 0.001f) * (1.f / 1.002f);
-                    Y2[r] = prow2 >= 0 ? dv * 1.002f * sg2 * (1.f - sg2) : 0.f;
-                    s_b2 += Y2[r];
-                }
+                for (int r = 0; r < 16; ++r) s_b2 += Y2[r];
             }
             s_d += dsq;
 #pragma unroll
