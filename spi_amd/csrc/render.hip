@@ -1276,8 +1276,10 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
         // ---- rare: points with a corner outside the window or outside the plane image, corner by corner (wave-uniform test first)
         if (slow_all != 0ull && !(a.dbg & 16)) {
             const unsigned mine = (unsigned)(upper ? (slow_all >> 32) : slow_all) & 0xffffu;
+            const unsigned either = (unsigned)((slow_all | (slow_all >> 32)) & 0xffffu);      // wave-uniform: point j of either half-wave is slow
 #pragma unroll
             for (int j = 0; j < 16; ++j) {
+                if (!((either >> j) & 1u)) continue;           // scalar branch: most waves have one or two such points, not sixteen
                 const float fx1 = half_bcast(my_wx, j, upper), fy1 = half_bcast(my_wy, j, upper);
                 const int pk = half_bcast(my_xy, j, upper);
                 if (!((mine >> j) & 1u)) continue;
