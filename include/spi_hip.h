@@ -27,11 +27,12 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 8   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 9   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive)
                              * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive)
-                             * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive) */
+                             * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive)
+                             * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -305,6 +306,10 @@ typedef struct spi_conv_desc {
     const int32_t* out_seg_flags;
     int dw_zeroed;            /* spi_conv2d_wgrad only: 1 = the caller already zeroed dw (saves the memset launch when dw is a slice of
                                * a buffer that was cleared together with other small gradients) */
+    int out_zeroed;           /* spi_conv2d_fwd / _dgrad only: 1 = the caller already zeroed the output.  Matters for the launches that ACCUMULATE
+                               * into it (split-K implicit GEMM of the 4^2..32^2 layers, channel-split Winograd: spi_conv2d_out_accumulates says
+                               * which): they skip their own fill launch -- a caller that clears all accumulators of an iteration with one fill
+                               * saves ~40 launches per generator pass.  Ignored by the launches that overwrite. */
     /* optional scratch memory (device, 16-byte aligned).  With at least spi_conv2d_workspace_bytes(d, pass) bytes the 3x3 / stride-1 /
      * pad-1 forward and data-gradient passes of large layers run as Winograd F(2x2, 3x3) and the weight-gradient pass as F(3x3, 2x2) -- fp32
      * operands, fp32 accumulation, 2.25x fewer MFMAs; the result differs from the direct sum by a few fp32 roundings (what cuDNN runs for
@@ -319,6 +324,9 @@ typedef struct spi_conv_desc {
  * output size: stride-1: H + 2*pad - kh + 1;  transposed: 2*H + kh - 2  (= 2H+1 for 3x3).          */
 /* bytes of workspace with which pass (0 forward, 1 dgrad, 2 wgrad) takes its Winograd path; 0 = the pass has none for this shape */
 int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass);
+/* 1 if pass (0 forward, 1 dgrad) of `d` -- with the workspace `d` carries -- accumulates into its output through atomics (and therefore clears
+ * it first unless d->out_zeroed), 0 if it overwrites, < 0 on a bad descriptor.  Host logic only: no launch, no device access. */
+int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass);
 int spi_conv2d_fwd  (const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream);
 int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, float* dx, spi_stream_t stream);
 /* dw has the layout/batching of w; with shared weights the batch is summed. */

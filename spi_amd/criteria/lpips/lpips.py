@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from ... import hip
+from ...torch_utils import zero_arena
 from .networks import VGG16, N_CHANNELS
 
 
@@ -21,7 +22,7 @@ class _LpipsTail(torch.autograd.Function):
         fx = fx.contiguous().float()
         fy = fy.contiguous().float()
         n, c, h, w = fx.shape
-        out = torch.zeros(n, device=fx.device, dtype=torch.float32)
+        out = zero_arena.zeros(n, fx.device)
         hip.call('spi_lpips_layer_fwd', hip.ptr(fx), hip.ptr(fy), hip.ptr(lin), n, c, h * w, hip.ptr(out), hip.stream())
         ctx.save_for_backward(fx, fy, lin)
         return out

@@ -1040,7 +1040,9 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
     }
 }
 
-static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st, int f16 = 0) {
+// tile configuration and number of K ranges of a forward / dgrad implicit GEMM (host logic shared by the launch and spi_conv2d_out_accumulates)
+struct IGemmPlan { int cfg, nsplit; };
+static IGemmPlan plan_igemm(const IGemmParams& P, int f16) {
     int maxpix = 0, maxT = 0;
     for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxT = std::max(maxT, P.cls[c].taps.T); }
     auto blocks = [&](int bm, int bn) { return (int64_t)((maxpix + bn - 1) / bn) * ((P.Mo + bm - 1) / bm) * P.N * P.ncls; };
@@ -1066,7 +1068,14 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     // (the 4^2..32^2 layers: a higher precision than asked for, on a small share of the FLOPs).
     // (~1024 blocks, >= 4 slabs per range: targets of 512 / 256 blocks and >= 8 slabs were measured within +-10 % on the 4^2..32^2 layers, round 3)
     if (nb < 512 && nslab >= 8 && !f16_ok) nsplit = (int)std::min<int64_t>(nslab / 4, (1024 + nb - 1) / nb);
-    if (nsplit > 1) {
+    return IGemmPlan{cfg, nsplit};
+}
+
+static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st, int f16 = 0,
+                          bool out_zeroed = false) {
+    const IGemmPlan plan = plan_igemm(P, f16);
+    const int cfg = plan.cfg, nsplit = plan.nsplit;
+    if (nsplit > 1 && !out_zeroed) {
         spi_zero_async(out, (int64_t)P.N * P.out_bs, st);
     }
     switch (cfg) {
@@ -1113,8 +1122,9 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
 }
 
 // channel-split Winograd: zero the output first, run the shared epilogue kernel afterwards
-static int wino_conv(WinoParams& Wp, const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, void* ws, hipStream_t st) {
-    if (Wp.ksplit > 1) {
+static int wino_conv(WinoParams& Wp, const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, void* ws, hipStream_t st,
+                     bool out_zeroed) {
+    if (Wp.ksplit > 1 && !out_zeroed) {
         int rc = spi_zero_async(out, (int64_t)P.N * P.out_bs, st); if (rc) return rc;
     }
     int rc = spi_wino_launch(Wp, in, w, out, ep, ws, st); if (rc) return rc;
@@ -1158,6 +1168,20 @@ int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass) {
     return make_wino(d, P, Wp) ? spi_wino_workspace_bytes(Wp) : 0;
 }
 
+int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass) {
+    if (validate(d, "spi_conv2d_out_accumulates")) return SPI_ERR_BAD_ARG;
+    if (pass < 0 || pass > 1) { spi_set_error("spi_conv2d_out_accumulates: pass must be 0 (forward) or 1 (dgrad)"); return SPI_ERR_BAD_ARG; }
+    IGemmParams P; WinoParams Wp;
+    if (pass == 0) {
+        make_forward(d, P);
+        if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
+    } else {
+        make_dgrad(d, P);
+    }
+    if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) return Wp.ksplit > 1 ? 1 : 0;
+    return plan_igemm(P, d->compute_f16).nsplit > 1 ? 1 : 0;
+}
+
 int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream) {
     int rc = validate(d, "spi_conv2d_fwd"); if (rc) return rc;
     SPI_REQUIRE(x && w && y, "spi_conv2d_fwd: null tensor");
@@ -1171,11 +1195,11 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     WinoParams Wp;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
-        rc = wino_conv(Wp, P, x, w, y, ep, d->workspace, as_stream(stream)); if (rc) return rc;
+        rc = wino_conv(Wp, P, x, w, y, ep, d->workspace, as_stream(stream), d->out_zeroed != 0); if (rc) return rc;
         SPI_LAUNCH_CHECK("spi_conv2d_fwd (winograd)");
         return SPI_OK;
     }
-    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16); if (rc) return rc;
+    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16, d->out_zeroed != 0); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_fwd");
     return SPI_OK;
 }
@@ -1188,11 +1212,11 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     WinoParams Wp;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_dgrad: workspace must be 16-byte aligned");
-        rc = wino_conv(Wp, P, dy, w, dx, ep, d->workspace, as_stream(stream)); if (rc) return rc;
+        rc = wino_conv(Wp, P, dy, w, dx, ep, d->workspace, as_stream(stream), d->out_zeroed != 0); if (rc) return rc;
         SPI_LAUNCH_CHECK("spi_conv2d_dgrad (winograd)");
         return SPI_OK;
     }
-    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16); if (rc) return rc;
+    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16, d->out_zeroed != 0); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_dgrad");
     return SPI_OK;
 }

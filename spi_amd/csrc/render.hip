@@ -1929,6 +1929,17 @@ __global__ void __launch_bounds__(256) decoder_gains_kernel(const float* __restr
     }
 }
 
+// The decoder's four gradient accumulators start at zero.  A caller that carves them from one buffer in the order dW1 | db1 | dW2 | db2
+// (the host wrapper does) gets one fill launch instead of four.
+static void zero_decoder_grads(float* dw1, float* db1, float* dw2, float* db2, hipStream_t st) {
+    if (db1 == dw1 + DEC_HID * DEC_IN && dw2 == db1 + DEC_HID && db2 == dw2 + DEC_OUT * DEC_HID) {
+        spi_zero_async(dw1, DEC_HID * DEC_IN + DEC_HID + DEC_OUT * DEC_HID + DEC_OUT, st);
+        return;
+    }
+    spi_zero_async(dw1, DEC_HID * DEC_IN, st); spi_zero_async(db1, DEC_HID, st);
+    spi_zero_async(dw2, DEC_OUT * DEC_HID, st); spi_zero_async(db2, DEC_OUT, st);
+}
+
 static int g_spi_debug = 0;
 extern "C" {
 
@@ -2072,8 +2083,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
 #define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, colors, d_sigma, part)
     if (wgrad) {
         if (d_rgb) SPI_BWD_LAUNCH(true, true); else SPI_BWD_LAUNCH(true, false);
-        spi_zero_async(dw1, 64 * 32, st); spi_zero_async(db1, 64, st);
-        spi_zero_async(dw2, 33 * 64, st); spi_zero_async(db2, 33, st);
+        zero_decoder_grads(dw1, db1, dw2, db2, st);
         hipLaunchKernelGGL(decoder_partial_reduce_kernel, dim3((PART_DB2 + 33 + 255) / 256, 32), dim3(256), 0, st, part, (int)grid * 4, dw1, db1, dw2, db2);
     } else {
         if (d_rgb) SPI_BWD_LAUNCH(false, true); else SPI_BWD_LAUNCH(false, false);
@@ -2099,8 +2109,7 @@ int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, f
     SPI_REQUIRE(dump && dw1 && db1 && dw2 && db2 && cols > 0, "spi_decoder_wgrad: bad argument");
     SPI_REQUIRE(cols % 4 == 0 && ((uintptr_t)dump & 15) == 0, "spi_decoder_wgrad: dump must be 16-byte aligned with cols %% 4 == 0");
     hipStream_t st = as_stream(stream);
-    spi_zero_async(dw1, 64 * 32, st); spi_zero_async(db1, 64, st);
-    spi_zero_async(dw2, 33 * 64, st); spi_zero_async(db2, 33, st);
+    zero_decoder_grads(dw1, db1, dw2, db2, st);
     int64_t chunk = (cols + 1023) / 1024;                    // ~1024 blocks
     chunk = std::max<int64_t>(256, ((chunk + WG_BK - 1) / WG_BK) * WG_BK);
     const unsigned grid = (unsigned)ceil_div64(cols, chunk);

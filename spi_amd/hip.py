@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
-ABI_VERSION = 8          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
+ABI_VERSION = 9          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -22,7 +22,7 @@ c_p = ctypes.c_void_p
 class ConvDesc(ctypes.Structure):
     _fields_ = [('N', c_i), ('I', c_i), ('O', c_i), ('H', c_i), ('W', c_i), ('kh', c_i), ('kw', c_i), ('pad', c_i),
                 ('transposed', c_i), ('flip', c_i), ('w_tap_major', c_i), ('compute_f16', c_i), ('w_batch_stride', c_l), ('bias', c_p), ('noise', c_p),
-                ('noise_gain', c_p), ('act', c_i), ('alpha', c_f), ('gain', c_f), ('clamp', c_f), ('dy_seg_flags', c_p), ('out_seg_flags', c_p), ('dw_zeroed', c_i),
+                ('noise_gain', c_p), ('act', c_i), ('alpha', c_f), ('gain', c_f), ('clamp', c_f), ('dy_seg_flags', c_p), ('out_seg_flags', c_p), ('dw_zeroed', c_i), ('out_zeroed', c_i),
                 ('workspace', c_p), ('workspace_bytes', c_l)]
 
 
@@ -55,6 +55,7 @@ _SIGS = {
     'spi_filtered_lrelu_fused': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f] + [c_i] * 8 + [c_p], c_i),
     'spi_filtered_lrelu_act': ([c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_p], c_i),
     'spi_conv2d_workspace_bytes': ([ctypes.POINTER(ConvDesc), c_i], c_l),
+    'spi_conv2d_out_accumulates': ([ctypes.POINTER(ConvDesc), c_i], c_i),
     'spi_conv2d_fwd': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
     'spi_conv2d_dgrad': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
     'spi_conv2d_wgrad': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),

@@ -8,6 +8,7 @@ bias_act.cu: grad = 1).  Second-order gradients are not on the inversion path an
 import math
 import torch
 from ... import hip
+from .. import zero_arena
 
 _SQRT2 = math.sqrt(2.0)
 # name -> (act id, default alpha, default gain, which of x / y the gradient needs)
@@ -57,7 +58,7 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
     dz = torch.empty_like(dy) if y is not None else None
     want_s = want_pix and need_strength
     if zero_buf is None:
-        zero_buf = torch.zeros((c if need_bias else 0) + (hw if want_pix else 0) + (1 if want_s else 0), device=dy.device, dtype=torch.float32)
+        zero_buf = zero_arena.zeros((c if need_bias else 0) + (hw if want_pix else 0) + (1 if want_s else 0), dy.device)
     nb = c if need_bias else 0
     d_bias = zero_buf[:nb] if need_bias else None
     pix = zero_buf[nb:nb + hw].view(dy.shape[2:]) if want_pix else None

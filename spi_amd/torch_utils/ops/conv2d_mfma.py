@@ -19,6 +19,7 @@ import ctypes
 import torch
 from ... import hip
 from . import bias_act as _ba
+from .. import zero_arena
 
 # Sparse output gradients.  SPI's pseudo-view losses are masked (visibility / foreground masks, rot_bbox_cx_coach.py:94-140 of the
 # reference): most pixels of d(image) are exactly zero, and so are the gradients arriving at the super-resolution convolutions.
@@ -84,6 +85,29 @@ def _workspace(d, pass_id, device):
     return ws
 
 
+_accumulates = {}
+
+
+def _out_tensor(d, pass_id, shape, device):
+    """The output tensor of pass `pass_id` (0 forward, 1 dgrad) of the conv `d`.  Launches that ACCUMULATE into their output (split-K implicit
+    GEMM of the 4^2..32^2 layers, channel-split Winograd) clear it first; inside an optimisation iteration the output is instead a view of the
+    iteration's zero arena (`d.out_zeroed = 1`: the library skips its fill launch -- ~40 per generator pass)."""
+    if zero_arena.in_iteration():
+        key = (pass_id, d.N, d.I, d.O, d.H, d.W, d.kh, d.pad, d.transposed, d.compute_f16, d.w_batch_stride != 0, bool(d.out_seg_flags), bool(d.workspace))
+        acc = _accumulates.get(key)
+        if acc is None:
+            acc = _accumulates[key] = hip.lib().spi_conv2d_out_accumulates(ctypes.byref(d), pass_id) == 1
+        if acc:
+            n = 1
+            for s in shape:
+                n *= int(s)
+            v = zero_arena.take(n, device)
+            if v is not None:
+                d.out_zeroed = 1
+                return v.view(shape)
+    return torch.empty(shape, device=device, dtype=torch.float32)
+
+
 def out_size(h, k, pad, transposed):
     return 2 * h + k - 2 if transposed else h + 2 * pad - k + 1
 
@@ -100,7 +124,6 @@ class _Conv2d(torch.autograd.Function):
         assert w.shape[-1] == i and (not per_sample or w.shape[0] == n)
         wbs = o * i * k * k if per_sample else 0
         oh, ow = out_size(h, k, pad, transposed), out_size(wd, k, pad, transposed)
-        y = torch.empty(n, o, oh, ow, device=x.device, dtype=torch.float32)
         bb = bias.contiguous().float() if bias is not None else None
         nz = noise.contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
@@ -109,6 +132,7 @@ class _Conv2d(torch.autograd.Function):
             assert of.dtype == torch.int32 and tuple(of.shape) == (n, (oh * ow + 15) // 16), 'needed_output: flags must be int32 [N, ceil(OH*OW/16)]'
         d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16, out_flags=of)
         ws = _workspace(d, 0, x.device)                 # noqa: F841  (keeps the scratch tensor alive until the launch is enqueued)
+        y = _out_tensor(d, 0, (n, o, oh, ow), x.device)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
         ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)
@@ -126,7 +150,7 @@ class _Conv2d(torch.autograd.Function):
         # buffer: one fill launch instead of three
         n_tail = _ba.tail_zero_elems(dy, nz, ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2])
         n_dw = w.numel() if ctx.needs_input_grad[1] else 0
-        zbuf = torch.zeros(n_tail + n_dw, device=x.device, dtype=torch.float32) if n_tail + n_dw else None
+        zbuf = zero_arena.zeros(n_tail + n_dw, x.device) if n_tail + n_dw else None
         dz, d_noise, d_strength, d_bias = _ba.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
                                                             ctx.needs_input_grad[3], ctx.needs_input_grad[4], ctx.needs_input_grad[2],
                                                             zero_buf=zbuf)
@@ -135,8 +159,8 @@ class _Conv2d(torch.autograd.Function):
         d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16, dy_flags=flags, dw_zeroed=1)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
             ws = _workspace(d, 1, x.device)             # noqa: F841
+            dx = _out_tensor(d, 1, tuple(x.shape), x.device)
             hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w), hip.ptr(dx), hip.stream())
         if ctx.needs_input_grad[1]:
             dw = zbuf[n_tail:].view(w.shape)

@@ -7,6 +7,7 @@ import torch
 from ...configs import paths_config, hyperparameters, global_config
 from ...criteria.l2_loss import l2_loss
 from ...utils.rng import DeviceRNG
+from ...torch_utils import zero_arena
 from .base_coach import BaseCoach
 
 
@@ -29,6 +30,7 @@ class SingleIDCoach(BaseCoach):
     def train_step(self, image, camera, w_pivot, target_feats=None, rng=None):
         rng = rng or self.rng or DeviceRNG(self.device)
         G = self.G
+        zero_arena.begin(w_pivot.device, key='pti')
         m = G.neural_rendering_resolution ** 2
         rk = G.rendering_kwargs
         noise = (rng.rand(1, m, int(rk['depth_resolution']), 1), rng.rand(m, max(int(rk['depth_resolution_importance']), 1)))

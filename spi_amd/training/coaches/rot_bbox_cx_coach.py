@@ -25,6 +25,7 @@ from ...utils.camera_utils import cal_mirror_c, cal_camera_weight, sample_surrou
 from ...utils.rng import DeviceRNG
 from ...torch_utils.ops.conv2d_mfma import sparse_gradients
 from ...torch_utils.misc import trace_range
+from ...torch_utils import zero_arena
 from .base_coach import BaseCoach
 
 
@@ -211,6 +212,9 @@ class RotBboxCoach(BaseCoach):
         hp = hyperparameters
         G, rot_bs = self.G, self.rot_bs
         ws = w_pivot.detach()
+        # one cleared buffer for every accumulator of the iteration (weight / style / bias gradients, split-K outputs, the plane gradient);
+        # the pseudo-view iteration needs four times the plain one's, so the two kinds keep their own sizes
+        zero_arena.begin(ws.device, key=('stage2', i % rot_bs == 0))
         self.optimizer.zero_grad()
         # ONE backbone pass per iteration.  The reference re-runs G.synthesis -- backbone included -- for the main view and for each
         # pseudo-view branch (:60,92,112,133) and back-propagates each loss through it; w and G do not change inside an iteration,

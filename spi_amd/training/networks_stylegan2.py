@@ -21,7 +21,7 @@ import torch
 from .. import hip
 from ..configs import global_config
 from ..torch_utils.ops import bias_act, upfirdn2d, conv2d_mfma
-from ..torch_utils import misc
+from ..torch_utils import misc, zero_arena
 
 
 @misc.profiled_function
@@ -54,7 +54,7 @@ class _Modulate(torch.autograd.Function):
         n = styles.shape[0]
         g = g.contiguous().float()
         dw = torch.empty_like(weight) if ctx.needs_input_grad[0] else None
-        ds = torch.zeros_like(styles)
+        ds = zero_arena.zeros_like(styles)
         hip.call('spi_modulate_bwd', hip.ptr(weight), hip.ptr(styles), hip.ptr(dcoef), hip.ptr(g), hip.ptr(dw), hip.ptr(ds), n, o, i, kh * kw,
                  int(ctx.demodulate), ctx.style_gain, hip.stream())
         return dw, ds, None, None
@@ -87,7 +87,7 @@ class _ModConvFrozen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16, ww=None):
         import ctypes
-        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace, out_size
+        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace, _out_tensor, out_size
         x = x.contiguous().float()
         weight = weight.detach().contiguous().float()
         st = styles.detach().contiguous().float()
@@ -102,12 +102,12 @@ class _ModConvFrozen(torch.autograd.Function):
         if ns == 1:
             wbs = 0
         oh, ow = out_size(h, kh, pad, transposed), out_size(wd, kh, pad, transposed)
-        y = torch.empty(n, o, oh, ow, device=x.device, dtype=torch.float32)
         bb = bias.detach().contiguous().float() if bias is not None else None
         nz = noise.detach().contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
         d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16)
         ws = _workspace(d, 0, x.device)                 # noqa: F841  (Winograd scratch, alive until the launch is enqueued)
+        y = _out_tensor(d, 0, (n, o, oh, ow), x.device)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w2), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0 or bb is not None or nz is not None)
         ctx.save_for_backward(x, weight, st, w2, dcoef, y, bb, nz, ng, ww)
@@ -118,7 +118,7 @@ class _ModConvFrozen(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         import ctypes
-        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace
+        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace, _out_tensor
         x, weight, st, w2, dcoef, y, bb, nz, ng, ww = ctx.saved_tensors
         pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, demodulate, sgain, f16 = ctx.cfg
         o, i, kh, kw = weight.shape
@@ -126,13 +126,13 @@ class _ModConvFrozen(torch.autograd.Function):
         h, wd = x.shape[2], x.shape[3]
         # one zeroed buffer for every accumulator of this backward: layer-tail sums | <x_i, dx_i> | <dz_o, z_o>
         n_tail = bias_act.tail_zero_elems(dy, nz, ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3])
-        zb = torch.zeros(n_tail + n * i + (n * o if demodulate else 0), device=x.device, dtype=torch.float32)
+        zb = zero_arena.zeros(n_tail + n * i + (n * o if demodulate else 0), x.device)
         dz, d_noise, d_strength, d_bias = bias_act.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
                                                                  ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3],
                                                                  zero_buf=zb)
         d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, tap_major=1, f16=f16)
-        dx = torch.empty_like(x)
         ws = _workspace(d, 1, x.device)                 # noqa: F841
+        dx = _out_tensor(d, 1, tuple(x.shape), x.device)
         hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w2), hip.ptr(dx), hip.stream())
         a = zb[n_tail:n_tail + n * i]
         hip.call('spi_chan_dot', hip.ptr(x), hip.ptr(dx), hip.ptr(a), n * i, i, h * wd, None, None, None, 0, 0.0, 1.0, hip.stream())

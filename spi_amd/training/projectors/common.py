@@ -20,6 +20,7 @@ from ...configs import hyperparameters
 from ...utils.rng import DeviceRNG
 from ..optim import Adam
 from ...torch_utils.misc import trace_range
+from ...torch_utils import zero_arena
 from .schedule import stage1_schedule
 
 
@@ -36,7 +37,7 @@ def w_statistics(G, c, w_avg_samples, device):
 class _NoiseReg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, plan, *bufs):
-        loss = torch.zeros(1, device=bufs[0].device, dtype=torch.float32)
+        loss = zero_arena.zeros(1, bufs[0].device)
         pyramid = torch.empty(plan.T * plan.region, device=loss.device, dtype=torch.float32)
         means = torch.empty(plan.T * 16, device=loss.device, dtype=torch.float32)
         hip.call('spi_noise_reg_fwd', hip.ptr(plan.ptrs), hip.ptr(plan.res), plan.T, plan.max_res, hip.ptr(pyramid), hip.ptr(means),
@@ -208,6 +209,7 @@ class Projection:
 
     def _body(self, step, device_hyper, hyper_is_set=False):
         G, rng, w_opt = self.G, self.rng, self.w_opt
+        zero_arena.begin(w_opt.device, key='stage1')             # every accumulator of this step comes out of one buffer cleared by one launch
         if device_hyper:
             if not hyper_is_set:
                 self._set_hyper(step)

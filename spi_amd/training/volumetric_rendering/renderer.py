@@ -32,6 +32,7 @@ import os
 import torch
 
 from ... import hip
+from ...torch_utils import zero_arena
 from .ray_marcher import MipRayMarcher2, depth_range
 
 DEC_DUMP_ROWS = 193
@@ -128,6 +129,13 @@ def _decode_bwd(planes_nhwc, dec, d_rgb, d_sigma, d_planes, *, coords=None, rays
     return _decoder_wgrad(dump) if want_wgrad else None
 
 
+def _decoder_grad_buffers(dev):
+    """dW1 [64,32] | db1 [64] | dW2 [33,64] | db2 [33] carved from ONE buffer in this order: the library then clears them with one fill
+    launch instead of four (spi_triplane_decode_bwd_sorted / spi_decoder_wgrad test for exactly this adjacency)."""
+    buf = torch.empty(64 * 32 + 64 + 33 * 64 + 33, device=dev, dtype=torch.float32)
+    return buf[:2048].view(64, 32), buf[2048:2112], buf[2112:4224].view(33, 64), buf[4224:4257]
+
+
 def _decoder_wgrad(dump):
     """(dW1 [64,32], db1 [64], dW2 [33,64], db2 [33]) from an activation dump [193, cols]: one streaming MFMA kernel."""
     dev = dump.device
@@ -136,8 +144,7 @@ def _decoder_wgrad(dump):
         pad = 4 - cols % 4
         dump = torch.cat([dump, dump.new_zeros(dump.shape[0], pad)], dim=1).contiguous()
         cols += pad
-    gw1 = torch.empty(64, 32, device=dev); gb1 = torch.empty(64, device=dev)
-    gw2 = torch.empty(33, 64, device=dev); gb2 = torch.empty(33, device=dev)
+    gw1, gb1, gw2, gb2 = _decoder_grad_buffers(dev)
     hip.call('spi_decoder_wgrad', hip.ptr(dump), cols, hip.ptr(gw1), hip.ptr(gb1), hip.ptr(gw2), hip.ptr(gb2), hip.stream())
     return gw1, gb1, gw2, gb2
 
@@ -263,7 +270,7 @@ class _Render(torch.autograd.Function):
             e1.record()
             MARCH_BWD_EVENTS.append((e0, e1, r, active))
         want_w = any(ctx.needs_input_grad[1:5])
-        d_planes = torch.zeros_like(planes_nhwc)
+        d_planes = zero_arena.zeros_like(planes_nhwc)
         # one pass over all Sc+Sf samples in sorted order, 8x8 ray patches (LDS-aggregated scatter)
         _, _, hh, ww, _ = planes_nhwc.shape
         res = int(round(math.sqrt(m)))
@@ -271,7 +278,7 @@ class _Render(torch.autograd.Function):
         ws = torch.empty(hip.lib().spi_triplane_decode_bwd_sorted_ws(n, m, s, ray_w), device=dev, dtype=torch.float32)
         gw = None
         if want_w:                               # decoder weight gradients come out of the same kernel (no activation dump)
-            gw = (torch.empty(64, 32, device=dev), torch.empty(64, device=dev), torch.empty(33, 64, device=dev), torch.empty(33, device=dev))
+            gw = _decoder_grad_buffers(dev)
         timed_dec = _timed(DECODE_BWD_EVENTS)
         if timed_dec:
             f0 = torch.cuda.Event(enable_timing=True)
@@ -311,7 +318,7 @@ class _RunModel(torch.autograd.Function):
         d_rgb = d_rgb.contiguous().float() if d_rgb is not None else torch.zeros(n, p, 32, device=coords.device)
         d_sigma = d_sigma.reshape(n, p).contiguous().float() if d_sigma is not None else torch.zeros(n, p, device=coords.device)
         want_w = any(ctx.needs_input_grad[1:5])
-        d_planes = torch.zeros_like(planes_nhwc)
+        d_planes = zero_arena.zeros_like(planes_nhwc)
         gw = _decode_bwd(planes_nhwc, (w1t, b1, w2, b2), d_rgb, d_sigma, d_planes, coords=coords, box_warp=box_warp, want_wgrad=want_w)
         g_planes = planes_to_nchw(d_planes) if ctx.needs_input_grad[0] else None
         gw1 = gb1 = gw2 = gb2 = None
@@ -365,7 +372,7 @@ class _SamplePlanes(torch.autograd.Function):
     def backward(ctx, d_out):
         coords, = ctx.saved_tensors
         n, p, c, h, w, box_warp = ctx.meta
-        d_planes = torch.zeros(n, 3, h, w, c, device=coords.device, dtype=torch.float32)
+        d_planes = zero_arena.zeros((n, 3, h, w, c), coords.device)
         hip.call('spi_sample_from_planes_bwd', hip.ptr(d_out.contiguous().float()), hip.ptr(coords), n, p, h, w, box_warp, hip.ptr(d_planes), hip.stream())
         return planes_to_nchw(d_planes), None, None
 

@@ -565,3 +565,50 @@ def test_conv_split_bf16_modes_vs_fp32_reference(case, prec, tol):
         assert_close(hw, gw, 10 * tol, f'split x{prec} wgrad')
         if prec == 2 and H >= 40 and not tr:       # (grids that need split-K run the exact fp32 kernels whatever was asked for)
             assert not torch.equal(y, y0), 'the 2-piece mode must really run different arithmetic'
+
+
+def test_conv_out_zeroed_flag_and_zero_arena():
+    """ABI 9: `spi_conv2d_out_accumulates` tells which forward / dgrad launches add into their output (split-K at 16^2, channel-split
+    Winograd at 64^2 x 512) and `out_zeroed = 1` makes exactly those skip their fill launch; inside an iteration (`zero_arena.begin`) the
+    wrapper hands such launches a view of the iteration's one cleared buffer.  Same values as the self-clearing call."""
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.torch_utils import zero_arena
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(21)
+    lib = hip.lib()
+    for (I, O, H, expect) in ((512, 512, 16, 1), (512, 512, 64, 1), (128, 128, 256, 0)):
+        x = torch.randn(1, I, H, H, generator=gen).to(DEV)
+        w = (torch.randn(1, O, 3, 3, I, generator=gen) / (3 * I ** 0.5)).to(DEV)        # tap-major, per sample
+        d = conv2d_mfma._desc(1, I, O, H, H, 3, 1, False, True, O * I * 9, tap_major=1)
+        ws = conv2d_mfma._workspace(d, 0, x.device)                                    # noqa: F841
+        assert lib.spi_conv2d_out_accumulates(ctypes.byref(d), 0) == expect, (I, O, H)
+        y_ref = torch.full((1, O, H, H), 3.25, device=DEV)                             # dirty: the library clears it itself
+        hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y_ref), hip.stream())
+        d.out_zeroed = 1
+        y_dirty = torch.full((1, O, H, H), 3.25, device=DEV)
+        hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y_dirty), hip.stream())
+        if expect:                                                                     # the flag is honoured: the launch ADDED to what was there
+            assert_close(y_dirty - 3.25, y_ref, 1e-5, f'out_zeroed on a dirty buffer {I}x{H}')
+        else:
+            assert torch.equal(y_dirty, y_ref)
+        # through the wrapper, inside an iteration: the second iteration of a kind serves the output from the arena
+        zero_arena.reset()
+        try:
+            outs = []
+            for it in range(2):
+                zero_arena.begin(x.device, key='test')
+                xr = x.clone().requires_grad_(True)
+                y = conv2d_mfma.conv2d(xr, w, padding=1, flip=True, tap_major=True)
+                gx, = torch.autograd.grad(y, [xr], torch.ones_like(y))
+                outs.append((y.detach().clone(), gx.clone()))
+                if it == 1 and expect:
+                    buf = zero_arena._s.buf
+                    assert buf is not None and buf.data_ptr() <= y.data_ptr() < buf.data_ptr() + 4 * buf.numel(), 'forward output not from the arena'
+            zero_arena.finish()
+            assert (zero_arena._s.peaks.get('test', 0) > 0) == bool(expect)
+            assert_close(outs[1][0], y_ref, 1e-5, 'arena forward')
+            assert_close(outs[1][0], outs[0][0], 1e-5, 'arena vs own fill: forward')
+            assert_close(outs[1][1], outs[0][1], 1e-5, 'arena vs own fill: dgrad')
+        finally:
+            zero_arena.reset()

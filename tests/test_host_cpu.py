@@ -721,3 +721,42 @@ def test_landmark_crop_transform_and_heatmap_decoding_known_answers():
     assert np.allclose(pts, np.array(truth), atol=1e-4)
     dets = np.array([[10, 10, 60, 60, 0.9], [12, 12, 62, 62, 0.8], [100, 100, 150, 150, 0.7], [11, 9, 59, 61, 0.95]], dtype=np.float32)
     assert nms(dets, 0.3) == [3, 2] == ofr.nms(dets, 0.3)
+
+
+def test_zero_arena_serves_the_second_iteration_of_a_kind_from_one_buffer():
+    """spi_amd/torch_utils/zero_arena.py: the first iteration of a kind records what it needs (every request is its own torch.zeros), later ones
+    get aligned views of ONE cleared buffer; kinds keep separate sizes; outside an iteration nothing is recorded."""
+    import torch
+    from spi_amd.torch_utils import zero_arena as za
+    za.reset()
+    try:
+        assert not za.in_iteration() and za.take(10, 'cpu') is None and za.zeros((2, 3), 'cpu').shape == (2, 3)
+        assert za._s.peaks == {}
+        for it in range(3):
+            za.begin('cpu', key='a')
+            assert za.in_iteration()
+            t1, t2, t3 = za.zeros(10, 'cpu'), za.zeros((3, 70), 'cpu'), za.zeros_like(torch.ones(5))
+            assert t1.shape == (10,) and t2.shape == (3, 70) and t3.shape == (5,)
+            assert float(t1.sum() + t2.sum() + t3.sum()) == 0.0
+            if it == 0:
+                assert za._s.buf is None
+            else:
+                base = za._s.buf.data_ptr()
+                assert [t.data_ptr() - base for t in (t1, t2, t3)] == [0, 256, 256 + 4 * 256]      # 10 -> 64 floats, 210 -> 256 floats
+                assert za._s.buf.numel() == 64 + 256 + 64
+            t1.add_(1.0); t2.add_(2.0)                                   # accumulators get dirty: the next iteration must see zeros again
+        za.begin('cpu', key='b')
+        assert za._s.buf is None                                         # another kind: its own size, not yet known
+        big = za.zeros(1000, 'cpu')
+        assert big.shape == (1000,)
+        za.begin('cpu', key='a')
+        assert za._s.peaks == {'a': 384, 'b': 1024}
+        assert za.take(385, 'cpu') is None                               # does not fit: the caller falls back; the demand is remembered
+        za.finish()
+        assert za._s.peaks['a'] == 448
+        za.enabled = False
+        za.begin('cpu', key='a')
+        assert za._s.buf is None and not za.in_iteration()
+    finally:
+        za.enabled = True
+        za.reset()
