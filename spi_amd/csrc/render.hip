@@ -1794,6 +1794,16 @@ __global__ void __launch_bounds__(64 * RM_WAVES) __attribute__((amdgpu_waves_per
 // ------------------------------------------------------------------------------------------------
 // sample_importance / sample_pdf (renderer.py:194-253): one wave per ray.
 // ------------------------------------------------------------------------------------------------
+// Stable rank order of the two rank sorts below: does `o` (at an earlier position iff `o_first`) come before `v`?  A total order -- NaNs sort last,
+// among themselves by position, like torch.sort -- so that the ranks of a row are ALWAYS a permutation.  (With the plain `o < v || (o == v && ...)`
+// every NaN got rank 0: the slots at the end of the row were never written, and the permutation the decoder backward indexes with kept whatever the
+// buffer held before -- a diverged ray turned into an out-of-range read instead of a NaN in the loss.)
+__device__ __forceinline__ int rank_before(float o, float v, bool o_first) {
+    const bool on = o != o, vn = v != v;
+    if (on || vn) return (!on && vn) || (on && vn && o_first);
+    return (o < v) || (o == v && o_first);
+}
+
 __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict__ depths, const float* __restrict__ weights,
                                                          const float* __restrict__ u, int64_t R, int S, int Sf,
                                                          float* __restrict__ fine, int sort_out) {
@@ -1856,7 +1866,7 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
     for (int j = lane; j < Sf; j += 64) {
         const float v = tv[j];
         int rank = 0;
-        for (int m2 = 0; m2 < Sf; ++m2) { const float o = tv[m2]; rank += (o < v) || (o == v && m2 < j); }
+        for (int m2 = 0; m2 < Sf; ++m2) rank += rank_before(tv[m2], v, m2 < j);
         fine[r * Sf + rank] = v;
     }
 }
@@ -1899,10 +1909,7 @@ __global__ void __launch_bounds__(256) merge_sort_kernel(const float* __restrict
     for (int k = lane; k < S; k += 64) {
         const float v = d[k];
         int rank = 0;
-        for (int m = 0; m < S; ++m) {
-            const float o = d[m];
-            rank += (o < v) || (o == v && m < k);
-        }
+        for (int m = 0; m < S; ++m) rank += rank_before(d[m], v, m < k);
         sorted[r * S + rank] = v;
         perm[r * S + rank] = k;
     }

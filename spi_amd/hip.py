@@ -150,10 +150,22 @@ def check(rc, name):
 _fns = {}
 
 
+_TRACE_CALLS = bool(os.environ.get('SPI_TRACE_CALLS'))       # debugging aid: name every library call on stderr and wait for it (a GPU memory
+                                                              # fault aborts the process: the last name printed is the faulting launch)
+
+
 def call(name, *args):
     fn = _fns.get(name)
     if fn is None:
         fn = _fns[name] = getattr(lib(), name)
+    if _TRACE_CALLS:
+        import sys
+        print(f'[spi call] {name} {[a if isinstance(a, (int, float)) else type(a).__name__ for a in args]}', file=sys.stderr, flush=True)
     rc = fn(*args)
     if rc != 0:
         check(rc, name)
+    if _TRACE_CALLS:
+        import torch
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.synchronize()
+

@@ -218,6 +218,38 @@ def test_merge_sort_matches_torch_sort():
         assert torch.equal(perm.long(), idx)
 
 
+def test_rank_sorts_stay_permutations_with_nans():
+    """A diverged ray (NaN depths / weights) must show up as NaN in the loss, like in the reference's torch.sort (NaNs last), not as an
+    out-of-range read: the rank sorts of spi_merge_sort_depths / spi_importance_sample order NaNs last by position, so every output slot is
+    written and `perm` is a permutation.  (Until round 4 every NaN got rank 0: the slots at the row's end kept what the buffer held before,
+    and the decoder backward indexed with that -- an illegal address once the buffer's previous tenant was not a permutation.)"""
+    from spi_amd import hip
+    gen = torch.Generator().manual_seed(5)
+    r, sc, sf = 64, 96, 96
+    dc = torch.sort(torch.rand(r, sc, generator=gen), dim=1)[0]
+    df = torch.sort(torch.rand(r, sf, generator=gen), dim=1)[0]
+    df[3, 10] = float('nan'); df[7, :] = float('nan'); dc[9, 0] = float('nan'); df[11, 95] = float('nan'); df[11, 0] = float('nan')
+    dc, df = dc.to(DEV), df.to(DEV)
+    out = torch.full((r, sc + sf), -7.0, device=DEV)                       # dirty buffers: an unwritten slot keeps the sentinel
+    perm = torch.full((r, sc + sf), 10 ** 9, device=DEV, dtype=torch.int32)
+    hip.call('spi_merge_sort_depths', hip.ptr(dc), hip.ptr(df), r, sc, sf, hip.ptr(out), hip.ptr(perm), hip.stream())
+    ref, idx = torch.sort(torch.cat([dc, df], 1), dim=1, stable=True)      # torch: NaNs last, stable
+    assert torch.equal(torch.sort(perm.long(), dim=1)[0], torch.arange(sc + sf, device=DEV).expand(r, -1)), 'perm is not a permutation'
+    assert torch.equal(perm.long(), idx)
+    assert torch.equal(torch.isnan(out), torch.isnan(ref)) and torch.equal(torch.nan_to_num(out, nan=9.0), torch.nan_to_num(ref, nan=9.0))
+    # importance sampling with NaN weights on some rays: all Sf slots of every ray are written (NaN where the ray diverged), no stale values
+    dep = torch.sort(torch.rand(r, sc, generator=gen) + 2.0, dim=1)[0].to(DEV)
+    w = torch.rand(r, sc - 1, generator=gen)
+    w[5, 40] = float('nan'); w[6, :] = float('nan')
+    u = torch.rand(r, sf, generator=gen).to(DEV)
+    fine = torch.full((r, sf), -7.0, device=DEV)
+    hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(w.to(DEV)), hip.ptr(u), r, sc, sf, hip.ptr(fine), 1, hip.stream())
+    assert not bool((fine == -7.0).any()), 'unwritten slots'
+    ok_rows = [i for i in range(r) if i not in (5, 6)]
+    assert bool(torch.isfinite(fine[ok_rows]).all()) and bool((fine[ok_rows][:, 1:] >= fine[ok_rows][:, :-1]).all())
+    assert bool(torch.isnan(fine[6]).all())
+
+
 def test_full_render_golden_fwd_bwd(golden):
     from spi_amd.training.volumetric_rendering.renderer import ImportanceRenderer
     g = golden('renderer')

@@ -18,6 +18,32 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'tests')]
 
 
+def free_blocks(default_pool_only=False):
+    """[(address, bytes)] of the caching allocator's inactive blocks (optionally: of the default pool only, not of graph-private pools)."""
+    torch.cuda.synchronize()
+    out = []
+    for seg in torch.cuda.memory_snapshot():
+        if default_pool_only and tuple(seg.get('segment_pool_id', (0, 0))) != (0, 0):
+            continue
+        addr = seg['address']
+        for blk in seg['blocks']:
+            if blk['state'] == 'inactive' and blk['size'] >= 4:
+                out.append((addr, blk['size']))
+            addr += blk['size']
+    return out
+
+
+def poison_blocks(blocks, pattern=0x7FC00000):
+    hipl = ctypes.CDLL('libamdhip64.so')
+    hipl.hipMemsetD32.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]
+    hipl.hipMemsetD32.restype = ctypes.c_int
+    for addr, size in blocks:
+        rc = hipl.hipMemsetD32(ctypes.c_void_p(addr), ctypes.c_int(pattern - (1 << 32) if pattern >= (1 << 31) else pattern), size // 4)
+        assert rc == 0, rc
+    torch.cuda.synchronize()
+    return sum(b[1] for b in blocks)
+
+
 def poison_free_blocks(pattern=0x7FC00000):
     """Fill every inactive block of the caching allocator with `pattern` (default: a quiet NaN).  -> bytes written."""
     torch.cuda.synchronize()
