@@ -32,6 +32,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import spi_amd  # noqa: E402,F401  (before the first GPU call: sets the HIP runtime switch that makes graph replays safe, spi_amd/__init__.py)
 
 # Algorithmic bytes of the FINAL march per ray: read S*(C+1+1)*4 (colours, density, depth), write (C+1+1)*4 (rgb, depth, sum w).
 # SURVEY.md 8d's 27 008 B/ray also counts the S-1 per-sample weights; the final march does not write them (only their sum
@@ -437,7 +438,7 @@ def main():
 
     marks = {}
 
-    def run(n1, n2, s1_base, s2_base, s2_warm=0):
+    def run(n1, n2, s1_base, s2_base):
         ta = time.perf_counter()
         for i in range(n1):
             proj.step(s1_base + i)
@@ -445,10 +446,6 @@ def main():
         torch.cuda.synchronize()                                 # one sync between the stages: SURVEY 8d asks for both rates separately
         marks['stage1_s'] = time.perf_counter() - ta
         marks['stage1_ms_per_step'] = marks['stage1_s'] / max(n1, 1) * 1e3
-        for i in range(s2_warm):                                 # (`pti` workload: the stage-2 warm-up sits between the two timed stages, see below)
-            stage2_step(s2_base - s2_warm + i)
-        if s2_warm:
-            torch.cuda.synchronize()
         tb = time.perf_counter()
         per_iter = [] if os.environ.get('SPI_BENCH_ITER_TIMES') else None      # debugging aid (synchronises every iteration: NOT for the benchmark value)
         for i in range(n2):
@@ -476,12 +473,7 @@ def main():
     elif args.only == 'stage2':
         (w1, w2), (k1, k2) = (0, (args.warmup + 3) // 4 * 4), (0, (args.steps + 3) // 4 * 4)
         args.steps = k2
-    # `pti` workload (configs[2]): ALL stage-1 steps -- warm-up and timed -- run before the first PTI iteration, as in a real run (500 projector
-    # steps, then 1000 PTI iterations); the stage-2 warm-up sits between the two timed stages, outside both per-stage clocks the value is formed
-    # from.  Interleaving the two (projector graph replays AFTER eager PTI iterations on the same device) was found in round 4 to leave the W
-    # projector's replays with a constant garbage image and a NaN latent (`state_finite_after_timed_steps`; not understood: DESIGN.md 11) --
-    # an order no inversion run produces.
-    run(w1, 0 if pti else w2, 25, 0)                             # untimed warm-up (past the 5 % lr ramp-up)
+    run(w1, w2, 25, 0)                                           # untimed warm-up (past the 5 % lr ramp-up)
     if os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0':
         # A full (generation-2) collection of the Python heap -- modules, the generator's parameter objects, autograd nodes -- was measured as a
         # one-off 50-80 ms pause inside the timed region of the FIRST process on a fresh box (`SPI_BENCH_ITER_TIMES=1`: the fifth branch
@@ -516,7 +508,7 @@ def main():
     else:
         ok = 1.0
         try:
-            run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4, s2_warm=(w2 if pti else 0))
+            run(k1, k2, 25 + w1, ((w2 + 3) // 4) * 4)
         except Exception:                                        # a failing rank still reaches the reduce below: it cannot hang the others
             import traceback
             traceback.print_exc()
@@ -527,8 +519,9 @@ def main():
     n_ok = int(sum(rank_ok))
     rank_devices = gather_rank_devices(sdist, rank, world, local, dev)
     graph_ranks = int(sdist.reduce_stats([1.0 if getattr(proj, '_graph', None) is not None else 0.0], device=dev)[0])
-    # the loops' state after the timed steps: a diverged optimisation (NaN latent / weights) would time different work (every masked branch
-    # skips nothing or everything) -- reported, so that such a number cannot pass silently
+    # the loops' state after the timed steps: a diverged optimisation (NaN latent / weights) would time different work -- reported, so that
+    # such a number cannot pass silently.  (Round 4: with the HIP runtime's graph packet capture on, projector replays that followed eager
+    # PTI iterations ran with stale kernel arguments and left a NaN latent; spi_amd/__init__.py switches the capture off.)
     state_finite = {'stage1_latent_and_noise': bool(torch.isfinite(proj.optimizer.flat_p).all()),
                     'stage2_generator': bool(torch.isfinite(coach.optimizer.flat_p).all()) if getattr(coach, 'optimizer', None) is not None else None}
     if not all(v is not False for v in state_finite.values()):
@@ -698,7 +691,7 @@ def main():
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else '')), 'step_mix': {'value_mix': 'stage1:stage2 = 1:2 exact (500:1000), computed from the per-stage rates' if (k1 and k2) else 'single stage', 'timed_steps': {'stage1_mir': k1, 'stage2_rotbbox': k2}},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
-                       'state_finite_after_timed_steps': state_finite, 'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph and not pti and getattr(coach, '_g2', None) is not None and not getattr(coach, '_graph_failed', False)),
+                       'state_finite_after_timed_steps': state_finite, 'hip_graph_packet_capture_env': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), 'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph and not pti and getattr(coach, '_g2', None) is not None and not getattr(coach, '_graph_failed', False)),
                        'stage2_graph_build_iterations_before_warmup': setup_iters,
                        'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
                                    if global_config.conv_winograd and global_config.conv_precision in (0, 3) else 'implicit GEMM'),

@@ -101,8 +101,20 @@ def graph_policy(enabled):
     """Whether the stage-1 step is replayed from a HIP graph.  The same answer with and without an initialised process group: the ranks of a
     multi-GPU run (one process per GPU, spi_amd/dist.py) take exactly the code path the single-GPU number is measured on.  (Round 2 switched
     the graph off beside a process group because RCCL's watchdog thread issues HIP calls of its own, which a capture in GLOBAL error mode
-    rejects; the capture now runs in thread-local mode there, see capture_mode().)"""
-    return bool(enabled)
+    rejects; the capture now runs in thread-local mode there, see capture_mode().)
+    Only in a process whose HIP runtime runs with its graph packet capture switched off (spi_amd/__init__.py: with it on, replays after
+    ~10^3 eager launches return garbage on ROCm 7): otherwise the iterations are enqueued eagerly, with a note on stderr, once."""
+    if not enabled:
+        return False
+    import spi_amd
+    if not spi_amd.hip_graphs_safe():
+        if not getattr(graph_policy, '_warned', False):
+            graph_policy._warned = True
+            import sys
+            print('[spi_amd] HIP-graph replay is off: the HIP runtime of this process was initialised without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 '
+                  '(import spi_amd before the first GPU call, or export the variable); iterations are enqueued eagerly', file=sys.stderr)
+        return False
+    return True
 
 
 def capture_mode():

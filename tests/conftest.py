@@ -9,6 +9,8 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+import spi_amd  # noqa: E402,F401  (before the first GPU call: the HIP runtime switch for graph replays, spi_amd/__init__.py)
+
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 

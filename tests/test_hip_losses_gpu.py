@@ -288,6 +288,52 @@ def test_stage1_hip_graph_replay_equals_eager_steps_full_size():
     assert max(e_n) <= 1e-4, e_n
 
 
+def test_hip_graph_replays_stay_correct_after_eager_launches():
+    """ROCm 7 defect found in round 4 (tools/ubench/graph_after_eager.py): with the HIP runtime's AQL packet capture of graphs on (its default),
+    a graph replayed after ~10^3 ordinary launches runs some kernel nodes with stale arguments -- the W projector's replays after eager PTI
+    iterations returned a constant garbage distance and a NaN latent.  `import spi_amd` switches the capture off before the runtime starts
+    (spi_amd/__init__.py) and the loops replay graphs only then.  Here: the ATen-only reproducer, and a captured projector step of the narrow
+    generator in `w` mode with the feature distance of the W projector, each replayed before and after 3000 eager launches."""
+    import os
+    import spi_amd
+    assert spi_amd.hip_graphs_safe() and os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE') == '0'
+    gen = torch.Generator().manual_seed(0)
+    feats = [torch.randn(1, c, r, r, generator=gen).to(DEV) for c, r in ((64, 256), (128, 128), (256, 64), (512, 32), (512, 16))]
+
+    def body():
+        return sum(torch.sum(f * f, dim=1, keepdim=True).sum() for f in feats)
+    ref = float(body())
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = body()
+    g.replay()
+    assert float(out) == ref
+    t = torch.zeros(1024, device=DEV)
+    for _ in range(3000):
+        t.add_(1.0)
+    g.replay()
+    assert float(out) == ref, (float(out), ref)                  # (with the packet capture on: 7.98e6 -> 7.79e6)
+    # the projector step the defect was found on
+    from spi_amd.criteria.sg_vgg import SgVgg16
+    from spi_amd.training.projectors.common import Projection
+    from spi_amd.training.projectors.w_projector import sg_distance
+    from spi_amd.utils.rng import DeviceRNG
+    from spi_amd.utils import camera_utils as cu
+    G = _narrow()
+    cam = cu.cal_canonical_c(0.4, 0.0).to(DEV).reshape(1, 25)
+    target = torch.tanh(torch.randn(1, 3, 512, 512, generator=gen)).to(DEV)
+    proj = Projection(G, cam, sg_distance(target, SgVgg16(seed=3).to(DEV).eval(), DEV), w_mode='w', initial_w=None, num_steps=100, w_avg_samples=32,
+                      device=DEV, rng=DeviceRNG(DEV))
+    d = [float(proj.step(10 + i)['dist']) for i in range(4)]
+    assert getattr(proj, '_graph', None) is not None
+    for _ in range(3000):
+        t.add_(1.0)
+    d += [float(proj.step(14 + i)['dist']) for i in range(3)]
+    assert all(torch.isfinite(torch.tensor(d))) and bool(torch.isfinite(proj.w_opt).all()), d
+    assert max(d[4:]) <= 1.5 * max(d[:4]), d                     # (garbage replays returned 2e-44, 2e5, -1.8e12, NaN)
+
+
 def test_stage1_hip_graph_captures_beside_an_rccl_process_group():
     """Multi-GPU ranks take the measured code path: with an initialised RCCL process group (watchdog thread
     running, communicator created by a first collective) the stage-1 step is still captured -- in thread-local capture mode -- and its
