@@ -1863,6 +1863,17 @@ __global__ void __launch_bounds__(256) importance_kernel(const float* __restrict
     // coarse+fine together afterwards (renderer.py:157-163); the merged result is the same set either way, and
     // sorted fine rows make the final march read two monotone streams through its permutation.
     __builtin_amdgcn_wave_barrier();
+    bool nan_here = false;
+    for (int j = lane; j < Sf; j += 64) nan_here = nan_here || (tv[j] != tv[j]);
+    if (!__any(nan_here)) {                                  // the normal case (wave-uniform): plain comparisons, 2 instead of ~7 operations per pair
+        for (int j = lane; j < Sf; j += 64) {
+            const float v = tv[j];
+            int rank = 0;
+            for (int m2 = 0; m2 < Sf; ++m2) { const float o = tv[m2]; rank += (o < v) || (o == v && m2 < j); }
+            fine[r * Sf + rank] = v;
+        }
+        return;
+    }
     for (int j = lane; j < Sf; j += 64) {
         const float v = tv[j];
         int rank = 0;
