@@ -69,3 +69,27 @@ def quiet_gc():
         yield
     finally:
         gc.unfreeze()
+
+
+_capture_streams = {}
+
+
+@contextlib.contextmanager
+def capture_graph(g, capture_error_mode='global'):
+    """``with torch.cuda.graph(g, capture_error_mode=...)`` without its ``torch.cuda.empty_cache()``.  torch empties the caching allocator before
+    every capture "to free as much memory as we can for the graph"; on a 288 GB part that buys nothing and costs the loops their warm allocator:
+    the pool reserved at start-up (dist.reserve_allocator_pool) and every cached block go back to the driver, and the eager iterations after the
+    capture pay hipMalloc for GBs again -- most of the ~1 s per image the two stage-2 captures used to cost (tools/soak_cli.py).  Same stream
+    discipline as torch's context manager: a dedicated capture stream per device, device-wide synchronisation first."""
+    import torch
+    dev = torch.cuda.current_device()
+    stream = _capture_streams.get(dev)
+    if stream is None:
+        stream = _capture_streams[dev] = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(stream):
+        g.capture_begin(capture_error_mode=capture_error_mode)
+        try:
+            yield
+        finally:
+            g.capture_end()

@@ -39,6 +39,7 @@ class SingleIDCoach(BaseCoach):
         self.optimizer.zero_grad()
         stop_flag = self._async_flag(loss_lpips <= hyperparameters.LPIPS_value_threshold) if loss_lpips is not None else None
         loss.backward()                                        # enqueued before the flag is read: the GPU stays busy during the host wait
+        zero_arena.finish()
         if stop_flag is not None and stop_flag():              # (:95-96) stops before the optimiser step; the extra gradients are discarded
             return True, dict(loss=loss.detach(), lpips=loss_lpips.detach())
         self.optimizer.step()

@@ -24,7 +24,7 @@ from ...utils.mask_utils import calculate_face_mask
 from ...utils.camera_utils import cal_mirror_c, cal_camera_weight, sample_surrounding_camera, sample_camera, cal_camera_gauss_weight
 from ...utils.rng import DeviceRNG
 from ...torch_utils.ops.conv2d_mfma import sparse_gradients
-from ...torch_utils.misc import trace_range
+from ...torch_utils.misc import trace_range, capture_graph
 from ...torch_utils import zero_arena
 from .base_coach import BaseCoach
 
@@ -163,7 +163,7 @@ class RotBboxCoach(BaseCoach):
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 from ..projectors.common import capture_mode
-                with torch.cuda.graph(g, capture_error_mode=capture_mode()):
+                with capture_graph(g, capture_error_mode=capture_mode()):
                     _, losses = self._forward_backward(i, ctx, w_pivot, rng, flag_buf=self._g2['stop'])
             except Exception as e:                               # noqa: BLE001  (capture is an optimisation: the eager iteration is always valid)
                 import sys
@@ -349,6 +349,7 @@ class RotBboxCoach(BaseCoach):
                     p.grad = g
         # detached: a caller that keeps the dict must not keep the iteration's autograd graph alive with it (with the previous iteration's
         # graph still referenced, ending a HIP-graph capture of the next one crashed inside the runtime)
+        zero_arena.finish()
         return stop_flag, {k: v.detach() for k, v in losses.items()}
 
     def optimise_image(self, ctx, w_pivot, image_name='', rng=None):

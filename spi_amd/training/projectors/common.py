@@ -19,7 +19,7 @@ from ... import hip
 from ...configs import hyperparameters
 from ...utils.rng import DeviceRNG
 from ..optim import Adam
-from ...torch_utils.misc import trace_range
+from ...torch_utils.misc import trace_range, capture_graph
 from ...torch_utils import zero_arena
 from .schedule import stage1_schedule
 
@@ -200,7 +200,7 @@ class Projection:
         try:
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, capture_error_mode=capture_mode()):
+            with capture_graph(g, capture_error_mode=capture_mode()):
                 out = self._body(step, device_hyper=True, hyper_is_set=True)
         except Exception as e:                                   # noqa: BLE001  (capture is an optimisation: the eager step is always valid)
             import sys
@@ -247,6 +247,7 @@ class Projection:
         with trace_range('stage1/optimizer'):
             self.optimizer.step(hyper=self._hyper[:3] if device_hyper else None)
             self.noise_reg.renorm()
+        zero_arena.finish()                                      # nothing outside the step may be handed a view of this step's (possibly graph-owned) buffer
         return dict(dist=dist.detach(), reg=reg_loss.detach(), loss=loss.detach())
 
 

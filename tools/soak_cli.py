@@ -4,6 +4,22 @@ sys.path.insert(0, '.')
 from spi_amd import run_inversion
 from spi_amd.configs import hyperparameters as hp
 hp.LPIPS_value_threshold = -1.0
+if os.environ.get('PHASES'):                                  # wall time of the phases of one image (device-synchronised): stage 1, stage 2, outputs
+    import torch
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+
+    def timed(name):
+        inner = getattr(RotBboxCoach, name)
+
+        def wrapper(self, *a, **k):
+            torch.cuda.synchronize(); t = time.time()
+            out = inner(self, *a, **k)
+            torch.cuda.synchronize()
+            print(f'[phase] {name}: {time.time() - t:.2f} s', file=sys.stderr, flush=True)
+            return out
+        setattr(RotBboxCoach, name, wrapper)
+    for n_ in ('prepare_image', 'restart_training', 'get_inversion', 'optimise_image', 'finish_image', 'post_process'):
+        timed(n_)
 t0 = time.time()
 buf = io.StringIO()
 with contextlib.redirect_stdout(buf):
