@@ -714,11 +714,20 @@ def main():
             per_ray_b = S * 34 * 4 + 33 * 4 + S * 2 * 4
             ach = sum(act) * per_ray_b / (sum(bwd_ms) / 1e3) / 1e9
             dense = [(m, a) for m, a, (_, _, r, _) in zip(bwd_ms, act, bwd_events) if a == r]
+            masked = [(m, a, r) for m, a, (_, _, r, _) in zip(bwd_ms, act, bwd_events) if a != r]
+
+            def part(rows):
+                by = sum(a for _, a in rows) * per_ray_b
+                return {'launches': len(rows), 'achieved': by / (sum(m for m, _ in rows) / 1e3) / 1e9, 'frac': by / (sum(m for m, _ in rows) / 1e3) / 1e9 / HBM_PEAK_GBS,
+                        'avg_launch_us': sum(m for m, _ in rows) / len(rows) * 1e3} if rows else None
             out['roofline_march_bwd'] = {'kernel': 'raymarch_bwd_kernel<%d> (S=%d, C=32)' % ((S + 63) // 64, S), 'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS,
                                          'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'launches': len(bwd_ms), 'avg_launch_us': sum(bwd_ms) / len(bwd_ms) * 1e3,
                                          'bytes_per_active_ray': per_ray_b, 'active_rays_per_launch': sum(act) / len(act),
-                                         'dense_launches_only': ({'launches': len(dense), 'achieved': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9,
-                                                                  'frac': sum(a for _, a in dense) * per_ray_b / (sum(m for m, _ in dense) / 1e3) / 1e9 / HBM_PEAK_GBS} if dense else None)}
+                                         'dense_launches_only': part(dense),
+                                         # the pseudo-view branches' launches (rays with an all-zero incoming gradient are flagged and skipped, 0 bytes): bytes of the live rays
+                                         'masked_launches_only': (dict(part([(m, a) for m, a, _ in masked]), live_ray_share=sum(a for _, a, _ in masked) / sum(r for _, _, r in masked))
+                                                                  if masked else None),
+                                         'note': 'depth-only launches (SPI depth branch: no colour gradient, no colour rows read) carry no march event and are not in this line'}
         # the fused gather + decoder forward is bound by cache-level gather bandwidth + VALU, not by HBM: report the effective gather
         # rate (12 corner rows x 128 B per point, served by L1 / L2 / MALL) against the L2 figure of MI355X_MICROARCH.md and the decoder's
         # vector FLOP rate against the fp32 vector peak.

@@ -10,7 +10,9 @@ HBM rate; `zeros()` hands out 256-byte aligned views of it.  The views keep the 
 accumulator of the iteration dies (torch's caching allocator recycles the block: no device allocation after warm-up), and a capture
 of the iteration in a HIP graph records the one fill like any other launch.
 
-Outside an iteration (`begin()` never called: the operator tests, inference) and whenever a request does not fit (the first
+The loops close the iteration with `finish()` (the next `begin()` implies it): after it nothing is handed a view of that buffer any more -- which
+matters when the iteration was captured into a HIP graph and the buffer belongs to the graph's memory pool.
+Outside an iteration (`begin()` never called or `finish()`ed: the operator tests, inference) and whenever a request does not fit (the first
 iteration of a kind, a larger batch) `zeros()` is `torch.zeros` and `take()` returns None -- same values either way.
 """
 import os
