@@ -27,12 +27,13 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 9   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 10   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive)
                              * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive)
                              * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive)
-                             * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates */
+                             * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates
+                             * 10: + spi_affine_multi_fwd / _bwd (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -413,6 +414,22 @@ int spi_affine_fwd(const float* x, const float* w, const float* b, float gain, f
 /* g [N,O] -> dx [N,I] = gain * g W and / or dw [O,I] = gain * g^T x in one launch (either output may be NULL;
  * w is read for dx only, x for dw only).  The bias gradient is the column sum of g (caller's). */
 int spi_affine_bwd(const float* g, const float* x, const float* w, float gain, float* dx, float* dw, int N, int I, int O, spi_stream_t stream);
+/* ALL affine layers of a synthesis network in one launch each way (SynthesisNetwork.forward, networks_stylegan2.py:499-515: every SynthesisLayer /
+ * ToRGBLayer maps its row of ws through its own FullyConnectedLayer -- 20 matrix-vector products of 5 us in the backbone, 6 per super-resolution
+ * call).  jobs: HOST array of n_jobs <= SPI_AFFINE_MAX_JOBS descriptors (copied into the launch).  Row n of a job's input is x + n * x_row_stride
+ * (rows of ws [N, L, I]: x = ws + l * I, x_row_stride = L * I).
+ *   _fwd: y [N,O] = b + gain * x W^T per job.
+ *   _bwd: per job g [N,O] (NULL: the job is skipped) -> dx_acc[n * x_row_stride ..] += gain * g W (atomic: jobs that read the same row of ws add
+ *         into the same place; the caller zeroes; NULL = not wanted) and dw [O,I] = gain * g^T x (overwritten; NULL = not wanted). */
+#define SPI_AFFINE_MAX_JOBS 32
+typedef struct {
+    const float* x; const float* w; const float* b;      /* input rows, weight [O,I], bias [O] or NULL */
+    float* y;                                             /* _fwd output [N,O] */
+    const float* g; float* dx_acc; float* dw;             /* _bwd */
+    float gain; int O;
+} spi_affine_job;
+int spi_affine_multi_fwd(const spi_affine_job* jobs, int n_jobs, int N, int I, int64_t x_row_stride, spi_stream_t stream);
+int spi_affine_multi_bwd(const spi_affine_job* jobs, int n_jobs, int N, int I, int64_t x_row_stride, spi_stream_t stream);
 /* spi_adam_multi predicated on a DEVICE byte: *skip != 0 -> nothing is written.  The reference tests `loss_lpips <= threshold` on the
  * host before optimizer.step() (rot_bbox_cx_coach.py:148-151); a loop that enqueues iterations ahead of that read leaves the decision in
  * device memory and lets this launch honour it, so the parameters end exactly where the reference's break leaves them. */

@@ -828,6 +828,104 @@ __global__ void __launch_bounds__(1024) affine_bwd_kernel(const float* __restric
     }
 }
 
+// ---- all affine layers of a network in one launch each way: the same two kernels over a table of jobs (by value: <= 32 x 64 B of kernel arguments)
+struct AffineJobs { int n; int blk0[SPI_AFFINE_MAX_JOBS + 1]; spi_affine_job job[SPI_AFFINE_MAX_JOBS]; };
+
+__device__ __forceinline__ int affine_find_job(const AffineJobs& J, int blk) {      // block-uniform: the job whose block range holds blk
+    int j = 0;
+    while (j + 1 < J.n && blk >= J.blk0[j + 1]) ++j;
+    return j;
+}
+
+__global__ void __launch_bounds__(256) affine_multi_fwd_kernel(AffineJobs J, int N, int I, int64_t xs) {
+    const int j = affine_find_job(J, blockIdx.x);
+    const spi_affine_job& q = J.job[j];
+    const int lane = threadIdx.x & 63;
+    const int o = ((int)blockIdx.x - J.blk0[j]) * 4 + (threadIdx.x >> 6);
+    if (o >= q.O) return;                                    // wave-uniform
+    float acc[AFF_NMAX];
+#pragma unroll
+    for (int n = 0; n < AFF_NMAX; ++n) acc[n] = 0.f;
+    const float4* w4 = reinterpret_cast<const float4*>(q.w + (int64_t)o * I);
+    for (int i4 = lane; i4 < I / 4; i4 += 64) {
+        const float4 wv = w4[i4];
+#pragma unroll
+        for (int n = 0; n < AFF_NMAX; ++n) {
+            if (n < N) {
+                const float4 xv = reinterpret_cast<const float4*>(q.x + (int64_t)n * xs)[i4];
+                acc[n] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[n]))));      // same chain as affine_fwd_kernel: bit-equal
+            }
+        }
+    }
+    const float bo = q.b ? q.b[o] : 0.f;
+#pragma unroll
+    for (int n = 0; n < AFF_NMAX; ++n) {
+        if (n < N) {
+            const float s = wave_sum(acc[n]);
+            if (lane == 0) q.y[(int64_t)n * q.O + o] = fmaf(q.gain, s, bo);
+        }
+    }
+}
+
+// per job: ceil(I / 64) blocks for dx (if wanted), then ceil(O * I / 4096) blocks for dw (if wanted); blk0[] holds the running totals
+__global__ void __launch_bounds__(1024) affine_multi_bwd_kernel(AffineJobs J, int N, int I, int64_t xs) {
+    __shared__ float red[16][AFF_NMAX][64];
+    const int j = affine_find_job(J, blockIdx.x);
+    const spi_affine_job& q = J.job[j];
+    const int O = q.O;
+    const float gain = q.gain;
+    const float* __restrict__ g = q.g;
+    const int local = (int)blockIdx.x - J.blk0[j];
+    const int dx_blocks = q.dx_acc ? (I + 63) / 64 : 0;
+    if (local >= dx_blocks) {
+        const int64_t e = ((int64_t)(local - dx_blocks) * 1024 + threadIdx.x) * 4;
+        if (e >= (int64_t)O * I) return;
+        const int o = (int)(e / I), i = (int)(e - (int64_t)o * I);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int n = 0; n < AFF_NMAX; ++n) {
+            if (n < N) {
+                const float gv = g[(int64_t)n * O + o];
+                const float4 xv = *reinterpret_cast<const float4*>(q.x + (int64_t)n * xs + i);
+                acc.x = fmaf(gv, xv.x, acc.x); acc.y = fmaf(gv, xv.y, acc.y); acc.z = fmaf(gv, xv.z, acc.z); acc.w = fmaf(gv, xv.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(q.dw + e) = make_float4(gain * acc.x, gain * acc.y, gain * acc.z, gain * acc.w);
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = local * 64 + lane;
+    const int cc = min(c, I - 1);
+    float acc[AFF_NMAX];
+#pragma unroll
+    for (int n = 0; n < AFF_NMAX; ++n) acc[n] = 0.f;
+    for (int o0 = wave; o0 < O; o0 += 16 * 8) {
+        float wv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wv[k] = q.w[(int64_t)min(o0 + 16 * k, O - 1) * I + cc];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int o = o0 + 16 * k;
+            if (o < O) {
+#pragma unroll
+                for (int n = 0; n < AFF_NMAX; ++n)
+                    if (n < N) acc[n] = fmaf(g[(int64_t)n * O + o], wv[k], acc[n]);
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < AFF_NMAX; ++n) red[wave][n][lane] = acc[n];
+    __syncthreads();
+    for (int t = threadIdx.x; t < N * 64; t += 1024) {
+        const int n = t >> 6, l = t & 63;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][n][l];
+        const int col = local * 64 + l;
+        if (col < I) atomicAdd(q.dx_acc + (int64_t)n * xs + col, gain * s);      // <= 2 jobs share a row of ws: a + b = b + a, the sum does not depend on the order
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stage-1 noise regulariser: one 1024-thread block per noise buffer walks the whole pooling pyramid
 // (<= 6 levels of a 256^2 buffer) with block-level reductions; pooled levels live in an L2-resident
@@ -1560,6 +1658,48 @@ int spi_affine_bwd(const float* g, const float* x, const float* w, float gain, f
     const int dw_blocks = dw ? (int)ceil_div64((int64_t)O * I, 4096) : 0;
     hipLaunchKernelGGL(affine_bwd_kernel, dim3((unsigned)(dx_blocks + dw_blocks)), dim3(1024), 0, as_stream(stream), g, x, w, gain, dx, dw, N, I, O, dx_blocks);
     SPI_LAUNCH_CHECK("spi_affine_bwd");
+    return SPI_OK;
+}
+
+static int affine_jobs_check(const spi_affine_job* jobs, int n_jobs, int N, int I, int64_t xs, const char* who) {
+    SPI_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= SPI_AFFINE_MAX_JOBS && N >= 1 && N <= AFF_NMAX && I >= 4 && I % 4 == 0 && xs >= I && xs % 4 == 0,
+                "%s: need 1 <= n_jobs <= %d, 1 <= N <= %d rows, in_features a multiple of 4, x_row_stride >= I and a multiple of 4 (got n_jobs = %d, N = %d, I = %d, stride = %lld)",
+                who, SPI_AFFINE_MAX_JOBS, AFF_NMAX, n_jobs, N, I, (long long)xs);
+    for (int j = 0; j < n_jobs; ++j)
+        SPI_REQUIRE(jobs[j].O >= 1 && jobs[j].w && jobs[j].x, "%s: job %d: O >= 1, x and w non-NULL", who, j);      // (parameters are views of one flat buffer: 4-byte aligned, like spi_affine_fwd takes them)
+    return SPI_OK;
+}
+
+int spi_affine_multi_fwd(const spi_affine_job* jobs, int n_jobs, int N, int I, int64_t x_row_stride, spi_stream_t stream) {
+    if (int rc = affine_jobs_check(jobs, n_jobs, N, I, x_row_stride, "spi_affine_multi_fwd")) return rc;
+    AffineJobs J;
+    J.n = n_jobs;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        SPI_REQUIRE(jobs[j].y, "spi_affine_multi_fwd: job %d has no output", j);
+        J.job[j] = jobs[j]; J.blk0[j] = blocks; blocks += (jobs[j].O + 3) / 4;
+    }
+    J.blk0[n_jobs] = blocks;
+    hipLaunchKernelGGL(affine_multi_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), J, N, I, x_row_stride);
+    SPI_LAUNCH_CHECK("spi_affine_multi_fwd");
+    return SPI_OK;
+}
+
+int spi_affine_multi_bwd(const spi_affine_job* jobs, int n_jobs, int N, int I, int64_t x_row_stride, spi_stream_t stream) {
+    if (int rc = affine_jobs_check(jobs, n_jobs, N, I, x_row_stride, "spi_affine_multi_bwd")) return rc;
+    AffineJobs J;
+    J.n = 0;
+    int blocks = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        if (!jobs[j].g || (!jobs[j].dx_acc && !jobs[j].dw)) continue;              // no incoming gradient / nothing wanted: skipped
+        J.job[J.n] = jobs[j]; J.blk0[J.n] = blocks;
+        blocks += (jobs[j].dx_acc ? (I + 63) / 64 : 0) + (jobs[j].dw ? (int)ceil_div64((int64_t)jobs[j].O * I, 4096) : 0);
+        ++J.n;
+    }
+    if (J.n == 0) return SPI_OK;
+    J.blk0[J.n] = blocks;
+    hipLaunchKernelGGL(affine_multi_bwd_kernel, dim3((unsigned)blocks), dim3(1024), 0, as_stream(stream), J, N, I, x_row_stride);
+    SPI_LAUNCH_CHECK("spi_affine_multi_bwd");
     return SPI_OK;
 }
 

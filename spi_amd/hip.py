@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
-ABI_VERSION = 9          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
+ABI_VERSION = 10          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -25,6 +25,13 @@ class ConvDesc(ctypes.Structure):
                 ('noise_gain', c_p), ('act', c_i), ('alpha', c_f), ('gain', c_f), ('clamp', c_f), ('dy_seg_flags', c_p), ('out_seg_flags', c_p), ('dw_zeroed', c_i), ('out_zeroed', c_i),
                 ('workspace', c_p), ('workspace_bytes', c_l)]
 
+
+class AffineJob(ctypes.Structure):
+    """spi_affine_job of include/spi_hip.h"""
+    _fields_ = [('x', c_p), ('w', c_p), ('b', c_p), ('y', c_p), ('g', c_p), ('dx_acc', c_p), ('dw', c_p), ('gain', c_f), ('O', c_i)]
+
+
+AFFINE_MAX_JOBS = 32
 
 _SIGS = {
     'spi_abi_version': ([], c_i),
@@ -79,6 +86,8 @@ _SIGS = {
     'spi_decoder_gains': ([c_p] * 4 + [c_f] * 4 + [c_p] * 4 + [c_i, c_p], c_i),
     'spi_affine_fwd': ([c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p], c_i),
     'spi_affine_bwd': ([c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p], c_i),
+    'spi_affine_multi_fwd': ([ctypes.POINTER(AffineJob), c_i, c_i, c_i, c_l, c_p], c_i),
+    'spi_affine_multi_bwd': ([ctypes.POINTER(AffineJob), c_i, c_i, c_i, c_l, c_p], c_i),
     'spi_adam_multi_dev': ([c_p, c_p, c_i, c_l, c_p, c_f, c_f, c_f, c_p], c_i),
 }
 EXPORTS = sorted(list(_SIGS) + ['spi_last_error'])

@@ -246,6 +246,86 @@ class _LinearGain(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _MultiAffine(torch.autograd.Function):
+    """Every affine (style) layer of a synthesis network in ONE launch each way (`spi_affine_multi_fwd / _bwd`): layer l maps row idx[l] of
+    ws [N, L, 512] through its FullyConnectedLayer (networks_stylegan2.py:95-127 of the reference, activation 'linear').  The backbone has 20 of them
+    and a super-resolution call 6 -- 5 us matrix-vector launches that head (forward) and tail (backward) every layer's chain; the same arithmetic
+    per element as the per-layer `_LinearGain` (bit-equal forward), the ws gradient is summed over the layers that share a row inside the launch.
+    Inputs: ws, then (weight, bias) per layer.  Outputs: one style tensor [N, O_l] per layer (views of one buffer)."""
+
+    @staticmethod
+    def forward(ctx, ws, idx, gains, *wb):
+        n, L, I = ws.shape
+        nl = len(idx)
+        weights, biases = wb[0::2], wb[1::2]
+        outs = [w_.shape[0] for w_ in weights]
+        flat = torch.empty(n * sum(outs), device=ws.device, dtype=torch.float32)
+        ys, off = [], 0
+        for o in outs:
+            ys.append(flat[off:off + n * o].view(n, o))
+            off += n * o
+        jobs = (hip.AffineJob * nl)()
+        base = ws.data_ptr()
+        for l in range(nl):
+            jobs[l].x, jobs[l].w, jobs[l].b, jobs[l].y = base + 4 * I * idx[l], weights[l].data_ptr(), biases[l].data_ptr(), ys[l].data_ptr()
+            jobs[l].gain, jobs[l].O = gains[l], outs[l]
+        hip.call('spi_affine_multi_fwd', jobs, nl, n, I, L * I, hip.stream())
+        ctx.save_for_backward(ws, *weights)
+        ctx.idx, ctx.gains, ctx.outs = idx, gains, outs
+        ctx.set_materialize_grads(False)                         # a layer whose styles reach no loss arrives as None in backward and is skipped
+        return tuple(ys)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        ws, *weights = ctx.saved_tensors
+        n, L, I = ws.shape
+        nl = len(ctx.idx)
+        need_ws = ctx.needs_input_grad[0]
+        d_ws = zero_arena.zeros((n, L, I), ws.device) if need_ws else None
+        jobs = (hip.AffineJob * nl)()
+        base, dbase = ws.data_ptr(), (d_ws.data_ptr() if need_ws else 0)
+        grads = [None] * (2 * nl)
+        keep, k = [], 0
+        for l in range(nl):
+            g = gs[l]
+            if g is None:                                        # the layer's styles reached no loss
+                continue
+            g = g.contiguous().float()
+            keep.append(g)
+            need_w, need_b = ctx.needs_input_grad[3 + 2 * l], ctx.needs_input_grad[4 + 2 * l]
+            j = jobs[k]
+            k += 1
+            j.x, j.w, j.g = base + 4 * I * ctx.idx[l], weights[l].data_ptr(), g.data_ptr()
+            j.gain, j.O = ctx.gains[l], ctx.outs[l]
+            if need_ws:
+                j.dx_acc = dbase + 4 * I * ctx.idx[l]
+            if need_w:
+                grads[2 * l] = torch.empty_like(weights[l])
+                j.dw = grads[2 * l].data_ptr()
+            if need_b:
+                grads[2 * l + 1] = g[0] if n == 1 else g.sum(0)
+        if k:
+            hip.call('spi_affine_multi_bwd', jobs, k, n, I, L * I, hip.stream())
+        return (d_ws, None, None, *grads)
+
+
+def multi_affine(ws, layers):
+    """Styles of `layers` = [(module with .affine, row of ws)] in one launch, or None when the fast path does not apply (then every layer runs its own
+    affine): fp32 ws [N <= 8, L, 512] on the GPU, linear FullyConnectedLayers with bias, at most 32 of them."""
+    if not (ws.is_cuda and ws.dtype == torch.float32 and ws.dim() == 3 and 1 <= ws.shape[0] <= 8 and ws.shape[2] % 4 == 0 and 1 <= len(layers) <= hip.AFFINE_MAX_JOBS):
+        return None
+    wb, gains, idx = [], [], []
+    for mod, row in layers:
+        a = mod.affine
+        if a.activation != 'linear' or a.bias is None or a.weight.dtype != torch.float32 or a.bias_gain != 1 or a.weight.shape[1] != ws.shape[2]:
+            return None
+        wb += [a.weight.contiguous(), a.bias.contiguous()]
+        gains.append(float(a.weight_gain))
+        idx.append(int(row))
+    return _MultiAffine.apply(ws.contiguous(), tuple(idx), tuple(gains), *wb)
+
+
 class FullyConnectedLayer(torch.nn.Module):
     def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
         super().__init__()
@@ -328,10 +408,12 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, fp16=False, noise_rng=None):
-        """noise_rng (extension): draw source with ``randn(*shape)`` for noise_mode='random' (tests replay recorded draws)."""
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, fp16=False, noise_rng=None, styles=None):
+        """noise_rng (extension): draw source with ``randn(*shape)`` for noise_mode='random' (tests replay recorded draws).
+        styles (extension): this layer's ``self.affine(w)``, already computed (all layers of a network in one launch: `multi_affine`)."""
         assert noise_mode in ['random', 'const', 'none']
-        styles = self.affine(w)
+        if styles is None:
+            styles = self.affine(w)
         noise = strength = None
         if self.use_noise and noise_mode == 'random':
             shape = [1, 1, self.resolution, self.resolution]                           # the reference's draw shape (:317) at N = 1
@@ -360,8 +442,9 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True, fp16=False):
-        styles = self.affine(w)                                    # * weight_gain happens inside the modulation kernel
+    def forward(self, x, w, fused_modconv=True, fp16=False, styles=None):
+        if styles is None:
+            styles = self.affine(w)                                # * weight_gain happens inside the modulation kernel
         return modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
                                 bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp, style_gain=self.weight_gain, fp16=fp16)
 
@@ -389,8 +472,16 @@ class SynthesisBlock(torch.nn.Module):
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_torgb += 1
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
+    def affine_layers(self):
+        """the block's style layers in execution order"""
+        return ([self.conv0] if self.in_channels != 0 else []) + [self.conv1, self.torgb]
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, **layer_kwargs):
         rows = ws if isinstance(ws, (tuple, list)) else None          # SynthesisNetwork hands over the rows of ONE unbind (see there)
+        if styles is None and rows is None:                           # called on its own (super-resolution module): the block's 2-3 affines in one launch
+            styles = multi_affine(ws, [(m, k) for k, m in enumerate(self.affine_layers())])
+        s_iter = iter(styles) if styles is not None else None
+        nxt = (lambda: next(s_iter)) if s_iter is not None else (lambda: None)
         if rows is None:
             assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim
         else:
@@ -407,11 +498,11 @@ class SynthesisBlock(torch.nn.Module):
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).repeat([(rows[0] if rows is not None else ws).shape[0], 1, 1, 1])
         else:
-            x = self.conv0(x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
-        x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, **layer_kwargs)
+            x = self.conv0(x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, styles=nxt(), **layer_kwargs)
+        x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, styles=nxt(), **layer_kwargs)
         if img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16)
+        y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, styles=nxt())
         img = img + y if img is not None else y
         return x, img
 
@@ -443,10 +534,20 @@ class SynthesisNetwork(torch.nn.Module):
         # the reference narrows ws per block (:509-511) and unbinds inside it: per block a zero-filled [N, num_ws, 512] gradient, a slice copy and an
         # accumulation in the backward.  One unbind for the whole network gives the same rows and ONE stack in the backward.
         rows = ws.unbind(dim=1)
+        # every style layer of the network reads its row of ws through its own affine: all of them in one launch (and one in the backward)
+        layers, k = [], 0
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
-            x, img = block(x, img, rows[w_idx:w_idx + block.num_conv + block.num_torgb], **block_kwargs)
+            layers += [(m, k + j) for j, m in enumerate(block.affine_layers())]
+            k += block.num_conv
+        styles = multi_affine(ws, layers)
+        s_pos = 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            nb = block.num_conv + block.num_torgb
+            x, img = block(x, img, rows[w_idx:w_idx + nb], styles=(styles[s_pos:s_pos + nb] if styles is not None else None), **block_kwargs)
             w_idx += block.num_conv
+            s_pos += nb
         return img
 
 

@@ -258,6 +258,47 @@ def test_affine_layer_matrix_vector_kernels(n, i, o):
     assert_close(dx, dxr.float(), 3e-6, 'affine dx (frozen)')
 
 
+@pytest.mark.parametrize('n', [1, 3])
+def test_multi_affine_equals_the_per_layer_affines(n):
+    """`multi_affine` (spi_affine_multi_fwd / _bwd): all style layers of a network in one launch each way -- outputs bit-equal to the per-layer
+    FullyConnectedLayers, ws / weight / bias gradients equal to theirs (the ws gradient sums the layers that share a row: a + b, commutative),
+    layers with no incoming gradient skipped, frozen weights (stage 1) ask for d ws only."""
+    from spi_amd.training.networks_stylegan2 import FullyConnectedLayer, multi_affine
+    gen = torch.Generator().manual_seed(40 + n)
+    outs, rows = [512, 512, 96 * 0 + 256, 64, 32, 512], [0, 1, 1, 2, 3, 3]
+
+    class L(torch.nn.Module):
+        def __init__(self, o):
+            super().__init__()
+            self.affine = FullyConnectedLayer(512, o, bias_init=1)
+    mods = [L(o).to(DEV) for o in outs]
+    with torch.no_grad():
+        for m in mods:
+            m.affine.weight.copy_(torch.randn(m.affine.weight.shape, generator=gen)); m.affine.bias.copy_(torch.randn(m.affine.bias.shape, generator=gen))
+    ws = torch.randn(n, 5, 512, generator=gen).to(DEV).requires_grad_(True)
+    gys = [torch.randn(n, o, generator=gen).to(DEV) for o in outs]
+    params = [p for m in mods for p in (m.affine.weight, m.affine.bias)]
+    ref = [m.affine(ws[:, r]) for m, r in zip(mods, rows)]
+    got = multi_affine(ws, list(zip(mods, rows)))
+    assert got is not None and len(got) == len(mods)
+    for a, b in zip(got, ref):
+        assert torch.equal(a, b)
+    use = [0, 1, 2, 4, 5]                                        # layer 3 gets no gradient
+    g_ref = torch.autograd.grad([ref[i] for i in use], [ws] + params, [gys[i] for i in use], allow_unused=True)
+    g_got = torch.autograd.grad([got[i] for i in use], [ws] + params, [gys[i] for i in use], allow_unused=True)
+    for k, (a, b) in enumerate(zip(g_got, g_ref)):
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert_close(a, b, 1e-6, f'multi-affine gradient {k}')
+    for m in mods:
+        m.requires_grad_(False)
+    got = multi_affine(ws, list(zip(mods, rows)))
+    (d1,) = torch.autograd.grad(sum(g.square().sum() for g in got), [ws])
+    (d2,) = torch.autograd.grad(sum(m.affine(ws[:, r]).square().sum() for m, r in zip(mods, rows)), [ws])
+    assert_close(d1, d2, 2e-6, 'multi-affine d ws (frozen weights)')
+    assert multi_affine(ws.double(), list(zip(mods, rows))) is None and multi_affine(ws.cpu(), list(zip(mods, rows))) is None
+
+
 # ---- the typed plugin boundary (round 4): fp16 tensors and channels_last strides, as the reference's plugins are instantiated ----------------
 def _half_ulps(a, b):
     """largest difference of two fp16 tensors in units of b's ulp (0 = bit-equal)"""
