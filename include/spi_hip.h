@@ -33,7 +33,7 @@ typedef void* spi_stream_t;           /* hipStream_t */
                              * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive)
                              * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive)
                              * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates
-                             * 10: + spi_affine_multi_fwd / _bwd (additive) */
+                             * 10: + spi_affine_multi_fwd / _bwd, spi_modulate_multi_fwd / _bwd (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -357,6 +357,19 @@ int spi_modulate_fwd(const float* weight, const float* styles, float* w_out, flo
 int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoef, const float* g, float* d_weight,
                      float* d_styles, int N, int O, int I, int T, int demodulate, float style_gain,
                      spi_stream_t stream);
+/* The weight modulation of ALL layers of a synthesis network in one launch each way (every layer's styles are known before its first
+ * convolution runs: spi_affine_multi_fwd).  jobs: HOST array of n_jobs <= SPI_MODULATE_MAX_JOBS descriptors (copied into the launch); the
+ * fields are the arguments of spi_modulate_fwd / spi_modulate_bwd for one layer; N (style rows) is common.  _bwd: d_styles is ADDED to
+ * (caller zeroes), d_weight may be NULL. */
+#define SPI_MODULATE_MAX_JOBS 32
+typedef struct {
+    const float* weight; const float* styles; float* w_out; float* dcoef;      /* _fwd: dcoef may be NULL iff !demodulate */
+    const float* g; float* d_weight; float* d_styles;                          /* _bwd */
+    float style_gain; int O, I, T, demodulate;
+} spi_modulate_job;
+int spi_modulate_multi_fwd(const spi_modulate_job* jobs, int n_jobs, int N, spi_stream_t stream);
+int spi_modulate_multi_bwd(const spi_modulate_job* jobs, int n_jobs, int N, spi_stream_t stream);
+
 
 /* Noise regulariser of the stage-1 projectors (mirror_projector.py:106-116, w_plus_projector.py likewise):
  *   reg = sum_bufs sum_levels  mean(x * roll(x,1,W))^2 + mean(x * roll(x,1,H))^2,   x -> avg_pool2d(x,2) while size > 8

@@ -1464,13 +1464,12 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void __launch_bounds__(256) modulate_fwd_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
-                                                           float* __restrict__ w_out, float* __restrict__ dcoef, int N, int O,
-                                                           int I, int T, int demod, float sgain) {
-    extern __shared__ float smem[];
+// one block = one output channel `o` of one layer; `smem`: I * T floats of dynamic LDS
+__device__ __forceinline__ void modulate_fwd_body(const float* __restrict__ weight, const float* __restrict__ styles,
+                                                  float* __restrict__ w_out, float* __restrict__ dcoef, int N, int O,
+                                                  int I, int T, int demod, float sgain, int o, float* smem, float* red) {
     float* Ws = smem;                  // [I][T] copy of W[o] in storage order (one coalesced sweep; read back with lane stride T: odd, conflict-free)
-    __shared__ float red[4];
-    const int o = blockIdx.x, tid = threadIdx.x, IT = I * T;
+    const int tid = threadIdx.x, IT = I * T;
     const float* wr = weight + (int64_t)o * IT;
     // loops are (tap, channel) nests: no per-element division by T or modulo I (each costs ~30 VALU instructions on gfx950)
     for (int e = tid; e < IT; e += 256) Ws[e] = wr[e];
@@ -1495,17 +1494,24 @@ __global__ void __launch_bounds__(256) modulate_fwd_kernel(const float* __restri
     }
 }
 
-__global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
-                                                           const float* __restrict__ dcoef, const float* __restrict__ g,
-                                                           float* __restrict__ d_weight, float* __restrict__ d_styles, int N,
-                                                           int O, int I, int T, int demod, float sgain) {
+__global__ void __launch_bounds__(256) modulate_fwd_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
+                                                           float* __restrict__ w_out, float* __restrict__ dcoef, int N, int O,
+                                                           int I, int T, int demod, float sgain) {
     extern __shared__ float smem[];
+    __shared__ float red[4];
+    modulate_fwd_body(weight, styles, w_out, dcoef, N, O, I, T, demod, sgain, (int)blockIdx.x, smem, red);
+}
+
+// one block = one output channel `o` of one layer; `smem`: 3 * I * T floats of dynamic LDS
+__device__ __forceinline__ void modulate_bwd_body(const float* __restrict__ weight, const float* __restrict__ styles,
+                                                  const float* __restrict__ dcoef, const float* __restrict__ g,
+                                                  float* __restrict__ d_weight, float* __restrict__ d_styles, int N,
+                                                  int O, int I, int T, int demod, float sgain, int o, float* smem, float* red) {
     const int IT = I * T;
     float* Ws = smem;                  // [I][T] the weight row, in storage order
     float* Acc = smem + IT;            // [I][T] running dW, in storage order
     float* Gs = smem + 2 * IT;         // [T][I] this sample's gradient of the modulated row (tap-major, as the conv kernels read it)
-    __shared__ float red[4];
-    const int o = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const float* wr = weight + (int64_t)o * IT;
     // Every global access is a linear, coalesced sweep over the row (round 3; the [I][T] <-> [T][I] transposition happens in the LDS
     // indices: lanes walk channels, stride T = 9 or 1 floats -- odd, so conflict-free).  Until then thread i read and wrote its 9 taps
@@ -1548,6 +1554,40 @@ __global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restri
     }
 }
 
+__global__ void __launch_bounds__(256) modulate_bwd_kernel(const float* __restrict__ weight, const float* __restrict__ styles,
+                                                           const float* __restrict__ dcoef, const float* __restrict__ g,
+                                                           float* __restrict__ d_weight, float* __restrict__ d_styles, int N,
+                                                           int O, int I, int T, int demod, float sgain) {
+    extern __shared__ float smem[];
+    __shared__ float red[4];
+    modulate_bwd_body(weight, styles, dcoef, g, d_weight, d_styles, N, O, I, T, demod, sgain, (int)blockIdx.x, smem, red);
+}
+
+// ---- the modulation of ALL layers of a network in one launch each way: the same bodies over a table of jobs (by value)
+struct ModulateJobs { int n; int blk0[SPI_MODULATE_MAX_JOBS + 1]; spi_modulate_job job[SPI_MODULATE_MAX_JOBS]; };
+
+__device__ __forceinline__ int modulate_find_job(const ModulateJobs& J, int blk) {
+    int j = 0;
+    while (j + 1 < J.n && blk >= J.blk0[j + 1]) ++j;
+    return j;
+}
+
+__global__ void __launch_bounds__(256) modulate_multi_fwd_kernel(ModulateJobs J, int N) {
+    extern __shared__ float smem[];
+    __shared__ float red[4];
+    const int j = modulate_find_job(J, blockIdx.x);
+    const spi_modulate_job& q = J.job[j];
+    modulate_fwd_body(q.weight, q.styles, q.w_out, q.dcoef, N, q.O, q.I, q.T, q.demodulate, q.style_gain, (int)blockIdx.x - J.blk0[j], smem, red);
+}
+
+__global__ void __launch_bounds__(256) modulate_multi_bwd_kernel(ModulateJobs J, int N) {
+    extern __shared__ float smem[];
+    __shared__ float red[4];
+    const int j = modulate_find_job(J, blockIdx.x);
+    const spi_modulate_job& q = J.job[j];
+    modulate_bwd_body(q.weight, q.styles, q.dcoef, q.g, q.d_weight, q.d_styles, N, q.O, q.I, q.T, q.demodulate, q.style_gain, (int)blockIdx.x - J.blk0[j], smem, red);
+}
+
 int spi_modulate_fwd(const float* weight, const float* styles, float* w_out, float* dcoef, int N, int O, int I, int T,
                      int demodulate, float style_gain, spi_stream_t stream) {
     SPI_REQUIRE(weight && styles && w_out, "spi_modulate_fwd: null tensor");
@@ -1569,6 +1609,31 @@ int spi_modulate_bwd(const float* weight, const float* styles, const float* dcoe
     SPI_LAUNCH_CHECK("spi_modulate_bwd");
     return SPI_OK;
 }
+
+static int modulate_multi(const spi_modulate_job* jobs, int n_jobs, int N, bool bwd, spi_stream_t stream) {
+    const char* who = bwd ? "spi_modulate_multi_bwd" : "spi_modulate_multi_fwd";
+    SPI_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= SPI_MODULATE_MAX_JOBS && N > 0, "%s: need 1 <= n_jobs <= %d and N > 0", who, SPI_MODULATE_MAX_JOBS);
+    ModulateJobs J;
+    J.n = n_jobs;
+    int blocks = 0;
+    int64_t max_it = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const spi_modulate_job& q = jobs[j];
+        SPI_REQUIRE(q.weight && q.styles && q.O > 0 && q.I > 0 && q.T > 0 && (int64_t)q.I * q.T * 12 <= 64 * 1024, "%s: job %d: null tensor or bad sizes (I*T must be <= 5461)", who, j);
+        SPI_REQUIRE(!q.demodulate || q.dcoef, "%s: job %d: demodulation needs dcoef", who, j);
+        SPI_REQUIRE(bwd ? (q.g && q.d_styles) : (q.w_out != nullptr), "%s: job %d: missing %s", who, j, bwd ? "g / d_styles" : "w_out");
+        J.job[j] = q; J.blk0[j] = blocks; blocks += q.O;
+        max_it = std::max<int64_t>(max_it, (int64_t)q.I * q.T);
+    }
+    J.blk0[n_jobs] = blocks;
+    if (bwd) hipLaunchKernelGGL(modulate_multi_bwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)max_it * 12, as_stream(stream), J, N);
+    else hipLaunchKernelGGL(modulate_multi_fwd_kernel, dim3((unsigned)blocks), dim3(256), (size_t)max_it * 4, as_stream(stream), J, N);
+    SPI_LAUNCH_CHECK(who);
+    return SPI_OK;
+}
+
+int spi_modulate_multi_fwd(const spi_modulate_job* jobs, int n_jobs, int N, spi_stream_t stream) { return modulate_multi(jobs, n_jobs, N, false, stream); }
+int spi_modulate_multi_bwd(const spi_modulate_job* jobs, int n_jobs, int N, spi_stream_t stream) { return modulate_multi(jobs, n_jobs, N, true, stream); }
 
 int spi_noise_reg_fwd(const float* const* bufs, const int32_t* res, int T, int max_res, float* pyramid, float* means,
                       float* loss, spi_stream_t stream) {

@@ -33,6 +33,15 @@ class AffineJob(ctypes.Structure):
 
 AFFINE_MAX_JOBS = 32
 
+
+class ModulateJob(ctypes.Structure):
+    """spi_modulate_job of include/spi_hip.h"""
+    _fields_ = [('weight', c_p), ('styles', c_p), ('w_out', c_p), ('dcoef', c_p), ('g', c_p), ('d_weight', c_p), ('d_styles', c_p),
+                ('style_gain', c_f), ('O', c_i), ('I', c_i), ('T', c_i), ('demodulate', c_i)]
+
+
+MODULATE_MAX_JOBS = 32
+
 _SIGS = {
     'spi_abi_version': ([], c_i),
     'spi_sizeof_conv_desc': ([], c_i),
@@ -86,6 +95,8 @@ _SIGS = {
     'spi_decoder_gains': ([c_p] * 4 + [c_f] * 4 + [c_p] * 4 + [c_i, c_p], c_i),
     'spi_affine_fwd': ([c_p, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_p], c_i),
     'spi_affine_bwd': ([c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_p], c_i),
+    'spi_modulate_multi_fwd': ([ctypes.POINTER(ModulateJob), c_i, c_i, c_p], c_i),
+    'spi_modulate_multi_bwd': ([ctypes.POINTER(ModulateJob), c_i, c_i, c_p], c_i),
     'spi_affine_multi_fwd': ([ctypes.POINTER(AffineJob), c_i, c_i, c_i, c_l, c_p], c_i),
     'spi_affine_multi_bwd': ([ctypes.POINTER(AffineJob), c_i, c_i, c_i, c_l, c_p], c_i),
     'spi_adam_multi_dev': ([c_p, c_p, c_i, c_l, c_p, c_f, c_f, c_f, c_p], c_i),

@@ -65,6 +65,98 @@ def modulate_weights(weight, styles, demodulate=True, style_gain=1.0):
     return _Modulate.apply(weight, styles, bool(demodulate), float(style_gain))
 
 
+class _MultiModulate(torch.autograd.Function):
+    """`_Modulate` for ALL layers of a network in one launch each way (`spi_modulate_multi_fwd / _bwd`): every layer's styles exist before its first
+    convolution runs (`multi_affine`), so the 20 + 6 per-layer modulation launches that head every layer's forward chain -- and the 26 that tail its
+    backward -- collapse into one; small layers no longer run on a quarter of the chip.  Same kernel bodies, bit-equal results.
+    Inputs: cfg = ((demodulate, style_gain), ...), then the styles [N, I_l] of every layer, then the weights [O_l, I_l, k, k]."""
+
+    @staticmethod
+    def forward(ctx, cfg, *sw):
+        nl = len(cfg)
+        styles = [s.contiguous().float() for s in sw[:nl]]
+        weights = [w.contiguous().float() for w in sw[nl:]]
+        n = styles[0].shape[0]
+        dev = weights[0].device
+        wflat = torch.empty(sum(n * w.numel() for w in weights), device=dev, dtype=torch.float32)
+        dflat = torch.empty(sum(n * w.shape[0] for w, c in zip(weights, cfg) if c[0]), device=dev, dtype=torch.float32)
+        jobs = (hip.ModulateJob * nl)()
+        outs, dcoefs, wo, do = [], [], 0, 0
+        for l, (w, s, (demod, sgain)) in enumerate(zip(weights, styles, cfg)):
+            o, i, kh, kw = w.shape
+            assert s.shape == (n, i)
+            w2 = wflat[wo:wo + n * w.numel()].view(n, o, kh, kw, i)
+            wo += n * w.numel()
+            dc = None
+            if demod:
+                dc = dflat[do:do + n * o].view(n, o)
+                do += n * o
+            outs.append(w2); dcoefs.append(dc)
+            j = jobs[l]
+            j.weight, j.styles, j.w_out, j.dcoef = w.data_ptr(), s.data_ptr(), w2.data_ptr(), (dc.data_ptr() if dc is not None else None)
+            j.style_gain, j.O, j.I, j.T, j.demodulate = float(sgain), o, i, kh * kw, int(demod)
+        hip.call('spi_modulate_multi_fwd', jobs, nl, n, hip.stream())
+        ctx.save_for_backward(dflat, *styles, *weights)
+        ctx.cfg = cfg
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *gs):
+        cfg = ctx.cfg
+        nl = len(cfg)
+        dflat, *sw = ctx.saved_tensors
+        styles, weights = sw[:nl], sw[nl:]
+        n = styles[0].shape[0]
+        dsflat = zero_arena.zeros(sum(s.numel() for s in styles), styles[0].device)
+        jobs = (hip.ModulateJob * nl)()
+        ds, dws, keep, k, so, do = [None] * nl, [None] * nl, [], 0, 0, 0
+        for l, (w, s, (demod, sgain)) in enumerate(zip(weights, styles, cfg)):
+            o, i, kh, kw = w.shape
+            dsl = dsflat[so:so + n * i].view(n, i)
+            so += n * i
+            dc = None
+            if demod:
+                dc = dflat[do:do + n * o]
+                do += n * o
+            g = gs[l]
+            if g is None:
+                continue
+            g = g.contiguous().float()
+            keep.append(g)
+            ds[l] = dsl
+            if ctx.needs_input_grad[1 + nl + l]:
+                dws[l] = torch.empty_like(w)
+            j = jobs[k]
+            k += 1
+            j.weight, j.styles, j.dcoef, j.g = w.data_ptr(), s.data_ptr(), (dc.data_ptr() if dc is not None else None), g.data_ptr()
+            j.d_weight, j.d_styles = (dws[l].data_ptr() if dws[l] is not None else None), dsl.data_ptr()
+            j.style_gain, j.O, j.I, j.T, j.demodulate = float(sgain), o, i, kh * kw, int(demod)
+        if k:
+            hip.call('spi_modulate_multi_bwd', jobs, k, n, hip.stream())
+        return (None, *ds, *dws)
+
+
+def multi_modulate(layers, styles):
+    """Modulated weights of `layers` (SynthesisLayer / ToRGBLayer modules, execution order) from their `styles` in one launch, or None when the
+    fast path does not apply: any layer on the frozen-weight path of stage 1 (it modulates inside its own function and needs no weight gradient),
+    non-fp32 / non-GPU tensors, more than 32 layers."""
+    if styles is None or not (1 <= len(layers) <= hip.MODULATE_MAX_JOBS):
+        return None
+    cfg, ws_ = [], []
+    for m, s in zip(layers, styles):
+        w = m.weight
+        if not (w.is_cuda and w.dtype == torch.float32 and s.dtype == torch.float32 and w.shape[1] * w.shape[2] * w.shape[3] * 12 <= 64 * 1024):
+            return None
+        if torch.is_grad_enabled() and not w.requires_grad and s.requires_grad:
+            return None                                            # stage 1: _ModConvFrozen
+        torgb = isinstance(m, ToRGBLayer)
+        cfg.append((not torgb, float(m.weight_gain) if torgb else 1.0))
+        ws_.append(w)
+    return _MultiModulate.apply(tuple(cfg), *styles, *ws_)
+
+
 def _tap_energy(weight):
     """sum_t W[o,i,t]^2 [O, I] of a FROZEN conv weight.  Cached ON the parameter object (so it lives and dies with it) and recomputed
     when the tensor has been written since (``_version``): stage 1 evaluates it 500 times per image on unchanged weights."""
@@ -156,7 +248,7 @@ class _ModConvFrozen(torch.autograd.Function):
 @misc.profiled_function
 def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
                      flip_weight=True, fused_modconv=True, noise_strength=None, bias=None, act=None, gain=None, clamp=None,
-                     style_gain=1.0, fp16=False):
+                     style_gain=1.0, fp16=False, w_mod=None):
     """Modulate -> (demodulate) -> conv [-> FIR] [-> + noise -> + bias -> act], reference :34-91 (fused path).
 
     ``noise`` may be the final noise tensor (reference style) or, with ``noise_strength`` given, the
@@ -189,7 +281,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                                  float(style_gain), conv2d_mfma.precision(fp16), _tap_energy(weight) if demodulate else None)
         return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
                                             padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
-    w = modulate_weights(weight, styles, demodulate, style_gain)
+    w = w_mod if w_mod is not None else modulate_weights(weight, styles, demodulate, style_gain)   # w_mod: this layer's share of `multi_modulate`
     if styles.shape[0] == 1 and n > 1:
         w = w[0]
     if up == 1:
@@ -408,7 +500,7 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, fp16=False, noise_rng=None, styles=None):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, fp16=False, noise_rng=None, styles=None, w_mod=None):
         """noise_rng (extension): draw source with ``randn(*shape)`` for noise_mode='random' (tests replay recorded draws).
         styles (extension): this layer's ``self.affine(w)``, already computed (all layers of a network in one launch: `multi_affine`)."""
         assert noise_mode in ['random', 'const', 'none']
@@ -427,7 +519,7 @@ class SynthesisLayer(torch.nn.Module):
         return modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, noise_strength=strength, up=self.up,
                                 padding=self.padding, resample_filter=self.resample_filter, flip_weight=(self.up == 1),
                                 fused_modconv=fused_modconv, bias=self.bias, act=self.activation, gain=self.act_gain * gain,
-                                clamp=clamp, fp16=fp16)
+                                clamp=clamp, fp16=fp16, w_mod=w_mod)
 
     def extra_repr(self):
         return f'in_channels={self.in_channels:d}, out_channels={self.out_channels:d}, resolution={self.resolution:d}, up={self.up}'
@@ -442,11 +534,11 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward(self, x, w, fused_modconv=True, fp16=False, styles=None):
+    def forward(self, x, w, fused_modconv=True, fp16=False, styles=None, w_mod=None):
         if styles is None:
             styles = self.affine(w)                                # * weight_gain happens inside the modulation kernel
         return modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv,
-                                bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp, style_gain=self.weight_gain, fp16=fp16)
+                                bias=self.bias, act='linear', gain=1, clamp=self.conv_clamp, style_gain=self.weight_gain, fp16=fp16, w_mod=w_mod)
 
 
 class SynthesisBlock(torch.nn.Module):
@@ -476,12 +568,13 @@ class SynthesisBlock(torch.nn.Module):
         """the block's style layers in execution order"""
         return ([self.conv0] if self.in_channels != 0 else []) + [self.conv1, self.torgb]
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, **layer_kwargs):
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, styles=None, w_mods=None, **layer_kwargs):
         rows = ws if isinstance(ws, (tuple, list)) else None          # SynthesisNetwork hands over the rows of ONE unbind (see there)
         if styles is None and rows is None:                           # called on its own (super-resolution module): the block's 2-3 affines in one launch
             styles = multi_affine(ws, [(m, k) for k, m in enumerate(self.affine_layers())])
-        s_iter = iter(styles) if styles is not None else None
-        nxt = (lambda: next(s_iter)) if s_iter is not None else (lambda: None)
+            w_mods = multi_modulate(self.affine_layers(), styles)
+        s_iter = iter(zip(styles, w_mods if w_mods is not None else [None] * len(styles))) if styles is not None else None
+        nxt = (lambda: dict(zip(('styles', 'w_mod'), next(s_iter)))) if s_iter is not None else (lambda: {})
         if rows is None:
             assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim
         else:
@@ -498,11 +591,11 @@ class SynthesisBlock(torch.nn.Module):
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).repeat([(rows[0] if rows is not None else ws).shape[0], 1, 1, 1])
         else:
-            x = self.conv0(x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, styles=nxt(), **layer_kwargs)
-        x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, styles=nxt(), **layer_kwargs)
+            x = self.conv0(x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, **nxt(), **layer_kwargs)
+        x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, **nxt(), **layer_kwargs)
         if img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
-        y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, styles=nxt())
+        y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, **nxt())
         img = img + y if img is not None else y
         return x, img
 
@@ -541,11 +634,13 @@ class SynthesisNetwork(torch.nn.Module):
             layers += [(m, k + j) for j, m in enumerate(block.affine_layers())]
             k += block.num_conv
         styles = multi_affine(ws, layers)
+        w_mods = multi_modulate([m for m, _ in layers], styles)       # ... and so is every layer's weight modulation (not on stage 1's frozen-weight path)
         s_pos = 0
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
             nb = block.num_conv + block.num_torgb
-            x, img = block(x, img, rows[w_idx:w_idx + nb], styles=(styles[s_pos:s_pos + nb] if styles is not None else None), **block_kwargs)
+            x, img = block(x, img, rows[w_idx:w_idx + nb], styles=(styles[s_pos:s_pos + nb] if styles is not None else None),
+                           w_mods=(w_mods[s_pos:s_pos + nb] if w_mods is not None else None), **block_kwargs)
             w_idx += block.num_conv
             s_pos += nb
         return img

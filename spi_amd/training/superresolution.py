@@ -47,11 +47,12 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
             x = torch.nn.functional.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
             rgb = torch.nn.functional.interpolate(rgb, size=size, mode='bilinear', align_corners=False, antialias=self.sr_antialias)
         # the six style layers of the two blocks in one launch (one more in the backward)
-        from .networks_stylegan2 import multi_affine
+        from .networks_stylegan2 import multi_affine, multi_modulate
         l0, l1 = self.block0.affine_layers(), self.block1.affine_layers()
         st = multi_affine(ws, [(m, k) for k, m in enumerate(l0)] + [(m, k) for k, m in enumerate(l1)])
-        x, rgb = self.block0(x, rgb, ws, styles=(st[:len(l0)] if st is not None else None), **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, styles=(st[len(l0):] if st is not None else None), **block_kwargs)
+        wm = multi_modulate(l0 + l1, st)
+        x, rgb = self.block0(x, rgb, ws, styles=(st[:len(l0)] if st is not None else None), w_mods=(wm[:len(l0)] if wm is not None else None), **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, styles=(st[len(l0):] if st is not None else None), w_mods=(wm[len(l0):] if wm is not None else None), **block_kwargs)
         return rgb
 
 

@@ -612,3 +612,39 @@ def test_conv_out_zeroed_flag_and_zero_arena():
             assert_close(outs[1][1], outs[0][1], 1e-5, 'arena vs own fill: dgrad')
         finally:
             zero_arena.reset()
+
+
+@pytest.mark.parametrize('n', [1, 2])
+def test_multi_modulate_equals_the_per_layer_modulation(n):
+    """`multi_modulate` (spi_modulate_multi_fwd / _bwd): the weight modulation of all layers of a network in one launch each way -- the same kernel
+    bodies over a job table: modulated weights bit-equal to `modulate_weights` per layer (3x3 demodulated convs and 1x1 ToRGB layers with their
+    weight gain), style and weight gradients equal, a layer without an incoming gradient skipped, None on stage 1's frozen-weight path."""
+    from spi_amd.training.networks_stylegan2 import SynthesisLayer, ToRGBLayer, modulate_weights, multi_modulate
+    gen = torch.Generator().manual_seed(60 + n)
+    layers = [SynthesisLayer(64, 128, 512, 16), SynthesisLayer(128, 128, 512, 16), ToRGBLayer(128, 96, 512), SynthesisLayer(128, 32, 512, 32, up=2),
+              ToRGBLayer(32, 3, 512)]
+    layers = [m.to(DEV) for m in layers]
+    with torch.no_grad():
+        for m in layers:
+            m.weight.copy_(torch.randn(m.weight.shape, generator=gen))
+    styles = [(torch.randn(n, m.weight.shape[1], generator=gen) + 1).to(DEV).requires_grad_(True) for m in layers]
+    ref = [modulate_weights(m.weight, s, not isinstance(m, ToRGBLayer), m.weight_gain if isinstance(m, ToRGBLayer) else 1.0) for m, s in zip(layers, styles)]
+    got = multi_modulate(layers, styles)
+    assert got is not None and len(got) == len(layers)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape and torch.equal(a, b)
+    gws = [torch.randn(r.shape, generator=gen).to(DEV) for r in ref]
+    use = [0, 1, 2, 4]                                           # layer 3 gets no gradient
+    params = [m.weight for m in layers]
+    g_ref = torch.autograd.grad([ref[i] for i in use], styles + params, [gws[i] for i in use], allow_unused=True)
+    g_got = torch.autograd.grad([got[i] for i in use], styles + params, [gws[i] for i in use], allow_unused=True)
+    for k, (a, b) in enumerate(zip(g_got, g_ref)):
+        assert (a is None) == (b is None), k
+        if a is not None:
+            assert_close(a, b, 1e-6, f'multi-modulate gradient {k}')
+    for m in layers:
+        m.requires_grad_(False)
+    assert multi_modulate(layers, styles) is None                # frozen weights + styles that need a gradient: stage 1's own path
+    with torch.no_grad():
+        got = multi_modulate(layers, styles)                     # inference: fine
+    assert got is not None and torch.equal(got[2], ref[2])
