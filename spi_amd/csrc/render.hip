@@ -1108,25 +1108,61 @@ __device__ __forceinline__ int half_bcast(int v, int j, bool upper) {
 }
 __device__ __forceinline__ float half_bcast(float v, int j, bool upper) { return __int_as_float(half_bcast(__float_as_int(v), j, upper)); }
 
-__global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, float* __restrict__ d_planes) {
+// The footprint of every decoder tile in every plane -- the four corner rays of its ray patch at the depths of the tile's first and last
+// point, one texel of slack -- as {x0, x1, y0, y1} (texels).  Round 5: plane_scatter_kernel evaluated these eight points per tile in EVERY one
+// of its waves (~200 vector instructions of block-uniform arithmetic per tile and wave, a fifth of the kernel); one thread per (tile, plane)
+// of this kernel does it once, and the scatter blocks read the four numbers through scalar loads.
+__global__ void __launch_bounds__(256) tile_bbox_kernel(TiledArgs a, int4* __restrict__ bbox) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.tiles * 3) return;
+    const int tile = e / 3, pl = e - tile * 3;
+    const int pidx = tile / a.kchunks, kc = tile - pidx * a.kchunks;
+    const int n = pidx / a.patches, patch = pidx - n * a.patches;
+    const int live = a.count[pidx];
+    if (kc * DT >= live) { bbox[e] = make_int4(0, 0, 0, 0); return; }
+    const uint16_t* porder = a.order + (int64_t)pidx * (64 * a.S);
+    auto depth_of = [&](int id) -> float {
+        const int64_t ray = (int64_t)n * a.M + min(patch_ray(patch, (id >> 8) & 63, a.ray_w, a.patch2d), a.M - 1);
+        return a.depths[ray * a.S + min(id & 255, a.S - 1)];
+    };
+    const float dfirst = depth_of(porder[kc * DT]), dlast = depth_of(porder[min(kc * DT + DT - 1, live - 1)]);
+    int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rl = (r & 1 ? 7 : 0) + (r & 2 ? 56 : 0);                // rays (0,0), (0,7), (7,0), (7,7) of the 8 x 8 patch
+        const int64_t ray = (int64_t)n * a.M + min(patch_ray(patch, rl, a.ray_w, a.patch2d), a.M - 1);
+        const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float dpt = q ? dlast : dfirst;
+            float gx, gy;
+            plane_uv(pl, (o[0] + dpt * d[0]) * a.scale, (o[1] + dpt * d[1]) * a.scale, (o[2] + dpt * d[2]) * a.scale, gx, gy);
+            const Corner cc = make_corner(gx, gy, a.W, a.H);
+            bx0 = min(bx0, cc.x0); bx1 = max(bx1, cc.x0 + 1); by0 = min(by0, cc.y0); by1 = max(by1, cc.y0 + 1);
+        }
+    }
+    bbox[e] = make_int4(bx0 - 1, bx1 + 1, by0 - 1, by1 + 1);            // (a depth bin is not infinitely thin: one texel of slack)
+}
+
+__global__ void __launch_bounds__(SCT, 4) plane_scatter_kernel(TiledArgs a, const int4* __restrict__ bbox, float* __restrict__ d_planes) {
     // Structure (what the first versions of this kernel got wrong, measured -- profiles/r03*):
     //  * a tile is only 256 points x 4 row-atomics, so anything paid per tile dominates.  A block-wide reduction for the window centre,
     //    point data handed from the computing thread to the scattering lanes through LDS arrays and four barriers cost 17 k cycles per
     //    tile for 5 k cycles of atomics.  Now the window position comes from block-UNIFORM data -- the patch's four corner rays at the
-    //    depth of the tile's first and last point -- so every wave computes it by itself and the window only moves when that footprint
-    //    no longer fits; only such a move needs barriers (the rows that leave are flushed by their owners between two of them).
-    //  * every half-wave prepares the corners of its own 16 points in lanes 0..15 and takes them from there with v_readlane: no LDS arrays.
-    //    What is left is VALU-issue bound (profiles/r03l_pmc_scatter_summary.txt: ~1000 vector instructions per tile and wave at 4 cycles
-    //    each = 93 % of the SIMD's time; a 64-lane variant with one point per wave-instruction and weights prepared once per point
-    //    needed as many -- the per-tile set-up outweighs the shorter loop -- and ran slower).
+    //    depth of the tile's first and last point (tile_bbox_kernel) -- and the window only moves when that footprint no longer fits;
+    //    only such a move needs barriers (the rows that leave are flushed by their owners between two of them).
+    //  * every half-wave prepares the corners of its own 16 points in lanes 0..15 and hands them to its 32 lanes through a 24-byte LDS record.
+    //  * Round 5: the kernel was VALU-issue bound on PER-TILE work (~1000 vector instructions per 256-point tile and wave, the atomics' own
+    //    loop a third of it; profiles/r05a_bench_render.txt: 0.38 ms of vector work beside 0.26 ms of LDS atomics).  Gone: the footprint
+    //    (-> tile_bbox_kernel + scalar loads), the row loads' address arithmetic (raw buffer loads: wave-uniform tile base in the scalar
+    //    offset, the row in the immediate; rows past the patch's last point read as zeros), the copies of the row registers (two
+    //    buffers whose roles alternate), the cell-offset arithmetic of the loop (records carry cell << 8: one v_and_or / SDWA-or per corner).
+    //    Measured and dropped on the way: 512-point tiles with one point per thread (the slab is twice as thick, its XZ / ZX footprint no
+    //    longer fits the 16 x 16 window: 1.79 vs 1.63 ms per image) and 256-thread blocks with 32 points per half-wave (half the per-tile
+    //    work, but at 2 waves per SIMD the LDS round trips of the loop are exposed: 1.83 ms).
     __shared__ __attribute__((aligned(16))) double pwin[WIN * WIN * DEC_IN];        // the persistent window: cell ((y & 15) << 4 | (x & 15)), 32 channels each
-    // Round 4: what a point contributes to this plane -- its four corner weights and its four window cells -- is prepared ONCE by the lane that owns
-    // the point and handed to the half-wave that scatters it through a 20-byte LDS record (one broadcast ds_read_b128 + ds_read_b32 per point)
-    // instead of three v_readlane pairs + selects and ~15 instructions of weight / cell arithmetic repeated by all 32 lanes for every point
-    // (the loop was VALU-issue bound: profiles/r04a_bench_render.txt, the scatter costs 0.5 ms of its 0.69 even without its atomics).
-    // A half-wave only ever reads the records its own wave wrote (LDS operations of one wave execute in order): no barrier.
     __shared__ __attribute__((aligned(16))) float tabw[SCT / 32][16][4];          // per half-wave, per point: w00 w01 w10 w11
-    __shared__ unsigned tabc[SCT / 32][16];                                       // cells c00 | c01 << 8 | c10 << 16 | c11 << 24, or PC_SKIP / PC_SLOW
+    __shared__ __attribute__((aligned(8))) unsigned tabc[SCT / 32][16][2];        // byte offsets of the cells: (c00 << 8) | (c01 << 24), (c10 << 8) | (c11 << 24)
     const int t = threadIdx.x;
     const int hw = t >> 5, ch = t & 31;
     const bool upper = (t & 32) != 0;
@@ -1167,56 +1203,37 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
         const float* o = a.ray_o + ray * 3; const float* d = a.ray_d + ray * 3;
         r.o0 = o[0]; r.o1 = o[1]; r.o2 = o[2]; r.d0 = d[0]; r.d1 = d[1]; r.d2 = d[2];
     };
-    auto uv_of = [&](const RawPoint& r, float dpt, float& gx, float& gy) {
-        plane_uv(pl, (r.o0 + dpt * r.d0) * a.scale, (r.o1 + dpt * r.d1) * a.scale, (r.o2 + dpt * r.d2) * a.scale, gx, gy);
-    };
-    // the patch's four corner rays (rays (0,0), (0,7), (7,0), (7,7) of the 8 x 8 patch): block-uniform, they bound its footprint
-    RawPoint corner[4];
-    load_raw(0 << 8, corner[0]); load_raw(7 << 8, corner[1]); load_raw(56 << 8, corner[2]); load_raw(63 << 8, corner[3]);
+    const int4* const pbox = bbox + ((int64_t)pidx * a.kchunks) * 3 + pl;       // + 3 kc: this plane's footprint of tile kc (block-uniform -> scalar loads)
     const int myp = hw * 16 + (t & 15);                      // the point whose corner this lane prepares (lanes 16..31 of a half-wave mirror 0..15)
-    const float* drows = a.dfeat + (int64_t)pidx * (64 * a.S) * DEC_IN;
-    // this half-wave's 16 rows of a tile, one channel per lane, requested TWO tiles ahead (one tile is ~1.5 us of work, less than an HBM
-    // round trip under load)
-    float dv[16], dvn[16], dvnn[16];
+    // this half-wave's 16 rows of a tile, one channel per lane, requested one tile ahead (a tile is several us of work): the patch's rows are one buffer of live_pts * 128 bytes -- rows of decoder tiles that were never written
+    // (past the last live point) read as zeros
+    const __amdgpu_buffer_rsrc_t rrs = make_rsrc(a.dfeat + (int64_t)pidx * (64 * a.S) * DEC_IN, (int64_t)live_pts * (DEC_IN * 4));
+    const int voff = (hw * 16) * (DEC_IN * 4) + ch * 4;      // per lane: its half-wave's first row, its channel
+    auto load_rows = [&](int kc, float (&d)[16]) __attribute__((always_inline)) {
+        const int soff = min(kc, ntiles - 1) * (DT * DEC_IN * 4);         // (uniform)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dvn[j] = drows[((int64_t)kc_begin * DT + hw * 16 + j) * DEC_IN + ch];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) dvnn[j] = drows[((int64_t)min(kc_begin + 1, ntiles - 1) * DT + hw * 16 + j) * DEC_IN + ch];
+        for (int j = 0; j < 16; ++j) d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, voff + j * (DEC_IN * 4), soff, 0));
+    };
+    float dva[16], dvb[16];
+    load_rows(kc_begin, dva);
     int id_cur = load_id(kc_begin, myp), id_n = load_id(kc_begin + 1, myp);
-    int idf_cur = load_id(kc_begin, 0), idl_cur = load_id(kc_begin, DT - 1), idf_n = load_id(kc_begin + 1, 0), idl_n = load_id(kc_begin + 1, DT - 1);      // first / last entry of the tile: uniform
     RawPoint raw_n;
     load_raw(id_cur, raw_n);
-    float dfirst_n = a.depths[ray_of(idf_cur) * a.S + min(idf_cur & 255, a.S - 1)];
-    float dlast_n = a.depths[ray_of(idl_cur) * a.S + min(idl_cur & 255, a.S - 1)];
-    constexpr int CELL_SKIP = -1, CELL_SLOW = -2;
-    for (int kc = kc_begin; kc < kc_end; ++kc) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) { dv[j] = dvn[j]; dvn[j] = dvnn[j]; }
+    int4 box_n = pbox[3 * kc_begin];
+    const unsigned chb = (unsigned)ch * 8u;                  // this lane's channel inside a cell (256 B per cell)
+    char* const wbase = reinterpret_cast<char*>(pwin);
+    // one tile: `dv` holds its rows, `dvnext` receives those of tile kc + 1
+    auto do_tile = [&](int kc, const float (&dv)[16], float (&dvnext)[16]) __attribute__((always_inline)) {
         const RawPoint raw = raw_n;
-        const float dfirst = dfirst_n, dlast = dlast_n;
+        const int4 box = box_n;
         const bool valid = kc * DT + myp < live_pts;
-        id_cur = id_n; idf_cur = idf_n; idl_cur = idl_n;
-        id_n = load_id(kc + 2, myp); idf_n = load_id(kc + 2, 0); idl_n = load_id(kc + 2, DT - 1);
-        {
-            const int64_t rowbase = (int64_t)min(kc + 2, ntiles - 1) * DT + hw * 16;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) dvnn[j] = drows[(rowbase + j) * DEC_IN + ch];
-        }
+        id_cur = id_n;
+        id_n = load_id(kc + 2, myp);
+        load_rows(kc + 1, dvnext);
         load_raw(id_cur, raw_n);                             // (id_cur was requested during the previous iteration)
-        dfirst_n = a.depths[ray_of(idf_cur) * a.S + min(idf_cur & 255, a.S - 1)];
-        dlast_n = a.depths[ray_of(idl_cur) * a.S + min(idl_cur & 255, a.S - 1)];
-        // ---- the tile's footprint in this plane: the four corner rays at the depths of its first and last point (block-uniform)
-        int bx0 = 0x7fffffff, bx1 = -0x7fffffff, by0 = 0x7fffffff, by1 = -0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                float cgx, cgy;
-                uv_of(corner[r], e ? dlast : dfirst, cgx, cgy);
-                const Corner cc = make_corner(cgx, cgy, a.W, a.H);
-                bx0 = min(bx0, cc.x0); bx1 = max(bx1, cc.x0 + 1); by0 = min(by0, cc.y0); by1 = max(by1, cc.y0 + 1);
-            }
-        bx0 -= 1; by0 -= 1; bx1 += 1; by1 += 1;           // (a depth bin is not infinitely thin: one texel of slack)
+        box_n = pbox[3 * min(kc + 1, ntiles - 1)];
+        // ---- the tile's footprint in this plane (block-uniform): does the window hold it?
+        const int bx0 = box.x, bx1 = box.y, by0 = box.z, by1 = box.w;
         const bool fits = placed && bx0 >= ox && bx1 < ox + WIN && by0 >= oy && by1 < oy + WIN;
         if (!fits) {
             const int wx0 = (bx0 + bx1 + 1) / 2 - WIN / 2, wy0 = (by0 + by1 + 1) / 2 - WIN / 2;      // centred on the footprint
@@ -1231,9 +1248,9 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
             }
             ox = wx0; oy = wy0; placed = true;
         }
-        // ---- this lane's point: corner, bilinear fractions, window cell
+        // ---- this lane's point: corner, bilinear fractions, window cells
         float gx, gy;
-        uv_of(raw, raw.dpt, gx, gy);
+        plane_uv(pl, (raw.o0 + raw.dpt * raw.d0) * a.scale, (raw.o1 + raw.dpt * raw.d1) * a.scale, (raw.o2 + raw.dpt * raw.d2) * a.scale, gx, gy);
         const Corner c = make_corner(gx, gy, a.W, a.H);
         // points whose four corners all lie outside the plane image contribute nothing to this plane (padding_mode zeros)
         const bool vin = valid && c.x0 + 1 >= 0 && c.x0 < a.W && c.y0 + 1 >= 0 && c.y0 < a.H;
@@ -1253,24 +1270,39 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
                 // points that are skipped (padding, outside the plane) or take the slow path below get ZERO weights on cell 0: the main loop has
                 // no branch (a branch on a value that has just been read from LDS costs the LDS latency per point -- measured, first version)
                 *reinterpret_cast<float4*>(&tabw[hw][t & 15][0]) = fast ? make_float4(fx0 * fy0, fx1 * fy0, fx0 * fy1, fx1 * fy1) : make_float4(0.f, 0.f, 0.f, 0.f);
-                tabc[hw][t & 15] = fast ? ((unsigned)my_base | ((unsigned)c01 << 8) | ((unsigned)c10 << 16) | ((unsigned)c11 << 24)) : 0u;
+                *reinterpret_cast<uint2*>(&tabc[hw][t & 15][0]) = fast ? make_uint2(((unsigned)my_base << 8) | ((unsigned)c01 << 24), ((unsigned)c10 << 8) | ((unsigned)c11 << 24))
+                                                                       : make_uint2(0u, 0u);
             }
             asm volatile("" ::: "memory");
         }
         const unsigned long long slow_all = __ballot(vin && !fast && (t & 16) == 0);     // bits 0..15: lower half-wave's points, 32..47: upper's
-        char* const wch = reinterpret_cast<char*>(pwin) + ch * 8;                 // this lane's channel inside a cell (256 B per cell)
         // ---- a half-wave (32 lanes = the 32 channels of one texel row) per point: four ds_add_f64 of 32 consecutive doubles, straight-line code
+        // The records are read four points at a time, the NEXT four before the atomics of the current four are issued: LDS operations of a
+        // wave complete in order, so a record read issued behind 16 atomics waits for all of them (and for the other 15 waves' atomics queued
+        // in between) -- with one read per point the loop ran at the LDS round-trip latency, not at the atomics' rate.
         if (!(a.dbg & 32)) {
+            uint2 pcb[2][4]; float4 wb[2][4];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const unsigned pc = tabc[hw][j];
-                const float4 w = *reinterpret_cast<const float4*>(&tabw[hw][j][0]);
-                const float dvj = dv[j];
-                // the product in fp32 (what grid_sample's backward forms too), the SUM in fp64
-                atomicAdd(reinterpret_cast<double*>(wch + ((pc & 0xffu) << 8)), (double)(dvj * w.x));
-                atomicAdd(reinterpret_cast<double*>(wch + (pc & 0xff00u)), (double)(dvj * w.y));
-                atomicAdd(reinterpret_cast<double*>(wch + ((pc >> 8) & 0xff00u)), (double)(dvj * w.z));
-                atomicAdd(reinterpret_cast<double*>(wch + ((pc >> 16) & 0xff00u)), (double)(dvj * w.w));
+            for (int i = 0; i < 4; ++i) { pcb[0][i] = *reinterpret_cast<const uint2*>(&tabc[hw][i][0]); wb[0][i] = *reinterpret_cast<const float4*>(&tabw[hw][i][0]); }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (g < 3) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { pcb[(g + 1) & 1][i] = *reinterpret_cast<const uint2*>(&tabc[hw][4 * g + 4 + i][0]); wb[(g + 1) & 1][i] = *reinterpret_cast<const float4*>(&tabw[hw][4 * g + 4 + i][0]); }
+                }
+                asm volatile("" ::: "memory");                 // (keeps the reads above the atomics)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint2 pc = pcb[g & 1][i];
+                    const float4 w = wb[g & 1][i];
+                    const float dvj = dv[4 * g + i];
+                    // the product in fp32 (what grid_sample's backward forms too), the SUM in fp64
+                    atomicAdd(reinterpret_cast<double*>(wbase + ((pc.x & 0xff00u) | chb)), (double)(dvj * w.x));
+                    atomicAdd(reinterpret_cast<double*>(wbase + ((pc.x >> 16) | chb)), (double)(dvj * w.y));
+                    atomicAdd(reinterpret_cast<double*>(wbase + ((pc.y & 0xff00u) | chb)), (double)(dvj * w.z));
+                    atomicAdd(reinterpret_cast<double*>(wbase + ((pc.y >> 16) | chb)), (double)(dvj * w.w));
+                }
+                asm volatile("" ::: "memory");
             }
         }
         // ---- rare: points with a corner outside the window or outside the plane image, corner by corner (wave-uniform test first)
@@ -1300,6 +1332,10 @@ __global__ void __launch_bounds__(SCT, 2) plane_scatter_kernel(TiledArgs a, floa
                 }
             }
         }
+    };
+    for (int kc = kc_begin; kc < kc_end; kc += 2) {
+        do_tile(kc, dva, dvb);
+        if (kc + 1 < kc_end) do_tile(kc + 1, dvb, dva);
     }
     // ---- the block's tiles are done: everything still resident goes to HBM
     __syncthreads();
@@ -2094,6 +2130,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     uint16_t* order = reinterpret_cast<uint16_t*>(count + (((int64_t)N * a.patches + 31) & ~(int64_t)31));
     const int64_t order_floats = (((int64_t)N * a.patches * 64 * S + 1) / 2 + 31) & ~(int64_t)31;
     a.dfeat = reinterpret_cast<float*>(order) + order_floats;
+    int4* bbox = reinterpret_cast<int4*>(a.dfeat + (int64_t)N * a.patches * 64 * S * DEC_IN);      // footprint of every (tile, plane): tile_bbox_kernel
     a.order = order; a.count = count;
     hipLaunchKernelGGL(bin_points_kernel, dim3((unsigned)(N * a.patches)), dim3(256), 0, st, depths_sorted, ray_active, M, S, ray_w, a.patch2d,
                        a.patches, order, count);
@@ -2107,8 +2144,10 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
         if (d_rgb) SPI_BWD_LAUNCH(false, true); else SPI_BWD_LAUNCH(false, false);
     }
 #undef SPI_BWD_LAUNCH
-    if (!(a.dbg & 1))                                          // (tools/bench_render.py: 1 = decoder only)
-        hipLaunchKernelGGL(plane_scatter_kernel, dim3((unsigned)(N * a.patches), 3, 2), dim3(SCT), 0, st, a, d_planes_nhwc);
+    if (!(a.dbg & 1)) {                                        // (tools/bench_render.py: 1 = decoder only)
+        hipLaunchKernelGGL(tile_bbox_kernel, dim3((unsigned)((tiles * 3 + 255) / 256)), dim3(256), 0, st, a, bbox);
+        hipLaunchKernelGGL(plane_scatter_kernel, dim3((unsigned)(N * a.patches), 3, 2), dim3(SCT), 0, st, a, bbox, d_planes_nhwc);
+    }
     SPI_LAUNCH_CHECK("spi_triplane_decode_bwd_sorted");
     return SPI_OK;
 }
@@ -2120,7 +2159,7 @@ int64_t spi_triplane_decode_bwd_sorted_ws(int N, int M, int S, int ray_w) {
     const int64_t counts = ((int64_t)N * patches + 31) & ~(int64_t)31;               // int32 per patch (regions kept 128-byte aligned)
     const int64_t order = (((int64_t)N * patches * 64 * S + 1) / 2 + 31) & ~(int64_t)31;     // uint16 per point, in floats
     const int64_t dfeat = (int64_t)N * patches * 64 * S * DEC_IN;                    // the d_feat rows handed from the decoder kernel to the scatter kernel
-    return FRAG_TOTAL + 32 + std::min<int64_t>(tiles, BWD_MAX_GRID) * 4 * PART_ROW + counts + order + dfeat;
+    return FRAG_TOTAL + 32 + std::min<int64_t>(tiles, BWD_MAX_GRID) * 4 * PART_ROW + counts + order + dfeat + tiles * 3 * 4;      // + the footprint boxes (int4 per tile and plane)
 }
 
 int spi_decoder_wgrad(const float* dump, int64_t cols, float* dw1, float* db1, float* dw2, float* db2, spi_stream_t stream) {
