@@ -337,7 +337,7 @@ def dry_run(args, sdist, rank, world):
         ok = 0.0
     dt, rank_s, rank_ok = reduce_run_stats(sdist, rank, world, t0, time.perf_counter() - t0, ok, None)
     devices = gather_rank_devices(sdist, rank, world, int(os.environ.get('LOCAL_RANK', rank)), None)
-    affinity = sdist.pin_rank_affinity(int(os.environ.get('LOCAL_RANK', rank)), int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    affinity = sdist.pin_rank_affinity(int(os.environ.get('LOCAL_RANK', rank)), sdist.local_world_size(world))
     affinity_report = gather_affinity(sdist, rank, world, affinity, None)
     from spi_amd.configs import global_config
     from spi_amd.training.projectors.common import graph_policy, capture_mode
@@ -366,7 +366,7 @@ def main():
     dev_index = sdist.device_index(local)                        # HIP_VISIBLE_DEVICES honoured
     torch.cuda.set_device(dev_index)
     dev = torch.device(f'cuda:{dev_index}')
-    affinity = sdist.pin_rank_affinity(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
+    affinity = sdist.pin_rank_affinity(local, sdist.local_world_size(world))
     from spi_amd import hip
     hip.lib()                                                    # fail loudly if libspi_hip.so is missing
     from spi_amd.configs import hyperparameters, paths_config, global_config
@@ -691,7 +691,7 @@ def main():
                                    f'{args.depth}+{args.depth} samples' + (', fp16 MFMA super-resolution' if args.sr_fp16 else '')), 'step_mix': {'value_mix': 'stage1:stage2 = 1:2 exact (500:1000), computed from the per-stage rates' if (k1 and k2) else 'single stage', 'timed_steps': {'stage1_mir': k1, 'stage2_rotbbox': k2}},
                        'parallelism': f'{world} independent image(s), no data-path collective', 'narrow_debug_model': bool(args.narrow),
                        'only_stage': args.only, 'stage1_hip_graph': bool(global_config.stage1_hip_graph and getattr(proj, '_graph', None) is not None),
-                       'state_finite_after_timed_steps': state_finite, 'hip_graph_packet_capture_env': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), 'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph and not pti and getattr(coach, '_g2', None) is not None and not getattr(coach, '_graph_failed', False)),
+                       'state_finite_after_timed_steps': state_finite, 'hip_graph_packet_capture_env': os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE'), 'hip_graph_self_test': __import__('spi_amd').hip_graphs_status()['self_test'], 'stage1_graph_build_steps_before_warmup': graph_build_steps, 'allocator_pool_reserved_gib_before_warmup': pool_gib, 'python_gc_frozen_after_warmup': os.environ.get('SPI_BENCH_GC_FREEZE', '1') != '0', 'stage2_hip_graph': bool(global_config.stage2_hip_graph and not pti and getattr(coach, '_g2', None) is not None and not getattr(coach, '_graph_failed', False)),
                        'stage2_graph_build_iterations_before_warmup': setup_iters,
                        'conv3x3': ('Winograd F(2x2,3x3) forward / dgrad on the >= 128^2 layers (fp32 operands and accumulation), implicit GEMM elsewhere'
                                    if global_config.conv_winograd and global_config.conv_precision in (0, 3) else 'implicit GEMM'),

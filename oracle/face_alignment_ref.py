@@ -145,7 +145,8 @@ def landmarks_from_face(Pfan, image, box):
             x0, x1 = max(0, ul[0]), min(W, br[0])
             if x1 > x0:
                 patch[yy, x0 - ul[0]:x1 - ul[0]] = image[sy, x0:x1]
-    inp = F.interpolate(torch.from_numpy(patch).permute(2, 0, 1)[None], size=(256, 256), mode='bilinear', align_corners=False) / 255.0
+    inp = F.interpolate(torch.from_numpy(patch).permute(2, 0, 1)[None], size=(256, 256), mode='bilinear', align_corners=False)
+    inp = torch.floor(inp + 0.5).clamp(0, 255) / 255.0              # the package resizes the uint8 crop with cv2 (rounds to uint8) before scaling
     with torch.no_grad():
         hm = fan_forward(Pfan, inp)[-1][0]
     inv64 = np.linalg.inv(_t((cx, cy), scale, 64))

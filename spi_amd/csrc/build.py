@@ -29,7 +29,11 @@ HIPCC_SERIES = '7.2'
 
 def check_compiler(hipcc):
     """-> the compiler's 'HIP version' string; raises unless it is the series the kernels were verified with (SPI_ALLOW_ANY_HIPCC=1 overrides)."""
-    out = subprocess.run([hipcc, '--version'], capture_output=True, text=True).stdout
+    try:
+        out = subprocess.run([hipcc, '--version'], capture_output=True, text=True).stdout
+    except OSError as e:
+        raise RuntimeError(f'cannot run {hipcc} ({e}): libspi_hip.so must be (re)built with ROCm {HIPCC_SERIES}.x hipcc -- set HIPCC=/path/to/hipcc '
+                           '(SPI_ALLOW_ANY_HIPCC=1 accepts another series; re-run the GPU tests then)') from e
     ver = next((ln.split(':', 1)[1].strip() for ln in out.splitlines() if ln.startswith('HIP version')), '')
     if not ver.startswith(HIPCC_SERIES + '.') and os.environ.get('SPI_ALLOW_ANY_HIPCC') != '1':
         raise RuntimeError(f'{hipcc} reports HIP version {ver or "?"}; the kernels are verified with {HIPCC_SERIES}.x '
@@ -72,6 +76,8 @@ def build(force=False, verbose=True):
     subprocess.check_call(cmd)
     with open(STAMP, 'w') as f:
         f.write(dig)
+    with open(STAMP + '.compiler', 'w') as f:                    # which compiler built the library that the stamp vouches for
+        f.write(ver + '\n')
     return LIB
 
 

@@ -84,15 +84,28 @@ def plan_affinity(local_world, allowed, numa_cpus=None):
     return plan
 
 
+def local_world_size(world):
+    """Ranks on THIS host: LOCAL_WORLD_SIZE when the launcher exports it (torchrun does), else the GPUs this process sees (a multi-node run
+    without torchrun must not split the host's cores by the GLOBAL world size), at most `world`."""
+    v = os.environ.get('LOCAL_WORLD_SIZE')
+    if v is not None:
+        return int(v)
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return max(1, min(world, n)) if n else world
+
+
 def pin_rank_affinity(local_rank, local_world):
     """One process per GPU on one host: give every rank its own host cores, next to its GPU.  An eager stage-2 iteration needs ~25 ms of
     single-thread launch work per ~25 ms of GPU time, so ranks that share cores (or sit on the far socket) lose throughput to each other;
     8 ranks with one all-core OpenMP pool each would also oversubscribe the host.  No-op for a single-rank run, on platforms without
-    sched_setaffinity, and when SPI_PIN_AFFINITY=0.  -> the CPU list this rank now holds (or None)."""
+    sched_setaffinity, and when SPI_PIN_AFFINITY=0; an even split of the allowed cores when the process cannot see all local GPUs.  -> the CPU list this rank now holds (or None)."""
     if local_world <= 1 or os.environ.get('SPI_PIN_AFFINITY', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
         return None
     allowed = os.sched_getaffinity(0)
-    numa = [_gpu_numa_cpus(device_index(r)) for r in range(local_world)] if torch.cuda.is_available() else None
+    # NUMA placement needs every local rank's PHYSICAL device.  Under a launcher that shows each rank only its own GPU (HIP_VISIBLE_DEVICES=<rank>)
+    # device_index(r) is 0 for every r: all ranks would believe they share this rank's node and take 1 / local_world of it.  Then: even split.
+    sees_all = torch.cuda.is_available() and torch.cuda.device_count() >= local_world
+    numa = [_gpu_numa_cpus(device_index(r)) for r in range(local_world)] if sees_all else None
     mine = plan_affinity(local_world, allowed, numa)[local_rank]
     try:
         os.sched_setaffinity(0, mine)

@@ -19,10 +19,14 @@ def face_alignment_detector():
         import face_alignment
         kind = getattr(face_alignment.LandmarksType, 'TWO_D', None) or face_alignment.LandmarksType._2D
         det = face_alignment.FaceAlignment(kind)
+        which = 'pip package face_alignment %s' % getattr(face_alignment, '__version__', '?')
     except ImportError:
         from ..third_part import face_alignment as own            # S3FD + 2D-FAN-4 on the HIP convs; raises FileNotFoundError without the weight files
         from ..configs import global_config
         det = own.FaceAlignment(own.LandmarksType._2D, device=global_config.device)
+        which = 'spi_amd.third_part.face_alignment (S3FD + 2D-FAN-4 on the HIP convs; parity with the pip package unpinned)'
+    import sys
+    print(f'[spi_amd] landmark detector: {which}', file=sys.stderr)      # two machines must not differ silently in which detector ran
 
     def fn(image):
         lm = det.get_landmarks_from_image(np.array(image))

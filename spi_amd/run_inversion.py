@@ -102,7 +102,7 @@ def run(argv=None):
     dev_index = sdist.device_index(local)                         # HIP_VISIBLE_DEVICES honoured (the reference pins CUDA_VISIBLE_DEVICES='0', :109)
     global_config.device = f'cuda:{dev_index}'
     torch.cuda.set_device(dev_index)
-    sdist.pin_rank_affinity(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))      # own host cores per rank, next to its GPU
+    sdist.pin_rank_affinity(local, sdist.local_world_size(world))      # own host cores per rank, next to its GPU
     sdist.reserve_allocator_pool(global_config.device)           # the measured path of bench.py: pool reserved once; the loops freeze the GC (quiet_gc)
     _, loader = build_dataset(args, rank, world)
     G = load_utils.load_eg3d(device=global_config.device, synthetic=args.synthetic > 0)
@@ -127,7 +127,10 @@ def run(argv=None):
     tot = sdist.reduce_stats([iters, len(stats)], device=global_config.device)
     tmax = sdist.reduce_stats([dt], device=global_config.device, op='max')[0]
     if rank == 0:
-        print(json.dumps(dict(images=int(tot[1]), iterations=int(tot[0]), seconds=tmax, iters_per_sec=tot[0] / max(tmax, 1e-9), n_gpus=world)))
+        import spi_amd
+        gs = spi_amd.hip_graphs_status()
+        print(json.dumps(dict(images=int(tot[1]), iterations=int(tot[0]), seconds=tmax, iters_per_sec=tot[0] / max(tmax, 1e-9), n_gpus=world,
+                              hip_graphs=('replayed' if (gs['env'] and gs['self_test']) else 'off: eager iterations'), hip_graphs_status=gs)))
     return global_config.run_name
 
 

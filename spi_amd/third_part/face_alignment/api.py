@@ -51,7 +51,9 @@ def crop(image, center, scale, resolution=256):
     new[ny[0] - 1:ny[1], nx[0] - 1:nx[1]] = image[oy[0] - 1:oy[1], ox[0] - 1:ox[1], :]
     t = torch.from_numpy(new).permute(2, 0, 1).unsqueeze(0)
     # cv2.resize(..., INTER_LINEAR) in the package: half-pixel-centre bilinear without antialiasing == align_corners=False
-    return F.interpolate(t, size=(resolution, resolution), mode='bilinear', align_corners=False)[0]
+    # ... applied to a uint8 image: the package's crop stays uint8 (cv2 rounds to nearest, saturating) before it is scaled by 1 / 255
+    r = F.interpolate(t, size=(resolution, resolution), mode='bilinear', align_corners=False)[0]
+    return torch.floor(r + 0.5).clamp_(0, 255)
 
 
 def get_preds_fromhm(hm, center, scale):

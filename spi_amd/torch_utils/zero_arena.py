@@ -15,6 +15,7 @@ matters when the iteration was captured into a HIP graph and the buffer belongs 
 Outside an iteration (`begin()` never called or `finish()`ed: the operator tests, inference) and whenever a request does not fit (the first
 iteration of a kind, a larger batch) `zeros()` is `torch.zeros` and `take()` returns None -- same values either way.
 """
+import contextlib
 import os
 import torch
 
@@ -48,6 +49,32 @@ def finish():
     if _s.demand > _s.peaks.get(_s.key, 0):
         _s.peaks[_s.key] = _s.demand
     _s.buf, _s.off, _s.demand, _s.open = None, 0, 0, False
+
+
+@contextlib.contextmanager
+def iteration(device, key=None):
+    """``with zero_arena.iteration(device, key):`` = `begin()` ... `finish()` with the `finish()` guaranteed: an exception (or a failed HIP-graph
+    capture) inside an iteration must not leave the arena open -- later work in the process (inference, operator tests, video export) would draw
+    its 'zeros' from a stale buffer that may belong to the failed capture's memory pool."""
+    begin(device, key)
+    try:
+        yield
+    finally:
+        finish()
+
+
+def closes_iteration(fn):
+    """Decorator for the loops' iteration bodies (they call `begin()` themselves, where the key is known): whatever happens inside, the
+    iteration is `finish()`ed on the way out."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        try:
+            return fn(*a, **kw)
+        finally:
+            finish()
+    return wrapped
 
 
 def reset():

@@ -27,6 +27,7 @@ class SingleIDCoach(BaseCoach):
             loss = loss + loss_lpips * hyperparameters.pt_lpips_lambda
         return loss, loss_lpips
 
+    @zero_arena.closes_iteration
     def train_step(self, image, camera, w_pivot, target_feats=None, rng=None):
         rng = rng or self.rng or DeviceRNG(self.device)
         G = self.G

@@ -206,6 +206,7 @@ class RotBboxCoach(BaseCoach):
         self.optimizer.step()
         return False, losses
 
+    @zero_arena.closes_iteration
     def _forward_backward(self, i, ctx, w_pivot, rng, flag_buf):
         """Everything of an iteration up to the early-stop test: forward passes, losses, backward passes, gradients folded into .grad.
         flag_buf None: returns (callable waiting for `lpips <= threshold` on the host, losses); else the flag goes into that device byte."""

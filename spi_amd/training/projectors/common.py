@@ -103,7 +103,8 @@ def graph_policy(enabled):
     the graph off beside a process group because RCCL's watchdog thread issues HIP calls of its own, which a capture in GLOBAL error mode
     rejects; the capture now runs in thread-local mode there, see capture_mode().)
     Only in a process whose HIP runtime runs with its graph packet capture switched off (spi_amd/__init__.py: with it on, replays after
-    ~10^3 eager launches return garbage on ROCm 7): otherwise the iterations are enqueued eagerly, with a note on stderr, once."""
+    ~10^3 eager launches return garbage on ROCm 7) -- checked, not inferred: `hip_graphs_safe()` runs the defect's reproducer once on the
+    device -- otherwise the iterations are enqueued eagerly, with a note on stderr, once."""
     if not enabled:
         return False
     import spi_amd
@@ -111,8 +112,9 @@ def graph_policy(enabled):
         if not getattr(graph_policy, '_warned', False):
             graph_policy._warned = True
             import sys
-            print('[spi_amd] HIP-graph replay is off: the HIP runtime of this process was initialised without DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 '
-                  '(import spi_amd before the first GPU call, or export the variable); iterations are enqueued eagerly', file=sys.stderr)
+            print('[spi_amd] HIP-graph replay is off in this process (%r): DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was not in effect when the HIP runtime '
+                  'started, or the replay self-test failed (import spi_amd before the first GPU call, or export the variable); iterations are '
+                  'enqueued eagerly' % (spi_amd.hip_graphs_status(),), file=sys.stderr)
         return False
     return True
 
@@ -219,6 +221,7 @@ class Projection:
             return self._graph_step(step)
         return self._body(step, device_hyper=False)
 
+    @zero_arena.closes_iteration
     def _body(self, step, device_hyper, hyper_is_set=False):
         G, rng, w_opt = self.G, self.rng, self.w_opt
         zero_arena.begin(w_opt.device, key='stage1')             # every accumulator of this step comes out of one buffer cleared by one launch
