@@ -27,13 +27,14 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 10   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 11   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive)
                              * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive)
                              * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive)
                              * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates
-                             * 10: + spi_affine_multi_fwd / _bwd, spi_modulate_multi_fwd / _bwd (additive) */
+                             * 10: + spi_affine_multi_fwd / _bwd, spi_modulate_multi_fwd / _bwd (additive)
+                             * 11: + spi_conv2d_plan (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -328,6 +329,11 @@ int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass);
 /* 1 if pass (0 forward, 1 dgrad) of `d` -- with the workspace `d` carries -- accumulates into its output through atomics (and therefore clears
  * it first unless d->out_zeroed), 0 if it overwrites, < 0 on a bad descriptor.  Host logic only: no launch, no device access. */
 int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass);
+/* How pass (0 forward, 1 dgrad, 2 wgrad) of `d` -- with the workspace `d` carries -- would be launched: out8 = {path (0 implicit GEMM,
+ * 1 Winograd), block tile rows (out channels), block tile columns (pixels; wgrad: weight columns), number of K ranges (split-K / channel
+ * split; wgrad: pixel ranges), workgroups of the launch, threads per workgroup, 0, 0}.  Host logic only (tools/igemm_shapes.py: the per-shape
+ * efficiency table); 0 or a negative error code. */
+int spi_conv2d_plan(const spi_conv_desc* d, int pass, int32_t* out8);
 int spi_conv2d_fwd  (const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream);
 int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, float* dx, spi_stream_t stream);
 /* dw has the layout/batching of w; with shared weights the batch is summed. */

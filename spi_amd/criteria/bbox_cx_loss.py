@@ -53,7 +53,8 @@ class _RoiAlign(torch.autograd.Function):
         boxes, = ctx.saved_tensors
         n, c, h, w, o = ctx.shape
         dx = torch.empty(n, c, h, w, device=dy.device)
-        hip.call('spi_roi_align_bwd', hip.ptr(boxes), hip.ptr(dy.contiguous().float()), hip.ptr(dx), n, c, h, w, o, hip.stream())
+        dy = dy.contiguous().float()                           # bound to a name: a temporary would be freed before the launch is enqueued
+        hip.call('spi_roi_align_bwd', hip.ptr(boxes), hip.ptr(dy), hip.ptr(dx), n, c, h, w, o, hip.stream())
         return dx, None, None
 
 
@@ -109,7 +110,8 @@ class _ContextualCX(torch.autograd.Function):
         sim, stats, row_argmin, col_argmax = ctx.saved_tensors
         b, p1, p2 = sim.shape
         d_sim = torch.empty_like(sim)
-        hip.call('spi_contextual_bwd', hip.ptr(sim), hip.ptr(d_out.contiguous().float()), b, p1, p2, ctx.band_width, hip.ptr(stats[0]), hip.ptr(stats[1]),
+        d_out = d_out.contiguous().float()
+        hip.call('spi_contextual_bwd', hip.ptr(sim), hip.ptr(d_out), b, p1, p2, ctx.band_width, hip.ptr(stats[0]), hip.ptr(stats[1]),
                  row_argmin.data_ptr(), col_argmax.data_ptr(), hip.ptr(d_sim), hip.stream())
         return d_sim, None
 

@@ -33,7 +33,8 @@ class _LpipsTail(torch.autograd.Function):
         fx, fy, lin = ctx.saved_tensors
         n, c, h, w = fx.shape
         d_fx = torch.empty_like(fx)
-        hip.call('spi_lpips_layer_bwd', hip.ptr(fx), hip.ptr(fy), hip.ptr(lin), hip.ptr(d_out.contiguous().float()), n, c, h * w,
+        d_out = d_out.contiguous().float()                     # bound to a name: a temporary would be freed before the launch is enqueued
+        hip.call('spi_lpips_layer_bwd', hip.ptr(fx), hip.ptr(fy), hip.ptr(lin), hip.ptr(d_out), n, c, h * w,
                  hip.ptr(d_fx), hip.stream())
         return d_fx, None, None
 

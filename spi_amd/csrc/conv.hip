@@ -1182,6 +1182,48 @@ int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass) {
     return plan_igemm(P, d->compute_f16).nsplit > 1 ? 1 : 0;
 }
 
+int spi_conv2d_plan(const spi_conv_desc* d, int pass, int32_t* out8) {
+    int rc = validate(d, "spi_conv2d_plan"); if (rc) return rc;
+    SPI_REQUIRE(out8 && pass >= 0 && pass <= 2, "spi_conv2d_plan: pass must be 0, 1 or 2 and out8 non-null");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    IGemmParams P; WinoParams Wp;
+    if (pass == 2) {
+        make_forward(d, P);
+        if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_wino_wgrad(d, P, Wp)) {
+            out8[0] = 1; out8[1] = 64; out8[2] = 64; out8[3] = 1; out8[4] = -1; out8[5] = 256;        // (grid: see spi_wino_wgrad_launch)
+            return SPI_OK;
+        }
+        const int BN = 128, BM = P.Mo <= 32 ? 32 : 128;
+        int maxpix = 0, maxcols = 0;
+        for (int c = 0; c < P.ncls; ++c) { maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp); maxcols = std::max(maxcols, P.Ci * P.cls[c].taps.T); }
+        const int tiles = ((P.Mo + BM - 1) / BM) * ((maxcols + BN - 1) / BN);
+        int64_t active = 0;
+        for (int c = 0; c < P.ncls; ++c) active += (int64_t)((P.Mo + BM - 1) / BM) * ((P.Ci * P.cls[c].taps.T + BN - 1) / BN);
+        const int64_t splits = std::max<int64_t>(1, 1024 / std::max<int64_t>(1, active * P.N));
+        int ppb = (int)((maxpix + splits - 1) / splits);
+        ppb = std::max(256, ((ppb + BK - 1) / BK) * BK);
+        const int nrange = (maxpix + ppb - 1) / ppb;
+        out8[0] = 0; out8[1] = BM; out8[2] = BN; out8[3] = nrange; out8[4] = (int32_t)((int64_t)nrange * tiles * P.N * P.ncls); out8[5] = 256;
+        return SPI_OK;
+    }
+    if (pass == 0) {
+        make_forward(d, P);
+        if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
+    } else make_dgrad(d, P);
+    if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
+        out8[0] = 1; out8[1] = 64; out8[2] = 256; out8[3] = Wp.ksplit; out8[4] = (int32_t)((int64_t)Wp.bx * Wp.by * (Wp.ocp / 64) * P.N * Wp.ksplit); out8[5] = 256;
+        return SPI_OK;
+    }
+    const IGemmPlan plan = plan_igemm(P, d->compute_f16);
+    static const int bm_of[6] = {32, 128, 64, 32, 64, 128}, bn_of[6] = {128, 128, 64, 32, 256, 256}, nt_of[6] = {256, 256, 256, 64, 256, 256};
+    int maxpix = 0;
+    for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
+    const int bm = bm_of[plan.cfg], bn = bn_of[plan.cfg];
+    out8[0] = 0; out8[1] = bm; out8[2] = bn; out8[3] = plan.nsplit;
+    out8[4] = (int32_t)((int64_t)((maxpix + bn - 1) / bn) * ((P.Mo + bm - 1) / bm) * P.N * P.ncls * plan.nsplit); out8[5] = nt_of[plan.cfg];
+    return SPI_OK;
+}
+
 int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float* y, spi_stream_t stream) {
     int rc = validate(d, "spi_conv2d_fwd"); if (rc) return rc;
     SPI_REQUIRE(x && w && y, "spi_conv2d_fwd: null tensor");

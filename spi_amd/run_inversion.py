@@ -130,7 +130,9 @@ def run(argv=None):
         import spi_amd
         gs = spi_amd.hip_graphs_status()
         print(json.dumps(dict(images=int(tot[1]), iterations=int(tot[0]), seconds=tmax, iters_per_sec=tot[0] / max(tmax, 1e-9), n_gpus=world,
-                              hip_graphs=('replayed' if (gs['env'] and gs['self_test']) else 'off: eager iterations'), hip_graphs_status=gs)))
+                              hip_graphs=('replayed' if (gs['env'] and gs['self_test']) else 'off: eager iterations'), hip_graphs_status=gs,
+                              per_image=[{k: s[k] for k in ('name', 'iters', 'stage1_iters', 'seconds_loop', 'seconds_outputs', 'stage2_graph_captures') if k in s}
+                                         for s in stats])))
     return global_config.run_name
 
 

@@ -53,8 +53,9 @@ class _NoiseReg(torch.autograd.Function):
         pyramid, means = ctx.saved_tensors
         grads = torch.empty(plan.total, device=pyramid.device, dtype=torch.float32)
         gpyr = torch.empty_like(pyramid)
+        g1 = gout.reshape(1).contiguous().float()
         hip.call('spi_noise_reg_bwd', hip.ptr(plan.ptrs), hip.ptr(plan.res), plan.T, plan.max_res, hip.ptr(pyramid), hip.ptr(means),
-                 hip.ptr(gout.reshape(1).contiguous().float()), hip.ptr(grads), hip.ptr(plan.goff), hip.ptr(gpyr), hip.stream())
+                 hip.ptr(g1), hip.ptr(grads), hip.ptr(plan.goff), hip.ptr(gpyr), hip.stream())
         return (None,) + tuple(g.view(r, r) for g, r in zip(torch.split(grads, plan.sizes), plan.res_list))
 
 
@@ -148,6 +149,38 @@ class Projection:
         self.optimizer = Adam([self.w_opt] + list(self.noise_bufs.values()), betas=(0.9, 0.999), lr=hyperparameters.first_inv_lr)
         self.noise_reg = NoiseRegulariser(self.noise_bufs.values())          # after Adam: it moves the parameters into its flat buffer
 
+    # ---- re-use across images (round 5) -------------------------------------------------------------------------------------------
+    # The reference builds a fresh projector per image (deep copy of G, w_avg from 600 mapped samples, new optimiser: mirror_projector.py:28-64),
+    # and so did this class -- plus one eager step and a graph capture per image.  Everything a captured step reads lives in device tensors
+    # of fixed shape (cameras, the target's LPIPS features, w_opt, the noise maps, Adam's flat state), so the NEXT image overwrites them in
+    # place and replays the first image's graph: `run_projection` keeps the projector and calls `rebind`.
+    def rebind(self, G, cameras, dist_fn, initial_w, w_avg_samples):
+        """Point this projector at another image: same generator instance / shapes / objective type.  -> False when it cannot be re-used."""
+        new_state, old_state = getattr(dist_fn, 'state', None), getattr(self.dist_fn, 'state', None)
+        if new_state is None or old_state is None or len(new_state) != len(old_state) or getattr(self, '_graph_failed', False):
+            return False
+        if tuple(cameras.shape) != tuple(self.cameras.shape) or any(a.shape != b.shape or a.dtype != b.dtype for a, b in zip(old_state, new_state)):
+            return False
+        src, dst = G.state_dict(), self.G.state_dict()
+        if src.keys() != dst.keys() or any(src[k].shape != dst[k].shape for k in src):
+            return False
+        with torch.no_grad():
+            for k, v in dst.items():
+                v.copy_(src[k])                                   # the caller's generator may have been reset / tuned since (restart_training)
+            self.cameras.copy_(cameras)
+            for a, b in zip(old_state, new_state):
+                a.copy_(b)
+            w_avg, self.w_std = w_statistics(self.G, self.cameras[:1], w_avg_samples, self.w_opt.device)
+            start_w = initial_w if initial_w is not None else w_avg
+            if self.w_mode == 'w+' and initial_w is None:
+                start_w = np.repeat(start_w, self.num_ws, axis=1)
+            self.w_opt.copy_(torch.as_tensor(start_w, dtype=torch.float32, device=self.w_opt.device))
+            for buf in self.noise_bufs.values():
+                buf.copy_(self.rng.randn(*buf.shape))
+        self.optimizer.reset_state()
+        self.images_bound = getattr(self, 'images_bound', 1) + 1
+        return True
+
     # ---- HIP-graph replay -------------------------------------------------------------------------------------------------------
     # A stage-1 step is ~600 launches with no data-dependent host decision: after one eager warm-up step the second is CAPTURED
     # (torch.cuda.graph: forward, backward, Adam, re-normalisation) and every later step is one graph launch.  What changes from step
@@ -156,6 +189,7 @@ class Projection:
     # Only with the device generator (ReplayRNG draws come from a host list) and only on the GPU; a failed capture falls back to eager
     # steps and says so once.
     GRAPH_WARMUP = 1                                             # eager steps before the capture (lazy initialisations, allocator warm-up)
+    captures_total = 0                                           # stage-1 graph captures of this process (all projectors)
     HYPER_RING = 32                                              # pinned slots for the per-step scalars = how far the host may run ahead
 
     def _graph_ok(self):
@@ -213,6 +247,7 @@ class Projection:
             print(''.join(traceback.format_tb(e.__traceback__)[-6:]), file=sys.stderr)
             return self._body(step, device_hyper=False)
         self._graph, self._graph_out = g, out
+        Projection.captures_total += 1                            # (tests / bench: image k >= 2 must not capture again)
         g.replay()                                               # capture records, it does not execute: run the captured step once
         return {k: v.clone() for k, v in out.items()}
 
@@ -254,15 +289,41 @@ class Projection:
         return dict(dist=dist.detach(), reg=reg_loss.detach(), loss=loss.detach())
 
 
+_projectors = {}            # (id(G), settings) -> (weakref to G, Projection): the projector of a coach's generator survives from image to image
+
+
+def _cached_projection(G, cameras, dist_fn, *, w_mode, initial_w, num_steps, w_avg_samples, device, rng, regularize_noise_weight, schedule_kwargs):
+    import weakref
+    from ...configs import global_config
+    # (the device generator only -- rng None means exactly that; DeviceRNG instances are stateless views of torch's default generator)
+    if not (global_config.reuse_graphs_across_images and (rng is None or isinstance(rng, DeviceRNG))):
+        return None, None
+    key = (id(G), w_mode, int(num_steps), int(w_avg_samples), str(device), float(regularize_noise_weight), tuple(sorted((schedule_kwargs or {}).items())))
+    hit = _projectors.get(key)
+    if hit is not None and hit[0]() is G and hit[1].rebind(G, cameras, dist_fn, initial_w, w_avg_samples):
+        return hit[1], key
+    for k in [k for k, v in _projectors.items() if v[0]() is None or k[0] == id(G)]:     # one projector per generator; dead generators drop theirs
+        del _projectors[k]
+    return None, (key, weakref.ref(G))
+
+
 def run_projection(G, cameras, dist_fn, *, w_mode, initial_w, num_steps, w_avg_samples, device, rng=None, log=None,
                    regularize_noise_weight=1e5, schedule_kwargs=None):
-    """Generic stage-1 loop.  ``cameras`` [B,25]; ``dist_fn(images [B,3,R,R]) -> scalar``; w_mode 'w' | 'w+'."""
-    proj = Projection(G, cameras, dist_fn, w_mode=w_mode, initial_w=initial_w, num_steps=num_steps, w_avg_samples=w_avg_samples,
-                      device=device, rng=rng, regularize_noise_weight=regularize_noise_weight, schedule_kwargs=schedule_kwargs)
+    """Generic stage-1 loop.  ``cameras`` [B,25]; ``dist_fn(images [B,3,R,R]) -> scalar``; w_mode 'w' | 'w+'.
+    A ``dist_fn`` that exposes its per-image tensors as ``dist_fn.state`` (list) lets the projector of the previous image of the same
+    generator be re-used (`Projection.rebind`: the image's tensors are overwritten in place, the captured step is replayed as is)."""
+    proj, slot = _cached_projection(G, cameras, dist_fn, w_mode=w_mode, initial_w=initial_w, num_steps=num_steps, w_avg_samples=w_avg_samples,
+                                    device=device, rng=rng, regularize_noise_weight=regularize_noise_weight, schedule_kwargs=schedule_kwargs)
+    if proj is None:
+        proj = Projection(G, cameras, dist_fn, w_mode=w_mode, initial_w=initial_w, num_steps=num_steps, w_avg_samples=w_avg_samples,
+                          device=device, rng=rng, regularize_noise_weight=regularize_noise_weight, schedule_kwargs=schedule_kwargs)
+        if slot is not None:
+            _projectors[slot[0]] = (slot[1], proj)
     from ...torch_utils.misc import quiet_gc
     with quiet_gc():
         for step in range(num_steps):
             out = proj.step(step)
             if log is not None:
                 log.append(dict(out, w=proj.w_opt.detach().clone(), grad_w=proj.w_opt.grad.detach().clone()))
-    return proj.w_opt
+    # a cached projector's w_opt is overwritten by the next image: hand out a copy
+    return proj.w_opt.detach().clone() if slot is not None else proj.w_opt

@@ -31,6 +31,8 @@ def mirror_setup(target, c, lpips_func, device):
         if feats is not None:
             return lpips_func(images[:1], y_feats=feats) + lpips_func(images[1:], y_feats=feats_m) * weight_m
         return lpips_func(images[:1], target) + lpips_func(images[1:], target_m) * weight_m
+    if both is not None:
+        dist_fn.state = list(both) + [sw]          # every per-image tensor the objective reads: lets the projector be re-used for the next image
     return cameras, dist_fn
 
 

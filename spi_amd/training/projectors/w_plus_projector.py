@@ -12,6 +12,8 @@ def project(G, target, c, lpips_func, *, initial_w=None, num_steps=1000, w_avg_s
 
     def dist_fn(images):
         return lpips_func(images, y_feats=feats) if feats is not None else lpips_func(images, target)
+    if feats is not None:
+        dist_fn.state = list(feats)                # the per-image tensors of the objective (run_projection re-uses the projector across images)
 
     sched = dict(initial_learning_rate=initial_learning_rate, initial_noise_factor=initial_noise_factor,
                  lr_rampdown_length=lr_rampdown_length, lr_rampup_length=lr_rampup_length, noise_ramp_length=noise_ramp_length)

@@ -25,6 +25,8 @@ def sg_distance(target, vgg16, device):
 
     def dist_fn(images):
         return (target_features - vgg16(prep(images), resize_images=False, return_lpips=True)).square().sum()
+    if torch.is_tensor(target_features):
+        dist_fn.state = [target_features]          # the per-image tensor of the objective (run_projection re-uses the projector across images)
     return dist_fn
 
 

@@ -373,7 +373,8 @@ class _SamplePlanes(torch.autograd.Function):
         coords, = ctx.saved_tensors
         n, p, c, h, w, box_warp = ctx.meta
         d_planes = zero_arena.zeros((n, 3, h, w, c), coords.device)
-        hip.call('spi_sample_from_planes_bwd', hip.ptr(d_out.contiguous().float()), hip.ptr(coords), n, p, h, w, box_warp, hip.ptr(d_planes), hip.stream())
+        d_out = d_out.contiguous().float()                     # bound to a name: a temporary would be freed before the launch is enqueued
+        hip.call('spi_sample_from_planes_bwd', hip.ptr(d_out), hip.ptr(coords), n, p, h, w, box_warp, hip.ptr(d_planes), hip.stream())
         return planes_to_nchw(d_planes), None, None
 
 

@@ -9,6 +9,17 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# ---- bounds-checked pass (SPI_EFENCE=1, tools/efence_pytest.sh): every torch device allocation becomes its own mapping between unmapped guard
+# pages (tools/efence/efence_alloc.cpp), so an out-of-range access of any kernel faults inside the test that made it.  One tensor per
+# mapping needs the per-iteration accumulator arena and the HIP-graph memory pools off (both carve many tensors out of one allocation).
+EFENCE = os.environ.get('SPI_EFENCE') == '1'
+if EFENCE:
+    os.environ['SPI_ZERO_ARENA'] = '0'
+    os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '1'           # -> spi_amd.hip_graphs_safe() is False: eager iterations, no capture-time allocations
+    _so = os.path.join(ROOT, 'tools', 'efence', 'libefence.so')
+    assert os.path.exists(_so), f'{_so} missing: hipcc -O2 -shared -fPIC -o {_so} tools/efence/efence_alloc.cpp'
+    torch.cuda.memory.change_current_allocator(torch.cuda.memory.CUDAPluggableAllocator(_so, 'efence_malloc', 'efence_free'))
+
 import spi_amd  # noqa: E402,F401  (before the first GPU call: the HIP runtime switch for graph replays, spi_amd/__init__.py)
 
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')

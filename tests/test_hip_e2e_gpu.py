@@ -273,3 +273,52 @@ def test_cli_falls_back_to_eager_when_hip_started_before_import(tmp_path):
     assert stats['iterations'] == 5 and stats['images'] == 1
     assert stats['hip_graphs'].startswith('off') and stats['hip_graphs_status']['env'] is False
     assert 'HIP-graph replay is off' in r.stderr
+
+
+def test_cli_second_image_replays_the_first_images_graphs(tmp_path, capsys):
+    """graphs bake in addresses, not values -- with the per-image inputs of both loops in persistent per-coach buffers
+    (rot_bbox_cx_coach._adopt_ctx / _bind_pivot, projectors.common.Projection.rebind) the second image of a run captures NOTHING: it replays the
+    first image's stage-1 graph and both stage-2 graphs from its first iteration on.  And it computes the same thing: both images' pivots,
+    tuned generators and final losses agree with a run that captures per image (SPI_REUSE_GRAPHS=0: the round-4 behaviour)."""
+    from spi_amd import run_inversion
+    import spi_amd
+    from spi_amd.configs import hyperparameters as hp, global_config
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.training.projectors.common import Projection
+    if not spi_amd.hip_graphs_safe():
+        pytest.skip('HIP-graph replay is off in this process')
+    hp.LPIPS_value_threshold = -1.0
+    hp.log_video = False
+    coach = 'RotBboxCoach_mir_3_RotBbox_6_rot_0.1_mirrorrot_0.05_depth_1.0_tv_0.0'
+    res = {}
+    try:
+        for mode in ('reuse', 'percapture'):
+            global_config.reuse_graphs_across_images = (mode == 'reuse')
+            out = str(tmp_path) + f'/{mode}/'
+            c1, c2 = Projection.captures_total, RotBboxCoach.captures_total
+            run_inversion.run(['--output_root', out, '--synthetic', '2', '--not_use_wandb', '--depth_resolution', '12', '--depth_resolution_importance', '12',
+                               '--first_inv_type', 'mir', '--first_inv_steps', '3', '--G_1_type', 'RotBbox', '--G_1_step', '6',
+                               '--pt_rot_lambda', '0.1', '--pt_mirror_rot_lambda', '0.05', '--pt_depth_lambda', '1.0'])
+            line = [l for l in capsys.readouterr().out.splitlines() if l.startswith('{')][-1]
+            stats = json.loads(line)
+            assert stats['images'] == 2 and stats['iterations'] == 2 * (3 + 6)
+            d = os.path.join(out, 'checkpoints')
+            sub = os.listdir(d)
+            assert len(sub) == 1, sub
+            cks = [torch.load(os.path.join(d, sub[0], f'synthetic_0000{i}.pt'), map_location='cpu') for i in range(2)]
+            res[mode] = dict(cks=cks, stage1=Projection.captures_total - c1, stage2=RotBboxCoach.captures_total - c2)
+    finally:
+        del hp.log_video
+    assert res['percapture']['stage1'] == 2 and res['percapture']['stage2'] == 4, res['percapture']        # per image: one stage-1 graph, two stage-2 graphs
+    assert res['reuse']['stage1'] == 1 and res['reuse']['stage2'] == 2, (res['reuse']['stage1'], res['reuse']['stage2'])
+    for i in range(2):
+        a, b = res['reuse']['cks'][i], res['percapture']['cks'][i]
+        ew = ((a['w'] - b['w']).norm() / b['w'].norm()).item()
+        assert ew <= 2e-3, (i, ew)
+        worst = 0.0
+        for k, v in b['G'].items():
+            if v.dtype.is_floating_point and v.numel() > 1 and 'noise_const' not in k and 'resample_filter' not in k:
+                worst = max(worst, ((a['G'][k] - v).norm() / v.norm().clamp_min(1e-12)).item())
+        assert worst <= 5e-3, (i, worst)
+    # the second image is a different optimisation from the first (its own pivot and generator)
+    assert not torch.equal(res['reuse']['cks'][0]['w'], res['reuse']['cks'][1]['w'])

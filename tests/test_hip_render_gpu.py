@@ -243,7 +243,9 @@ def test_rank_sorts_stay_permutations_with_nans():
     w[5, 40] = float('nan'); w[6, :] = float('nan')
     u = torch.rand(r, sf, generator=gen).to(DEV)
     fine = torch.full((r, sf), -7.0, device=DEV)
-    hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(w.to(DEV)), hip.ptr(u), r, sc, sf, hip.ptr(fine), 1, hip.stream())
+    wd = w.to(DEV)             # (kept alive across the launch: `hip.ptr(w.to(DEV))` frees the temporary BEFORE the kernel runs -- harmless with the
+    #                            caching allocator, a use-after-free under the guard-page allocator of tools/efence, which is how it was found)
+    hip.call('spi_importance_sample', hip.ptr(dep), hip.ptr(wd), hip.ptr(u), r, sc, sf, hip.ptr(fine), 1, hip.stream())
     assert not bool((fine == -7.0).any()), 'unwritten slots'
     ok_rows = [i for i in range(r) if i not in (5, 6)]
     assert bool(torch.isfinite(fine[ok_rows]).all()) and bool((fine[ok_rows][:, 1:] >= fine[ok_rows][:, :-1]).all())

@@ -706,7 +706,8 @@ def test_landmark_crop_transform_and_heatmap_decoding_known_answers():
     br = api.transform([256, 256], center, scale, 256, True).astype(np.int64)
     assert tuple(ul) == (13, 23) and tuple(br) == (268, 278)    # the package's crop is (br - ul) = 255 px wide before it is resized to 256
     patch = torch.from_numpy(img[ul[1]:br[1], ul[0]:br[0]].astype(np.float32)).permute(2, 0, 1)[None]
-    assert torch.equal(c, torch.nn.functional.interpolate(patch, size=(256, 256), mode='bilinear', align_corners=False)[0])
+    # (rounded to the uint8 grid like the package's cv2.resize of a uint8 crop: round-4 advisor)
+    assert torch.equal(c, torch.floor(torch.nn.functional.interpolate(patch, size=(256, 256), mode='bilinear', align_corners=False)[0] + 0.5).clamp(0, 255))
     edge = api.crop(img, [5.0, 8.0], scale)                      # a crop hanging over the top-left corner: zeros outside the image
     assert float(edge[:, :100, :100].abs().max()) == 0 and float(edge[:, 200:, 200:].abs().min()) >= 0 and float(edge.abs().max()) > 0
     hm = torch.zeros(68, 64, 64)
