@@ -34,7 +34,7 @@ typedef void* spi_stream_t;           /* hipStream_t */
                              * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive)
                              * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates
                              * 10: + spi_affine_multi_fwd / _bwd, spi_modulate_multi_fwd / _bwd (additive)
-                             * 11: + spi_conv2d_plan (additive) */
+                             * 11: + spi_conv2d_plan (additive); spi_conv_desc gained act_dtype (fp16 activation tensors; appended: 0 = the behaviour of 10) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -320,6 +320,12 @@ typedef struct spi_conv_desc {
      * compute_f16 = 0 and 3 (the 6-product split asks for fp32-equivalent products, which fp32 Winograd delivers faster on these layers). */
     void* workspace;
     int64_t workspace_bytes;
+    /* element type of the ACTIVATION tensors of all three passes (x, y, dy, dx): SPI_DTYPE_F32 (0, default) or SPI_DTYPE_F16 -- fp16 only
+     * together with compute_f16 = 1 and channel counts that are multiples of 16: the reference's use_fp16 blocks keep their activations
+     * in half precision in memory (networks_stylegan2.py:421-436; conv2d on half tensors accumulates in fp32 and rounds once).  Weights, weight
+     * gradients, bias and noise stay fp32. */
+    int act_dtype;
+    int reserved0;
 } spi_conv_desc;
 /* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
  * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).

@@ -108,6 +108,27 @@ __device__ __forceinline__ void store_f16_run(float* lds, int LD, int row, int k
     }
 }
 
+// the same for a run that already IS fp16 (fp16 activations in HBM, `IOH`): pairs are packed as they are -- no conversion
+template <int PER>
+__device__ __forceinline__ void store_f16_run(float* lds, int LD, int row, int k0, const _Float16 (&v)[PER]) {
+    static_assert(PER == 2 || PER == 4 || PER == 8 || PER == 16, "run length");
+    typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+    unsigned pk[PER / 2];
+#pragma unroll
+    for (int i = 0; i < PER / 2; ++i) {
+        const half2_t h = {v[2 * i], v[2 * i + 1]};
+        pk[i] = __builtin_bit_cast(unsigned, h);
+    }
+    unsigned* d = reinterpret_cast<unsigned*>(lds) + ((((k0 >> 3) * LD + row) << 3) + (k0 & 7)) / 2;
+    if (PER == 2) d[0] = pk[0];
+    else if (PER == 4) *reinterpret_cast<uint2*>(d) = make_uint2(pk[0], pk[1]);
+    else if (PER == 8) *reinterpret_cast<uint4*>(d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    else {
+        *reinterpret_cast<uint4*>(d) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        *reinterpret_cast<uint4*>(d + LD * 4) = make_uint4(pk[4 % (PER / 2)], pk[5 % (PER / 2)], pk[6 % (PER / 2)], pk[7 % (PER / 2)]);
+    }
+}
+
 // x -> up to three bf16 pieces (bit patterns), truncating: x == f(c0) + f(c1) + f(c2) + O(2^-24 |x|)
 template <int NS>
 __device__ __forceinline__ void split_bf16(float x, unsigned short (&c)[3]) {
@@ -171,10 +192,18 @@ __device__ __forceinline__ f32x16 mfma_split(const bf16x8_t (&a)[3], const bf16x
     return acc;
 }
 
-template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF, bool AMF = false, int PREC = 0>
-__global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in,
-                                                            const float* __restrict__ wgt, float* __restrict__ out,
+//   IOH (PREC 1 / 4 only, round 5): the ACTIVATIONS -- `in` and `out` -- are fp16 tensors in HBM (the reference's use_fp16 blocks keep them in
+//   half precision end to end, networks_stylegan2.py:421-436); weights, bias, noise and the accumulators stay fp32.  Loads are 2-byte
+//   buffer loads, a run is packed as it arrives (no conversion), the epilogue rounds once on its way out.
+template <int WM, int WN, int TM, int TN, bool SPLITK, bool BUF, bool AMF = false, int PREC = 0, bool IOH = false>
+__global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, const float* __restrict__ in_,
+                                                            const float* __restrict__ wgt, float* __restrict__ out_,
                                                             Epilogue ep, int nsplit) {
+    static_assert(!IOH || PREC == 1 || PREC == 4, "fp16 activation tensors go with the fp16 operand modes");
+    using AT = std::conditional_t<IOH, _Float16, float>;             // element type of the activation tensors
+    constexpr int ES = IOH ? 2 : 4;
+    const AT* __restrict__ in = reinterpret_cast<const AT*>(in_);
+    AT* __restrict__ out = reinterpret_cast<AT*>(out_);
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -212,7 +241,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         s_beg = split * per; s_end = min(s_beg + per, nslab_all);
         if (s_beg >= s_end) return;
     }
-    const float* inb = in + (int64_t)n * P.in_bs;
+    const AT* inb = in + (int64_t)n * P.in_bs;
     const float* wb = wgt + (int64_t)n * P.wbs;
     const int64_t chs = (int64_t)P.IH * P.IW;
 
@@ -229,12 +258,12 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
             for (int sg = ((row + xa * P.osx) >> 4) + tid; sg <= s1; sg += NT) any |= fl[sg];
         }
         if (!__syncthreads_or(any)) {
-            float* ob = out + (int64_t)n * P.out_bs;
+            AT* ob = out + (int64_t)n * P.out_bs;
             for (int e = tid; e < BM * BN; e += NT) {
                 const int m = m0 + e / BN, pp = p0 + e % BN;
                 if (m < P.Mo && pp < npix) {
                     const int Yo = pp / C.OWp, Xo = pp - Yo * C.OWp;
-                    ob[(int64_t)m * P.OH * P.OW + (int64_t)(Yo * P.osy + C.ooy) * P.OW + (Xo * P.osx + C.oox)] = 0.f;
+                    ob[(int64_t)m * P.OH * P.OW + (int64_t)(Yo * P.osy + C.ooy) * P.OW + (Xo * P.osx + C.oox)] = (AT)0.f;
                 }
             }
             return;
@@ -261,10 +290,10 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
             for (int sg = ((iy * P.IW + xlo) >> 4) + tid; sg <= s1; sg += NT) any |= fl[sg];
         }
         if (!__syncthreads_or(any)) {
-            float* ob = out + (int64_t)n * P.out_bs;
+            AT* ob = out + (int64_t)n * P.out_bs;
             for (int e = tid; e < BM * BN; e += NT) {
                 const int m = m0 + e / BN, pp = p0 + e % BN;
-                if (m < P.Mo && pp < npix) ob[(int64_t)m * npix + pp] = 0.f;
+                if (m < P.Mo && pp < npix) ob[(int64_t)m * npix + pp] = (AT)0.f;
             }
             return;
         }
@@ -296,14 +325,14 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     // part of every address is a SCALAR offset.  That matters because on gfx950 the fp32 MFMA shares the FP32
     // lanes with the VALU: every vector instruction in the loop costs ~2.6 matrix-pipe cycles
     // (tools/ubench/mfma_valu.hip: 157 TF with no VALU beside the MFMAs, 118 TF with 8 per MFMA).
-    struct Stage { float ra[A_PER]; float rb[B_PER]; unsigned am, bm; };
+    struct Stage { float ra[A_PER]; AT rb[B_PER]; unsigned am, bm; };
     Stage st0, st1;
     constexpr unsigned OOB = 0x80000000u;
     __amdgpu_buffer_rsrc_t rsA, rsB;
     unsigned voffA[A_PER];
     if (BUF) {
         rsA = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, (int)(P.w_elems * 4), 0x00020000);
-        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * 4), 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * ES), 0x00020000);
 #pragma unroll
         for (int j = 0; j < A_PER; ++j) {
             const int m = m0 + a_m + ((AMF || SPL) ? 0 : j * A_MSTEP);
@@ -312,8 +341,8 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         }
     }
     // per-slab addressing state (scalars + one vector offset), computed once per slab by slab_setup()
-    const int chs4 = __builtin_amdgcn_readfirstlane((int)chs * 4);               // bytes between input channels (scalar)
-    const int kstr4 = __builtin_amdgcn_readfirstlane((SPL ? 1 : B_KSTEP) * (int)chs * 4);     // bytes between the channels one thread loads
+    const int chs4 = __builtin_amdgcn_readfirstlane((int)chs * ES);              // bytes between input channels (scalar)
+    const int kstr4 = __builtin_amdgcn_readfirstlane((SPL ? 1 : B_KSTEP) * (int)chs * ES);    // bytes between the channels one thread loads
     struct SlabAddr { int t, c0; int soffA; unsigned voffB; int soffB; bool okB; int iy, ix; };
     auto slab_setup = [&](int s) {
         SlabAddr q;
@@ -322,7 +351,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         q.iy = iy0 + C.taps.dy[q.t]; q.ix = ix0 + C.taps.dx[q.t];
         q.okB = pv && q.iy >= 0 && q.iy < P.IH && q.ix >= 0 && q.ix < P.IW;
         q.soffA = __builtin_amdgcn_readfirstlane((q.c0 * P.wsc + C.taps.widx[q.t]) * 4);     // wave-uniform by construction: keep it in an SGPR
-        q.voffB = q.okB ? (unsigned)((q.iy * P.IW + q.ix + b_k * (int)chs) * 4) : OOB;
+        q.voffB = q.okB ? (unsigned)((q.iy * P.IW + q.ix + b_k * (int)chs) * ES) : OOB;
         q.soffB = __builtin_amdgcn_readfirstlane(q.c0 * chs4);
         return q;
     };
@@ -355,7 +384,8 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
     };
     auto load_b = [&](Stage& S, const SlabAddr& q, int j) {
         if (BUF) {
-            S.rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)q.voffB, q.soffB + j * kstr4, 0));
+            if constexpr (IOH) S.rb[j] = __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rsB, (int)q.voffB, q.soffB + j * kstr4, 0));
+            else S.rb[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)q.voffB, q.soffB + j * kstr4, 0));
         } else {
             const int64_t poff = (int64_t)min(max(q.iy, 0), P.IH - 1) * P.IW + min(max(q.ix, 0), P.IW - 1);
             const int c = q.c0 + b_k + j * B_KSTEP;
@@ -390,7 +420,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
         } else if constexpr (F16) {
             const int k = b_k + j * B_KSTEP;
             reinterpret_cast<_Float16*>(Bs[buf])[((k >> 3) * LDB + b_p) * 8 + (k & 7)] = (_Float16)S.rb[j];
-        } else Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? S.rb[j] : 0.f;
+        } else Bs[buf][(b_k + j * B_KSTEP) * LDB + b_p] = (BUF || ((S.bm >> j) & 1u)) ? (float)S.rb[j] : 0.f;
     };
 
     f32x16 acc[TM][TN];
@@ -558,7 +588,7 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
 
     // ---- epilogue: C/D layout col = lane & 31 (pixel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel)
     const float ng = (!SPLITK && ep.noise) ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
-    float* ob = out + (int64_t)n * P.out_bs;
+    AT* ob = out + (int64_t)n * P.out_bs;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int pp = p0 + (wn * TN + j) * 32 + fr;
@@ -572,13 +602,13 @@ __global__ void __launch_bounds__(64 * WM * WN) igemm_kernel(IGemmParams P, cons
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (m < P.Mo) {
-                    float* dst = ob + (int64_t)m * P.OH * P.OW + opix;
-                    if (SPLITK) atomicAdd(dst, acc[i][j][r]);
+                    AT* dst = ob + (int64_t)m * P.OH * P.OW + opix;
+                    if constexpr (SPLITK) atomicAdd(dst, acc[i][j][r]);
                     else {
                         float v = acc[i][j][r] + nz;
                         if (ep.bias) v += ep.bias[m];
                         if (ep.act) v = epilogue_act(ep, v);
-                        *dst = v;
+                        *dst = (AT)v;
                     }
                 }
             }
@@ -612,10 +642,16 @@ __global__ void conv_epilogue_kernel(float* __restrict__ y, int64_t total, int O
 //   range whose dOut segments are flagged into an LDS list and then runs the pipeline over that list only (masked losses: most
 //   slabs multiply by an all-zero A operand).
 constexpr int WG_LISTMAX = 2048;
-template <int WM, int WN, int TM, int TN, int PREC = 0, bool FAST = false, bool SPARSE = false>
-__global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in,
-                                                            const float* __restrict__ dout, float* __restrict__ dw,
+//   IOH (PREC 1 only, round 5): `in` and `dout` are fp16 tensors in HBM (see igemm_kernel); dw stays fp32.
+template <int WM, int WN, int TM, int TN, int PREC = 0, bool FAST = false, bool SPARSE = false, bool IOH = false>
+__global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, const float* __restrict__ in_,
+                                                            const float* __restrict__ dout_, float* __restrict__ dw,
                                                             int pix_per_block) {
+    static_assert(!IOH || PREC == 1, "fp16 activation tensors go with the fp16 operand mode");
+    using AT = std::conditional_t<IOH, _Float16, float>;
+    constexpr int ES = IOH ? 2 : 4;
+    const AT* __restrict__ in = reinterpret_cast<const AT*>(in_);
+    const AT* __restrict__ dout = reinterpret_cast<const AT*>(dout_);
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -641,10 +677,14 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     // dense: blockIdx.x owns a pixel range; SPARSE: an equal share of the class's flagged slabs (ranked below)
     const int pbeg = SPARSE ? 0 : blockIdx.x * pix_per_block, pend = SPARSE ? npix : min(pbeg + pix_per_block, npix);
     if (pbeg >= npix) return;
-    const float* inb = in + (int64_t)n * P.in_bs;
-    const float* dob = dout + (int64_t)n * P.out_bs;
-    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(P.out_bs * 4), 0x00020000);
-    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * 4), 0x00020000);
+    const AT* inb = in + (int64_t)n * P.in_bs;
+    const AT* dob = dout + (int64_t)n * P.out_bs;
+    __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)dob, 0, (int)(P.out_bs * ES), 0x00020000);
+    __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)inb, 0, (int)(P.in_bs * ES), 0x00020000);
+    auto ld = [&](const __amdgpu_buffer_rsrc_t& rs, int voff, int soff) -> AT {
+        if constexpr (IOH) return __builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    };
 
     const int l_p = tid % BK;                  // pixel within slab
     const int l_r = tid / BK;                  // first row (m for A, column j for B)
@@ -654,14 +694,14 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
 #pragma unroll
     for (int q = 0; q < A_PER; ++q) {
         const int m = m0 + l_r + q * ROWSTEP;
-        rowA[q] = m < P.Mo ? (unsigned)(m * P.OH * P.OW * 4) : OOB;
+        rowA[q] = m < P.Mo ? (unsigned)(m * P.OH * P.OW * ES) : OOB;
     }
 #pragma unroll
     for (int q = 0; q < B_PER; ++q) {
         const int j = j0 + l_r + q * ROWSTEP;
         const int t = j < Kc ? j / P.Ci : 0;
         const int c = j < Kc ? j - t * P.Ci : 0;
-        chanB[q] = j < Kc ? (unsigned)(c * P.IH * P.IW * 4) : OOB;
+        chanB[q] = j < Kc ? (unsigned)(c * P.IH * P.IW * ES) : OOB;
         bdy[q] = C.taps.dy[t]; bdx[q] = C.taps.dx[t];
     }
     // one tap for the whole tile?  (block-uniform: channel counts that are multiples of the tile width)
@@ -671,9 +711,9 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     // incrementally (no division per slab): ~25 vector instructions per slab instead of ~100, all branch-free selects (on
     // gfx950 each VALU instruction beside the fp32 MFMAs costs ~2.6 matrix-pipe cycles).  The scalar offset is not
     // range-checked by the hardware, hence the "all rows / channels exist" condition.
-    const int sstepA = __builtin_amdgcn_readfirstlane(ROWSTEP * P.OH * P.OW * 4);
-    const int sstepB = __builtin_amdgcn_readfirstlane(ROWSTEP * P.IH * P.IW * 4);
-    struct Stage { float ra[A_PER]; float rb[B_PER]; };
+    const int sstepA = __builtin_amdgcn_readfirstlane(ROWSTEP * P.OH * P.OW * ES);
+    const int sstepB = __builtin_amdgcn_readfirstlane(ROWSTEP * P.IH * P.IW * ES);
+    struct Stage { AT ra[A_PER]; AT rb[B_PER]; };
     Stage st0, st1;
     int curY = 0, curX = 0;                    // FAST: pixel of the next slab to load (load_all is called with pk = pbeg, +BK, +2BK, ...)
     if (FAST) { const int p0 = min(pbeg + l_p, npix - 1); curY = p0 / C.OWp; curX = p0 - curY * C.OWp; }
@@ -686,37 +726,37 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
             const bool wrap = nx >= C.OWp;
             curX = wrap ? nx - C.OWp : nx;
             curY += wrap ? 1 : 0;
-            const unsigned pixA = pvld ? (unsigned)(((Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox)) * 4) : OOB;
+            const unsigned pixA = pvld ? (unsigned)(((Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox)) * ES) : OOB;
             const int iy = Y * P.isy + bdy[0], ix = X * P.isx + bdx[0];
             const bool inb = pvld & (iy >= 0) & (iy < P.IH) & (ix >= 0) & (ix < P.IW);
-            const unsigned pixB = inb ? (unsigned)((iy * P.IW + ix) * 4) : OOB;
+            const unsigned pixB = inb ? (unsigned)((iy * P.IW + ix) * ES) : OOB;
             const unsigned voA = pixA + rowA[0], voB = pixB + chanB[0];
 #pragma unroll
             for (int q = 0; q < A_PER; ++q)
-                S.ra[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, (int)voA, q * sstepA, 0));
+                S.ra[q] = ld(rsA, (int)voA, q * sstepA);
 #pragma unroll
             for (int q = 0; q < B_PER; ++q)
-                S.rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)voB, q * sstepB, 0));
+                S.rb[q] = ld(rsB, (int)voB, q * sstepB);
         } else {
         const int pc = min(p, npix - 1);
         const int Y = pc / C.OWp, X = pc - Y * C.OWp;
-        const unsigned pixA = pvld ? (unsigned)(((Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox)) * 4) : OOB;
+        const unsigned pixA = pvld ? (unsigned)(((Y * P.osy + C.ooy) * P.OW + (X * P.osx + C.oox)) * ES) : OOB;
 #pragma unroll
         for (int q = 0; q < A_PER; ++q)
-            S.ra[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsA, (int)(rowA[q] + pixA), 0, 0));
+            S.ra[q] = ld(rsA, (int)(rowA[q] + pixA), 0);
         const int iyb = Y * P.isy, ixb = X * P.isx;
         if (uni) {
             const int iy = iyb + bdy[0], ix = ixb + bdx[0];
-            const unsigned pixB = (pvld && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) ? (unsigned)((iy * P.IW + ix) * 4) : OOB;
+            const unsigned pixB = (pvld && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) ? (unsigned)((iy * P.IW + ix) * ES) : OOB;
 #pragma unroll
             for (int q = 0; q < B_PER; ++q)
-                S.rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)(chanB[q] + pixB), 0, 0));
+                S.rb[q] = ld(rsB, (int)(chanB[q] + pixB), 0);
         } else {
 #pragma unroll
             for (int q = 0; q < B_PER; ++q) {
                 const int iy = iyb + bdy[q], ix = ixb + bdx[q];
-                const unsigned pixB = (pvld && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) ? (unsigned)((iy * P.IW + ix) * 4) : OOB;
-                S.rb[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsB, (int)(chanB[q] + pixB), 0, 0));
+                const unsigned pixB = (pvld && iy >= 0 && iy < P.IH && ix >= 0 && ix < P.IW) ? (unsigned)((iy * P.IW + ix) * ES) : OOB;
+                S.rb[q] = ld(rsB, (int)(chanB[q] + pixB), 0);
             }
         }
         }
@@ -724,22 +764,22 @@ __global__ void __launch_bounds__(64 * WM * WN) wgrad_kernel(IGemmParams P, cons
     auto store_a = [&](const Stage& S, int buf, int q) {
         if constexpr (SPL) {
             unsigned short c[3];
-            split_bf16<NS>(S.ra[q], c);
+            split_bf16<NS>((float)S.ra[q], c);
             unsigned short* base = reinterpret_cast<unsigned short*>(As[buf]) + (((l_p >> 3) * LDA + l_r + q * ROWSTEP) << 3) + (l_p & 7);
 #pragma unroll
             for (int z = 0; z < NS; ++z) base[z * 2 * LDA * 8] = c[z];
         } else if constexpr (F16) reinterpret_cast<_Float16*>(As[buf])[((l_p >> 3) * LDA + l_r + q * ROWSTEP) * 8 + (l_p & 7)] = (_Float16)S.ra[q];
-        else As[buf][l_p * LDA + l_r + q * ROWSTEP] = S.ra[q];
+        else As[buf][l_p * LDA + l_r + q * ROWSTEP] = (float)S.ra[q];
     };
     auto store_b = [&](const Stage& S, int buf, int q) {
         if constexpr (SPL) {
             unsigned short c[3];
-            split_bf16<NS>(S.rb[q], c);
+            split_bf16<NS>((float)S.rb[q], c);
             unsigned short* base = reinterpret_cast<unsigned short*>(Bs[buf]) + (((l_p >> 3) * LDB + l_r + q * ROWSTEP) << 3) + (l_p & 7);
 #pragma unroll
             for (int z = 0; z < NS; ++z) base[z * 2 * LDB * 8] = c[z];
         } else if constexpr (F16) reinterpret_cast<_Float16*>(Bs[buf])[((l_p >> 3) * LDB + l_r + q * ROWSTEP) * 8 + (l_p & 7)] = (_Float16)S.rb[q];
-        else Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = S.rb[q];
+        else Bs[buf][l_p * LDB + l_r + q * ROWSTEP] = (float)S.rb[q];
     };
 
     f32x16 acc[TM][TN];
@@ -936,6 +976,7 @@ static int validate(const spi_conv_desc* d, const char* who) {
     SPI_REQUIRE(d->pad >= 0 && d->pad < d->kh, "%s: bad padding", who);
     SPI_REQUIRE((int64_t)d->I * d->kh * d->kw < 65536 && (int64_t)d->O * d->kh * d->kw < 65536, "%s: channel count too large", who);
     SPI_REQUIRE(d->compute_f16 >= 0 && d->compute_f16 <= 3, "%s: compute_f16 must be 0 (fp32 MFMA), 1 (fp16), 2 (bf16 x3 split) or 3 (bf16 x6 split)", who);
+    SPI_REQUIRE(d->act_dtype == SPI_DTYPE_F32 || (d->act_dtype == SPI_DTYPE_F16 && d->compute_f16 == 1), "%s: act_dtype must be fp32, or fp16 together with compute_f16 = 1", who);
     return SPI_OK;
 }
 
@@ -1016,7 +1057,7 @@ static void make_dgrad(const spi_conv_desc* d, IGemmParams& P) {
 }
 
 template <int WM, int WN, int TM, int TN>
-static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, int nsplit, hipStream_t st, int prec) {
+static void launch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, int nsplit, hipStream_t st, int prec, bool ioh) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     int maxpix = 0;
     for (int c = 0; c < P.ncls; ++c) maxpix = std::max(maxpix, P.cls[c].OHp * P.cls[c].OWp);
@@ -1028,10 +1069,11 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
         else if (buf) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
         else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, true, false>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, nsplit);
     } else if (prec && buf && (prec == 1 || P.wsm == 1 || P.wsc == 1)) {      // split-bf16 without channels-innermost weights: exact fp32 below
-#define SPI_IG_PREC(PR) do { if (P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true, PR>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); \
-                             else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, false, PR>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); } while (0)
-        if (prec == 1) { if (P.wsm == 1 || P.wsc == 1) SPI_IG_PREC(4); else SPI_IG_PREC(1); }        // fp16: run-staged when the weights are channel-contiguous
-        else if (prec == 2) SPI_IG_PREC(2); else SPI_IG_PREC(3);
+#define SPI_IG_PREC(PR, IOF) do { if (P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true, PR, IOF>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); \
+                             else hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, false, PR, IOF>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1); } while (0)
+        if (prec == 1 && ioh) { if (P.wsm == 1 || P.wsc == 1) SPI_IG_PREC(4, true); else SPI_IG_PREC(1, true); }      // fp16 activation tensors
+        else if (prec == 1) { if (P.wsm == 1 || P.wsc == 1) SPI_IG_PREC(4, false); else SPI_IG_PREC(1, false); }        // fp16: run-staged when the weights are channel-contiguous
+        else if (prec == 2) SPI_IG_PREC(2, false); else SPI_IG_PREC(3, false);
 #undef SPI_IG_PREC
     } else {
         if (buf && P.wsm == 1) hipLaunchKernelGGL((igemm_kernel<WM, WN, TM, TN, false, true, true>), grid, dim3(64 * WM * WN), 0, st, P, in, w, out, ep, 1);
@@ -1072,19 +1114,24 @@ static IGemmPlan plan_igemm(const IGemmParams& P, int f16) {
 }
 
 static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, hipStream_t st, int f16 = 0,
-                          bool out_zeroed = false) {
+                          bool out_zeroed = false, bool ioh = false) {
     const IGemmPlan plan = plan_igemm(P, f16);
     const int cfg = plan.cfg, nsplit = plan.nsplit;
+    if (ioh) {
+        // fp16 activation tensors exist on the buffer-descriptor path of the fp16 operand mode only (whole 16-channel slabs, < 2 GiB per sample)
+        SPI_REQUIRE(f16 == 1 && nsplit == 1 && (P.Ci % BK == 0) && (P.in_bs * 2 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31)),
+                    "spi_conv2d: act_dtype = fp16 needs compute_f16 = 1 and a reduction channel count that is a multiple of 16 (got %d)", P.Ci);
+    }
     if (nsplit > 1 && !out_zeroed) {
         spi_zero_async(out, (int64_t)P.N * P.out_bs, st);
     }
     switch (cfg) {
-    case 0: launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
-    case 1: launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, nsplit, st, f16); break;
-    case 2: launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
-    case 4: launch_igemm<1, 4, 2, 2>(P, in, w, out, ep, nsplit, st, f16); break;
-    case 5: launch_igemm<2, 2, 2, 4>(P, in, w, out, ep, nsplit, st, f16); break;
-    default: launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, nsplit, st, f16); break;
+    case 0: launch_igemm<1, 4, 1, 1>(P, in, w, out, ep, nsplit, st, f16, ioh); break;
+    case 1: launch_igemm<2, 2, 2, 2>(P, in, w, out, ep, nsplit, st, f16, ioh); break;
+    case 2: launch_igemm<2, 2, 1, 1>(P, in, w, out, ep, nsplit, st, f16, ioh); break;
+    case 4: launch_igemm<1, 4, 2, 2>(P, in, w, out, ep, nsplit, st, f16, ioh); break;
+    case 5: launch_igemm<2, 2, 2, 4>(P, in, w, out, ep, nsplit, st, f16, ioh); break;
+    default: launch_igemm<1, 1, 1, 1>(P, in, w, out, ep, nsplit, st, f16, ioh); break;
     }
     if (nsplit > 1 && (ep.bias || ep.noise || ep.act)) {
         const int64_t total = (int64_t)P.N * P.out_bs;
@@ -1241,7 +1288,7 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
         SPI_LAUNCH_CHECK("spi_conv2d_fwd (winograd)");
         return SPI_OK;
     }
-    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16, d->out_zeroed != 0); if (rc) return rc;
+    rc = dispatch_igemm(P, x, w, y, ep, as_stream(stream), d->compute_f16, d->out_zeroed != 0, d->act_dtype == SPI_DTYPE_F16); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_fwd");
     return SPI_OK;
 }
@@ -1258,7 +1305,7 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
         SPI_LAUNCH_CHECK("spi_conv2d_dgrad (winograd)");
         return SPI_OK;
     }
-    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16, d->out_zeroed != 0); if (rc) return rc;
+    rc = dispatch_igemm(P, dy, w, dx, ep, as_stream(stream), d->compute_f16, d->out_zeroed != 0, d->act_dtype == SPI_DTYPE_F16); if (rc) return rc;
     SPI_LAUNCH_CHECK("spi_conv2d_dgrad");
     return SPI_OK;
 }
@@ -1303,11 +1350,13 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     for (int c = 0; c < P.ncls; ++c) fastw = fastw && P.cls[c].OWp >= BK;
     const bool sparse = d->dy_seg_flags != nullptr && ppb / BK + 1 <= WG_LISTMAX && (maxpix + BK - 1) / BK <= 64 * 256;
     if (sparse) { P.seg_flags = d->dy_seg_flags; P.nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
-#define SPI_WG_LAUNCH(PR, FASTF, SPF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, PR, FASTF, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
-#define SPI_WG_SKINNY(PR, SPF) hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1, PR, false, SPF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
-#define SPI_WG_BY_PREC(CALL, ...) do { switch (prec) { case 1: CALL(1, __VA_ARGS__); break; case 2: CALL(2, __VA_ARGS__); break; case 3: CALL(3, __VA_ARGS__); break; \
-                                                         default: CALL(0, __VA_ARGS__); } } while (0)
+#define SPI_WG_LAUNCH(PR, IOF, FASTF, SPF) hipLaunchKernelGGL((wgrad_kernel<2, 2, 2, 2, PR, FASTF, SPF, IOF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
+#define SPI_WG_SKINNY(PR, IOF, SPF) hipLaunchKernelGGL((wgrad_kernel<1, 4, 1, 1, PR, false, SPF, IOF>), grid, dim3(256), 0, as_stream(stream), P, x, dy, dw, ppb)
+#define SPI_WG_BY_PREC(CALL, ...) do { switch (prec) { case 1: if (ioh) CALL(1, true, __VA_ARGS__); else CALL(1, false, __VA_ARGS__); break; case 2: CALL(2, false, __VA_ARGS__); break; \
+                                                         case 3: CALL(3, false, __VA_ARGS__); break; default: CALL(0, false, __VA_ARGS__); } } while (0)
     const int prec = d->compute_f16;
+    const bool ioh = d->act_dtype == SPI_DTYPE_F16;
+    SPI_REQUIRE(!ioh || (P.in_bs * 2 < (1ll << 30) && P.out_bs * 2 < (1ll << 30)), "spi_conv2d_wgrad: a per-sample activation must be < 1 GiB");
     if (BM == 32) { if (sparse) SPI_WG_BY_PREC(SPI_WG_SKINNY, true); else SPI_WG_BY_PREC(SPI_WG_SKINNY, false); }
     else if (sparse) SPI_WG_BY_PREC(SPI_WG_LAUNCH, false, true);
     else if (fastw) SPI_WG_BY_PREC(SPI_WG_LAUNCH, true, false);

@@ -187,14 +187,34 @@ static int launch_bias_act_t(const void* x, const void* b, const void* xref, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16 activation tensors (round 5; the reference's use_fp16 blocks, networks_stylegan2.py:421-436): the kernels of the super-resolution
+// path that stream activations -- layer-tail backward, channel dot products, gradient-segment map, the tiled 4x4 FIR with its fused tail --
+// are instantiated for float and _Float16 TENSORS; arithmetic and every accumulator stay fp32, a value is rounded once when it is stored.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load4(const float* p, float (&v)[4], bool nt) {
+    const f32x4_t t = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p)) : *reinterpret_cast<const f32x4_t*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+typedef _Float16 f16x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load4(const _Float16* p, float (&v)[4], bool nt) {
+    const f16x4_t t = nt ? __builtin_nontemporal_load(reinterpret_cast<const f16x4_t*>(p)) : *reinterpret_cast<const f16x4_t*>(p);
+    v[0] = (float)t.x; v[1] = (float)t.y; v[2] = (float)t.z; v[3] = (float)t.w;
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) { *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d); }
+__device__ __forceinline__ void store4(_Float16* p, float a, float b, float c, float d) {
+    const f16x4_t t = {(_Float16)a, (_Float16)b, (_Float16)c, (_Float16)d};
+    *reinterpret_cast<f16x4_t*>(p) = t;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Layer-tail backward: activation gradient + bias gradient (sum over n, hw) + noise gradient
 // (sum over n, c) in one pass.  Block = 256 threads x PX consecutive pixels; blockIdx.y picks a chunk
 // of channels.  Per channel the block adds 4 wave-partials to d_bias[c]; the per-pixel sums stay in
 // registers over the channel loop and are added to d_pixsum once.
 // ------------------------------------------------------------------------------------------------
-template <int PX>
-__global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                       float* __restrict__ dz, float* __restrict__ d_bias,
+template <int PX, typename T = float>
+__global__ void __launch_bounds__(256) tail_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                       T* __restrict__ dz, float* __restrict__ d_bias,
                                                        float* __restrict__ d_pixsum, const float* __restrict__ noise,
                                                        float* __restrict__ d_strength, int N, int C, int64_t HW, int cchunk,
                                                        ActParams ap) {
@@ -221,11 +241,10 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
             const int c = c_beg + q / N, n = q - (q / N) * N;
             off[u] = ((int64_t)n * C + c) * HW + p0;
             if (ok) {
-                if (PX == 4) {
-                    const f32x4_t g4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(dy + off[u]));      // dy and y are read once
-                    g[u][0] = g4.x; g[u][1] = g4.y; g[u][2] = g4.z; g[u][3] = g4.w;
-                    if (y) { const f32x4_t y4 = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(y + off[u])); yy[u][0] = y4.x; yy[u][1] = y4.y; yy[u][2] = y4.z; yy[u][3] = y4.w; }
-                } else { g[u][0] = dy[off[u]]; if (y) yy[u][0] = y[off[u]]; }
+                if constexpr (PX == 4) {
+                    load4(dy + off[u], g[u], true);                                   // dy and y are read once
+                    if (y) load4(y + off[u], yy[u], true);
+                } else { g[u][0] = (float)dy[off[u]]; if (y) yy[u][0] = (float)y[off[u]]; }
             } else {
 #pragma unroll
                 for (int j = 0; j < PX; ++j) g[u][j] = 0.f;
@@ -255,8 +274,8 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
                     g[u][j] = v;
                 }
                 if (dz) {
-                    if (PX == 4) *reinterpret_cast<float4*>(dz + off[u]) = make_float4(g[u][0], g[u][1], g[u][2], g[u][3]);
-                    else dz[off[u]] = g[u][0];
+                    if constexpr (PX == 4) store4(dz + off[u], g[u][0], g[u][1], g[u][2], g[u][3]);
+                    else dz[off[u]] = (T)g[u][0];
                 }
             }
 #pragma unroll
@@ -298,14 +317,15 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------
 // per-row dot products  out[r] += sum_p a[r,p] * b'[r,p]  (b' = b, or the conv result reconstructed from a layer output)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) chan_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+template <typename T = float>
+__global__ void __launch_bounds__(256) chan_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ out,
                                                        int C, int64_t HW, int64_t per_block, const float* __restrict__ bias,
                                                        const float* __restrict__ noise, const float* __restrict__ noise_gain,
                                                        int act, float alpha, float gain) {
     const int64_t r = blockIdx.y;
     const int c = (int)(r % C);
     const int64_t p0 = (int64_t)blockIdx.x * per_block, p1 = min(p0 + per_block, HW);
-    const float* ar = a + r * HW; const float* br = b + r * HW;
+    const T* ar = a + r * HW; const T* br = b + r * HW;
     const float bv = (act && bias) ? bias[c] : 0.f;
     const float ng = (act && noise) ? (noise_gain ? noise_gain[0] : 1.f) : 0.f;
     const float inv_gain = act ? 1.f / gain : 1.f;
@@ -319,26 +339,26 @@ __global__ void __launch_bounds__(256) chan_dot_kernel(const float* __restrict__
     const bool vec = (HW % 4 == 0) && (((uintptr_t)ar | (uintptr_t)br) % 16 == 0);
     if (vec) {
         for (int64_t p = p0 + threadIdx.x * 4; p < p1; p += 4096) {
-            float4 av[4], bvv[4];
+            float av[4][4], bvv[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t q = min(p + u * 1024, HW - 4);
-                av[u] = *reinterpret_cast<const float4*>(ar + q); bvv[u] = *reinterpret_cast<const float4*>(br + q);
+                load4(ar + q, av[u], false); load4(br + q, bvv[u], false);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t q = p + u * 1024;
                 if (q < p1) {
-                    s0 += term(av[u].x, bvv[u].x, q) + term(av[u].y, bvv[u].y, q + 1);
-                    s1 += term(av[u].z, bvv[u].z, q + 2) + term(av[u].w, bvv[u].w, q + 3);
+                    s0 += term(av[u][0], bvv[u][0], q) + term(av[u][1], bvv[u][1], q + 1);
+                    s1 += term(av[u][2], bvv[u][2], q + 2) + term(av[u][3], bvv[u][3], q + 3);
                 }
             }
         }
     } else {
         for (int64_t p = p0 + threadIdx.x; p < p1; p += 512) {
-            s0 += term(ar[p], br[p], p);
+            s0 += term((float)ar[p], (float)br[p], p);
             const int64_t p2 = p + 256;
-            if (p2 < p1) s1 += term(ar[p2], br[p2], p2);
+            if (p2 < p1) s1 += term((float)ar[p2], (float)br[p2], p2);
         }
     }
     __shared__ float red[4];
@@ -542,8 +562,9 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_kernel(const float* __restr
 // consumed (1.1 loads per output instead of 7); each thread then reads its 7 x 7 patch as fourteen 16-byte LDS
 // reads and writes 4 x 4 outputs.  HBM-bound: 8 B/output algorithmic.
 constexpr int FT_W = 64, FT_H = 64, FT_LD = 68, FT_ROWS = FT_H + 3, FT_PASS = (FT_ROWS + 3) / 4;
-__global__ void __launch_bounds__(256) upfirdn2d_4x4_tiled_kernel(const float* __restrict__ x, const float* __restrict__ f,
-                                                                  float* __restrict__ y, UpfirdnParams p,
+template <typename T = float>
+__global__ void __launch_bounds__(256) upfirdn2d_4x4_tiled_kernel(const T* __restrict__ x, const float* __restrict__ f,
+                                                                  T* __restrict__ y, UpfirdnParams p,
                                                                   const float* __restrict__ pre_bias, const float* __restrict__ noise,
                                                                   const float* __restrict__ noise_gain, const float* __restrict__ bias,
                                                                   ActParams ap) {
@@ -556,12 +577,17 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_tiled_kernel(const float* _
     }
     const int nc = blockIdx.z, c = nc % p.C;
     const int ox0 = blockIdx.x * FT_W, oy0 = blockIdx.y * FT_H;
-    const float* xp = x + (int64_t)nc * p.inH * p.inW;
+    const T* xp = x + (int64_t)nc * p.inH * p.inW;
     const float pb = pre_bias ? pre_bias[c] : 0.f;
     const int bx = ox0 - p.padx0, by = oy0 - p.pady0;
+    constexpr unsigned ES = sizeof(T);
+    auto ldx = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> float {
+        if constexpr (sizeof(T) == 2) return (float)__builtin_bit_cast(_Float16, __builtin_amdgcn_raw_buffer_load_b16(rs, (int)off, 0, 0));
+        else return buf_load_f32(rs, off);
+    };
     {   // stage the window: lanes along x (64 columns), 4 rows per pass; the 3 halo columns 64..66 by the first threads.
         // Branch-free buffer loads (out-of-image -> hardware zero), so all 18 are in flight together.
-        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xp, (int64_t)p.inH * p.inW * 4);
+        const __amdgpu_buffer_rsrc_t rs = make_rsrc(xp, (int64_t)p.inH * p.inW * ES);
         const int lc = tid & 63, lr = tid >> 6;
         const int ix = bx + lc;
         const bool xin = ix >= 0 && ix < p.inW;
@@ -570,13 +596,13 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_tiled_kernel(const float* _
         for (int k = 0; k < FT_PASS; ++k) {
             const int iy = by + lr + 4 * k;
             const bool ok = xin && iy >= 0 && iy < p.inH;
-            v[k] = buf_load_f32(rs, ok ? (unsigned)((iy * p.inW + ix) * 4) : BUF_OOB);
+            v[k] = ldx(rs, ok ? (unsigned)(iy * p.inW + ix) * ES : BUF_OOB);
             if (pre_bias) v[k] = ok ? v[k] + pb : 0.f;
         }
         const int hr = min(tid / 3, FT_ROWS - 1), hc = 64 + tid % 3;
         const int iyh = by + hr, ixh = bx + hc;
         const bool okh = tid < FT_ROWS * 3 && iyh >= 0 && iyh < p.inH && ixh >= 0 && ixh < p.inW;
-        float h = buf_load_f32(rs, okh ? (unsigned)((iyh * p.inW + ixh) * 4) : BUF_OOB);
+        float h = ldx(rs, okh ? (unsigned)(iyh * p.inW + ixh) * ES : BUF_OOB);
         if (pre_bias) h = okh ? h + pb : 0.f;
 #pragma unroll
         for (int k = 0; k < FT_PASS; ++k) tile[(lr + 4 * k) * FT_LD + lc] = v[k];
@@ -618,7 +644,7 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_tiled_kernel(const float* _
         const int oy = oy0 + 4 * ty + o;
         if (oy >= p.outH) break;
         const int64_t pix = (int64_t)oy * p.outW + ox;
-        float* yp = y + (int64_t)nc * p.outH * p.outW + pix;
+        T* yp = y + (int64_t)nc * p.outH * p.outW + pix;
         float r4[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -631,10 +657,10 @@ __global__ void __launch_bounds__(256) upfirdn2d_4x4_tiled_kernel(const float* _
             }
             r4[j] = a;
         }
-        if (vec) *reinterpret_cast<float4*>(yp) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        if (vec) store4(yp, r4[0], r4[1], r4[2], r4[3]);
         else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (ox + j < p.outW) yp[j] = r4[j];
+            for (int j = 0; j < 4; ++j) if (ox + j < p.outW) yp[j] = (T)r4[j];
         }
     }
 }
@@ -1135,13 +1161,15 @@ __global__ void adam_multi_kernel(void* const* __restrict__ ptrs, const int64_t*
 // ================================================================================================
 // flags[n, s] = any(x[n, :, 16 s .. 16 s + 15] != 0): one block per 1024 pixels of one sample, lanes along pixels (coalesced rows),
 // every thread ORs the bit patterns of its 4 pixels over all channels, segments are combined through LDS.
-__global__ void __launch_bounds__(256) seg_flags_kernel(const float* __restrict__ x, int32_t* __restrict__ flags, int C, int64_t HW, int nseg) {
+template <typename T = float>
+__global__ void __launch_bounds__(256) seg_flags_kernel(const T* __restrict__ x, int32_t* __restrict__ flags, int C, int64_t HW, int nseg) {
+    using U = std::conditional_t<sizeof(T) == 2, unsigned short, unsigned>;      // the element's bit pattern
     __shared__ int s_f[64];
     const int tid = threadIdx.x, n = blockIdx.y;
     const int64_t base = (int64_t)blockIdx.x * 1024;
     if (tid < 64) s_f[tid] = 0;
     __syncthreads();
-    const unsigned* xb = reinterpret_cast<const unsigned*>(x) + (int64_t)n * C * HW;
+    const U* xb = reinterpret_cast<const U*>(x) + (int64_t)n * C * HW;
     int64_t pix[4]; bool ok[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const int64_t p = base + tid + 256 * k; ok[k] = p < HW; pix[k] = ok[k] ? p : HW - 1; }
@@ -1163,7 +1191,7 @@ __global__ void __launch_bounds__(256) seg_flags_kernel(const float* __restrict_
         for (int k = 0; k < 4; ++k) acc[k] |= xb[(int64_t)c * HW + pix[k]];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-        if (ok[k] && (acc[k] << 1) != 0u) s_f[(tid + 256 * k) >> 4] = 1;      // << 1: -0.0 counts as zero
+        if (ok[k] && (acc[k] & (sizeof(T) == 2 ? 0x7fffu : 0x7fffffffu)) != 0u) s_f[(tid + 256 * k) >> 4] = 1;      // sign bit masked: -0.0 counts as zero
     __syncthreads();
     const int seg = blockIdx.x * 64 + tid;
     if (tid < 64 && seg < nseg) flags[(int64_t)n * nseg + seg] = s_f[tid];
@@ -1278,7 +1306,7 @@ static int launch_upfirdn(const float* x, const float* f, float* y, const Upfird
     const bool k44 = p.fH == 4 && p.fW == 4 && p.upx == p.upy && p.downx == p.downy && p.upx <= 2 && p.downx <= 2 && !(p.upx == 2 && p.downx == 2);
     if (k44 && p.upx == 1 && p.downx == 1 && p.outW >= 100 && p.outH >= 100 && (ap.act == 0 || ap.act == SPI_ACT_LINEAR || ap.act == SPI_ACT_LRELU) && (int64_t)p.N * p.C <= 65535) {
         const dim3 g((unsigned)((p.outW + FT_W - 1) / FT_W), (unsigned)((p.outH + FT_H - 1) / FT_H), (unsigned)(p.N * p.C));
-        hipLaunchKernelGGL(upfirdn2d_4x4_tiled_kernel, g, dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
+        hipLaunchKernelGGL(upfirdn2d_4x4_tiled_kernel<float>, g, dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
     } else if (k44 && small && p.upx == 1 && p.downx == 1) {
         const unsigned g4 = (unsigned)std::min<int64_t>(ceil_div64((total + 3) / 4 + (int64_t)p.N * p.C * p.outH, 256), 256 * 32);
         hipLaunchKernelGGL((upfirdn2d_4x4_kernel<1, 1>), dim3(g4), dim3(256), 0, as_stream(stream), x, f, y, p, pre_bias, noise, noise_gain, bias, ap);
@@ -1311,8 +1339,8 @@ int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, floa
     int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? pix_cap : 1024)));
     const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
     splits = (C + cchunk - 1) / cchunk;
-    if (vec) hipLaunchKernelGGL(tail_bwd_kernel<4>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
-    else hipLaunchKernelGGL(tail_bwd_kernel<1>, dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
+    if (vec) hipLaunchKernelGGL((tail_bwd_kernel<4, float>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
+    else hipLaunchKernelGGL((tail_bwd_kernel<1, float>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
     SPI_LAUNCH_CHECK("spi_tail_bwd");
     return SPI_OK;
 }
@@ -1326,7 +1354,7 @@ int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C
     const int64_t want = std::max<int64_t>(1, 1024 / rows);
     const int64_t per_block = std::max<int64_t>(4096, ((HW + want - 1) / want + 4095) / 4096 * 4096);
     dim3 grid((unsigned)ceil_div64(HW, per_block), (unsigned)rows);
-    hipLaunchKernelGGL(chan_dot_kernel, grid, dim3(256), 0, as_stream(stream), a, b, out, C, HW, per_block, bias, noise, noise_gain, act, alpha, gain);
+    hipLaunchKernelGGL(chan_dot_kernel<float>, grid, dim3(256), 0, as_stream(stream), a, b, out, C, HW, per_block, bias, noise, noise_gain, act, alpha, gain);
     SPI_LAUNCH_CHECK("spi_chan_dot");
     return SPI_OK;
 }
@@ -1344,7 +1372,7 @@ int spi_style_grad(const float* a, const float* cv, const float* st, const float
 int spi_seg_flags(const float* x, int32_t* flags, int N, int C, int64_t HW, spi_stream_t stream) {
     SPI_REQUIRE(x && flags && N > 0 && N < 65536 && C > 0 && HW > 0 && HW < (1ll << 31), "spi_seg_flags: bad argument");
     const int nseg = (int)ceil_div64(HW, SPI_SEG_PIXELS);
-    hipLaunchKernelGGL(seg_flags_kernel, dim3((unsigned)ceil_div64(HW, 1024), (unsigned)N), dim3(256), 0, as_stream(stream), x, flags, C, HW, nseg);
+    hipLaunchKernelGGL(seg_flags_kernel<float>, dim3((unsigned)ceil_div64(HW, 1024), (unsigned)N), dim3(256), 0, as_stream(stream), x, flags, C, HW, nseg);
     SPI_LAUNCH_CHECK("spi_seg_flags");
     return SPI_OK;
 }
