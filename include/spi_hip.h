@@ -34,7 +34,8 @@ typedef void* spi_stream_t;           /* hipStream_t */
                              * 8: + spi_bias_act_t / spi_upfirdn2d_t: the plugin entry points with a dtype (fp32 / fp16) and strides (additive)
                              * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates
                              * 10: + spi_affine_multi_fwd / _bwd, spi_modulate_multi_fwd / _bwd (additive)
-                             * 11: + spi_conv2d_plan (additive); spi_conv_desc gained act_dtype (fp16 activation tensors; appended: 0 = the behaviour of 10) */
+                             * 11: + spi_conv2d_plan (additive); spi_conv_desc gained act_dtype (fp16 activation tensors; appended: 0 = the behaviour of 10),
+                             *     + spi_upfirdn2d_fused_t / spi_tail_bwd_t / spi_chan_dot_t / spi_seg_flags_t (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -240,6 +241,24 @@ int spi_bias_act_t(const void* x, const void* b, const void* xref, const void* y
 int spi_upfirdn2d_t(const void* x, const float* f, void* y, int N, int C, int inH, int inW, const int64_t* x_strides,
                     const int64_t* y_strides, int fH, int fW, int upx, int upy, int downx, int downy, int padx0, int padx1, int pady0,
                     int pady1, int flip, float gain, int outH, int outW, int dtype, spi_stream_t stream);
+
+/* fp16 ACTIVATION TENSORS through a whole use_fp16 block (ABI 11; networks_stylegan2.py:421-436: x = x.to(float16), every conv / FIR / bias_act of
+ * the block reads and writes half tensors).  `dtype` is the element type of the activation arguments (void*); bias, noise, per-channel and
+ * per-pixel sums and every accumulator stay fp32; a value is rounded to fp16 once, when it is stored.  dtype = SPI_DTYPE_F32 is the untyped
+ * entry point of the same name.  spi_conv_desc.act_dtype does the same for the convolutions.
+ *   spi_upfirdn2d_fused_t  spi_upfirdn2d with its fused layer tail (fp16: the 4x4 filter, up = down = 1, images >= 100 px -- the FIR after a
+ *                          stride-2 transposed conv and its adjoint; other shapes: spi_upfirdn2d_t + spi_bias_act_t, SPI_ERR_UNSUPPORTED here)
+ *   spi_tail_bwd_t         spi_tail_bwd on fp16 dy / y / dz          spi_chan_dot_t   spi_chan_dot on fp16 a / b
+ *   spi_seg_flags_t        spi_seg_flags of an fp16 gradient */
+int spi_upfirdn2d_fused_t(const void* x, const float* f, void* y, int N, int C, int inH, int inW, int fH, int fW, int upx, int upy,
+                          int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
+                          const float* noise, const float* noise_gain, const float* bias, int act, float alpha, float act_gain,
+                          float clamp, int dtype, spi_stream_t stream);
+int spi_tail_bwd_t(const void* dy, const void* y, void* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
+                   int64_t HW, int act, float alpha, float gain, float clamp, int dtype, spi_stream_t stream);
+int spi_chan_dot_t(const void* a, const void* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
+                   const float* noise_gain, int act, float alpha, float gain, int dtype, spi_stream_t stream);
+int spi_seg_flags_t(const void* x, int32_t* flags, int N, int C, int64_t HW, int dtype, spi_stream_t stream);
 
 /* filtered_lrelu.cpp:20 `filtered_lrelu(x,fu,fd,b,si,up,down,px0,px1,py0,py1,sx,sy,gain,slope,clamp,flip,writeSigns)`
  * forward without sign tensors: bias -> up-FIR(gain up^2) -> lrelu*gain, clamp -> down-FIR.

@@ -241,5 +241,6 @@ def synthesis(P, ws, c, opts, neural_rendering_resolution=128, noise_mode='const
     if not skip_sr:
         out['image'] = sg.superresolution_8xdc(P, rgb, feat_img, ws,
                                                noise_mode=opts.get('superresolution_noise_mode', 'none'),
-                                               fp16_operands=bool(opts.get('sr_fp16_operands', False)))
+                                               fp16_operands=bool(opts.get('sr_fp16_operands', False)),
+                                               fp16_storage=bool(opts.get('sr_fp16_storage', False)))
     return out

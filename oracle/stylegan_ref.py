@@ -113,8 +113,9 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=SQ
     return upfirdn2d(x, fd, down=down, flip_filter=flip_filter)
 
 
-def conv2d_resample(x, w, f=None, up=1, padding=0, groups=1, flip_weight=True):
-    """Only the branches the generator reaches: up in {1,2}, down=1."""
+def conv2d_resample(x, w, f=None, up=1, padding=0, groups=1, flip_weight=True, store_f16=False):
+    """Only the branches the generator reaches: up in {1,2}, down=1.  store_f16: the transposed convolution's output is an fp16 tensor
+    (rounded once) before the FIR reads it -- the use_fp16 blocks' activation storage, see modulated_conv2d."""
     oc, icg, kh, kw = w.shape
     px0, px1, py0, py1 = _pad4(padding)
     fw = 1 if f is None else f.shape[-1]
@@ -141,6 +142,8 @@ def conv2d_resample(x, w, f=None, up=1, padding=0, groups=1, flip_weight=True):
         if flip_weight:   # transposed conv wants the opposite flip convention
             wt = wt.flip([2, 3])
         x = F.conv_transpose2d(x, wt, stride=up, padding=[pyt, pxt], groups=groups)
+        if store_f16:
+            x = x.half().float()
         return upfirdn2d(x, f, padding=(px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt), gain=up ** 2)
     assert px0 == px1 and py0 == py1 and px0 >= 0
     if not flip_weight and (kw > 1 or kh > 1):
@@ -149,11 +152,14 @@ def conv2d_resample(x, w, f=None, up=1, padding=0, groups=1, flip_weight=True):
 
 
 def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, f=None, demodulate=True,
-                     flip_weight=True, fp16_operands=False):
+                     flip_weight=True, fp16_operands=False, fp16_storage=False):
     """Fused (grouped-conv) path only: the one SPI takes (G.eval(), 'inference_only').
     fp16_operands: the arithmetic of the build's fp16-MFMA blocks (BASELINE config 5, `--sr_fp16`): tensors stay fp32, the two conv
     operands -- the activation and the modulated (demodulated) weight -- are rounded to fp16, products accumulate in fp32.  (The
-    reference's own use_fp16 blocks also STORE activations in fp16, networks_stylegan2.py:421-461; this is the build's variant.)"""
+    reference's own use_fp16 blocks also STORE activations in fp16, networks_stylegan2.py:421-461.)
+    fp16_storage (round 5, with fp16_operands): the activations ARE fp16 tensors, as in the reference's use_fp16 blocks -- restated at the build's
+    tensor boundaries: the block input, the transposed convolution's output (before its FIR) and every layer output (after bias / activation /
+    clamp) are rounded to fp16 once; products and sums in between are fp32 (cuDNN / the plugins accumulate half tensors in fp32 too)."""
     n = x.shape[0]
     oc, ic, kh, kw = weight.shape
     w = weight.unsqueeze(0) * styles.reshape(n, 1, ic, 1, 1)
@@ -164,7 +170,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, padding=0, f=None, dem
         x, w = x.half().float(), w.half().float()
     x = x.reshape(1, n * ic, *x.shape[2:])
     x = conv2d_resample(x, w.reshape(n * oc, ic, kh, kw), f=f, up=up, padding=padding, groups=n,
-                        flip_weight=flip_weight)
+                        flip_weight=flip_weight, store_f16=fp16_storage)
     x = x.reshape(n, oc, *x.shape[2:])
     if noise is not None:
         x = x + noise
@@ -196,7 +202,7 @@ def mapping(P, z, c, prefix='backbone.mapping.', num_layers=2, num_ws=14, lr_mul
     return x.unsqueeze(1).repeat(1, num_ws, 1)
 
 
-def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gain=1.0, noise_rng=None, fp16_operands=False):
+def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gain=1.0, noise_rng=None, fp16_operands=False, fp16_storage=False):
     styles = fully_connected(w, P[pfx + 'affine.weight'], P[pfx + 'affine.bias'])
     noise = None
     if noise_mode == 'const':
@@ -207,34 +213,38 @@ def synthesis_layer(P, pfx, x, w, up=1, noise_mode='const', conv_clamp=None, gai
         noise = draw * P[pfx + 'noise_strength']
     f = P[pfx + 'resample_filter']
     x = modulated_conv2d(x, P[pfx + 'weight'], styles, noise=noise, up=up, padding=1, f=f,
-                         flip_weight=(up == 1), fp16_operands=fp16_operands)
+                         flip_weight=(up == 1), fp16_operands=fp16_operands, fp16_storage=fp16_storage)
     clamp = conv_clamp * gain if conv_clamp is not None else None
-    return bias_act(x, P[pfx + 'bias'], act='lrelu', gain=SQRT2 * gain, clamp=clamp)
+    y = bias_act(x, P[pfx + 'bias'], act='lrelu', gain=SQRT2 * gain, clamp=clamp)
+    return y.half().float() if fp16_storage else y
 
 
-def torgb_layer(P, pfx, x, w, conv_clamp=None, fp16_operands=False):
+def torgb_layer(P, pfx, x, w, conv_clamp=None, fp16_operands=False, fp16_storage=False):
     wt = P[pfx + 'weight']
     styles = fully_connected(w, P[pfx + 'affine.weight'], P[pfx + 'affine.bias'])
     styles = styles * (1.0 / math.sqrt(wt.shape[1] * wt.shape[2] * wt.shape[3]))
     x = modulated_conv2d(x, wt, styles, demodulate=False, fp16_operands=fp16_operands)
-    return bias_act(x, P[pfx + 'bias'], clamp=conv_clamp)
+    y = bias_act(x, P[pfx + 'bias'], clamp=conv_clamp)
+    return y.half().float() if fp16_storage else y           # (:443 of the reference: y.to(torch.float32) of a half tensor)
 
 
-def synthesis_block(P, pfx, x, img, ws, first=False, noise_mode='const', conv_clamp=None, noise_rng=None, fp16_operands=False):
+def synthesis_block(P, pfx, x, img, ws, first=False, noise_mode='const', conv_clamp=None, noise_rng=None, fp16_operands=False, fp16_storage=False):
     """ws: [N, num_conv+1, 512] (conv0?, conv1, torgb)."""
     wi = 0
     if first:
         x = P[pfx + 'const'].unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
     else:
+        if fp16_storage:
+            x = x.half().float()                                   # (:436) x = x.to(dtype=torch.float16) at the block entry
         x = synthesis_layer(P, pfx + 'conv0.', x, ws[:, wi], up=2, noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng,
-                            fp16_operands=fp16_operands)
+                            fp16_operands=fp16_operands, fp16_storage=fp16_storage)
         wi += 1
     x = synthesis_layer(P, pfx + 'conv1.', x, ws[:, wi], noise_mode=noise_mode, conv_clamp=conv_clamp, noise_rng=noise_rng,
-                        fp16_operands=fp16_operands)
+                        fp16_operands=fp16_operands, fp16_storage=fp16_storage)
     wi += 1
     if img is not None:
         img = upsample2d(img, P[pfx + 'resample_filter'])
-    y = torgb_layer(P, pfx + 'torgb.', x, ws[:, wi], conv_clamp=conv_clamp, fp16_operands=fp16_operands)
+    y = torgb_layer(P, pfx + 'torgb.', x, ws[:, wi], conv_clamp=conv_clamp, fp16_operands=fp16_operands, fp16_storage=fp16_storage)
     img = y if img is None else img + y
     return x, img
 
@@ -253,12 +263,13 @@ def backbone_synthesis(P, ws, resolutions=(4, 8, 16, 32, 64, 128, 256), noise_mo
     return img
 
 
-def superresolution_8xdc(P, rgb, x, ws, noise_mode='none', conv_clamp=256, prefix='superresolution.', fp16_operands=False):
+def superresolution_8xdc(P, rgb, x, ws, noise_mode='none', conv_clamp=256, prefix='superresolution.', fp16_operands=False, fp16_storage=False):
     """rgb [N,3,128,128], x [N,32,128,128] -> [N,3,512,512]; every layer driven by ws[:, -1]."""
     w3 = ws[:, -1:, :].repeat(1, 3, 1)
     if x.shape[-1] != 128:     # superresolution.py:282-286 (only reached by reduced-size test configs)
         x = F.interpolate(x, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
         rgb = F.interpolate(rgb, size=(128, 128), mode='bilinear', align_corners=False, antialias=True)
-    x, rgb = synthesis_block(P, prefix + 'block0.', x, rgb, w3, noise_mode=noise_mode, conv_clamp=conv_clamp, fp16_operands=fp16_operands)
-    x, rgb = synthesis_block(P, prefix + 'block1.', x, rgb, w3, noise_mode=noise_mode, conv_clamp=conv_clamp, fp16_operands=fp16_operands)
+    kw = dict(noise_mode=noise_mode, conv_clamp=conv_clamp, fp16_operands=fp16_operands, fp16_storage=fp16_storage and fp16_operands)
+    x, rgb = synthesis_block(P, prefix + 'block0.', x, rgb, w3, **kw)
+    x, rgb = synthesis_block(P, prefix + 'block1.', x, rgb, w3, **kw)
     return rgb

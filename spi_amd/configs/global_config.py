@@ -18,6 +18,8 @@ synthetic_weights = False
 # fp16 MFMA in the generator blocks that the checkpoint marks `use_fp16` (the super-resolution blocks: sr_num_fp16_res = 4).
 # Off by default: fp32 everywhere reproduces the reference's CPU path, the parity target.  `--sr_fp16` / BASELINE config 5.
 enable_fp16_blocks = False
+# with enable_fp16_blocks: the blocks' activations are fp16 TENSORS in HBM (the reference's use_fp16 path), not only fp16 MFMA operands (round 5)
+fp16_storage = os.environ.get('SPI_FP16_STORAGE', '1') != '0'
 
 # stage 2: run the rot / mirror-rot / depth branches on their own HIP streams beside the main backward (rot_bbox_cx_coach.py).
 # Measured neutral on one MI355X (169.5 vs 169.3 ms per super-cycle: the big kernels of every chain fill the chip on their own

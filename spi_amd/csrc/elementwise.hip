@@ -4,6 +4,7 @@
 // wherever the layout allows.
 #include "common.hpp"
 #include <stdarg.h>
+#include <type_traits>
 #include <stdio.h>
 
 // ---- error text (thread-local) -------------------------------------------------------------------
@@ -336,7 +337,7 @@ __global__ void __launch_bounds__(256) chan_dot_kernel(const T* __restrict__ a, 
         return av * v;
     };
     // 16-byte loads, four of each operand in flight per thread (scalar loads two at a time ran at 2 TB/s); host guarantees per_block % 4096 == 0
-    const bool vec = (HW % 4 == 0) && (((uintptr_t)ar | (uintptr_t)br) % 16 == 0);
+    const bool vec = (HW % 4 == 0) && (((uintptr_t)ar | (uintptr_t)br) % (4 * sizeof(T)) == 0);
     if (vec) {
         for (int64_t p = p0 + threadIdx.x * 4; p < p1; p += 4096) {
             float av[4][4], bvv[4][4];
@@ -1320,14 +1321,16 @@ static int launch_upfirdn(const float* x, const float* f, float* y, const Upfird
     return SPI_OK;
 }
 
-int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
-                 int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream) {
+extern "C++" {
+template <typename T>
+static int tail_bwd_launch(const T* dy, const T* y, T* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
+                           int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream) {
     SPI_REQUIRE(dy && N > 0 && C > 0 && HW > 0, "spi_tail_bwd: bad argument");
     SPI_REQUIRE(!d_strength || (noise && d_pixsum), "spi_tail_bwd: d_strength needs noise and d_pixsum");
     SPI_REQUIRE(!y || (act >= SPI_ACT_LINEAR && act <= SPI_ACT_LRELU && gain != 0.f), "spi_tail_bwd: activation must be linear / relu / lrelu");
     SPI_REQUIRE(y || !dz, "spi_tail_bwd: dz without a saved output (dz == dy)");
     ActParams ap{act, 1, alpha, gain, clamp};
-    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz)) % 16 == 0);
+    const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dz)) % (4 * sizeof(T)) == 0);
     const int64_t per_block = vec ? 1024 : 256;
     const unsigned gx = (unsigned)ceil_div64(HW, per_block);
     // channel splits: enough blocks (~1024) to fill 256 CUs.  With the per-pixel sums every split adds ONE atomic per pixel address (HW * splits
@@ -1339,14 +1342,33 @@ int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, floa
     int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? pix_cap : 1024)));
     const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
     splits = (C + cchunk - 1) / cchunk;
-    if (vec) hipLaunchKernelGGL((tail_bwd_kernel<4, float>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
-    else hipLaunchKernelGGL((tail_bwd_kernel<1, float>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
+    if (vec) hipLaunchKernelGGL((tail_bwd_kernel<4, T>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
+    else hipLaunchKernelGGL((tail_bwd_kernel<1, T>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
     SPI_LAUNCH_CHECK("spi_tail_bwd");
     return SPI_OK;
 }
 
-int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
-                 const float* noise_gain, int act, float alpha, float gain, spi_stream_t stream) {
+}  // extern "C++"
+
+int spi_tail_bwd(const float* dy, const float* y, float* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
+                 int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream) {
+    return tail_bwd_launch<float>(dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, act, alpha, gain, clamp, stream);
+}
+
+// the typed variants (dtype: SPI_DTYPE_F32 / SPI_DTYPE_F16 = element type of the ACTIVATION tensors; sums, bias, noise stay fp32)
+#define SPI_DTYPE_CHECK(who) do { if (dtype != SPI_DTYPE_F32 && dtype != SPI_DTYPE_F16) { spi_set_error(who ": dtype %d (0 = fp32, 1 = fp16)", dtype); return SPI_ERR_UNSUPPORTED; } } while (0)
+int spi_tail_bwd_t(const void* dy, const void* y, void* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
+                   int64_t HW, int act, float alpha, float gain, float clamp, int dtype, spi_stream_t stream) {
+    SPI_DTYPE_CHECK("spi_tail_bwd_t");
+    if (dtype == SPI_DTYPE_F16)
+        return tail_bwd_launch<_Float16>((const _Float16*)dy, (const _Float16*)y, (_Float16*)dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, act, alpha, gain, clamp, stream);
+    return tail_bwd_launch<float>((const float*)dy, (const float*)y, (float*)dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, act, alpha, gain, clamp, stream);
+}
+
+extern "C++" {
+template <typename T>
+static int chan_dot_launch(const T* a, const T* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
+                           const float* noise_gain, int act, float alpha, float gain, spi_stream_t stream) {
     SPI_REQUIRE(a && b && out && rows > 0 && rows < 65536 && C > 0 && HW > 0, "spi_chan_dot: bad argument");
     SPI_REQUIRE(act == 0 || ((act == SPI_ACT_LINEAR || act == SPI_ACT_LRELU) && gain != 0.f && (act != SPI_ACT_LRELU || alpha != 0.f)),
                 "spi_chan_dot: only linear / lrelu outputs can be inverted");
@@ -1354,9 +1376,23 @@ int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C
     const int64_t want = std::max<int64_t>(1, 1024 / rows);
     const int64_t per_block = std::max<int64_t>(4096, ((HW + want - 1) / want + 4095) / 4096 * 4096);
     dim3 grid((unsigned)ceil_div64(HW, per_block), (unsigned)rows);
-    hipLaunchKernelGGL(chan_dot_kernel<float>, grid, dim3(256), 0, as_stream(stream), a, b, out, C, HW, per_block, bias, noise, noise_gain, act, alpha, gain);
+    hipLaunchKernelGGL(chan_dot_kernel<T>, grid, dim3(256), 0, as_stream(stream), a, b, out, C, HW, per_block, bias, noise, noise_gain, act, alpha, gain);
     SPI_LAUNCH_CHECK("spi_chan_dot");
     return SPI_OK;
+}
+
+}  // extern "C++"
+
+int spi_chan_dot(const float* a, const float* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
+                 const float* noise_gain, int act, float alpha, float gain, spi_stream_t stream) {
+    return chan_dot_launch<float>(a, b, out, rows, C, HW, bias, noise, noise_gain, act, alpha, gain, stream);
+}
+
+int spi_chan_dot_t(const void* a, const void* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
+                   const float* noise_gain, int act, float alpha, float gain, int dtype, spi_stream_t stream) {
+    SPI_DTYPE_CHECK("spi_chan_dot_t");
+    if (dtype == SPI_DTYPE_F16) return chan_dot_launch<_Float16>((const _Float16*)a, (const _Float16*)b, out, rows, C, HW, bias, noise, noise_gain, act, alpha, gain, stream);
+    return chan_dot_launch<float>((const float*)a, (const float*)b, out, rows, C, HW, bias, noise, noise_gain, act, alpha, gain, stream);
 }
 
 int spi_style_grad(const float* a, const float* cv, const float* st, const float* dcoef, const float* ww, float* ds, int N, int NS,
@@ -1377,6 +1413,16 @@ int spi_seg_flags(const float* x, int32_t* flags, int N, int C, int64_t HW, spi_
     return SPI_OK;
 }
 
+int spi_seg_flags_t(const void* x, int32_t* flags, int N, int C, int64_t HW, int dtype, spi_stream_t stream) {
+    SPI_DTYPE_CHECK("spi_seg_flags_t");
+    if (dtype == SPI_DTYPE_F32) return spi_seg_flags((const float*)x, flags, N, C, HW, stream);
+    SPI_REQUIRE(x && flags && N > 0 && N < 65536 && C > 0 && HW > 0 && HW < (1ll << 31), "spi_seg_flags_t: bad argument");
+    const int nseg = (int)ceil_div64(HW, SPI_SEG_PIXELS);
+    hipLaunchKernelGGL(seg_flags_kernel<_Float16>, dim3((unsigned)ceil_div64(HW, 1024), (unsigned)N), dim3(256), 0, as_stream(stream), (const _Float16*)x, flags, C, HW, nseg);
+    SPI_LAUNCH_CHECK("spi_seg_flags_t");
+    return SPI_OK;
+}
+
 int spi_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int inH, int inW, int fH, int fW, int upx, int upy,
                   int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
                   const float* noise, const float* noise_gain, const float* bias, int act, float alpha, float act_gain,
@@ -1390,6 +1436,30 @@ int spi_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int in
     UpfirdnParams p{N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, pady0, flip, outH, outW, gain};
     ActParams ap{act, 0, alpha, act_gain, clamp};
     return launch_upfirdn(x, f, y, p, nullptr, noise, noise_gain, bias, ap, stream);
+}
+
+// spi_upfirdn2d with its fused layer tail on fp16 (or fp32) NCHW tensors: the 4x4 / up = down = 1 FIR of the up-sampling layers and its adjoint on
+// images of >= 100 pixels (the LDS-tiled kernel); every other shape in fp16 goes through spi_upfirdn2d_t (+ spi_bias_act_t), as in the reference.
+int spi_upfirdn2d_fused_t(const void* x, const float* f, void* y, int N, int C, int inH, int inW, int fH, int fW, int upx, int upy,
+                          int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip, float gain, int outH, int outW,
+                          const float* noise, const float* noise_gain, const float* bias, int act, float alpha, float act_gain,
+                          float clamp, int dtype, spi_stream_t stream) {
+    SPI_DTYPE_CHECK("spi_upfirdn2d_fused_t");
+    if (dtype == SPI_DTYPE_F32)
+        return spi_upfirdn2d((const float*)x, f, (float*)y, N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain, outH, outW,
+                             noise, noise_gain, bias, act, alpha, act_gain, clamp, stream);
+    SPI_REQUIRE(x && f && y && N > 0 && C > 0 && inH > 0 && inW > 0, "spi_upfirdn2d_fused_t: bad argument");
+    const int eh = (inH * upy + pady0 + pady1 - fH + downy) / downy, ew = (inW * upx + padx0 + padx1 - fW + downx) / downx;
+    SPI_REQUIRE(outH == eh && outW == ew && outH > 0 && outW > 0, "spi_upfirdn2d_fused_t: output size must be %dx%d, got %dx%d", eh, ew, outH, outW);
+    const bool tiled = fH == 4 && fW == 4 && upx == 1 && upy == 1 && downx == 1 && downy == 1 && outW >= 100 && outH >= 100 &&
+                       (act == 0 || act == SPI_ACT_LINEAR || act == SPI_ACT_LRELU) && (int64_t)N * C <= 65535;
+    if (!tiled) { spi_set_error("spi_upfirdn2d_fused_t: fp16 tensors are served for the 4x4 filter with up = down = 1 on >= 100-pixel images (use spi_upfirdn2d_t)"); return SPI_ERR_UNSUPPORTED; }
+    UpfirdnParams p{N, C, inH, inW, fH, fW, upx, upy, downx, downy, padx0, pady0, flip, outH, outW, gain};
+    ActParams ap{act, 0, alpha, act_gain, clamp};
+    const dim3 g((unsigned)((outW + FT_W - 1) / FT_W), (unsigned)((outH + FT_H - 1) / FT_H), (unsigned)(N * C));
+    hipLaunchKernelGGL(upfirdn2d_4x4_tiled_kernel<_Float16>, g, dim3(256), 0, as_stream(stream), (const _Float16*)x, f, (_Float16*)y, p, (const float*)nullptr, noise, noise_gain, bias, ap);
+    SPI_LAUNCH_CHECK("spi_upfirdn2d_fused_t");
+    return SPI_OK;
 }
 
 int spi_bias_act_t(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y, int64_t n, int sizeB,

@@ -49,7 +49,9 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
     """Backward of  y = clamp(act(z + noise*strength + bias)*gain)  for dy [N,C,H,W] in one launch (spi_tail_bwd).
     ``y`` None: no activation/gain/clamp was applied (dz = dy).  Returns (dz, d_noise, d_strength, d_bias).
     ``zero_buf``: optional zeroed 1-D fp32 tensor whose first ``tail_zero_elems(...)`` entries become d_bias / the pixel sums."""
-    dy = dy.contiguous().float()
+    # fp16 activation tensors (the reference's use_fp16 blocks): dy / y / dz are half, every sum stays fp32
+    half = (y is not None and y.dtype == torch.float16) or (y is None and dy.dtype == torch.float16)
+    dy = dy.contiguous().to(torch.float16 if half else torch.float32)
     n, c = dy.shape[0], dy.shape[1]
     hw = dy[0, 0].numel()
     want_pix = noise is not None and (need_noise or need_strength)
@@ -64,8 +66,12 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
     pix = zero_buf[nb:nb + hw].view(dy.shape[2:]) if want_pix else None
     ds = zero_buf[nb + hw:nb + hw + 1] if want_s else None             # sum_hw pixsum * noise comes out of the same launch
     nzc = noise.contiguous().float() if want_s else None
-    hip.call('spi_tail_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), hip.ptr(nzc), hip.ptr(ds), n, c, hw, act_id, alpha,
-             gain, clamp, hip.stream())
+    if half:
+        hip.call('spi_tail_bwd_t', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), hip.ptr(nzc), hip.ptr(ds), n, c, hw, act_id, alpha,
+                 gain, clamp, hip.DTYPE_IDS[torch.float16], hip.stream())
+    else:
+        hip.call('spi_tail_bwd', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), hip.ptr(nzc), hip.ptr(ds), n, c, hw, act_id, alpha,
+                 gain, clamp, hip.stream())
     d_noise = d_strength = None
     if want_pix:
         if need_noise:

@@ -57,18 +57,30 @@ def needed_output(flags_by_shape):
 
 
 def seg_flags(x):
-    """[N, C, H, W] -> int32 [N, ceil(H*W/16)]: 1 where the 16-pixel segment (flat index) holds a non-zero in any channel."""
+    """[N, C, H, W] (fp32 or fp16) -> int32 [N, ceil(H*W/16)]: 1 where the 16-pixel segment (flat index) holds a non-zero in any channel."""
     n, c = x.shape[0], x.shape[1]
     hw = x[0, 0].numel()
     flags = torch.empty(n, (hw + 15) // 16, device=x.device, dtype=torch.int32)
-    hip.call('spi_seg_flags', hip.ptr(x), hip.ptr(flags), n, c, hw, hip.stream())
+    if x.dtype == torch.float16:
+        hip.call('spi_seg_flags_t', hip.ptr(x), hip.ptr(flags), n, c, hw, hip.DTYPE_IDS[torch.float16], hip.stream())
+    else:
+        hip.call('spi_seg_flags', hip.ptr(x), hip.ptr(flags), n, c, hw, hip.stream())
     return flags
 
 
+def half_io(x, f16):
+    """Does this conv run on fp16 ACTIVATION TENSORS?  When its input arrives as a half tensor and it computes with fp16 operands (the reference's
+    use_fp16 blocks cast x once at the block entry, networks_stylegan2.py:423-436, and everything after it stays half) and the reduction axis
+    is made of whole 16-channel slabs in both directions (the buffer-descriptor path)."""
+    return f16 == 1 and x.dtype == torch.float16
+
+
 def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, ng=None, act=0, alpha=0.0, gain=1.0, clamp=-1.0, tap_major=0,
-          f16=0, dy_flags=None, out_flags=None, dw_zeroed=0):
-    return hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), int(f16), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
-                        act, alpha, gain, clamp, hip.ptr(dy_flags), hip.ptr(out_flags), int(dw_zeroed))
+          f16=0, dy_flags=None, out_flags=None, dw_zeroed=0, half=False):
+    d = hip.ConvDesc(n, i, o, h, w, k, k, pad, int(transposed), int(flip), int(tap_major), int(f16), wbs, hip.ptr(bias), hip.ptr(noise), hip.ptr(ng),
+                     act, alpha, gain, clamp, hip.ptr(dy_flags), hip.ptr(out_flags), int(dw_zeroed))
+    d.act_dtype = 1 if half else 0
+    return d
 
 
 def _workspace(d, pass_id, device):
@@ -105,7 +117,23 @@ def _out_tensor(d, pass_id, shape, device):
             if v is not None:
                 d.out_zeroed = 1
                 return v.view(shape)
-    return torch.empty(shape, device=device, dtype=torch.float32)
+    return torch.empty(shape, device=device, dtype=torch.float16 if d.act_dtype == 1 else torch.float32)
+
+
+def pad_o16(dz, w, o):
+    """fp16 activation tensors: the data-gradient pass reduces over the OUTPUT channels in whole 16-channel slabs (buffer-descriptor path).  The
+    3-channel torgb layers get 13 zero channels (gradient) / zero rows (tap-major weights [.., O, k, k, I]): 16 x H x W halves beside the
+    layer's 128+ x H x W input -- a few percent of its traffic.  -> (dz, w, padded O)"""
+    o16 = (o + 15) // 16 * 16
+    if o16 == o:
+        return dz, w, o
+    dzp = torch.zeros(dz.shape[0], o16, dz.shape[2], dz.shape[3], device=dz.device, dtype=dz.dtype)
+    dzp[:, :o] = dz
+    shape = list(w.shape)
+    shape[-4] = o16
+    wp = torch.zeros(shape, device=w.device, dtype=w.dtype)
+    wp.narrow(-4, 0, o).copy_(w)
+    return dzp, wp, o16
 
 
 def out_size(h, k, pad, transposed):
@@ -116,7 +144,8 @@ class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, f16=False, may_be_sparse=False):
         # w is TAP-MAJOR here: [O, k, k, I] or [N, O, k, k, I]
-        x = x.contiguous().float()
+        half = half_io(x, f16)                             # fp16 activation tensors in, fp16 out (weights stay fp32)
+        x = x.contiguous() if half else x.contiguous().float()
         w = w.contiguous().float()
         n, i, h, wd = x.shape
         per_sample = (w.ndim == 5)
@@ -130,7 +159,7 @@ class _Conv2d(torch.autograd.Function):
         of = _needed[0].get((oh, ow)) if (may_be_sparse and _needed[0]) else None
         if of is not None:
             assert of.dtype == torch.int32 and tuple(of.shape) == (n, (oh * ow + 15) // 16), 'needed_output: flags must be int32 [N, ceil(OH*OW/16)]'
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16, out_flags=of)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16, out_flags=of, half=half)
         ws = _workspace(d, 0, x.device)                 # noqa: F841  (keeps the scratch tensor alive until the launch is enqueued)
         y = _out_tensor(d, 0, (n, o, oh, ow), x.device)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
@@ -156,12 +185,16 @@ class _Conv2d(torch.autograd.Function):
                                                             zero_buf=zbuf)
         # (only convs that opted in -- the generator's; the loss networks behind the masks see dense gradients)
         flags = seg_flags(dz) if (_sparse[0] and may_be_sparse and dz.shape[2] * dz.shape[3] >= SPARSE_MIN_PIXELS) else None
-        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16, dy_flags=flags, dw_zeroed=1)
+        d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, tap_major=1, f16=f16, dy_flags=flags, dw_zeroed=1, half=(x.dtype == torch.float16))
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            ws = _workspace(d, 1, x.device)             # noqa: F841
-            dx = _out_tensor(d, 1, tuple(x.shape), x.device)
-            hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w), hip.ptr(dx), hip.stream())
+            dd, dzd, wd_ = d, dz, w
+            if d.act_dtype == 1 and o % 16 != 0:       # (torgb: 3 output channels)
+                dzd, wd_, o16 = pad_o16(dz, w, o)
+                dd = _desc(n, i, o16, h, wd, k, pad, transposed, flip, (o16 * i * k * k if wbs else 0), tap_major=1, f16=f16, dy_flags=flags, half=True)
+            ws = _workspace(dd, 1, x.device)            # noqa: F841
+            dx = _out_tensor(dd, 1, tuple(x.shape), x.device)
+            hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(dzd), hip.ptr(wd_), hip.ptr(dx), hip.stream())
         if ctx.needs_input_grad[1]:
             dw = zbuf[n_tail:].view(w.shape)
             ws2 = _workspace(d, 2, x.device)            # noqa: F841  (opt-in to the F(3x3, 2x2) weight-gradient kernel)

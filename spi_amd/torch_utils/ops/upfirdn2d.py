@@ -64,15 +64,28 @@ def _launch(x, f2d, up, down, pad, flip, gain, epilogue=None):
     oh = (ih * upy + py0 + py1 - fh + dy) // dy
     ow = (iw * upx + px0 + px1 - fw + dx) // dx
     assert oh >= 1 and ow >= 1
-    y = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float32)
+    y = torch.empty(n, c, oh, ow, device=x.device, dtype=x.dtype)
     if epilogue is None:
         noise = ng = bias = None
         act, alpha, again, clamp = 0, 0.0, 1.0, -1.0
     else:
         noise, ng, bias, act, alpha, again, clamp = epilogue
+    if x.dtype == torch.float16:           # fp16 activation tensors (use_fp16 blocks): the LDS-tiled 4x4 kernel with its fused tail, typed
+        hip.call('spi_upfirdn2d_fused_t', hip.ptr(x), hip.ptr(f2d), hip.ptr(y), n, c, ih, iw, fh, fw, upx, upy, dx, dy, px0, px1, py0, py1,
+                 int(flip), float(gain), oh, ow, hip.ptr(noise), hip.ptr(ng), hip.ptr(bias), act, alpha, again, clamp, hip.DTYPE_IDS[torch.float16], hip.stream())
+        return y
     hip.call('spi_upfirdn2d', hip.ptr(x), hip.ptr(f2d), hip.ptr(y), n, c, ih, iw, fh, fw, upx, upy, dx, dy, px0, px1, py0, py1,
              int(flip), float(gain), oh, ow, hip.ptr(noise), hip.ptr(ng), hip.ptr(bias), act, alpha, again, clamp, hip.stream())
     return y
+
+
+def _half_tiled_ok(x, f, up, down, pad):
+    """fp16 NCHW tensor + the shape spi_upfirdn2d_fused_t serves (4x4 filter, up = down = 1, output >= 100 px): the FIR of the up-sampling layers"""
+    if not (x.dtype == torch.float16 and x.is_contiguous() and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4) and up == (1, 1) and down == (1, 1)):
+        return False
+    oh = x.shape[2] + pad[2] + pad[3] - 3
+    ow = x.shape[3] + pad[0] + pad[1] - 3
+    return oh >= 100 and ow >= 100 and x.shape[0] * x.shape[1] <= 65535
 
 
 def _launch_typed(x, f2d, up, down, pad, flip, gain):
@@ -101,6 +114,8 @@ def _launch_typed(x, f2d, up, down, pad, flip, gain):
 
 def _run(x, f, up, down, pad, flip, gain):
     """Non-differentiable core; handles None / separable filters like the reference (upfirdn2d.py:240-250)."""
+    if _half_tiled_ok(x, f, up, down, pad):
+        return _launch(x, f.to(x.device).float().contiguous(), up, down, pad, flip, gain)
     typed = x.dtype == torch.float16 or (x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
     if typed:
         if f is None:
@@ -180,7 +195,12 @@ class _UpfirdnBiasAct(torch.autograd.Function):
     """y = bias_act(upfirdn2d(x, f, pad, gain) + noise * strength, bias, act) with a 2-D filter, up = down = 1."""
     @staticmethod
     def forward(ctx, x, f, noise, strength, bias, pad, fgain, act_id, alpha, again, clamp):
-        x = x.contiguous().float()
+        if x.dtype == torch.float16:                       # fp16 activation tensors: half in, half out (bias / noise stay fp32)
+            x = x.contiguous()
+            if not _half_tiled_ok(x, f, (1, 1), (1, 1), pad):
+                raise NotImplementedError('upfirdn2d_bias_act on fp16 tensors serves the 4x4 FIR of the up-sampling layers on images >= 100 px')
+        else:
+            x = x.contiguous().float()
         f = f.to(x.device).float().contiguous()
         nz = noise.contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None

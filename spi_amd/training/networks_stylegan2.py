@@ -179,8 +179,9 @@ class _ModConvFrozen(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16, ww=None):
         import ctypes
-        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace, _out_tensor, out_size
-        x = x.contiguous().float()
+        from ..torch_utils.ops.conv2d_mfma import _desc, _workspace, _out_tensor, out_size, half_io
+        half = half_io(x, f16)                             # fp16 activation tensors (use_fp16 blocks): x, y, dy, dx are half
+        x = x.contiguous() if half else x.contiguous().float()
         weight = weight.detach().contiguous().float()
         st = styles.detach().contiguous().float()
         o, i, kh, kw = weight.shape
@@ -197,7 +198,7 @@ class _ModConvFrozen(torch.autograd.Function):
         bb = bias.detach().contiguous().float() if bias is not None else None
         nz = noise.detach().contiguous().float() if noise is not None else None
         ng = strength.detach().reshape(1).contiguous().float() if (noise is not None and strength is not None) else None
-        d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16)
+        d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16, half=half)
         ws = _workspace(d, 0, x.device)                 # noqa: F841  (Winograd scratch, alive until the launch is enqueued)
         y = _out_tensor(d, 0, (n, o, oh, ow), x.device)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w2), hip.ptr(y), hip.stream())
@@ -222,21 +223,29 @@ class _ModConvFrozen(torch.autograd.Function):
         dz, d_noise, d_strength, d_bias = bias_act.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
                                                                  ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3],
                                                                  zero_buf=zb)
-        d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, tap_major=1, f16=f16)
-        ws = _workspace(d, 1, x.device)                 # noqa: F841
-        dx = _out_tensor(d, 1, tuple(x.shape), x.device)
-        hip.call('spi_conv2d_dgrad', ctypes.byref(d), hip.ptr(dz), hip.ptr(w2), hip.ptr(dx), hip.stream())
+        half = x.dtype == torch.float16
+        d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, tap_major=1, f16=f16, half=half)
+        dd, dzd, w2d = d, dz, w2
+        if half and o % 16 != 0:                       # (torgb: 3 output channels; conv2d_mfma.pad_o16)
+            from ..torch_utils.ops.conv2d_mfma import pad_o16
+            dzd, w2d, o16 = pad_o16(dz, w2, o)
+            dd = _desc(n, i, o16, h, wd, kh, pad, transposed, flip, (o16 * i * kh * kw if wbs else 0), tap_major=1, f16=f16, half=True)
+        ws = _workspace(dd, 1, x.device)                # noqa: F841
+        dx = _out_tensor(dd, 1, tuple(x.shape), x.device)
+        hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(dzd), hip.ptr(w2d), hip.ptr(dx), hip.stream())
         a = zb[n_tail:n_tail + n * i]
-        hip.call('spi_chan_dot', hip.ptr(x), hip.ptr(dx), hip.ptr(a), n * i, i, h * wd, None, None, None, 0, 0.0, 1.0, hip.stream())
+        dt = (hip.DTYPE_IDS[torch.float16],) if half else ()
+        cd = 'spi_chan_dot_t' if half else 'spi_chan_dot'
+        hip.call(cd, hip.ptr(x), hip.ptr(dx), hip.ptr(a), n * i, i, h * wd, None, None, None, 0, 0.0, 1.0, *dt, hip.stream())
         cv = None
         if demodulate:
             cv = zb[n_tail + n * i:]
             hw_out = y.shape[2] * y.shape[3]
             if has_epi:
-                hip.call('spi_chan_dot', hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, hip.ptr(bb), hip.ptr(nz), hip.ptr(ng), act_id, alpha,
-                         gain, hip.stream())
+                hip.call(cd, hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, hip.ptr(bb), hip.ptr(nz), hip.ptr(ng), act_id, alpha,
+                         gain, *dt, hip.stream())
             else:
-                hip.call('spi_chan_dot', hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, None, None, None, 0, 0.0, 1.0, hip.stream())
+                hip.call(cd, hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, None, None, None, 0, 0.0, 1.0, *dt, hip.stream())
             if ww is None:
                 ww = weight.square().sum(dim=(2, 3)).contiguous()                  # [O, I]
         ds = torch.empty(ns, i, device=x.device, dtype=torch.float32)
@@ -585,17 +594,23 @@ class SynthesisBlock(torch.nn.Module):
             fused_modconv = not self.training
         # reference rule (:421-423): fp16 iff use_fp16 and not force_fp32 and the tensor is on 'cuda'.  Here it is opt-in
         # (global_config.enable_fp16_blocks, `--sr_fp16`): default fp32 everywhere = the reference's CPU path, which is the
-        # parity target.  fp16 blocks keep fp32 tensors and round the conv operands to fp16 on their way into the MFMAs.
+        # parity target.  Round 5: like the reference's (:423-436: `x = x.to(dtype=torch.float16)`, every conv / FIR / bias_act of the block on half
+        # tensors, `y.to(torch.float32)` for the skip image) the block's ACTIVATIONS are fp16 tensors in HBM -- NCHW, not channels_last: the kernels'
+        # pixel-major loaders stay coalesced -- with fp32 weights, bias, noise and accumulators (global_config.fp16_storage; off = rounds 3-4:
+        # fp32 tensors, conv operands rounded to fp16 on their way into the MFMAs).
         f16 = bool(self.use_fp16 and not force_fp32 and global_config.enable_fp16_blocks)
+        half = f16 and global_config.fp16_storage and x is not None and x.is_cuda and self.in_channels % 16 == 0 and self.conv1.out_channels % 16 == 0
         w_iter = iter(rows if rows is not None else ws.unbind(dim=1))   # (:432) one unbind -> one stack in the backward instead of a zero-fill + copy per row
         if self.in_channels == 0:
             x = self.const.unsqueeze(0).repeat([(rows[0] if rows is not None else ws).shape[0], 1, 1, 1])
         else:
-            x = self.conv0(x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, **nxt(), **layer_kwargs)
+            x = self.conv0(x.to(torch.float16) if half else x.float(), next(w_iter), fused_modconv=fused_modconv, fp16=f16, **nxt(), **layer_kwargs)
         x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, **nxt(), **layer_kwargs)
         if img is not None:
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, fp16=f16, **nxt())
+        if y.dtype != torch.float32:
+            y = y.float()                                          # (:443) the skip image is accumulated in fp32
         img = img + y if img is not None else y
         return x, img
 

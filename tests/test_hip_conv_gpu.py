@@ -172,6 +172,52 @@ def test_conv2d_fp16_operands_vs_rounded_reference(n, i, o, h, k, transposed):
     assert 1e-5 < e < 5e-3, e
 
 
+@pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 24, 3, False), (1, 64, 128, 40, 3, False), (2, 16, 3, 33, 1, False), (1, 32, 64, 12, 3, True),
+                                                  (1, 128, 128, 128, 3, False)])
+def test_conv2d_fp16_tensors_vs_rounded_reference(n, i, o, h, k, transposed):
+    """fp16 ACTIVATION TENSORS (round 5, spi_conv_desc.act_dtype; the reference's use_fp16 blocks, networks_stylegan2.py:421-436): x, y, dy, dx are
+    half tensors in HBM, weights / weight gradients fp32, fp32 accumulation.  Every pass equals the fp64 convolution of the fp16-rounded
+    operands ROUNDED ONCE to fp16 (outputs; half an ulp + the fp32 accumulation error) -- and the weight gradient, an fp32 tensor, to 2e-5.
+    Includes the 3-channel torgb shape, whose data gradient pads the output channels to a 16-channel slab."""
+    import torch.nn.functional as F
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(n * 100 + i + 7)
+    x = torch.randn(n, i, h, h, generator=gen).half()
+    w = torch.randn(n, o, i, k, k, generator=gen) * 0.2
+    pad = 0 if transposed else k // 2
+    r = lambda t: t.half().double()
+
+    def conv(xb, wb):
+        return F.conv_transpose2d(xb, wb.transpose(0, 1), stride=2) if transposed else F.conv2d(xb, wb.flip([2, 3]), padding=pad)
+    ref = torch.cat([conv(x[b:b + 1].double(), r(w[b])) for b in range(n)])
+    dy = torch.randn(ref.shape, generator=gen).half()
+    dxs, dws = [], []
+    for b in range(n):
+        xx, ww = x[b:b + 1].double().requires_grad_(True), w[b].double().requires_grad_(True)
+        (gx,) = torch.autograd.grad(conv(xx, r(w[b])), xx, dy[b:b + 1].double())
+        (gw,) = torch.autograd.grad(conv(x[b:b + 1].double(), ww), ww, dy[b:b + 1].double())
+        dxs.append(gx); dws.append(gw)
+    xd, wd = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    y = conv2d_mfma.conv2d(xd, wd, padding=pad, transposed=transposed, flip=not transposed, fp16=True)
+    assert y.dtype == torch.float16 and xd.dtype == torch.float16
+
+    def ulp_close(a, b64, what):
+        # a: half tensor from the kernel; b64: exact value.  |a - b| <= half an fp16 ulp of b (+ fp32 accumulation slack), element by element
+        a, b64 = a.detach().double().cpu(), b64.double()
+        ulp = torch.maximum(torch.ldexp(torch.ones_like(b64), torch.floor(torch.log2(b64.abs().clamp_min(6.1e-5))).to(torch.int32) - 10), torch.full_like(b64, 2.0 ** -24))
+        bad = ((a - b64).abs() > 0.5 * ulp + 2e-5 * b64.abs().max()).float().mean().item()
+        assert bad == 0.0, f'{what}: {bad:.2e} of the elements are further than half an fp16 ulp from the exact value'
+    ulp_close(y, ref, 'fp16-tensor conv fwd')
+    gx, gw = torch.autograd.grad(y, [xd, wd], dy.to(DEV))
+    assert gx.dtype == torch.float16 and gw.dtype == torch.float32
+    ulp_close(gx, torch.cat(dxs), 'fp16-tensor conv dgrad')
+    assert_close(gw, torch.stack(dws).float(), 2e-5, 'fp16-tensor conv wgrad')
+    # the fp32-tensor / fp16-operand mode of rounds 3-4 on the same values: same numbers before the final rounding
+    y32 = conv2d_mfma.conv2d(x.float().to(DEV), wd, padding=pad, transposed=transposed, flip=not transposed, fp16=True)
+    assert y32.dtype == torch.float32
+    ulp_close(y, y32.detach().cpu(), 'fp16-tensor vs fp32-tensor fp16-operand conv')
+
+
 @pytest.mark.parametrize('up,demod,shared,n', [(1, True, False, 2), (1, True, True, 3), (2, True, False, 1), (2, True, True, 2), (1, False, False, 2)])
 def test_frozen_weight_modconv_style_gradient(up, demod, shared, n):
     """Stage-1 path (weights frozen): d styles from  <x,dx>/s - s g^2 sum_o d_o^2 <dz_o,z_o> sum_t W^2  equals the autograd

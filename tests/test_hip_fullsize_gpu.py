@@ -195,9 +195,10 @@ def test_stage2_full_size_branch_iteration_vs_oracle():
 @pytest.mark.timeout(3000)
 def test_fp16_sr_full_size_128_vs_fp16_rounding_oracle():
     """BASELINE configs[4] at full size with its arithmetic: 128 + 128 samples and fp16-MFMA super-resolution
-    (`--sr_fp16`: fp32 tensors, both conv operands of every SR layer rounded to fp16 on their way into v_mfma_f32_32x32x8_f16, fp32
-    accumulation) against an oracle super-resolution network that rounds the SAME operands (oracle/stylegan_ref.modulated_conv2d
-    `fp16_operands`; superresolution.py:264-290): every SR layer on the oracle's own fp16-path input within 1e-4, the whole image
+    (`--sr_fp16`; round 5: the SR blocks' activations are fp16 TENSORS in HBM like the reference's use_fp16 blocks, networks_stylegan2.py:421-436,
+    both conv operands of every SR layer are fp16 on v_mfma_f32_32x32x16_f16, fp32 accumulation) against an oracle super-resolution network
+    that rounds at the SAME places (oracle/stylegan_ref.modulated_conv2d `fp16_operands` + `fp16_storage`; superresolution.py:264-290): every
+    SR layer on the oracle's own fp16-path input to within one fp16 ulp on a small share of the elements, the whole image
     statistically (see the comment below: fp16 rounding decorrelates two implementations after a few layers).  Then one PLAIN stage-2 iteration (i = 1: L2 + LPIPS, rot_bbox_cx_coach.py:68-85) in that
     arithmetic: both loss values within 1e-2 of the oracle's iteration with the same draws."""
     from oracle import losses_ref as olo, loops_ref as olp
@@ -209,7 +210,7 @@ def test_fp16_sr_full_size_128_vs_fp16_rounding_oracle():
     from spi_amd.utils.rng import ReplayRNG
     import tempfile
     P, G, ws, c, xi, u, opts, gen = _setup(128, seed=3)
-    opts16 = dict(opts, sr_fp16_operands=True)
+    opts16 = dict(opts, sr_fp16_operands=True, sr_fp16_storage=True)       # round 5: fp16 activation TENSORS through both SR blocks, like the reference's use_fp16 path
     with torch.no_grad():
         ref16 = orr.synthesis(P, ws, c, opts16, neural_rendering_resolution=128, xi=xi, u=u)
         ref32 = orr.synthesis(P, ws, c, opts, neural_rendering_resolution=128, xi=xi, u=u)
@@ -237,7 +238,9 @@ def test_fp16_sr_full_size_128_vs_fp16_rounding_oracle():
     # closer to the fp16-rounding oracle than the fp32 images do; (2) layer by layer, exact: every SR layer fed with the ORACLE's fp16-path
     # input reproduces the oracle's output to 1e-4 (no flips can build up inside one layer).
     assert erms['hip16_vs_oracle16'] <= 1.5e-3 and emax['hip16_vs_oracle16'] <= 5e-3, (erms, emax)
-    assert erms['hip16_vs_oracle16'] <= 0.75 * min(erms['hip32_vs_oracle16'], erms['oracle32_vs_oracle16']), erms
+    # (round 5, fp16 TENSORS: three more rounding points per block on both sides -- the two fp16 images decorrelate a little further: 1.39e-3 rms
+    #  between them against 1.78e-3 from either to the fp32 image; the ratio was 0.6 with fp32 tensors / fp16 operands)
+    assert erms['hip16_vs_oracle16'] <= 0.85 * min(erms['hip32_vs_oracle16'], erms['oracle32_vs_oracle16']), erms
     from oracle import stylegan_ref as sg
     global_config.enable_fp16_blocks = True
     with torch.no_grad():
@@ -245,17 +248,23 @@ def test_fp16_sr_full_size_128_vs_fp16_rounding_oracle():
         x_ref, worst_layer = ref16['feature_image'], 0.0
         for bname, block in (('block0', G.superresolution.block0), ('block1', G.superresolution.block1)):
             pfx = f'superresolution.{bname}.'
-            y0_ref = sg.synthesis_layer(P, pfx + 'conv0.', x_ref, w_last, up=2, noise_mode='none', conv_clamp=256, fp16_operands=True)
-            y0 = block.conv0(x_ref.to(DEV), w_last.to(DEV), noise_mode='none', fp16=True)
-            y1_ref = sg.synthesis_layer(P, pfx + 'conv1.', y0_ref, w_last, noise_mode='none', conv_clamp=256, fp16_operands=True)
-            y1 = block.conv1(y0_ref.to(DEV), w_last.to(DEV), noise_mode='none', fp16=True)
-            rgb_ref = sg.torgb_layer(P, pfx + 'torgb.', y1_ref, w_last, conv_clamp=256, fp16_operands=True)
-            rgb = block.torgb(y1_ref.to(DEV), w_last.to(DEV), fp16=True)
+            x_ref = x_ref.half().float()                           # the block entry's cast (networks_stylegan2.py:436)
+            kw16 = dict(fp16_operands=True, fp16_storage=True)
+            y0_ref = sg.synthesis_layer(P, pfx + 'conv0.', x_ref, w_last, up=2, noise_mode='none', conv_clamp=256, **kw16)
+            y0 = block.conv0(x_ref.to(DEV).half(), w_last.to(DEV), noise_mode='none', fp16=True)
+            y1_ref = sg.synthesis_layer(P, pfx + 'conv1.', y0_ref, w_last, noise_mode='none', conv_clamp=256, **kw16)
+            y1 = block.conv1(y0_ref.to(DEV).half(), w_last.to(DEV), noise_mode='none', fp16=True)
+            rgb_ref = sg.torgb_layer(P, pfx + 'torgb.', y1_ref, w_last, conv_clamp=256, **kw16)
+            rgb = block.torgb(y1_ref.to(DEV).half(), w_last.to(DEV), fp16=True)
             for nm, a_, b_ in (('conv0', y0, y0_ref), ('conv1', y1, y1_ref), ('torgb', rgb, rgb_ref)):
-                e = rel_err(a_, b_)
+                assert a_.dtype == torch.float16, (bname, nm, a_.dtype)      # the layer's activation IS an fp16 tensor
+                d_ = (a_.float().cpu() - b_).abs()
+                e, flips = (d_.max() / b_.abs().max()).item(), (d_ > 0).float().mean().item()
                 worst_layer = max(worst_layer, e)
-                print(f'  fp16 SR layer {bname}.{nm} on the oracle input: {e:.2e}')
-                assert e <= 1e-4, (bname, nm, e)
+                print(f'  fp16 SR layer {bname}.{nm} on the oracle input: max {e:.2e}, {flips:.2e} of the elements differ')
+                # both sides round the same fp32 value to fp16; where their fp32 values straddle a rounding boundary the results differ by ONE
+                # fp16 ulp (<= 2^-10 of the value): a small share of the elements, never more than an ulp of the largest one
+                assert e <= 1.1e-3 and flips <= 6e-2, (bname, nm, e, flips)      # (observed: 0.5 % after 288-term sums, 2.4 % after 2304-term sums)
             x_ref = y1_ref
     global_config.enable_fp16_blocks = False
 
