@@ -35,7 +35,8 @@ typedef void* spi_stream_t;           /* hipStream_t */
                              * 9: spi_conv_desc gained out_zeroed (in what was padding after dw_zeroed: 0 = the behaviour of 8), + spi_conv2d_out_accumulates
                              * 10: + spi_affine_multi_fwd / _bwd, spi_modulate_multi_fwd / _bwd (additive)
                              * 11: + spi_conv2d_plan (additive); spi_conv_desc gained act_dtype (fp16 activation tensors; appended: 0 = the behaviour of 10),
-                             *     + spi_upfirdn2d_fused_t / spi_tail_bwd_t / spi_chan_dot_t / spi_seg_flags_t (additive) */
+                             *     + spi_upfirdn2d_fused_t / spi_tail_bwd_t / spi_chan_dot_t / spi_seg_flags_t / spi_filtered_lrelu_t,
+                             *     SPI_DTYPE_F64 for spi_bias_act_t / spi_upfirdn2d_t (additive) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -235,7 +236,7 @@ int spi_upfirdn2d(const float* x, const float* f, float* y, int N, int C, int in
  * contract filtered_lrelu's rc = -1 has in the reference.
  * spi_upfirdn2d_t takes element strides {n, c, h, w} of x and y (NULL = dense NCHW): dense NCHW and channels_last are accepted, in any
  * combination, like the plugin's "non-overlapping and dense" rule (upfirdn2d.cpp:23).  No fused epilogue on this entry point. */
-enum { SPI_DTYPE_F32 = 0, SPI_DTYPE_F16 = 1 };
+enum { SPI_DTYPE_F32 = 0, SPI_DTYPE_F16 = 1, SPI_DTYPE_F64 = 2 };   /* F64: spi_bias_act_t / spi_upfirdn2d_t only (the plugins' double instantiation) */
 int spi_bias_act_t(const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y, int64_t n, int sizeB,
                    int64_t stepB, int grad, int act, float alpha, float gain, float clamp, int dtype, spi_stream_t stream);
 int spi_upfirdn2d_t(const void* x, const float* f, void* y, int N, int C, int inH, int inW, const int64_t* x_strides,
@@ -259,6 +260,11 @@ int spi_tail_bwd_t(const void* dy, const void* y, void* dz, float* d_bias, float
 int spi_chan_dot_t(const void* a, const void* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
                    const float* noise_gain, int act, float alpha, float gain, int dtype, spi_stream_t stream);
 int spi_seg_flags_t(const void* x, int32_t* flags, int N, int C, int64_t HW, int dtype, spi_stream_t stream);
+/* spi_filtered_lrelu on fp16 tensors (filtered_lrelu.cpp:151,265: the plugin is dispatched for half too): x [N,C,inH,inW], b [C] and y are
+ * `dtype` tensors, the filters and the intermediate `tmp` (N*C*midH*midW floats) stay fp32 = the plugin's internal type for half. */
+int spi_filtered_lrelu_t(const void* x, const float* fu, const float* fd, const void* b, float* tmp, void* y, int N, int C,
+                         int inH, int inW, int fuH, int fuW, int fdH, int fdW, int up, int down, int px0, int px1, int py0, int py1,
+                         float gain, float slope, float clamp, int flip, int outH, int outW, int dtype, spi_stream_t stream);
 
 /* filtered_lrelu.cpp:20 `filtered_lrelu(x,fu,fd,b,si,up,down,px0,px1,py0,py1,sx,sy,gain,slope,clamp,flip,writeSigns)`
  * forward without sign tensors: bias -> up-FIR(gain up^2) -> lrelu*gain, clamp -> down-FIR.

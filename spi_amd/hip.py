@@ -71,6 +71,7 @@ _SIGS = {
     'spi_tail_bwd_t': ([c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_p], c_i),
     'spi_chan_dot_t': ([c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_i, c_f, c_f, c_i, c_p], c_i),
     'spi_seg_flags_t': ([c_p, c_p, c_i, c_i, c_l, c_i, c_p], c_i),
+    'spi_filtered_lrelu_t': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p], c_i),
     'spi_filtered_lrelu': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f, c_i, c_i, c_i, c_p], c_i),
     'spi_filtered_lrelu_fused': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f] + [c_i] * 8 + [c_p], c_i),
     'spi_filtered_lrelu_act': ([c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_p], c_i),
@@ -129,8 +130,8 @@ def lib():
     return _lib
 
 
-_PTR_DTYPES = (torch.float32, torch.int32, torch.int64, torch.uint8, torch.float16)      # (float16: the typed entry points / spi_conv_desc.act_dtype only)
-DTYPE_IDS = {torch.float32: 0, torch.float16: 1}          # SPI_DTYPE_* of the typed plugin entry points (spi_bias_act_t, spi_upfirdn2d_t)
+_PTR_DTYPES = (torch.float32, torch.int32, torch.int64, torch.uint8, torch.float16, torch.float64)      # (float16: the typed entry points / spi_conv_desc.act_dtype only)
+DTYPE_IDS = {torch.float32: 0, torch.float16: 1, torch.float64: 2}          # SPI_DTYPE_* of the typed plugin entry points (spi_bias_act_t, spi_upfirdn2d_t)
 
 
 def ptr_any(t):

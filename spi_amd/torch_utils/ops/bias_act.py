@@ -30,7 +30,8 @@ def _launch(x, b, xref, yref, dy, grad, dim, act_id, alpha, gain, clamp):
     if b is not None:
         for d in x.shape[dim + 1:]:
             step_b *= d
-    if x.dtype == torch.float16:        # the reference's plugin is instantiated for half too (bias_act.cpp:81): fp32 arithmetic, one rounding at the store
+    if x.dtype in (torch.float16, torch.float64):        # the reference's plugin is instantiated for half and double too (bias_act.cpp:81): fp32 arithmetic
+        # and one rounding at the store for half, double arithmetic for double
         hip.call('spi_bias_act_t', hip.ptr_any(x), hip.ptr_any(b), hip.ptr_any(xref), hip.ptr_any(yref), hip.ptr_any(dy), hip.ptr_any(y), x.numel(),
                  size_b, step_b, grad, act_id, alpha, gain, clamp, hip.DTYPE_IDS[x.dtype], hip.stream())
         return y
@@ -84,7 +85,7 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b, dim, act_id, alpha, gain, clamp, ref):
-        dt = torch.float16 if x.dtype == torch.float16 else torch.float32          # half stays half (b follows x, bias_act.py:146-148 of the reference)
+        dt = x.dtype if x.dtype in (torch.float16, torch.float64) else torch.float32          # half / double stay (b follows x, bias_act.py:146-148 of the reference)
         x = x.contiguous().to(dt)
         bb = b.contiguous().to(dt) if b is not None else None
         y = _launch(x, bb, None, None, None, 0, dim, act_id, alpha, gain, clamp)
@@ -100,7 +101,7 @@ class _BiasAct(torch.autograd.Function):
         x, b, y = ctx.saved_tensors
         dim, act_id, alpha, gain, clamp, has_b = ctx.cfg
         ref_t = y if y is not None else x
-        dy = dy.contiguous().to(ref_t.dtype if ref_t is not None else (torch.float16 if dy.dtype == torch.float16 else torch.float32))
+        dy = dy.contiguous().to(ref_t.dtype if ref_t is not None else (dy.dtype if dy.dtype in (torch.float16, torch.float64) else torch.float32))
         dx = dy
         if act_id != 1 or gain != 1 or clamp >= 0:
             dx = _launch(dy, b, x, y, None, 1, dim, act_id, alpha, gain, clamp)

@@ -73,6 +73,29 @@ def _fused(x, fu, fd, b, up, down, padding, gain, slope, clamp, flip_filter, si,
     return y, so
 
 
+def _half_two_pass(x, fu, fd, b, up, down, padding, gain, slope, clamp, flip_filter):
+    """Half tensors (the plugin is dispatched for half as well, filtered_lrelu.cpp:151): `spi_filtered_lrelu_t` -- x, b and y fp16, filters and the
+    up-sampled intermediate fp32 (the plugin's internal type for half), one rounding at the store.  Inference path (no gradient); with a
+    gradient required the op runs in fp32 like the reference's generic fallback does (filtered_lrelu.py:121-131)."""
+    px0, px1, py0, py1 = padding
+    x = x.contiguous()
+    n, c, ih, iw = x.shape
+    one = torch.ones(1, 1, device=x.device)
+    fu = one if fu is None else fu.to(x.device).float().contiguous()
+    fd = one if fd is None else fd.to(x.device).float().contiguous()
+    fu = fu.reshape(1, 1) ** 2 if (fu.ndim == 1 and fu.numel() == 1) else fu
+    fd = fd.reshape(1, 1) ** 2 if (fd.ndim == 1 and fd.numel() == 1) else fd
+    mid_h, mid_w = ih * up + py0 + py1 - fu.shape[0] + 1, iw * up + px0 + px1 - fu.shape[1] + 1
+    oh, ow = (mid_h - fd.shape[0] + down) // down, (mid_w - fd.shape[1] + down) // down
+    tmp = torch.empty(n, c, mid_h, mid_w, device=x.device, dtype=torch.float32)
+    y = torch.empty(n, c, oh, ow, device=x.device, dtype=torch.float16)
+    bb = b.detach().to(torch.float16).contiguous() if b is not None else None
+    hip.call('spi_filtered_lrelu_t', hip.ptr(x), hip.ptr(fu), hip.ptr(fd), hip.ptr(bb), hip.ptr(tmp), hip.ptr(y), n, c, ih, iw, fu.shape[0], fu.shape[1],
+             fd.shape[0], fd.shape[1], up, down, px0, px1, py0, py1, gain, slope, float(-1 if clamp is None else clamp), int(flip_filter), oh, ow,
+             hip.DTYPE_IDS[torch.float16], hip.stream())
+    return y
+
+
 _op_cache = {}
 
 
@@ -138,6 +161,8 @@ def filtered_lrelu(x, fu=None, fd=None, b=None, up=1, down=1, padding=0, gain=ma
         y = _uf.upfirdn2d(y, fu, up=up, padding=_parse_padding(padding), gain=up ** 2, flip_filter=flip_filter)
         y = _ba.bias_act(y, act='lrelu', alpha=slope, gain=gain, clamp=clamp)
         return _uf.upfirdn2d(y, fd, down=down, flip_filter=flip_filter)
+    if x.dtype == torch.float16:
+        return _half_two_pass(x, fu, fd, b, int(up), int(down), tuple(_parse_padding(padding)), float(gain), float(slope), clamp, bool(flip_filter))
     one = torch.ones(1, 1, device=x.device)
     fu = one if fu is None else fu.to(x.device).float().contiguous()
     fd = one if fd is None else fd.to(x.device).float().contiguous()

@@ -116,7 +116,7 @@ def _run(x, f, up, down, pad, flip, gain):
     """Non-differentiable core; handles None / separable filters like the reference (upfirdn2d.py:240-250)."""
     if _half_tiled_ok(x, f, up, down, pad):
         return _launch(x, f.to(x.device).float().contiguous(), up, down, pad, flip, gain)
-    typed = x.dtype == torch.float16 or (x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
+    typed = x.dtype in (torch.float16, torch.float64) or (x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
     if typed:
         if f is None:
             f = torch.ones([1, 1], dtype=torch.float32, device=x.device)

@@ -377,8 +377,8 @@ def test_typed_entry_points_through_the_c_abi():
     xh, bh, yh = x.half(), b.half(), torch.empty_like(x, dtype=torch.float16)
     hip.call('spi_bias_act_t', xh.data_ptr(), bh.data_ptr(), None, None, None, yh.data_ptr(), x.numel(), 4, 36, 0, 3, 0.2, 1.4142, -1.0, 1, hip.stream())
     assert _half_ulps(yh, osg.bias_act(xh.float().cpu(), bh.float().cpu(), act='lrelu', gain=1.4142).half()) <= 1.0
-    rc = hip.lib().spi_bias_act_t(hip.ptr(x), None, None, None, None, hip.ptr(y1), x.numel(), 0, 0, 0, 3, 0.2, 1.0, -1.0, 2, hip.stream())
-    assert rc == -2 and b'dtype 2' in hip.lib().spi_last_error()
+    rc = hip.lib().spi_bias_act_t(hip.ptr(x), None, None, None, None, hip.ptr(y1), x.numel(), 0, 0, 0, 3, 0.2, 1.0, -1.0, 3, hip.stream())
+    assert rc == -2 and b'dtype 3' in hip.lib().spi_last_error()      # (2 = fp64 is served since round 5)
     f = torch.tensor([[1., 2.], [3., 4.]], device=DEV) / 10
     yo = torch.empty(2, 4, 5, 5, device=DEV)
     rc = hip.lib().spi_upfirdn2d_t(hip.ptr(x), hip.ptr(f), hip.ptr(yo), 2, 4, 6, 6, None, None, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, 5, 5, 7, hip.stream())
@@ -387,3 +387,40 @@ def test_typed_entry_points_through_the_c_abi():
     rc = hip.lib().spi_upfirdn2d_t(hip.ptr(x), hip.ptr(f), hip.ptr(yo), 2, 4, 6, 6, ctypes.cast(bad, ctypes.c_void_p), None, 2, 2, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0,
                                    5, 5, 0, hip.stream())
     assert rc == -1 and b'dense' in hip.lib().spi_last_error()
+
+
+def test_plugin_boundary_fp64_and_half_filtered_lrelu(golden):
+    """the rest of the plugins' dtype dispatch.  (a) bias_act.cpp:81 / upfirdn2d.cpp:67 instantiate the plugins for double:
+    `spi_bias_act_t` / `spi_upfirdn2d_t` with SPI_DTYPE_F64 compute in double (all golden activation / clamp cases forward and backward, all
+    golden pad / up / down cases, against the oracle run in fp64: 1e-7 -- the C ABI carries alpha / gain / clamp / the FIR taps as fp32 scalars, so
+    sqrt(2) arrives rounded to fp32; the arithmetic on the tensors is double).  (b) filtered_lrelu.cpp:151 dispatches half: `spi_filtered_lrelu_t`
+    on fp16 x / b / y with fp32 filters and intermediate -- the golden cases on fp16-rounded inputs within one fp16 ulp of the fp32 oracle."""
+    from spi_amd.torch_utils.ops import bias_act, upfirdn2d, filtered_lrelu
+    g = golden('ops')
+    cases = json.loads(str(g.z['ba_cases'][0]))
+    x64, b64, dy64 = g['ba_x'].double(), g['ba_b'].double(), g['ba_dy'].double()
+    for act, alpha, gain, clamp in cases:
+        x, b = x64.to(DEV).requires_grad_(True), b64.to(DEV).requires_grad_(True)
+        y = bias_act.bias_act(x, b, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        assert y.dtype == torch.float64
+        xr, br = x64.clone().requires_grad_(True), b64.clone().requires_grad_(True)
+        yr = osg.bias_act(xr, br, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        assert_close(y, yr, 1e-7, f'fp64 bias_act {act}')
+        gx, gb = torch.autograd.grad(y, [x, b], dy64.to(DEV))
+        gxr, gbr = torch.autograd.grad(yr, [xr, br], dy64)
+        assert gx.dtype == torch.float64
+        assert_close(gx, gxr, 1e-7, f'fp64 bias_act {act} dx')
+        assert_close(gb, gbr, 1e-7, f'fp64 bias_act {act} db')
+    f = g['fir']
+    for i, kw in enumerate(json.loads(str(g.z['uf_cases'][0]))):
+        y = upfirdn2d.upfirdn2d(g['uf_x'].double().to(DEV), f.to(DEV), **kw)
+        assert y.dtype == torch.float64
+        assert_close(y, osg.upfirdn2d(g['uf_x'].double(), f.double(), **kw), 1e-7, f'fp64 upfirdn2d[{i}]')
+    # (b) filtered_lrelu on half tensors
+    x16, b16 = g['fl_x'].half(), g['fl_b'].half()
+    for i, kw in enumerate(json.loads(str(g.z['fl_cases'][0]))):
+        with torch.no_grad():
+            y = filtered_lrelu.filtered_lrelu(x16.to(DEV), fu=g['fl_fu'].to(DEV), fd=g['fl_fd'].to(DEV), b=b16.to(DEV), **kw)
+        assert y.dtype == torch.float16
+        yr = osg.filtered_lrelu(x16.float(), fu=g['fl_fu'], fd=g['fl_fd'], b=b16.float(), **kw)
+        assert _half_ulps(y, yr.half()) <= 1.0, (i, _half_ulps(y, yr.half()))

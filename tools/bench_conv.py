@@ -57,17 +57,22 @@ def main():
     for name, N, I, O, H, k, tr, per in SHAPES:
         if only and only not in name:
             continue
+        half = os.environ.get('SPI_BENCH_HALF') == '1'          # fp16 activation TENSORS (with SPI_BENCH_F16=1): spi_conv_desc.act_dtype
+        if half and (I % 16 or O % 16):
+            continue
         x = torch.randn(N, I, H, H, device=dev)
         w = torch.randn(*((N,) if per else ()), O, I, k, k, device=dev) * 0.05
         pad = k // 2 if not tr else 0
         oh = cm.out_size(H, k, pad, tr)
-        y = torch.empty(N, O, oh, oh, device=dev)
+        y = torch.randn(N, O, oh, oh, device=dev)
+        if half:
+            x, y = x.half(), y.half()
         dx = torch.empty_like(x); dw = torch.empty_like(w)
         wbs = O * I * k * k if per else 0
-        d = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
+        d = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')), half=half)
         s = hip.stream()
         wino = os.environ.get('SPI_BENCH_WINO', '1') != '0'
-        dg = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
+        dg = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')), half=half)
         wsf = cm._workspace(d, 0, x.device) if wino else None
         wsg = cm._workspace(dg, 1, x.device) if wino else None
         name = name + (' [W]' if wsf is not None else '')
@@ -75,7 +80,7 @@ def main():
         reps = 3 if flops > 2e10 else 10
         f = timeit(lambda: hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), s), reps)
         g = timeit(lambda: hip.call('spi_conv2d_dgrad', ctypes.byref(dg), hip.ptr(y), hip.ptr(w), hip.ptr(dx), s), reps)
-        dwg = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
+        dwg = cm._desc(N, I, O, H, H, k, pad, tr, False, wbs, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')), half=half)
         wsw = cm._workspace(dwg, 2, x.device) if (wino and os.environ.get('SPI_BENCH_WINO_WGRAD', '1') != '0') else None
         if wsw is not None:
             name += '[Wg]'
