@@ -3,8 +3,11 @@
  *
  * Every entry point takes raw device pointers + explicit sizes and a HIP stream, never allocates,
  * keeps no global device state, launches asynchronously on `stream`, and returns 0 on success or a
- * negative SPI_ERR_* code (spi_last_error() gives the text).  All tensors are fp32 and densely
- * packed in the stated row-major shape unless a stride argument says otherwise.
+ * negative SPI_ERR_* code (spi_last_error() gives the text).  Tensors are fp32 and densely packed
+ * in the stated row-major shape unless an argument says otherwise: the `_t` entry points take a dtype
+ * (SPI_DTYPE_F32 / _F16, _F64 where stated) and, for upfirdn2d, strides -- the plugins' own dispatch
+ * (bias_act.cpp:81, upfirdn2d.cpp:67, filtered_lrelu.cpp:151) -- and spi_conv_desc.act_dtype makes the
+ * convolutions' activation tensors fp16 (the reference's use_fp16 blocks).
  *
  * Each function cites the reference interface it replaces (paths relative to the FeiiYin/SPI tree):
  * the three JIT-built CUDA plugins under eg3d/torch_utils/ops (bias_act.cpp:36, upfirdn2d.cpp:20,
