@@ -153,6 +153,7 @@ def cpu_baseline(depth, narrow, mode='sample', k1=8, k2=16):
         if os.path.exists(full):
             rec = json.load(open(full))
             res['full_protocol_recorded'] = rec                   # (recorded once per round by `bench.py --cpu-baseline full`, with that process's own GPU value beside it)
+            res['full_protocol_is_a_replayed_record'] = 'profiles/cpu_baseline_full.json: NOT measured in this process (this run timed the 2-iteration sample above)'
     res['sample'] += f'; 512^2, {depth}+{depth} samples, torch {torch.__version__} CPU fp32, {cores} threads of {ncpu}'
     return res
 
@@ -165,11 +166,15 @@ def conv_roofline(dev, f16, prec=0):
     from spi_amd import hip
     import ctypes
     n, i, o, h, k = 1, 128, 128, 512, 3
+    from spi_amd.configs import global_config as _gc
+    half = bool(f16 and _gc.fp16_storage)                       # configs[4]: the SR blocks' activations are fp16 tensors (spi_conv_desc.act_dtype)
     x = torch.randn(n, i, h, h, device=dev)
     w = torch.randn(n, o, k, k, i, device=dev) * 0.03
-    y = torch.empty(n, o, h, h, device=dev)
+    y = torch.randn(n, o, h, h, device=dev)
+    if half:
+        x, y = x.half(), y.half()
     dx, dw = torch.empty_like(x), torch.empty_like(w)
-    d = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1, f16=1 if f16 else prec)
+    d = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1, f16=1 if f16 else prec, half=half)
     flop = 2.0 * n * o * i * k * k * h * h
     # dense MFMA peaks (TFLOP/s), MI355X_MICROARCH.md: fp16 2500, fp32 157.3; split-bf16 modes: the bf16 peak / number of piece products
     peak = 2500.0 if f16 else {0: 157.3, 2: 2500.0 / 3, 3: 2500.0 / 6}[prec]
@@ -190,6 +195,9 @@ def conv_roofline(dev, f16, prec=0):
     out = {'kernel': 'igemm_kernel / wgrad_kernel (implicit GEMM, the kernels of the 1x1 / transposed / small layers) on SR b512.conv1 (128->128, 3x3, 512^2, N=1)', 'bound': 'mfma', 'achieved': worst, 'peak': peak,
            'unit': 'TFLOP/s', 'frac': worst / peak, 'flop_per_launch': flop, 'passes': res,
            'note': 'achieved = slowest of the three passes; wgrad includes its memset of dw'}
+    if f16:
+        out['fp16'] = {'activation_tensors': 'fp16 in HBM (act_dtype)' if half else 'fp32 in HBM, operands rounded on their way into LDS', 'peak': peak,
+                       'passes_frac_of_fp16_peak': {k_: v['achieved'] / peak for k_, v in res.items()}}
     # the same layer on the Winograd F(2x2, 3x3) path the loop actually takes for forward / dgrad of the >= 128^2 3x3 layers (exact fp32
     # mode only): `achieved` counts the direct convolution's FLOPs (the algorithmic work), `executed` the MFMA FLOPs issued (/ 2.25)
     from spi_amd.configs import global_config
@@ -812,6 +820,11 @@ def main():
             out['alt'] = alt
         if dense_leg is not None:
             out['dense'] = dense_leg
+        mb = (out.get('roofline_march_bwd') or {}).get('masked_launches_only') or {}
+        out['config']['data_driven_skipping'] = {
+            'on': bool(global_config.exploit_sparsity), 'what': 'exactly-zero gradient rays / 16-pixel gradient segments / unneeded SR tiles of the masked pseudo-view branches are not processed (result-identical)',
+            'masked_march_bwd_live_ray_share': mb.get('live_ray_share'), 'dense_value_iters_per_s': (dense_leg or {}).get('value'),
+            'note': 'the live share comes from the synthetic mask and random-init weights; `dense` is the same step with the skipping off = the robust lower bound of `value`'}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.depth, args.narrow, args.cpu_baseline, 1 if k1 else 0, 2 if k2 else 0)

@@ -135,7 +135,7 @@ def test_synthesis_fp16_superresolution_close_to_fp32(golden):
     assert rel_err(o32['image_raw'], o16['image_raw']) < 1e-5 and rel_err(o32['image_depth'], o16['image_depth']) < 1e-5
     e = rel_err(o16['image'], o32['image'])
     assert 1e-6 < e < 3e-3, e                       # really a different arithmetic, and within the north-star 1e-3-ish band
-    assert rel_err(g16, g32) < 2e-2
+    assert rel_err(g16, g32) < 4e-2                  # (round 5: the SR gradients are fp16 TENSORS now, like the activations: 2.4e-2 observed, 1.5e-2 with fp32 tensors)
 
 
 def test_orbit_video_and_sigma_grid(tmp_path):

@@ -7,8 +7,12 @@ from spi_amd import hip
 from spi_amd.torch_utils.ops import conv2d_mfma as cm
 N, I, O, H, k = 1, 128, 128, 512, 3
 x = torch.randn(N, I, H, H, device='cuda'); w = torch.randn(N, O, I, k, k, device='cuda') * 0.05
-y = torch.empty(N, O, H, H, device='cuda'); dx = torch.empty_like(x); dw = torch.empty_like(w)
-d = cm._desc(N, I, O, H, H, k, 1, False, False, O * I * k * k, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')))
+y = torch.randn(N, O, H, H, device='cuda')
+half = os.environ.get('SPI_BENCH_HALF') == '1'                   # fp16 activation tensors (with SPI_BENCH_F16=1)
+if half:
+    x, y = x.half(), y.half()
+dx = torch.empty_like(x); dw = torch.empty_like(w)
+d = cm._desc(N, I, O, H, H, k, 1, False, False, O * I * k * k, tap_major=1, f16=int(os.environ.get('SPI_BENCH_F16', '0')), half=half)
 ws = cm._workspace(d, 0, x.device) if os.environ.get('SPI_BENCH_WINO', '1') != '0' else None     # same size for forward and dgrad
 for _ in range(3):
     hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
