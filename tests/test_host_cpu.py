@@ -761,3 +761,67 @@ def test_zero_arena_serves_the_second_iteration_of_a_kind_from_one_buffer():
     finally:
         za.enabled = True
         za.reset()
+
+
+def test_persistent_ctx_adoption_and_arena_closing():
+    """Round 5 host logic that needs no GPU: (a) `RotBboxCoach._adopt_ctx` -- the per-image constants of the stage-2 loop live in ONE set of tensors per
+    coach (captured graphs bake in addresses): the next image's values are copied in place when the layout and the structure-shaping scalars
+    match, otherwise the image gets buffers (and a graph generation) of its own; (b) `zero_arena.closes_iteration` finishes the arena on any
+    exit; (c) `dist.local_world_size` without a launcher."""
+    import types
+    from spi_amd.training.coaches.rot_bbox_cx_coach import RotBboxCoach
+    from spi_amd.configs import global_config
+    from spi_amd.torch_utils import zero_arena
+    from spi_amd import dist as sdist
+    coach = object.__new__(RotBboxCoach)
+    coach.original_G = types.SimpleNamespace(_last_planes=None)
+
+    def ctx(seed, weight_m=0.4, yaw=0.2, lm_pts=68):
+        g = torch.Generator().manual_seed(seed)
+        return dict(image=torch.randn(1, 3, 8, 8, generator=g), camera=torch.randn(1, 25, generator=g), lm=torch.randn(1, lm_pts, 2, generator=g),
+                    target_feats=[torch.randn(1, 4, 4, 4, generator=g), torch.randn(1, 8, 2, 2, generator=g)], weight_m=weight_m, yaw_range=yaw)
+    global_config.reuse_graphs_across_images = True
+    a = coach._adopt_ctx(ctx(0))
+    ptrs = (a['image'].data_ptr(), a['target_feats'][1].data_ptr())
+    gen_a = a['generation']
+    coach.original_G._last_planes = planes = torch.zeros(1, 3, 2, 4, 4)           # the depth branch cached the frozen planes during image 1
+    b_new = ctx(1, weight_m=0.1)
+    b = coach._adopt_ctx(b_new)
+    assert b is a and b['generation'] == gen_a and (b['image'].data_ptr(), b['target_feats'][1].data_ptr()) == ptrs
+    assert torch.equal(b['image'], ctx(1)['image']) and torch.equal(b['target_feats'][0], ctx(1)['target_feats'][0]) and b['weight_m'] == 0.1
+    assert coach.original_G._last_planes is None and coach._frozen_planes_buf is planes and b['stable_planes_cached'] is False and b['images_adopted'] == 2
+    # the mirror branch switches off (weight_m == 0): another launch sequence -> own buffers, new generation
+    c = coach._adopt_ctx(ctx(2, weight_m=0.0))
+    assert c is not a and c['generation'] != gen_a and coach._frozen_planes_buf is None
+    # another landmark count (layout) or yaw range (a host float folded into launch arguments): no adoption either
+    d = coach._adopt_ctx(ctx(3, weight_m=0.0, lm_pts=5))
+    assert d is not c
+    e = coach._adopt_ctx(ctx(4, weight_m=0.0, lm_pts=5, yaw=0.3))
+    assert e is not d
+    global_config.reuse_graphs_across_images = False
+    f = coach._adopt_ctx(ctx(5, weight_m=0.0, lm_pts=5, yaw=0.3))
+    assert f is not e                                                             # SPI_REUSE_GRAPHS=0: per-image buffers as in round 4
+
+    @zero_arena.closes_iteration
+    def body(fail):
+        zero_arena.begin('cpu', key='t')
+        assert zero_arena.in_iteration() or not zero_arena.enabled
+        if fail:
+            raise ValueError('boom')
+        return 7
+    assert body(False) == 7 and not zero_arena.in_iteration()
+    with pytest.raises(ValueError):
+        body(True)
+    assert not zero_arena.in_iteration()                                           # an exception inside an iteration must not leave the arena open
+    with zero_arena.iteration('cpu', key='t2'):
+        pass
+    assert not zero_arena.in_iteration()
+    old = os.environ.pop('LOCAL_WORLD_SIZE', None)
+    try:
+        assert sdist.local_world_size(8) == 8                                      # no launcher, no visible GPU: the global size
+        os.environ['LOCAL_WORLD_SIZE'] = '4'
+        assert sdist.local_world_size(8) == 4
+    finally:
+        os.environ.pop('LOCAL_WORLD_SIZE', None)
+        if old is not None:
+            os.environ['LOCAL_WORLD_SIZE'] = old
