@@ -353,7 +353,10 @@ typedef struct spi_conv_desc {
      * in half precision in memory (networks_stylegan2.py:421-436; conv2d on half tensors accumulates in fp32 and rounds once).  Weights, weight
      * gradients, bias and noise stay fp32. */
     int act_dtype;
-    int reserved0;
+    /* forward / dgrad Winograd passes only: 1 = `workspace` still holds the transformed weights an EARLIER call of the same pass wrote for the same
+     * `w` (same layout flags) -- the weight-transform launch is skipped.  For frozen weights that are convolved again and again (the VGG feature
+     * extractors of the losses: 36 such launches per stage-2 iteration); the caller keeps one workspace per (weight tensor, pass) alive. */
+    int workspace_ready;
 } spi_conv_desc;
 /* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
  * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).

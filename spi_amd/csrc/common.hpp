@@ -43,7 +43,7 @@ struct WinoParams {
     int64_t u_bs_of() const { return (int64_t)16 * Ci * ocp; }      // floats of one transformed weight set
 };
 int64_t spi_wino_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));
-int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const Epilogue& ep, void* workspace, hipStream_t st)
+int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const Epilogue& ep, void* workspace, hipStream_t st, bool u_ready = false)
     __attribute__((visibility("hidden")));
 // F(3x3, 2x2) weight gradient of the same problem (x [N,Ci,H,W], dy [N,Mo,H,W]) added into a zeroed dw
 int spi_wino_wgrad_launch(const WinoParams& P, const float* x, const float* dy, float* dw, hipStream_t st) __attribute__((visibility("hidden")));

@@ -1170,11 +1170,11 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
 
 // channel-split Winograd: zero the output first, run the shared epilogue kernel afterwards
 static int wino_conv(WinoParams& Wp, const IGemmParams& P, const float* in, const float* w, float* out, const Epilogue& ep, void* ws, hipStream_t st,
-                     bool out_zeroed) {
+                     bool out_zeroed, bool u_ready = false) {
     if (Wp.ksplit > 1 && !out_zeroed) {
         int rc = spi_zero_async(out, (int64_t)P.N * P.out_bs, st); if (rc) return rc;
     }
-    int rc = spi_wino_launch(Wp, in, w, out, ep, ws, st); if (rc) return rc;
+    int rc = spi_wino_launch(Wp, in, w, out, ep, ws, st, u_ready); if (rc) return rc;
     if (Wp.ksplit > 1 && (ep.bias || ep.noise || ep.act)) {
         const int64_t total = (int64_t)P.N * P.out_bs;
         const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
@@ -1284,7 +1284,7 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     WinoParams Wp;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
-        rc = wino_conv(Wp, P, x, w, y, ep, d->workspace, as_stream(stream), d->out_zeroed != 0); if (rc) return rc;
+        rc = wino_conv(Wp, P, x, w, y, ep, d->workspace, as_stream(stream), d->out_zeroed != 0, d->workspace_ready != 0); if (rc) return rc;
         SPI_LAUNCH_CHECK("spi_conv2d_fwd (winograd)");
         return SPI_OK;
     }
@@ -1301,7 +1301,7 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     WinoParams Wp;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_dgrad: workspace must be 16-byte aligned");
-        rc = wino_conv(Wp, P, dy, w, dx, ep, d->workspace, as_stream(stream), d->out_zeroed != 0); if (rc) return rc;
+        rc = wino_conv(Wp, P, dy, w, dx, ep, d->workspace, as_stream(stream), d->out_zeroed != 0, d->workspace_ready != 0); if (rc) return rc;
         SPI_LAUNCH_CHECK("spi_conv2d_dgrad (winograd)");
         return SPI_OK;
     }

@@ -637,10 +637,10 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
 // -------------------------------------------------------------------------------------------------
 int64_t spi_wino_workspace_bytes(const WinoParams& P) { return (int64_t)P.nw * P.u_bs_of() * 4; }
 
-int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const WinoEpilogue& ep, void* workspace, hipStream_t st) {
+int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const WinoEpilogue& ep, void* workspace, hipStream_t st, bool u_ready) {
     float* U = static_cast<float*>(workspace);
     P.u_bs = P.nw > 1 ? P.u_bs_of() : 0;
-    {
+    if (!u_ready) {           // (u_ready: the workspace still holds the transform of these weights from an earlier call -- frozen weights, spi_conv_desc.workspace_ready)
         const int64_t total = (int64_t)P.nw * (P.Ci / WKC) * 2 * P.ocp;
         const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
         WinoParams Pw = P; Pw.u_bs = P.u_bs_of();

@@ -23,7 +23,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [('N', c_i), ('I', c_i), ('O', c_i), ('H', c_i), ('W', c_i), ('kh', c_i), ('kw', c_i), ('pad', c_i),
                 ('transposed', c_i), ('flip', c_i), ('w_tap_major', c_i), ('compute_f16', c_i), ('w_batch_stride', c_l), ('bias', c_p), ('noise', c_p),
                 ('noise_gain', c_p), ('act', c_i), ('alpha', c_f), ('gain', c_f), ('clamp', c_f), ('dy_seg_flags', c_p), ('out_seg_flags', c_p), ('dw_zeroed', c_i), ('out_zeroed', c_i),
-                ('workspace', c_p), ('workspace_bytes', c_l), ('act_dtype', c_i), ('reserved0', c_i)]
+                ('workspace', c_p), ('workspace_bytes', c_l), ('act_dtype', c_i), ('workspace_ready', c_i)]
 
 
 class AffineJob(ctypes.Structure):

@@ -83,15 +83,40 @@ def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, n
     return d
 
 
-def _workspace(d, pass_id, device):
+# Transformed weights of FROZEN shared-weight convolutions (the VGG feature extractors of LPIPS / BoxCX): the Winograd passes transform their weights
+# into the workspace with a launch of their own (`wino_weight_kernel`, 9 us) -- 36 launches per stage-2 iteration for weights that never change.
+# The workspace of such a conv is kept per (weight tensor, pass) and handed back with `workspace_ready = 1` (round 5); an in-place update of the
+# weights (`_version`) or another tensor at the same address drops it.
+_frozen_ws = {}
+
+
+def _frozen_key(w, pass_id, d):
+    return (w.data_ptr(), tuple(w.shape), pass_id, int(d.flip), int(d.w_tap_major), str(w.device))
+
+
+def _workspace(d, pass_id, device, w=None, frozen=False):
     """Scratch memory with which `pass_id` (0 forward, 1 dgrad, 2 wgrad) of the conv `d` takes its Winograd path (None: it has none, or
-    ``global_config.conv_winograd`` is off).  Comes from torch's caching allocator: no device allocation after warm-up."""
+    ``global_config.conv_winograd`` is off).  Comes from torch's caching allocator: no device allocation after warm-up.
+    `w` + `frozen` (shared weights that take no gradient): the transformed weights are cached across calls, see `_frozen_ws`."""
     from ...configs import global_config
     if not global_config.conv_winograd or d.kh != 3 or d.transposed or d.compute_f16 not in (0, 3):
         return None
     nbytes = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), pass_id)
     if nbytes <= 0:
         return None
+    if frozen and w is not None and pass_id < 2 and d.w_batch_stride == 0:
+        key = _frozen_key(w, pass_id, d)
+        hit = _frozen_ws.get(key)
+        if hit is not None and hit[0] == w._version and hit[1].numel() == nbytes:
+            d.workspace, d.workspace_bytes, d.workspace_ready = hit[1].data_ptr(), nbytes, 1
+            return hit[1]
+        if not torch.cuda.is_current_stream_capturing():       # (a workspace born inside a capture lives in the graph's pool: not cacheable)
+            if len(_frozen_ws) > 512:
+                _frozen_ws.clear()
+            ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
+            _frozen_ws[key] = (w._version, ws)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
+            return ws
     ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
     d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     return ws
@@ -160,12 +185,14 @@ class _Conv2d(torch.autograd.Function):
         if of is not None:
             assert of.dtype == torch.int32 and tuple(of.shape) == (n, (oh * ow + 15) // 16), 'needed_output: flags must be int32 [N, ceil(OH*OW/16)]'
         d = _desc(n, i, o, h, wd, k, pad, transposed, flip, wbs, bb, nz, ng, act_id, alpha, gain, clamp, tap_major=1, f16=f16, out_flags=of, half=half)
-        ws = _workspace(d, 0, x.device)                 # noqa: F841  (keeps the scratch tensor alive until the launch is enqueued)
+        frozen = (not per_sample) and not w.requires_grad          # shared weights that take no gradient (VGG extractors): cache their Winograd transform
+        ws = _workspace(d, 0, x.device, w, frozen)      # noqa: F841  (keeps the scratch tensor alive until the launch is enqueued)
         y = _out_tensor(d, 0, (n, o, oh, ow), x.device)
         hip.call('spi_conv2d_fwd', ctypes.byref(d), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())
         has_epi = act_id != 0 and (act_id != 1 or gain != 1 or clamp >= 0)
         ctx.save_for_backward(x, w, y if has_epi else None, nz, ng)
         ctx.cfg = (pad, transposed, flip, act_id, alpha, gain, clamp, has_epi, wbs, f16, may_be_sparse)
+        ctx.frozen_w = frozen
         return y
 
     @staticmethod
@@ -192,7 +219,7 @@ class _Conv2d(torch.autograd.Function):
             if d.act_dtype == 1 and o % 16 != 0:       # (torgb: 3 output channels)
                 dzd, wd_, o16 = pad_o16(dz, w, o)
                 dd = _desc(n, i, o16, h, wd, k, pad, transposed, flip, (o16 * i * k * k if wbs else 0), tap_major=1, f16=f16, dy_flags=flags, half=True)
-            ws = _workspace(dd, 1, x.device)            # noqa: F841
+            ws = _workspace(dd, 1, x.device, w, getattr(ctx, 'frozen_w', False) and dd is d)            # noqa: F841
             dx = _out_tensor(dd, 1, tuple(x.shape), x.device)
             hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(dzd), hip.ptr(wd_), hip.ptr(dx), hip.stream())
         if ctx.needs_input_grad[1]:

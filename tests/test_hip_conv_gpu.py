@@ -694,3 +694,34 @@ def test_multi_modulate_equals_the_per_layer_modulation(n):
     with torch.no_grad():
         got = multi_modulate(layers, styles)                     # inference: fine
     assert got is not None and torch.equal(got[2], ref[2])
+
+
+def test_frozen_weight_winograd_transform_is_cached_and_follows_the_weights():
+    """Round 5: shared weights that take no gradient (the VGG extractors of the losses) keep their Winograd-transformed weights per (tensor, pass)
+    -- `spi_conv_desc.workspace_ready` skips the transform launch of later calls.  Same numbers as the uncached path (weights that DO take a
+    gradient), forward and data gradient; an in-place update of the weights is seen (`_version`); the cache holds one entry per pass."""
+    from spi_amd.torch_utils.ops import conv2d_mfma as cm
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 64, 256, 256, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(64, 3, 3, 64, generator=gen) * 0.05).to(DEV)                     # tap-major [O, k, k, I], frozen
+    dy = torch.randn(1, 64, 256, 256, generator=gen).to(DEV)
+    cm._frozen_ws.clear()
+
+    def run(weights):
+        y = cm.conv2d(x, weights, padding=1, tap_major=True)
+        (gx,) = torch.autograd.grad(y, [x], dy)
+        return y, gx
+    y_ref, gx_ref = run(w.clone().requires_grad_(True))                              # takes a gradient: never cached
+    assert len(cm._frozen_ws) == 0
+    y1, gx1 = run(w)
+    assert len(cm._frozen_ws) == 2                                                   # forward + dgrad transforms of this tensor
+    y2, gx2 = run(w)                                                                 # served from the cache
+    assert len(cm._frozen_ws) == 2
+    assert torch.equal(y1, y_ref) and torch.equal(gx1, gx_ref) and torch.equal(y2, y_ref) and torch.equal(gx2, gx_ref)
+    w.mul_(2.0)                                                                      # in-place update: the cached transform is stale
+    y3, gx3 = run(w)
+    assert_close(y3, 2 * y_ref, 1e-6, 'cached transform after an in-place weight update') 
+    assert_close(gx3, 2 * gx_ref, 1e-6, 'cached dgrad transform after an in-place weight update')
+    y4, _ = run(w)
+    assert torch.equal(y4, y3)
+    cm._frozen_ws.clear()
