@@ -46,6 +46,10 @@ exploit_sparsity = True
 # gradients (winograd.hip): fp32 operands and accumulation, 2.25x fewer MFMAs; results differ from the direct sums by a few fp32 roundings.  Off = implicit GEMM everywhere.
 conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
 
+# fp16 activation tensors (configs[4]): the 3x3 / stride-1 forward and data-gradient passes whose output channels come in blocks of 128 run the
+# direct fp16 kernel (hconv.hip: the input patch staged once for all nine taps, weights pre-converted to their LDS image).  Off = implicit GEMM.
+conv_direct_fp16 = os.environ.get('SPI_CONV_DIRECT_FP16', '1') != '0'
+
 # stage 1: capture the projector step in a HIP graph after an eager warm-up step and replay it (projectors/common.py).  The step is
 # GPU-bound either way; the graph takes the ~10 ms of host enqueue work per step off the CPU.  Off: every step is enqueued eagerly.
 stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'

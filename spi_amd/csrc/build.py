@@ -9,7 +9,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ['elementwise.hip', 'render.hip', 'conv.hip', 'winograd.hip', 'losses.hip', 'flrelu.hip']
+SOURCES = ['elementwise.hip', 'render.hip', 'conv.hip', 'winograd.hip', 'losses.hip', 'flrelu.hip', 'hconv.hip']
 # winograd.hip keeps its 256 accumulators per lane in AGPRs (the other 256 registers hold operands and the loaders' state)
 NO_VGPR_FORM = {'winograd.hip'}
 LIB = os.path.join(HERE, 'libspi_hip.so')

@@ -48,6 +48,14 @@ int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, c
 // F(3x3, 2x2) weight gradient of the same problem (x [N,Ci,H,W], dy [N,Mo,H,W]) added into a zeroed dw
 int spi_wino_wgrad_launch(const WinoParams& P, const float* x, const float* dy, float* dw, hipStream_t st) __attribute__((visibility("hidden")));
 
+// Direct fp16 3x3 convolution of fp16 activation tensors (hconv.hip): forward / dgrad of a stride-1, pad-1 conv whose output-channel count is a multiple
+// of 128 and whose reduction channels come in whole 16-channel chunks.  The workspace receives the fp16 LDS image of the weights (`img_ready`: it
+// already holds it -- frozen weights).
+bool spi_hconv_eligible(const WinoParams& P) __attribute__((visibility("hidden")));
+int64_t spi_hconv_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));
+int spi_hconv_launch(const WinoParams& P, const void* in, const float* w, void* out, const Epilogue& ep, void* workspace, hipStream_t st, bool img_ready = false)
+    __attribute__((visibility("hidden")));
+
 // Zero `n_floats` floats on `st` with a kernel.  Not hipMemsetAsync: as a node of a captured HIP graph a memset whose byte count is not a
 // multiple of 16 (the decoder's 33-float bias gradient) leaves garbage behind on replays (ROCm 7.0; tools/ubench/graph_memset.py),
 // and the loops replay their steps from graphs.

@@ -1203,6 +1203,22 @@ static bool make_wino_wgrad(const spi_conv_desc* d, const IGemmParams& P, WinoPa
     Wp.nseg = d->dy_seg_flags ? (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS) : 0;
     return true;
 }
+// Direct fp16 conv (hconv.hip) eligibility of a forward / dgrad problem: fp16 activation tensors, fp16 operands, 3x3, stride 1, pad 1
+static bool make_hconv(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
+    if (d->act_dtype != SPI_DTYPE_F16 || d->compute_f16 != 1 || d->transposed || d->kh != 3 || d->pad != 1 || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
+    if (P.IH != P.OH || P.IW != P.OW) return false;
+    Wp.N = P.N; Wp.nw = d->w_batch_stride ? P.N : 1; Wp.Mo = P.Mo; Wp.Ci = P.Ci; Wp.H = P.OH; Wp.W = P.OW;
+    Wp.bx = Wp.by = 0; Wp.ocp = 0;
+    Wp.in_bs = P.in_bs; Wp.out_bs = P.out_bs; Wp.wbs = P.wbs; Wp.u_bs = 0; Wp.wsm = P.wsm; Wp.wsc = P.wsc;
+    const TapSet& T = P.cls[0].taps;
+    for (int t = 0; t < 9; ++t) {
+        if (T.dy[t] < -1 || T.dy[t] > 1 || T.dx[t] < -1 || T.dx[t] > 1) return false;
+        Wp.widx[(T.dy[t] + 1) * 3 + (T.dx[t] + 1)] = T.widx[t];
+    }
+    Wp.seg_flags = P.seg_flags; Wp.out_flags = P.out_flags; Wp.nseg = P.seg_flags ? P.nseg : P.out_nseg;
+    Wp.ksplit = 1;
+    return spi_hconv_eligible(Wp);
+}
 constexpr int64_t WINO_WGRAD_WS = 16;      // the pass needs no scratch; a (nominal) workspace is the caller's opt-in, as for the other passes
 
 extern "C" {
@@ -1212,6 +1228,7 @@ int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass) {
     IGemmParams P; WinoParams Wp;
     if (pass == 2) { make_forward(d, P); return make_wino_wgrad(d, P, Wp) ? WINO_WGRAD_WS : 0; }
     if (pass == 0) make_forward(d, P); else make_dgrad(d, P);
+    if (make_hconv(d, P, Wp)) return spi_hconv_workspace_bytes(Wp);
     return make_wino(d, P, Wp) ? spi_wino_workspace_bytes(Wp) : 0;
 }
 
@@ -1225,6 +1242,7 @@ int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass) {
     } else {
         make_dgrad(d, P);
     }
+    if (d->workspace && make_hconv(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) return 0;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) return Wp.ksplit > 1 ? 1 : 0;
     return plan_igemm(P, d->compute_f16).nsplit > 1 ? 1 : 0;
 }
@@ -1257,6 +1275,10 @@ int spi_conv2d_plan(const spi_conv_desc* d, int pass, int32_t* out8) {
         make_forward(d, P);
         if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
     } else make_dgrad(d, P);
+    if (d->workspace && make_hconv(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) {
+        out8[0] = 2; out8[1] = 128; out8[2] = 512; out8[3] = 1; out8[4] = (int32_t)((int64_t)((P.OW + 31) / 32) * ((P.OH + 15) / 16) * (P.Mo / 128) * P.N); out8[5] = 512;
+        return SPI_OK;
+    }
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         out8[0] = 1; out8[1] = 64; out8[2] = 256; out8[3] = Wp.ksplit; out8[4] = (int32_t)((int64_t)Wp.bx * Wp.by * (Wp.ocp / 64) * P.N * Wp.ksplit); out8[5] = 256;
         return SPI_OK;
@@ -1282,6 +1304,12 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
     Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
     WinoParams Wp;
+    if (d->workspace && make_hconv(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) {
+        SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
+        rc = spi_hconv_launch(Wp, x, w, y, ep, d->workspace, as_stream(stream), d->workspace_ready != 0); if (rc) return rc;
+        SPI_LAUNCH_CHECK("spi_conv2d_fwd (direct fp16)");
+        return SPI_OK;
+    }
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
         rc = wino_conv(Wp, P, x, w, y, ep, d->workspace, as_stream(stream), d->out_zeroed != 0, d->workspace_ready != 0); if (rc) return rc;
@@ -1299,6 +1327,12 @@ int spi_conv2d_dgrad(const spi_conv_desc* d, const float* dy, const float* w, fl
     IGemmParams P; make_dgrad(d, P);
     Epilogue ep{nullptr, nullptr, nullptr, 0, 0.f, 1.f, -1.f};
     WinoParams Wp;
+    if (d->workspace && make_hconv(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) {
+        SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_dgrad: workspace must be 16-byte aligned");
+        rc = spi_hconv_launch(Wp, dy, w, dx, ep, d->workspace, as_stream(stream), d->workspace_ready != 0); if (rc) return rc;
+        SPI_LAUNCH_CHECK("spi_conv2d_dgrad (direct fp16)");
+        return SPI_OK;
+    }
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_dgrad: workspace must be 16-byte aligned");
         rc = wino_conv(Wp, P, dy, w, dx, ep, d->workspace, as_stream(stream), d->out_zeroed != 0, d->workspace_ready != 0); if (rc) return rc;

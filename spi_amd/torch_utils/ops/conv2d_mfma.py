@@ -99,7 +99,8 @@ def _workspace(d, pass_id, device, w=None, frozen=False):
     ``global_config.conv_winograd`` is off).  Comes from torch's caching allocator: no device allocation after warm-up.
     `w` + `frozen` (shared weights that take no gradient): the transformed weights are cached across calls, see `_frozen_ws`."""
     from ...configs import global_config
-    if not global_config.conv_winograd or d.kh != 3 or d.transposed or d.compute_f16 not in (0, 3):
+    direct_f16 = d.compute_f16 == 1 and d.act_dtype == 1 and global_config.conv_direct_fp16     # hconv.hip: fp16 tensors, 3x3, stride 1
+    if d.kh != 3 or d.transposed or not (direct_f16 or (global_config.conv_winograd and d.compute_f16 in (0, 3))):
         return None
     nbytes = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), pass_id)
     if nbytes <= 0:

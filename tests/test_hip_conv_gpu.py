@@ -173,7 +173,7 @@ def test_conv2d_fp16_operands_vs_rounded_reference(n, i, o, h, k, transposed):
 
 
 @pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 24, 3, False), (1, 64, 128, 40, 3, False), (2, 16, 3, 33, 1, False), (1, 32, 64, 12, 3, True),
-                                                  (1, 128, 128, 128, 3, False)])
+                                                  (1, 128, 128, 128, 3, False), (2, 32, 256, 125, 3, False), (2, 128, 256, 128, 3, False)])      # last two: hconv.hip forward (+ dgrad)
 def test_conv2d_fp16_tensors_vs_rounded_reference(n, i, o, h, k, transposed):
     """fp16 ACTIVATION TENSORS (round 5, spi_conv_desc.act_dtype; the reference's use_fp16 blocks, networks_stylegan2.py:421-436): x, y, dy, dx are
     half tensors in HBM, weights / weight gradients fp32, fp32 accumulation.  Every pass equals the fp64 convolution of the fp16-rounded
@@ -216,6 +216,80 @@ def test_conv2d_fp16_tensors_vs_rounded_reference(n, i, o, h, k, transposed):
     y32 = conv2d_mfma.conv2d(x.float().to(DEV), wd, padding=pad, transposed=transposed, flip=not transposed, fp16=True)
     assert y32.dtype == torch.float32
     ulp_close(y, y32.detach().cpu(), 'fp16-tensor vs fp32-tensor fp16-operand conv')
+
+
+@pytest.mark.parametrize('n,i,o,h,wd,shared', [(2, 32, 256, 120, 136, False), (1, 128, 128, 256, 256, True), (2, 128, 256, 128, 128, True), (1, 16, 128, 250, 270, True)])
+def test_direct_fp16_conv_vs_implicit_gemm_epilogue_and_skipping(n, i, o, h, wd, shared):
+    """hconv.hip (fp16 activation tensors, 3x3 / stride 1, output channels in blocks of 128): the plan names it, its results equal the implicit
+    GEMM's (same fp16 products, fp32 sums in another order -> at most one fp16 ulp on a few elements) with the fused epilogue (noise, bias,
+    lrelu, gain, clamp), ragged tiles, per-sample and shared weights; needed-output maps and sparse gradients skip tiles without changing
+    the flagged / non-zero results."""
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.configs import global_config
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(n * 1000 + i + h)
+    x = torch.randn(n, i, h, wd, generator=gen).half().to(DEV).requires_grad_(True)
+    w = (torch.randn(*(() if shared else (n,)), o, i, 3, 3, generator=gen) / (i * 9) ** 0.5).to(DEV).requires_grad_(True)
+    bias = torch.randn(o, generator=gen).to(DEV)
+    noise = torch.randn(h, wd, generator=gen).to(DEV)
+    strength = torch.tensor(0.3, device=DEV)
+    kw = dict(bias=bias, noise=noise, noise_strength=strength, padding=1, flip=True, act='lrelu', gain=1.2, clamp=2.0, fp16=True, sparse_grad=True)
+    d = conv2d_mfma._desc(n, i, o, h, wd, 3, 1, False, True, 0 if shared else o * i * 9, tap_major=1, f16=True, half=True)
+    ws = conv2d_mfma._workspace(d, 0, x.device)
+    plan = (ctypes.c_int32 * 8)()
+    hip.call('spi_conv2d_plan', ctypes.byref(d), 0, plan)
+    assert ws is not None and plan[0] == 2 and plan[5] == 512, list(plan)
+
+    def ulps(a, b):
+        a, b = a.detach().float(), b.detach().float()
+        ulp = torch.ldexp(torch.ones_like(b), torch.floor(torch.log2(b.abs().clamp_min(6.1e-5))).to(torch.int32) - 10)
+        e = ((a - b).abs() - 2e-5 * b.abs().max()).clamp_min(0) / ulp        # (fp32 sums in another order: absolute slack for results that cancel to ~0)
+        return float(e.max()), float((e > 0).float().mean())
+
+    def run(direct, dy, sparse=False, needed=None):
+        old = global_config.conv_direct_fp16
+        global_config.conv_direct_fp16 = direct
+        try:
+            with conv2d_mfma.needed_output(needed):
+                y = conv2d_mfma.conv2d(x, w, **kw)
+            with conv2d_mfma.sparse_gradients(sparse):
+                gx, gw = torch.autograd.grad(y, [x, w], dy)
+        finally:
+            global_config.conv_direct_fp16 = old
+        return y.detach(), gx, gw
+    dy = torch.randn(n, o, h, wd, generator=gen).half().to(DEV)
+    ya, gxa, gwa = run(True, dy)
+    yb, gxb, gwb = run(False, dy)
+    assert ya.dtype == torch.float16 and gxa.dtype == torch.float16
+    for a, b, what in ((ya, yb, 'fwd'), (gxa, gxb, 'dgrad')):
+        mx, frac = ulps(a, b)
+        assert mx <= 1.0 and frac < 2e-2, (what, mx, frac)
+    assert_close(gwa, gwb, 1e-5, 'wgrad after the direct forward')
+    # sparse gradient operand: tiles whose receptive field holds no flagged segment are zeros, everything else unchanged
+    if True:
+        old_min = conv2d_mfma.SPARSE_MIN_PIXELS
+        conv2d_mfma.SPARSE_MIN_PIXELS = 1
+        try:
+            for kind in ('box', 'blobs', 'pixel', 'empty'):
+                dym = _masked_gradient((n, o, h, wd), gen, kind).half().to(DEV)
+                _, gd, _ = run(True, dym)
+                _, gs, _ = run(True, dym, sparse=True)
+                assert torch.equal(gs, gd), kind
+                if kind == 'empty':
+                    assert float(gs.float().abs().max()) == 0
+        finally:
+            conv2d_mfma.SPARSE_MIN_PIXELS = old_min
+    # needed-output map: flagged pixels bit-identical, an empty map gives zeros
+    for kind in ('box', 'blobs', 'pixel', 'empty'):
+        m = (_masked_gradient((n, 1, h, wd), gen, kind) != 0).to(DEV)
+        flags = conv2d_mfma.seg_flags(m.float())
+        yn, _, _ = run(True, dy, needed={(h, wd): flags})
+        assert torch.equal(yn * m, ya * m), kind
+        if kind == 'empty':
+            assert float(yn.float().abs().max()) == 0
+        if kind == 'box':
+            assert float((yn == 0).float().mean()) > 0.3
 
 
 @pytest.mark.parametrize('up,demod,shared,n', [(1, True, False, 2), (1, True, True, 3), (2, True, False, 1), (2, True, True, 2), (1, False, False, 2)])
