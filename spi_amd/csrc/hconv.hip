@@ -13,10 +13,12 @@
 //   * a wave owns 4 output rows x 32 pixels x 64 output channels: per (kx, chunk) it reads 6 input-row fragments and 6 weight fragments for
 //     24 MFMAs (an input-row fragment serves three output rows through ky, a weight fragment four rows): 0.5 LDS reads per MFMA, 72 MFMAs
 //     (2 304 matrix cycles) per barrier.
-// GEMM orientation as in conv.hip: A = weights (m = output channel), B = pixels; D layout col = lane & 31 (pixel), row = (r & 3) + 8 (r >> 2) +
-// 4 (lane >> 5).  fp32 accumulation, one rounding at the store; epilogue (noise, bias, activation, gain, clamp) on the accumulators.
+// GEMM orientation: A = pixels (m), B = weights (n = output channel): a lane ends up with runs of 4 consecutive pixels of ONE output channel,
+// which the epilogue (noise, bias, activation, gain, clamp on the fp32 accumulators, one rounding) packs into 8-byte LDS writes; the tile
+// leaves through LDS in 16-byte pieces.
 #include "common.hpp"
 #include <algorithm>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
@@ -28,6 +30,8 @@ constexpr int HC_IN_CELLS = 2 * HC_IY * HC_IX;                        // 1224 ce
 constexpr int HC_WT_CELLS = 9 * 2 * HC_BM;                            // 2304
 constexpr int HC_IN_PASSES = (HC_IN_CELLS + HC_NT - 1) / HC_NT;       // 3
 constexpr int HC_WT_PASSES = (HC_WT_CELLS + HC_NT - 1) / HC_NT;       // 5
+constexpr int HC_OST = HC_TY * HC_TX + 4;                             // halves per output channel of the epilogue's LDS tile (+4: conflict-free 8-byte writes)
+constexpr int HC_LDS_BYTES = (2 * (HC_IN_CELLS + HC_WT_CELLS) * 16 > HC_BM * HC_OST * 2) ? 2 * (HC_IN_CELLS + HC_WT_CELLS) * 16 : HC_BM * HC_OST * 2;
 
 struct HConvParams {
     int N, nw, Mo, Ci, H, W;
@@ -58,12 +62,19 @@ __global__ void __launch_bounds__(256) hconv_weight_kernel(WinoParams P, const f
 
 __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _Float16* __restrict__ in, const u32x4_t* __restrict__ wimg,
                                                          _Float16* __restrict__ out, Epilogue ep) {
-    __shared__ __attribute__((aligned(16))) u32x4_t In_s[2][HC_IN_CELLS];
-    __shared__ __attribute__((aligned(16))) u32x4_t Wt_s[2][HC_WT_CELLS];
+    // LDS: two (input patch, weight chunk) buffers during the channel loop; afterwards the same bytes hold the output tile for the transposing epilogue
+    __shared__ __attribute__((aligned(16))) u32x4_t smem[HC_LDS_BYTES / 16];
+    u32x4_t (*In_s)[HC_IN_CELLS] = reinterpret_cast<u32x4_t (*)[HC_IN_CELLS]>(smem);
+    u32x4_t (*Wt_s)[HC_WT_CELLS] = reinterpret_cast<u32x4_t (*)[HC_WT_CELLS]>(smem + 2 * HC_IN_CELLS);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
     const int rg = wave & 3, ch = wave >> 2;                  // row group (4 rows), output-channel half (64)
-    const int tyi = blockIdx.x / P.tx, txi = blockIdx.x - tyi * P.tx;
+    // workgroups go to the 8 XCDs round-robin: give every XCD a contiguous band of tiles, so that x-neighbours (which share the 128-byte lines of a
+    // row: a 34-pixel patch row straddles two of them) and the halo rows meet in ONE L2
+    int bx = blockIdx.x;
+    const int ntile = P.tx * P.ty;
+    if ((ntile & 7) == 0) bx = (bx & 7) * (ntile >> 3) + (bx >> 3);
+    const int tyi = bx / P.tx, txi = bx - tyi * P.tx;
     const int y0 = tyi * HC_TY, x0 = txi * HC_TX;
     const int mb = blockIdx.y, n = blockIdx.z;
     const int HW = P.H * P.W;
@@ -156,67 +167,134 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _F
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[r][i][q] = 0.f;
 
-    auto compute = [&](int buf) __attribute__((always_inline)) {
+    // one kx column of a chunk: 6 input-row fragments (A operand: m = pixel), 6 weight fragments (B operand: n = output channel), 24 MFMAs.
+    // D layout: lane & 31 = output channel, register q = pixel (q & 3) + 8 (q >> 2) + 4 (lane >> 5) of the 32-pixel row.
+    auto step = [&](int buf, int kx) __attribute__((always_inline)) {
         const half8_t* I = reinterpret_cast<const half8_t*>(In_s[buf]) + (fk * HC_IY + rg * 4) * HC_IX + fr;
         const half8_t* Wt = reinterpret_cast<const half8_t*>(Wt_s[buf]) + fk * HC_BM + ch * 64 + fr;
+        half8_t xf[6], wf[3][2];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            half8_t xf[6], wf[3][2];
+        for (int q = 0; q < 6; ++q) xf[q] = I[q * HC_IX + kx];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) xf[q] = I[q * HC_IX + kx];
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int i = 0; i < 2; ++i) wf[ky][i] = Wt[(ky * 3 + kx) * 2 * HC_BM + i * 32];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) wf[ky][i] = Wt[(ky * 3 + kx) * 2 * HC_BM + i * 32];
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[ky][i], xf[r + ky], acc[r][i], 0, 0, 0);
-        }
+                for (int i = 0; i < 2; ++i) acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[r + ky], wf[ky][i], acc[r][i], 0, 0, 0);
     };
+#define HC_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
-    // ---- pipeline: chunk c+1 is in flight (registers) while chunk c is multiplied; one barrier per chunk
+    // ---- pipeline (one register stage, two LDS buffers, one barrier per chunk).  Iteration c multiplies chunk c from LDS[c & 1]; behind its first
+    //      kx column the registers (chunk c+1, requested an iteration ago) are written to the other buffer -- free since the barrier that ended
+    //      iteration c-1 --, behind the second column the loads of chunk c+2 are issued into the same registers.  The fences keep the compiler
+    //      from gathering the stores / the packing arithmetic in front of the MFMAs (it waits for the loads wherever it puts them).
     issue(0);
     commit(0);
+    if (nchunk > 1) issue(1);
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunk) issue(c + 1);
-        asm volatile("" ::: "memory");                     // (the compiler otherwise sinks the LDS writes of `commit` in front of the MFMAs --
-        __builtin_amdgcn_sched_barrier(0);                 //  and with them the wait for the loads just issued)
-        compute(buf);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+        step(buf, 0);
+        HC_FENCE();
         if (c + 1 < nchunk) commit(buf ^ 1);
+        HC_FENCE();
+        step(buf, 1);
+        HC_FENCE();
+        if (c + 2 < nchunk) issue(c + 2);
+        HC_FENCE();
+        step(buf, 2);
         __syncthreads();
     }
 
-    // ---- epilogue
-    const float ng = ep.noise ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
-    const __amdgpu_buffer_rsrc_t rsO = make_rsrc(ob, (int64_t)HC_BM * HW * 2);
-    const int x = x0 + fr;
+    // ---- epilogue: noise, bias, activation, gain, clamp on the accumulators; ONE rounding; the tile goes through LDS as [channel][row][x] halves so
+    //      that it leaves in 16-byte pieces (8 pixels of a row) -- straight from the MFMA layout it would be 128 two-byte stores per lane, which
+    //      cost a third of the kernel (tools/ubench/hconv_probe.py: 28 of 92 k cycles per block)
+    _Float16* Ot = reinterpret_cast<_Float16*>(smem);
+    {
+        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+        // The element-wise work runs 128 times per lane at 4 cycles per vector instruction: the uniform decisions are taken ONCE (three code paths),
+        // not per element.  mode 0: nothing to apply (data gradient, plain conv).  mode 1: linear / lrelu with 0 <= slope <= 1 and gain > 0 --
+        // lrelu(v) * g == max(v * g, v * slope * g), NaN in -> NaN out like the select form; clamp with selects (NaN stays NaN, as torch.clamp).
+        // mode 2: everything else through conv_act_gain_clamp.
+        const float slope = ep.act == SPI_ACT_LRELU ? ep.alpha : 1.f;
+        const bool any_epi = ep.noise || ep.bias || ep.act;
+        const int mode = !any_epi ? 0 : ((ep.act == 0 || ((ep.act == SPI_ACT_LINEAR || ep.act == SPI_ACT_LRELU) && slope >= 0.f && slope <= 1.f && ep.gain > 0.f)) ? 1 : 2);
+        const float g1 = ep.act ? ep.gain : 1.f, g2 = g1 * slope;
+        const float cpos = (ep.act && ep.clamp >= 0.f) ? ep.clamp : __builtin_inff();
+        const float ng = ep.noise ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
+        const __amdgpu_buffer_rsrc_t rsN = make_rsrc(ep.noise, ep.noise ? (int64_t)HW * 4 : 0);
+        auto tile_out = [&](auto MODE) __attribute__((always_inline)) {
+            constexpr int M = decltype(MODE)::value;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int y = y0 + rg * 4 + r;
-        const bool ok = y < P.H && x < P.W;
-        const int pix = y * P.W + x;
-        const float nz = (ep.noise && ok) ? ep.noise[pix] * ng : 0.f;
-        const unsigned voff = ok ? (unsigned)((4 * fk * HW + pix) * 2) : BUF_OOB;
+            for (int r = 0; r < 4; ++r) {
+                const int row = rg * 4 + r;
+                const int pix0 = (y0 + row) * P.W + x0 + 4 * fk;          // (pixels beyond the row's end read the next row's noise: they are never stored)
+                float nz[16];
+                if (M != 0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+                    for (int q = 0; q < 16; ++q) nz[q] = ep.noise ? buf_load_f32(rsN, (unsigned)(pix0 + (q & 3) + 8 * (q >> 2)) * 4u) * ng : 0.f;
+                }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int mrow = ch * 64 + i * 32 + (q & 3) + 8 * (q >> 2);        // + 4 fk (in voff)
-                float v = acc[r][i][q] + nz;
-                if (ep.bias) v += ep.bias[mb * HC_BM + mrow + 4 * fk];
-                if (ep.act) v = conv_act_gain_clamp(ep.act, ep.alpha, ep.gain, ep.clamp, v);
-                __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (_Float16)v), rsO, (int)voff, mrow * chs2, 0);
+                for (int i = 0; i < 2; ++i) {
+                    const int co = ch * 64 + i * 32 + fr;
+                    const float b = (M != 0 && ep.bias) ? ep.bias[mb * HC_BM + co] : 0.f;
+                    _Float16* dst = Ot + co * HC_OST + row * HC_TX + 4 * fk;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        half4_t h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float v = acc[r][i][qq * 4 + e];
+                            if (M == 1) {
+                                v += nz[qq * 4 + e] + b;
+                                const float a = v * g1, c = v * g2;
+                                float w = fmaxf(a, c);
+                                w = (a != a) ? a : w;                      // (fmaxf drops a NaN operand only when the other is a number: both are NaN here; kept explicit)
+                                v = w > cpos ? cpos : (w < -cpos ? -cpos : w);
+                            } else if (M == 2) {
+                                v += nz[qq * 4 + e] + b;
+                                if (ep.act) v = conv_act_gain_clamp(ep.act, ep.alpha, ep.gain, ep.clamp, v);
+                            }
+                            h[e] = (_Float16)v;
+                        }
+                        *reinterpret_cast<half4_t*>(dst + 8 * qq) = h;
+                    }
+                }
+            }
+        };
+        if (mode == 0) tile_out(std::integral_constant<int, 0>{});
+        else if (mode == 1) tile_out(std::integral_constant<int, 1>{});
+        else tile_out(std::integral_constant<int, 2>{});
+    }
+    __syncthreads();
+    {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const bool wide = (P.W & 7) == 0 && (HW & 7) == 0 && (reinterpret_cast<uintptr_t>(ob) & 15) == 0;
+#pragma unroll 4
+        for (int k = 0; k < HC_BM * HC_TY * (HC_TX / 8) / HC_NT; ++k) {
+            const int id = tid + k * HC_NT;
+            const int xq = id & 3, row = (id >> 2) & (HC_TY - 1), co = id >> 6;
+            const int y = y0 + row, x = x0 + xq * 8;
+            const u32x2_t* src = reinterpret_cast<const u32x2_t*>(Ot + co * HC_OST + row * HC_TX + xq * 8);
+            const u32x2_t lo = src[0], hi = src[1];
+            if (y < P.H && x < P.W) {
+                _Float16* dst = ob + (int64_t)co * HW + (int64_t)y * P.W + x;
+                if (wide) *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+                else {
+                    const unsigned w4[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (x + e < P.W) dst[e] = __builtin_bit_cast(_Float16, (unsigned short)(w4[e >> 1] >> ((e & 1) * 16)));
+                }
             }
         }
     }
 }
+#undef HC_FENCE
 
 // ---- host side (called from conv.hip; WinoParams carries the problem: 3x3, stride 1, pad 1, weights addressed through wsm / wsc / widx)
 int64_t spi_hconv_workspace_bytes(const WinoParams& P) { return (int64_t)P.nw * P.Mo * P.Ci * 9 * 2; }
