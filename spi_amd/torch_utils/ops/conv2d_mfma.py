@@ -15,6 +15,7 @@ An optional fused epilogue applies ``+ noise * strength``, ``+ bias``, activatio
 accumulators (SynthesisLayer.forward tail, networks_stylegan2.py:320-329) for stride-1 convs.
 """
 import contextlib
+import weakref
 import ctypes
 import torch
 from ... import hip
@@ -91,7 +92,7 @@ _frozen_ws = {}
 
 
 def _frozen_key(w, pass_id, d):
-    return (w.data_ptr(), tuple(w.shape), pass_id, int(d.flip), int(d.w_tap_major), str(w.device))
+    return (id(w), w.data_ptr(), tuple(w.shape), pass_id, int(d.flip), int(d.w_tap_major), int(d.compute_f16), int(d.act_dtype), str(w.device))
 
 
 def _workspace(d, pass_id, device, w=None, frozen=False):
@@ -108,14 +109,16 @@ def _workspace(d, pass_id, device, w=None, frozen=False):
     if frozen and w is not None and pass_id < 2 and d.w_batch_stride == 0:
         key = _frozen_key(w, pass_id, d)
         hit = _frozen_ws.get(key)
-        if hit is not None and hit[0] == w._version and hit[1].numel() == nbytes:
+        # (the entry holds a weak reference to the tensor OBJECT: a temporary -- e.g. a freshly modulated weight under no_grad -- dies, and the
+        #  next temporary of that shape that the caching allocator puts at the same address must not inherit its transform)
+        if hit is not None and hit[2]() is w and hit[0] == w._version and hit[1].numel() == nbytes:
             d.workspace, d.workspace_bytes, d.workspace_ready = hit[1].data_ptr(), nbytes, 1
             return hit[1]
         if not torch.cuda.is_current_stream_capturing():       # (a workspace born inside a capture lives in the graph's pool: not cacheable)
             if len(_frozen_ws) > 512:
                 _frozen_ws.clear()
             ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
-            _frozen_ws[key] = (w._version, ws)
+            _frozen_ws[key] = (w._version, ws, weakref.ref(w))
             d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
             return ws
     ws = torch.empty(nbytes, device=device, dtype=torch.uint8)

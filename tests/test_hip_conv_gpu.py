@@ -798,4 +798,15 @@ def test_frozen_weight_winograd_transform_is_cached_and_follows_the_weights():
     assert_close(gx3, 2 * gx_ref, 1e-6, 'cached dgrad transform after an in-place weight update')
     y4, _ = run(w)
     assert torch.equal(y4, y3)
+    # a TEMPORARY weight tensor (e.g. freshly modulated weights under no_grad) dies; the next temporary of that shape lands on the same address
+    # with other values and must not be served the dead tensor's transform (the entry holds a weak reference to the tensor object)
+    cm._frozen_ws.clear()
+    t = w * 0.5
+    addr = t.data_ptr()
+    ya, _ = run(t)
+    del t
+    t = w * 3.0
+    assert t.data_ptr() == addr, 'the caching allocator was expected to reuse the block (test premise)'
+    yb, _ = run(t)
+    assert_close(yb, 6 * ya, 1e-6, 'a new tensor at a dead tensor\'s address')
     cm._frozen_ws.clear()
