@@ -1219,6 +1219,21 @@ static bool make_hconv(const spi_conv_desc* d, const IGemmParams& P, WinoParams&
     Wp.ksplit = 1;
     return spi_hconv_eligible(Wp);
 }
+// Direct fp16 weight gradient (hconv.hip) eligibility (P = make_forward(d)): as make_hconv, plus whole 4 x 32-pixel tiles and a dense gradient
+static bool make_hwgrad(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
+    if (d->act_dtype != SPI_DTYPE_F16 || d->compute_f16 != 1 || d->transposed || d->kh != 3 || d->pad != 1 || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
+    if (P.IH != P.OH || P.IW != P.OW) return false;
+    Wp.N = P.N; Wp.nw = d->w_batch_stride ? P.N : 1; Wp.Mo = P.Mo; Wp.Ci = P.Ci; Wp.H = P.OH; Wp.W = P.OW;
+    Wp.bx = Wp.by = 0; Wp.ocp = 0;
+    Wp.in_bs = P.in_bs; Wp.out_bs = P.out_bs; Wp.wbs = P.wbs; Wp.u_bs = 0; Wp.wsm = P.wsm; Wp.wsc = P.wsc;
+    const TapSet& T = P.cls[0].taps;
+    for (int t = 0; t < 9; ++t) {
+        if (T.dy[t] < -1 || T.dy[t] > 1 || T.dx[t] < -1 || T.dx[t] > 1) return false;
+        Wp.widx[(T.dy[t] + 1) * 3 + (T.dx[t] + 1)] = T.widx[t];
+    }
+    Wp.seg_flags = d->dy_seg_flags; Wp.out_flags = nullptr; Wp.nseg = 0; Wp.ksplit = 1;
+    return spi_hwgrad_eligible(Wp);
+}
 constexpr int64_t WINO_WGRAD_WS = 16;      // the pass needs no scratch; a (nominal) workspace is the caller's opt-in, as for the other passes
 
 extern "C" {
@@ -1226,7 +1241,7 @@ extern "C" {
 int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass) {
     if (validate(d, "spi_conv2d_workspace_bytes") || pass < 0 || pass > 2) return 0;
     IGemmParams P; WinoParams Wp;
-    if (pass == 2) { make_forward(d, P); return make_wino_wgrad(d, P, Wp) ? WINO_WGRAD_WS : 0; }
+    if (pass == 2) { make_forward(d, P); return (make_hwgrad(d, P, Wp) || make_wino_wgrad(d, P, Wp)) ? WINO_WGRAD_WS : 0; }
     if (pass == 0) make_forward(d, P); else make_dgrad(d, P);
     if (make_hconv(d, P, Wp)) return spi_hconv_workspace_bytes(Wp);
     return make_wino(d, P, Wp) ? spi_wino_workspace_bytes(Wp) : 0;
@@ -1254,6 +1269,10 @@ int spi_conv2d_plan(const spi_conv_desc* d, int pass, int32_t* out8) {
     IGemmParams P; WinoParams Wp;
     if (pass == 2) {
         make_forward(d, P);
+        if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_hwgrad(d, P, Wp)) {
+            out8[0] = 2; out8[1] = 128; out8[2] = 64; out8[3] = 1; out8[4] = -1; out8[5] = 512;        // (grid: see spi_hwgrad_launch)
+            return SPI_OK;
+        }
         if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_wino_wgrad(d, P, Wp)) {
             out8[0] = 1; out8[1] = 64; out8[2] = 64; out8[3] = 1; out8[4] = -1; out8[5] = 256;        // (grid: see spi_wino_wgrad_launch)
             return SPI_OK;
@@ -1358,6 +1377,11 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     }
     {
         WinoParams Wp;
+        if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_hwgrad(d, P, Wp)) {
+            rc = spi_hwgrad_launch(Wp, x, dy, dw, as_stream(stream)); if (rc) return rc;
+            SPI_LAUNCH_CHECK("spi_conv2d_wgrad (direct fp16)");
+            return SPI_OK;
+        }
         if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_wino_wgrad(d, P, Wp)) {
             rc = spi_wino_wgrad_launch(Wp, x, dy, dw, as_stream(stream)); if (rc) return rc;
             SPI_LAUNCH_CHECK("spi_conv2d_wgrad (winograd)");

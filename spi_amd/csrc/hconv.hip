@@ -296,6 +296,180 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _F
 }
 #undef HC_FENCE
 
+// =====================================================================================================================================
+// Direct fp16 weight gradient of the same layers: dW[co][tap][ci] += sum_pixels dy[co][y][x] * x[ci][y + ky - 1][x + kx - 1].
+// GEMM per tap: m = output channel, n = input channel, K = pixels -- and in NCHW eight consecutive pixels of one channel ARE the 16 bytes an MFMA
+// operand lane holds: both tiles go to LDS as straight 16-byte copies (no transpose, no conversion).  The implicit-GEMM wgrad_kernel stages
+// x once PER TAP with 2-byte loads and 2-byte LDS stores (0.11 of the fp16 peak); here
+//   * a block owns 128 output x 64 input channels x all nine taps (a wave: 32 x 32 x 9 = 144 accumulators) and walks 4-row x 32-pixel tiles:
+//     dy tile [co][4][32], x patch [ci][6 rows][2 + 32 + 2 pixels] staged ONCE per tile;
+//   * the kx = 0 / 2 operands are the kx = 1 fragment shifted by one pixel: 5 v_alignbit with the dword before / after (two 4-byte LDS reads),
+//     instead of shifted copies of the patch; a patch-row fragment triple serves the three dy rows it meets (ky), a dy fragment three patch rows;
+//   * one register stage + two LDS buffers, loads and LDS commits interleaved between thirds of a tile's 72 MFMAs (as hconv_kernel);
+//   * a block reduces a run of tiles in its accumulators and adds them into the zeroed dW with fp32 atomics (one per element and block).
+// Needs W % 32 == 0, H % 4 == 0, Mo % 128 == 0, Ci % 64 == 0 and a dense gradient (masked gradients keep wgrad_kernel's slab list).
+constexpr int HW_TY = 4, HW_TX = 32, HW_BM = 128, HW_BN = 64, HW_NT = 512;
+constexpr int HW_DY_ST = HW_TY * HW_TX * 2 + 16;       // bytes per output channel of the dy tile (+16: conflict-free 16-byte fragment reads)
+constexpr int HW_XROW = 96;                            // bytes per patch row: [12 unused | 4 left halo | 64 main | 4 right halo | 12 unused]
+constexpr int HW_X_ST = (HW_TY + 2) * HW_XROW + 16;    // bytes per input channel of the patch
+constexpr int HW_DY_BYTES = HW_BM * HW_DY_ST, HW_X_BYTES = HW_BN * HW_X_ST, HW_BUF = HW_DY_BYTES + HW_X_BYTES;
+
+struct HWgradParams {
+    int N, Mo, Ci, H, W;
+    int tx, ntile, tpb;            // tiles per row, tiles per image, tiles per block
+    int64_t in_bs, out_bs, wbs;    // elements per sample (x, dy), dW elements between samples (0: shared weights)
+    int wsm, wsc, widx[9];
+};
+
+__global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const _Float16* __restrict__ xin, const _Float16* __restrict__ dyin,
+                                                          float* __restrict__ dw) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HW_BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int cof = wave & 3, cih = wave >> 2;
+    const int ncib = P.Ci / HW_BN;
+    const int co0 = (blockIdx.y / ncib) * HW_BM, ci0 = (blockIdx.y % ncib) * HW_BN;
+    const int n = blockIdx.z;
+    const int HWp = P.H * P.W;
+    const int t_beg = blockIdx.x * P.tpb, t_end = min(t_beg + P.tpb, P.ntile);
+    if (t_beg >= t_end) return;
+    const _Float16* xb = xin + (int64_t)n * P.in_bs + (int64_t)ci0 * HWp;
+    const _Float16* db = dyin + (int64_t)n * P.out_bs + (int64_t)co0 * HWp;
+
+    // ---- staging coordinates relative to the tile origin (constant over the tiles)
+    int dy_g[4], dy_l[4];                        // dy: 2048 16-byte pieces
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int id = tid + k * HW_NT, co = id >> 4, row = (id >> 2) & 3, q = id & 3;
+        dy_g[k] = co * HWp + row * P.W + q * 8; dy_l[k] = co * HW_DY_ST + row * 64 + q * 16;
+    }
+    int xm_c[3], xm_r[3], xm_q[3], xm_l[3];      // patch main part: 1536 pieces
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int id = tid + k * HW_NT, ci = id / 24, rem = id - ci * 24;
+        xm_c[k] = ci * HWp; xm_r[k] = rem >> 2; xm_q[k] = (rem & 3) * 8; xm_l[k] = HW_DY_BYTES + ci * HW_X_ST + (rem >> 2) * HW_XROW + 16 + (rem & 3) * 16;
+    }
+    int xh_c[2], xh_r[2], xh_s[2], xh_l[2];      // patch halo dwords: 768 (the second pass is half full)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int id = min(tid + k * HW_NT, 64 * 12 - 1), ci = id / 12, rem = id - ci * 12;
+        xh_c[k] = ci * HWp; xh_r[k] = rem >> 1; xh_s[k] = rem & 1; xh_l[k] = HW_DY_BYTES + ci * HW_X_ST + (rem >> 1) * HW_XROW + ((rem & 1) ? 80 : 12);
+    }
+    u32x4_t rd[4], rm[3];
+    unsigned rh[2];
+    auto issue = [&](int t) __attribute__((always_inline)) {
+        t = min(t, t_end - 1);
+        const int tyi = t / P.tx, y0 = tyi * HW_TY, x0 = (t - tyi * P.tx) * HW_TX;
+        const int org = y0 * P.W + x0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rd[k] = *reinterpret_cast<const u32x4_t*>(db + org + dy_g[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int iy = y0 - 1 + xm_r[k];
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>(xb + xm_c[k] + min(max(iy, 0), P.H - 1) * P.W + x0 + xm_q[k]);   // (clamped address, zeroed below:
+            const bool ok = iy >= 0 && iy < P.H;                                                                                 //  a predicated load would be waited for at once)
+            rm[k] = u32x4_t{ok ? v[0] : 0u, ok ? v[1] : 0u, ok ? v[2] : 0u, ok ? v[3] : 0u};
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int iy = y0 - 1 + xh_r[k];
+            const int px = xh_s[k] ? x0 + HW_TX : x0 - 2;
+            const unsigned v = *reinterpret_cast<const unsigned*>(xb + xh_c[k] + min(max(iy, 0), P.H - 1) * P.W + min(max(px, 0), P.W - 2));
+            rh[k] = (iy >= 0 && iy < P.H && px >= 0 && px < P.W) ? v : 0u;
+        }
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* base = smem + buf * HW_BUF;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            asm volatile("" : "+v"(rd[k]));                    // (pins the zero-selects of `issue` and these stores BEHIND the MFMAs they are placed after)
+            *reinterpret_cast<u32x4_t*>(base + dy_l[k]) = rd[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            asm volatile("" : "+v"(rm[k]));
+            *reinterpret_cast<u32x4_t*>(base + xm_l[k]) = rm[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            asm volatile("" : "+v"(rh[k]));
+            if (k == 0 || tid < 64 * 12 - HW_NT) *reinterpret_cast<unsigned*>(base + xh_l[k]) = rh[k];
+        }
+    };
+
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+    // patch rows r' = RA .. RB-1 of one tile: r' meets dy row r = r' - ky
+    auto part = [&](int buf, auto RA_, auto RB_) __attribute__((always_inline)) {
+        constexpr int RA = decltype(RA_)::value, RB = decltype(RB_)::value;
+        const unsigned char* base = smem + buf * HW_BUF;
+        const unsigned char* dyp = base + (cof * 32 + fr) * HW_DY_ST + fk * 16;
+        const unsigned char* xp = base + HW_DY_BYTES + (cih * 32 + fr) * HW_X_ST + 16 + fk * 16;
+#pragma unroll
+        for (int rp = RA; rp < RB; ++rp) {
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+                const unsigned char* xa = xp + rp * HW_XROW + sg * 32;
+                const u32x4_t p0 = *reinterpret_cast<const u32x4_t*>(xa);
+                const unsigned pv = *reinterpret_cast<const unsigned*>(xa - 4), nx = *reinterpret_cast<const unsigned*>(xa + 16);
+                const unsigned s01 = __builtin_amdgcn_alignbit(p0[1], p0[0], 16), s12 = __builtin_amdgcn_alignbit(p0[2], p0[1], 16),
+                               s23 = __builtin_amdgcn_alignbit(p0[3], p0[2], 16);
+                const u32x4_t xl = {__builtin_amdgcn_alignbit(p0[0], pv, 16), s01, s12, s23};        // pixels x - 1 (kx = 0)
+                const u32x4_t xr = {s01, s12, s23, __builtin_amdgcn_alignbit(nx, p0[3], 16)};         // pixels x + 1 (kx = 2)
+                const half8_t b0 = __builtin_bit_cast(half8_t, xl), b1 = __builtin_bit_cast(half8_t, p0), b2 = __builtin_bit_cast(half8_t, xr);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int r = rp - ky;
+                    if (r < 0 || r >= HW_TY) continue;
+                    const half8_t a = *reinterpret_cast<const half8_t*>(dyp + r * 64 + sg * 32);
+                    acc[ky][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b0, acc[ky][0], 0, 0, 0);
+                    acc[ky][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b1, acc[ky][1], 0, 0, 0);
+                    acc[ky][2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b2, acc[ky][2], 0, 0, 0);
+                }
+            }
+        }
+    };
+#define HC_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    issue(t_beg);
+    commit(0);
+    issue(t_beg + 1);
+    __syncthreads();
+    for (int t = t_beg; t < t_end; ++t) {
+        const int buf = (t - t_beg) & 1;
+        part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        HC_FENCE();
+        if (t + 1 < t_end) commit(buf ^ 1);
+        HC_FENCE();
+        part(buf, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+        HC_FENCE();
+        if (t + 2 < t_end) issue(t + 2);
+        HC_FENCE();
+        part(buf, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+        __syncthreads();
+    }
+#undef HC_FENCE
+
+    // ---- D layout: lane & 31 = input channel (n), register q = output channel (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+    float* dwb = dw + (int64_t)n * P.wbs + (int64_t)(ci0 + cih * 32 + fr) * P.wsc;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            float* dt = dwb + P.widx[ky * 3 + kx];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int co = co0 + cof * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
+                atomicAdd(dt + (int64_t)co * P.wsm, acc[ky][kx][q]);
+            }
+        }
+}
+
 // ---- host side (called from conv.hip; WinoParams carries the problem: 3x3, stride 1, pad 1, weights addressed through wsm / wsc / widx)
 int64_t spi_hconv_workspace_bytes(const WinoParams& P) { return (int64_t)P.nw * P.Mo * P.Ci * 9 * 2; }
 
@@ -318,5 +492,29 @@ int spi_hconv_launch(const WinoParams& Wp, const void* in, const float* w, void*
     }
     dim3 grid((unsigned)(P.tx * P.ty), (unsigned)(Wp.Mo / HC_BM), (unsigned)Wp.N);
     hipLaunchKernelGGL(hconv_kernel, grid, dim3(HC_NT), 0, st, P, static_cast<const _Float16*>(in), img, static_cast<_Float16*>(out), ep);
+    return SPI_OK;
+}
+
+bool spi_hwgrad_eligible(const WinoParams& P) {
+    return P.Mo % HW_BM == 0 && P.Ci % HW_BN == 0 && P.W % HW_TX == 0 && P.H % HW_TY == 0 && P.H >= 8 && P.in_bs * 2 < (1ll << 31) && P.out_bs * 2 < (1ll << 31) &&
+           !P.seg_flags;
+}
+
+// dW must be zeroed (the caller's contract for every weight-gradient path); x [N, Ci, H, W] and dy [N, Mo, H, W] are fp16 tensors
+int spi_hwgrad_launch(const WinoParams& Wp, const void* x, const void* dy, float* dw, hipStream_t st) {
+    HWgradParams P;
+    P.N = Wp.N; P.Mo = Wp.Mo; P.Ci = Wp.Ci; P.H = Wp.H; P.W = Wp.W;
+    P.tx = Wp.W / HW_TX; P.ntile = P.tx * (Wp.H / HW_TY);
+    P.in_bs = Wp.in_bs; P.out_bs = Wp.out_bs; P.wbs = Wp.nw > 1 ? Wp.wbs : 0;
+    P.wsm = Wp.wsm; P.wsc = Wp.wsc;
+    for (int t = 0; t < 9; ++t) P.widx[t] = Wp.widx[t];
+    const int gy = (Wp.Mo / HW_BM) * (Wp.Ci / HW_BN);
+    // ~256 blocks (one per CU: 145 KB of LDS), but at least 4 tiles per block so that the 144 atomics per lane amortise
+    int gx = std::max(1, 256 / std::max(1, gy * Wp.N));
+    gx = std::min(gx, std::max(1, P.ntile / 4));
+    P.tpb = (P.ntile + gx - 1) / gx;
+    gx = (P.ntile + P.tpb - 1) / P.tpb;
+    hipLaunchKernelGGL(hwgrad_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)Wp.N), dim3(HW_NT), 0, st, P, static_cast<const _Float16*>(x),
+                       static_cast<const _Float16*>(dy), dw);
     return SPI_OK;
 }
