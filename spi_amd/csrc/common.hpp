@@ -58,7 +58,9 @@ int spi_hconv_launch(const WinoParams& P, const void* in, const float* w, void* 
 
 // Direct fp16 weight gradient of the same layers (hconv.hip): x [N,Ci,H,W] / dy [N,Mo,H,W] fp16 tensors, dw fp32 and zeroed
 bool spi_hwgrad_eligible(const WinoParams& P) __attribute__((visibility("hidden")));
-int spi_hwgrad_launch(const WinoParams& P, const void* x, const void* dy, float* dw, hipStream_t st) __attribute__((visibility("hidden")));
+int64_t spi_hwgrad_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));     // partial-sum buffer that replaces the atomics (optional)
+int spi_hwgrad_launch(const WinoParams& P, const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes, hipStream_t st)
+    __attribute__((visibility("hidden")));
 
 // Zero `n_floats` floats on `st` with a kernel.  Not hipMemsetAsync: as a node of a captured HIP graph a memset whose byte count is not a
 // multiple of 16 (the decoder's 33-float bias gradient) leaves garbage behind on replays (ROCm 7.0; tools/ubench/graph_memset.py),

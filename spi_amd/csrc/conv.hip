@@ -1241,7 +1241,11 @@ extern "C" {
 int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass) {
     if (validate(d, "spi_conv2d_workspace_bytes") || pass < 0 || pass > 2) return 0;
     IGemmParams P; WinoParams Wp;
-    if (pass == 2) { make_forward(d, P); return (make_hwgrad(d, P, Wp) || make_wino_wgrad(d, P, Wp)) ? WINO_WGRAD_WS : 0; }
+    if (pass == 2) {
+        make_forward(d, P);
+        if (make_hwgrad(d, P, Wp)) return spi_hwgrad_workspace_bytes(Wp);         // (any smaller non-null workspace still opts in: atomics instead of partial sums)
+        return make_wino_wgrad(d, P, Wp) ? WINO_WGRAD_WS : 0;
+    }
     if (pass == 0) make_forward(d, P); else make_dgrad(d, P);
     if (make_hconv(d, P, Wp)) return spi_hconv_workspace_bytes(Wp);
     return make_wino(d, P, Wp) ? spi_wino_workspace_bytes(Wp) : 0;
@@ -1372,16 +1376,21 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     SPI_REQUIRE(P.in_bs * 4 < (1ll << 30) && P.out_bs * 4 < (1ll << 30), "spi_conv2d_wgrad: a per-sample activation must be < 1 GiB");
     const int64_t wsz = (int64_t)d->O * d->I * d->kh * d->kw;
     const int64_t nw = (d->w_batch_stride == 0) ? 1 : d->N;
+    {
+        WinoParams Wp;
+        if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_hwgrad(d, P, Wp)) {
+            const bool parts = d->workspace_bytes >= spi_hwgrad_workspace_bytes(Wp) && (reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0;
+            if (!parts && !d->dw_zeroed) spi_zero_async(dw, nw * wsz, as_stream(stream));          // (the partial-sum path overwrites dw)
+            rc = spi_hwgrad_launch(Wp, x, dy, dw, parts ? d->workspace : nullptr, d->workspace_bytes, as_stream(stream)); if (rc) return rc;
+            SPI_LAUNCH_CHECK("spi_conv2d_wgrad (direct fp16)");
+            return SPI_OK;
+        }
+    }
     if (!d->dw_zeroed) {
         spi_zero_async(dw, nw * wsz, as_stream(stream));
     }
     {
         WinoParams Wp;
-        if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_hwgrad(d, P, Wp)) {
-            rc = spi_hwgrad_launch(Wp, x, dy, dw, as_stream(stream)); if (rc) return rc;
-            SPI_LAUNCH_CHECK("spi_conv2d_wgrad (direct fp16)");
-            return SPI_OK;
-        }
         if (d->workspace && d->workspace_bytes >= WINO_WGRAD_WS && make_wino_wgrad(d, P, Wp)) {
             rc = spi_wino_wgrad_launch(Wp, x, dy, dw, as_stream(stream)); if (rc) return rc;
             SPI_LAUNCH_CHECK("spi_conv2d_wgrad (winograd)");

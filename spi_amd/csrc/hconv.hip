@@ -316,13 +316,15 @@ constexpr int HW_DY_BYTES = HW_BM * HW_DY_ST, HW_X_BYTES = HW_BN * HW_X_ST, HW_B
 
 struct HWgradParams {
     int N, Mo, Ci, H, W;
-    int tx, ntile, tpb;            // tiles per row, tiles per image, tiles per block
+    int tx, tyc, tpb;              // tiles per row, tile rows, tiles per block (a vertical run of one tile column; tyc % tpb == 0)
+    int64_t part_stride;           // > 0: partial sums go to `part` (slot stride in floats) with plain stores instead of atomics into dw
+    int slots_per_set;             // partial slots per weight set
     int64_t in_bs, out_bs, wbs;    // elements per sample (x, dy), dW elements between samples (0: shared weights)
     int wsm, wsc, widx[9];
 };
 
 __global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const _Float16* __restrict__ xin, const _Float16* __restrict__ dyin,
-                                                          float* __restrict__ dw) {
+                                                          float* __restrict__ dw, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * HW_BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, fk = lane >> 5;
@@ -331,8 +333,14 @@ __global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const 
     const int co0 = (blockIdx.y / ncib) * HW_BM, ci0 = (blockIdx.y % ncib) * HW_BN;
     const int n = blockIdx.z;
     const int HWp = P.H * P.W;
-    const int t_beg = blockIdx.x * P.tpb, t_end = min(t_beg + P.tpb, P.ntile);
-    if (t_beg >= t_end) return;
+    // A block walks `tpb` vertically adjacent tiles of one tile column (the two halo rows of the next tile are L2 hits).  Workgroups go to the 8
+    // XCDs round-robin: the swizzle gives every XCD a band of whole image rows, so both halves of every 128-byte line (a tile row is 64 bytes) and
+    // the halo rows between its blocks are served by ONE L2.
+    int cidx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) cidx = (cidx & 7) * (gridDim.x >> 3) + (cidx >> 3);
+    const int col = cidx % P.tx, seg = cidx / P.tx;
+    const int t_beg = 0, t_end = P.tpb;
+    const int x0 = col * HW_TX, yseg = seg * P.tpb * HW_TY;
     const _Float16* xb = xin + (int64_t)n * P.in_bs + (int64_t)ci0 * HWp;
     const _Float16* db = dyin + (int64_t)n * P.out_bs + (int64_t)co0 * HWp;
 
@@ -357,9 +365,10 @@ __global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const 
     }
     u32x4_t rd[4], rm[3];
     unsigned rh[2];
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(xb, (int64_t)HW_BN * HWp * 2);
     auto issue = [&](int t) __attribute__((always_inline)) {
         t = min(t, t_end - 1);
-        const int tyi = t / P.tx, y0 = tyi * HW_TY, x0 = (t - tyi * P.tx) * HW_TX;
+        const int y0 = yseg + t * HW_TY;
         const int org = y0 * P.W + x0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) rd[k] = *reinterpret_cast<const u32x4_t*>(db + org + dy_g[k]);
@@ -374,8 +383,9 @@ __global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const 
         for (int k = 0; k < 2; ++k) {
             const int iy = y0 - 1 + xh_r[k];
             const int px = xh_s[k] ? x0 + HW_TX : x0 - 2;
-            const unsigned v = *reinterpret_cast<const unsigned*>(xb + xh_c[k] + min(max(iy, 0), P.H - 1) * P.W + min(max(px, 0), P.W - 2));
-            rh[k] = (iy >= 0 && iy < P.H && px >= 0 && px < P.W) ? v : 0u;
+            // (raw buffer load: an out-of-range offset returns 0 in hardware -- a select would make the compiler sink the load into a branch and wait for it there)
+            const bool ok = iy >= 0 && iy < P.H && px >= 0 && px < P.W;
+            rh[k] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rsX, ok ? (xh_c[k] + iy * P.W + px) * 2 : (int)BUF_OOB, 0, 0);
         }
     };
     auto commit = [&](int buf) __attribute__((always_inline)) {
@@ -406,7 +416,7 @@ __global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const 
             for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
     // patch rows r' = RA .. RB-1 of one tile: r' meets dy row r = r' - ky
-    auto part = [&](int buf, auto RA_, auto RB_) __attribute__((always_inline)) {
+    auto rows = [&](int buf, auto RA_, auto RB_) __attribute__((always_inline)) {
         constexpr int RA = decltype(RA_)::value, RB = decltype(RB_)::value;
         const unsigned char* base = smem + buf * HW_BUF;
         const unsigned char* dyp = base + (cof * 32 + fr) * HW_DY_ST + fk * 16;
@@ -442,21 +452,25 @@ __global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const 
     __syncthreads();
     for (int t = t_beg; t < t_end; ++t) {
         const int buf = (t - t_beg) & 1;
-        part(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+        rows(buf, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
         HC_FENCE();
         if (t + 1 < t_end) commit(buf ^ 1);
         HC_FENCE();
-        part(buf, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
+        rows(buf, std::integral_constant<int, 2>{}, std::integral_constant<int, 4>{});
         HC_FENCE();
         if (t + 2 < t_end) issue(t + 2);
         HC_FENCE();
-        part(buf, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
+        rows(buf, std::integral_constant<int, 4>{}, std::integral_constant<int, 6>{});
         __syncthreads();
     }
 #undef HC_FENCE
 
     // ---- D layout: lane & 31 = input channel (n), register q = output channel (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
-    float* dwb = dw + (int64_t)n * P.wbs + (int64_t)(ci0 + cih * 32 + fr) * P.wsc;
+    //      With a partial-sum buffer the block's result is WRITTEN (plain coalesced stores) into its own slot and hwgrad_reduce_kernel sums the
+    //      slots: fp32 atomics run at ~0.4 T adds/s whatever the address pattern -- 19 M of them cost a third of the kernel (tools/ubench/hconv_probe.py).
+    const bool to_part = P.part_stride > 0;
+    const int slot = P.wbs ? (int)blockIdx.x : n * (int)gridDim.x + (int)blockIdx.x;
+    float* dwb = (to_part ? part + ((int64_t)(P.wbs ? n : 0) * P.slots_per_set + slot) * P.part_stride : dw + (int64_t)n * P.wbs) + (int64_t)(ci0 + cih * 32 + fr) * P.wsc;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -465,9 +479,25 @@ __global__ void __launch_bounds__(HW_NT, 2) hwgrad_kernel(HWgradParams P, const 
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int co = co0 + cof * 32 + (q & 3) + 8 * (q >> 2) + 4 * fk;
-                atomicAdd(dt + (int64_t)co * P.wsm, acc[ky][kx][q]);
+                if (to_part) dt[(int64_t)co * P.wsm] = acc[ky][kx][q];
+                else atomicAdd(dt + (int64_t)co * P.wsm, acc[ky][kx][q]);
             }
         }
+}
+
+// dw[set][e] = sum over the set's slots of part[set][slot][e]
+__global__ void __launch_bounds__(256) hwgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, int64_t E, int slots, int64_t dw_set_stride) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const float* p = part + (int64_t)blockIdx.y * slots * E + e;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int g = 0;
+    for (; g + 8 <= slots; g += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += p[(int64_t)(g + j) * E];
+    }
+    for (; g < slots; ++g) a[0] += p[(int64_t)g * E];
+    dw[(int64_t)blockIdx.y * dw_set_stride + e] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
 // ---- host side (called from conv.hip; WinoParams carries the problem: 3x3, stride 1, pad 1, weights addressed through wsm / wsc / widx)
@@ -500,21 +530,42 @@ bool spi_hwgrad_eligible(const WinoParams& P) {
            !P.seg_flags;
 }
 
-// dW must be zeroed (the caller's contract for every weight-gradient path); x [N, Ci, H, W] and dy [N, Mo, H, W] are fp16 tensors
-int spi_hwgrad_launch(const WinoParams& Wp, const void* x, const void* dy, float* dw, hipStream_t st) {
+// grid of the weight-gradient launch: ~256 blocks (one per CU: 145 KB of LDS); a block owns a vertical run of `tpb` tiles, tpb a divisor of the tile rows
+static void hwgrad_grid(const WinoParams& Wp, int& gx, int& gy, int& tpb) {
+    const int tx = Wp.W / HW_TX, tyc = Wp.H / HW_TY;
+    gy = (Wp.Mo / HW_BM) * (Wp.Ci / HW_BN);
+    const int target = std::max(1, 256 / std::max(1, gy * Wp.N));
+    tpb = tyc;
+    for (int d = 2; d <= tyc; ++d)
+        if (tyc % d == 0 && tx * (tyc / d) <= target) { tpb = d; break; }                  // smallest run that keeps the grid within the target
+    gx = tx * (tyc / tpb);
+}
+
+// floats of the partial-sum buffer with which the launch avoids atomics (0 if the shape is not eligible)
+int64_t spi_hwgrad_workspace_bytes(const WinoParams& Wp) {
+    int gx, gy, tpb; hwgrad_grid(Wp, gx, gy, tpb);
+    const int64_t E = (int64_t)Wp.Mo * Wp.Ci * 9;
+    return (int64_t)(Wp.nw > 1 ? Wp.N * gx : Wp.N * gx) * E * 4;
+}
+
+// x [N, Ci, H, W] and dy [N, Mo, H, W] are fp16 tensors.  With `workspace` (>= spi_hwgrad_workspace_bytes) dw is overwritten with the sum of per-block
+// partial sums (deterministic); without it dw must be zeroed and receives fp32 atomics.
+int spi_hwgrad_launch(const WinoParams& Wp, const void* x, const void* dy, float* dw, void* workspace, int64_t workspace_bytes, hipStream_t st) {
     HWgradParams P;
     P.N = Wp.N; P.Mo = Wp.Mo; P.Ci = Wp.Ci; P.H = Wp.H; P.W = Wp.W;
-    P.tx = Wp.W / HW_TX; P.ntile = P.tx * (Wp.H / HW_TY);
+    P.tx = Wp.W / HW_TX; P.tyc = Wp.H / HW_TY;
     P.in_bs = Wp.in_bs; P.out_bs = Wp.out_bs; P.wbs = Wp.nw > 1 ? Wp.wbs : 0;
     P.wsm = Wp.wsm; P.wsc = Wp.wsc;
     for (int t = 0; t < 9; ++t) P.widx[t] = Wp.widx[t];
-    const int gy = (Wp.Mo / HW_BM) * (Wp.Ci / HW_BN);
-    // ~256 blocks (one per CU: 145 KB of LDS), but at least 4 tiles per block so that the 144 atomics per lane amortise
-    int gx = std::max(1, 256 / std::max(1, gy * Wp.N));
-    gx = std::min(gx, std::max(1, P.ntile / 4));
-    P.tpb = (P.ntile + gx - 1) / gx;
-    gx = (P.ntile + P.tpb - 1) / P.tpb;
+    int gx, gy; hwgrad_grid(Wp, gx, gy, P.tpb);
+    const int64_t E = (int64_t)Wp.Mo * Wp.Ci * 9;
+    const bool parts = workspace && workspace_bytes >= spi_hwgrad_workspace_bytes(Wp);
+    P.part_stride = parts ? E : 0;
+    P.slots_per_set = Wp.nw > 1 ? gx : Wp.N * gx;
     hipLaunchKernelGGL(hwgrad_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)Wp.N), dim3(HW_NT), 0, st, P, static_cast<const _Float16*>(x),
-                       static_cast<const _Float16*>(dy), dw);
+                       static_cast<const _Float16*>(dy), dw, static_cast<float*>(workspace));
+    if (parts)
+        hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3((unsigned)((E + 255) / 256), (unsigned)(Wp.nw > 1 ? Wp.N : 1)), dim3(256), 0, st,
+                           static_cast<const float*>(workspace), dw, E, P.slots_per_set, Wp.nw > 1 ? Wp.wbs : 0);
     return SPI_OK;
 }
