@@ -198,6 +198,29 @@ def conv_roofline(dev, f16, prec=0):
     if f16:
         out['fp16'] = {'activation_tensors': 'fp16 in HBM (act_dtype)' if half else 'fp32 in HBM, operands rounded on their way into LDS', 'peak': peak,
                        'passes_frac_of_fp16_peak': {k_: v['achieved'] / peak for k_, v in res.items()}}
+    # fp16 activation tensors: the same layer on the direct kernels the loop actually takes for its 3x3 / stride-1 layers (hconv.hip: forward / dgrad
+    # incl. the launch that converts the weights to their fp16 LDS image, weight gradient incl. its partial-sum reduction)
+    if half and _gc.conv_direct_fp16:
+        dres = {}
+        for name, pid, fn in (('fwd', 0, lambda dd: hip.call('spi_conv2d_fwd', ctypes.byref(dd), hip.ptr(x), hip.ptr(w), hip.ptr(y), hip.stream())),
+                              ('dgrad', 1, lambda dd: hip.call('spi_conv2d_dgrad', ctypes.byref(dd), hip.ptr(y), hip.ptr(w), hip.ptr(dx), hip.stream())),
+                              ('wgrad', 2, lambda dd: hip.call('spi_conv2d_wgrad', ctypes.byref(dd), hip.ptr(x), hip.ptr(y), hip.ptr(dw), hip.stream()))):
+            dd = cm._desc(n, i, o, h, h, k, 1, False, True, o * i * k * k, tap_major=1, f16=1, half=True)
+            ws = cm._workspace(dd, pid, x.device)
+            if ws is None:
+                continue
+            for _ in range(3):
+                fn(dd)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+            for a, b in ev:
+                a.record(); fn(dd); b.record()
+            torch.cuda.synchronize()
+            avg = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+            dres[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12, 'frac': flop / (avg * 1e-3) / 1e12 / peak}
+        out['fp16']['direct'] = {'kernel': 'hconv_weight_kernel + hconv_kernel (fwd, dgrad), hwgrad_kernel + hwgrad_reduce_kernel (wgrad), same layer',
+                                 'passes': dres, 'passes_frac_of_fp16_peak': {k_: v['frac'] for k_, v in dres.items()},
+                                 'note': 'these are the kernels the loop runs for this layer; `passes_frac_of_fp16_peak` one level up is the implicit GEMM '
+                                         '(transposed / 1x1 / small layers)'}
     # the same layer on the Winograd F(2x2, 3x3) path the loop actually takes for forward / dgrad of the >= 128^2 3x3 layers (exact fp32
     # mode only): `achieved` counts the direct convolution's FLOPs (the algorithmic work), `executed` the MFMA FLOPs issued (/ 2.25)
     from spi_amd.configs import global_config

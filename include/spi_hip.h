@@ -345,7 +345,13 @@ typedef struct spi_conv_desc {
      * operands, fp32 accumulation, 2.25x fewer MFMAs; the result differs from the direct sum by a few fp32 roundings (what cuDNN runs for
      * the reference's fp32 3x3 convs).  The weight-gradient pass needs no scratch: its spi_conv2d_workspace_bytes is a nominal 16.
      * NULL / too small: the implicit-GEMM kernels run.  The workspace holds the transformed weights of THIS call only.  Offered for
-     * compute_f16 = 0 and 3 (the 6-product split asks for fp32-equivalent products, which fp32 Winograd delivers faster on these layers). */
+     * compute_f16 = 0 and 3 (the 6-product split asks for fp32-equivalent products, which fp32 Winograd delivers faster on these layers).
+     * fp16 activation tensors (act_dtype = SPI_DTYPE_F16, compute_f16 = 1): the same opt-in selects the DIRECT fp16 kernels for 3x3 / stride-1 / pad-1
+     * layers -- forward / dgrad (output channels a multiple of 128, reduction channels a multiple of 16, at least 128 tiles of 16 x 32 pixels): the
+     * workspace receives the weights converted to fp16 in their LDS layout (`workspace_ready` applies); weight gradient (128 | O, 64 | I, 32 | W,
+     * 4 | H, no dy_seg_flags): the workspace receives one partial sum per workgroup and dw is OVERWRITTEN with their sum (deterministic); a smaller
+     * non-null workspace still selects the kernel, which then adds into the zeroed dw with fp32 atomics.  Same products and fp32 accumulation as the
+     * implicit GEMM, another summation order. */
     void* workspace;
     int64_t workspace_bytes;
     /* element type of the ACTIVATION tensors of all three passes (x, y, dy, dx): SPI_DTYPE_F32 (0, default) or SPI_DTYPE_F16 -- fp16 only
@@ -353,7 +359,7 @@ typedef struct spi_conv_desc {
      * in half precision in memory (networks_stylegan2.py:421-436; conv2d on half tensors accumulates in fp32 and rounds once).  Weights, weight
      * gradients, bias and noise stay fp32. */
     int act_dtype;
-    /* forward / dgrad Winograd passes only: 1 = `workspace` still holds the transformed weights an EARLIER call of the same pass wrote for the same
+    /* forward / dgrad Winograd (and direct fp16) passes only: 1 = `workspace` still holds the transformed weights an EARLIER call of the same pass wrote for the same
      * `w` (same layout flags) -- the weight-transform launch is skipped.  For frozen weights that are convolved again and again (the VGG feature
      * extractors of the losses: 36 such launches per stage-2 iteration); the caller keeps one workspace per (weight tensor, pass) alive. */
     int workspace_ready;
@@ -361,13 +367,14 @@ typedef struct spi_conv_desc {
 /* weight layout: [O, I, kh, kw] (or [O, kh, kw, I] with w_tap_major) in both modes
  * (transposed: out[o,2y+ky,2x+kx] += x[i,y,x] * w[o,i,ky,kx]).
  * output size: stride-1: H + 2*pad - kh + 1;  transposed: 2*H + kh - 2  (= 2H+1 for 3x3).          */
-/* bytes of workspace with which pass (0 forward, 1 dgrad, 2 wgrad) takes its Winograd path; 0 = the pass has none for this shape */
+/* bytes of workspace with which pass (0 forward, 1 dgrad, 2 wgrad) takes its Winograd path (fp16 activation tensors: its direct fp16 kernel); 0 = the
+ * pass has none for this shape */
 int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass);
 /* 1 if pass (0 forward, 1 dgrad) of `d` -- with the workspace `d` carries -- accumulates into its output through atomics (and therefore clears
  * it first unless d->out_zeroed), 0 if it overwrites, < 0 on a bad descriptor.  Host logic only: no launch, no device access. */
 int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass);
 /* How pass (0 forward, 1 dgrad, 2 wgrad) of `d` -- with the workspace `d` carries -- would be launched: out8 = {path (0 implicit GEMM,
- * 1 Winograd), block tile rows (out channels), block tile columns (pixels; wgrad: weight columns), number of K ranges (split-K / channel
+ * 1 Winograd, 2 direct fp16), block tile rows (out channels), block tile columns (pixels; wgrad: weight columns), number of K ranges (split-K / channel
  * split; wgrad: pixel ranges), workgroups of the launch, threads per workgroup, 0, 0}.  Host logic only (tools/igemm_shapes.py: the per-shape
  * efficiency table); 0 or a negative error code. */
 int spi_conv2d_plan(const spi_conv_desc* d, int pass, int32_t* out8);
