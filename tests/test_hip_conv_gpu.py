@@ -292,6 +292,46 @@ def test_direct_fp16_conv_vs_implicit_gemm_epilogue_and_skipping(n, i, o, h, wd,
             assert float((yn == 0).float().mean()) > 0.3
 
 
+def test_direct_fp16_wgrad_partial_sums_and_atomics_agree_through_the_c_abi():
+    """spi_conv2d_wgrad with fp16 activation tensors: a workspace of spi_conv2d_workspace_bytes(d, 2) bytes selects the partial-sum form of hwgrad_kernel
+    (dw is OVERWRITTEN -- garbage in dw does not matter, two runs are bit-identical), a smaller non-null workspace the atomic form (adds into the
+    zeroed dw); both equal the fp64 weight gradient of the fp16 operands; dy_seg_flags sends the call back to the implicit GEMM's slab list."""
+    import ctypes
+    import torch.nn.functional as F
+    from spi_amd import hip
+    from spi_amd.torch_utils.ops import conv2d_mfma as cm
+    gen = torch.Generator().manual_seed(3)
+    n, i, o, h, wd = 2, 64, 128, 64, 96
+    x = torch.randn(n, i, h, wd, generator=gen).half()
+    dy = (torch.randn(n, o, h, wd, generator=gen) * 0.1).half()
+    w64 = torch.zeros(o, i, 3, 3, dtype=torch.float64, requires_grad=True)
+    (ref,) = torch.autograd.grad(F.conv2d(x.double(), w64, padding=1), w64, dy.double())
+    ref = ref.permute(0, 2, 3, 1).float()                                         # tap-major [O, k, k, I]
+    xd, dyd = x.to(DEV), dy.to(DEV)
+
+    def run(ws_bytes, poison):
+        d = cm._desc(n, i, o, h, wd, 3, 1, False, False, 0, tap_major=1, f16=True, half=True)
+        need = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2)
+        assert need > 16
+        ws = torch.empty(need if ws_bytes is None else ws_bytes, device=DEV, dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel()
+        plan = (ctypes.c_int32 * 8)()
+        hip.call('spi_conv2d_plan', ctypes.byref(d), 2, plan)
+        assert plan[0] == 2, list(plan)
+        dw = torch.full((o, 3, 3, i), float(poison), device=DEV)
+        if ws_bytes is not None:
+            dw.zero_(); d.dw_zeroed = 1
+        hip.call('spi_conv2d_wgrad', ctypes.byref(d), hip.ptr(xd), hip.ptr(dyd), hip.ptr(dw), hip.stream())
+        return dw.cpu()
+    a1, a2 = run(None, 7.0), run(None, float('nan'))
+    assert torch.equal(a1, a2)                                                    # partial sums: deterministic, dw overwritten
+    assert_close(a1, ref, 2e-5, 'direct fp16 wgrad (partial sums)')
+    assert_close(run(16, 0.0), ref, 2e-5, 'direct fp16 wgrad (atomics)')
+    # a masked gradient keeps the implicit GEMM (plan path 0)
+    d = cm._desc(n, i, o, h, wd, 3, 1, False, False, 0, tap_major=1, f16=True, half=True, dy_flags=cm.seg_flags(dyd))
+    assert hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), 2) == 0
+
+
 @pytest.mark.parametrize('up,demod,shared,n', [(1, True, False, 2), (1, True, True, 3), (2, True, False, 1), (2, True, True, 2), (1, False, False, 2)])
 def test_frozen_weight_modconv_style_gradient(up, demod, shared, n):
     """Stage-1 path (weights frozen): d styles from  <x,dx>/s - s g^2 sum_o d_o^2 <dz_o,z_o> sum_t W^2  equals the autograd
