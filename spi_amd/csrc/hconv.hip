@@ -167,24 +167,54 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _F
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[r][i][q] = 0.f;
 
-    // one kx column of a chunk: 6 input-row fragments (A operand: m = pixel), 6 weight fragments (B operand: n = output channel), 24 MFMAs.
+    // one kx column of a chunk: 6 input-row fragments (A operand: m = pixel), 6 weight fragments (B operand: n = output channel), 24 MFMAs in three
+    // ky groups of 8.  The operands of a column's FIRST group (4 input rows, 2 weight fragments: `xq`, `wq`) are read one group ahead -- behind the
+    // first group of the column before -- so that only the first column of a chunk (its buffer becomes readable at the barrier) waits for LDS.
     // D layout: lane & 31 = output channel, register q = pixel (q & 3) + 8 (q >> 2) + 4 (lane >> 5) of the 32-pixel row.
-    auto step = [&](int buf, int kx) __attribute__((always_inline)) {
+    half8_t xq[4], wq[2];
+    auto preload = [&](int buf) __attribute__((always_inline)) {
         const half8_t* I = reinterpret_cast<const half8_t*>(In_s[buf]) + (fk * HC_IY + rg * 4) * HC_IX + fr;
         const half8_t* Wt = reinterpret_cast<const half8_t*>(Wt_s[buf]) + fk * HC_BM + ch * 64 + fr;
-        half8_t xf[6], wf[3][2];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) xf[q] = I[q * HC_IX + kx];
+        for (int q = 0; q < 4; ++q) xq[q] = I[q * HC_IX];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int i = 0; i < 2; ++i) wq[i] = Wt[i * 32];
+    };
+    auto step = [&](int buf, auto KX_) __attribute__((always_inline)) {
+        constexpr int kx = decltype(KX_)::value;
+        const half8_t* I = reinterpret_cast<const half8_t*>(In_s[buf]) + (fk * HC_IY + rg * 4) * HC_IX + fr;
+        const half8_t* Wt = reinterpret_cast<const half8_t*>(Wt_s[buf]) + fk * HC_BM + ch * 64 + fr;
+        half8_t xr4 = I[4 * HC_IX + kx], xr5 = I[5 * HC_IX + kx], w1[2], w2[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wf[ky][i] = Wt[(ky * 3 + kx) * 2 * HC_BM + i * 32];
+        for (int i = 0; i < 2; ++i) { w1[i] = Wt[(3 + kx) * 2 * HC_BM + i * 32]; w2[i] = Wt[(6 + kx) * 2 * HC_BM + i * 32]; }
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int i = 0; i < 2; ++i) acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xq[r], wq[i], acc[r][i], 0, 0, 0);
+        half8_t nx[4], nw[2];
+        if (kx < 2) {
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[r + ky], wf[ky][i], acc[r][i], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) nx[q] = I[q * HC_IX + kx + 1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) nw[i] = Wt[(kx + 1) * 2 * HC_BM + i * 32];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const half8_t xrow[6] = {xq[0], xq[1], xq[2], xq[3], xr4, xr5};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xrow[r + 1], w1[i], acc[r][i], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xrow[r + 2], w2[i], acc[r][i], 0, 0, 0);
+        if (kx < 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xq[q] = nx[q];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wq[i] = nw[i];
+        }
     };
 #define HC_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 
@@ -198,15 +228,30 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _F
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
         const int buf = c & 1;
-        step(buf, 0);
-        HC_FENCE();
-        if (c + 1 < nchunk) commit(buf ^ 1);
-        HC_FENCE();
-        step(buf, 1);
-        HC_FENCE();
-        if (c + 2 < nchunk) issue(c + 2);
-        HC_FENCE();
-        step(buf, 2);
+        // (the two waves of a SIMD -- wave w and w + 4, i.e. the two channel halves -- place their commit / issue phases behind DIFFERENT columns:
+        //  while one packs and writes, the other one's MFMAs keep the matrix pipe busy)
+        preload(buf);
+        if (ch == 0) {
+            step(buf, std::integral_constant<int, 0>{});
+            HC_FENCE();
+            if (c + 1 < nchunk) commit(buf ^ 1);
+            HC_FENCE();
+            step(buf, std::integral_constant<int, 1>{});
+            HC_FENCE();
+            if (c + 2 < nchunk) issue(c + 2);
+            HC_FENCE();
+            step(buf, std::integral_constant<int, 2>{});
+        } else {
+            step(buf, std::integral_constant<int, 0>{});
+            HC_FENCE();
+            step(buf, std::integral_constant<int, 1>{});
+            HC_FENCE();
+            if (c + 1 < nchunk) commit(buf ^ 1);
+            HC_FENCE();
+            if (c + 2 < nchunk) issue(c + 2);
+            HC_FENCE();
+            step(buf, std::integral_constant<int, 2>{});
+        }
         __syncthreads();
     }
 

@@ -63,12 +63,12 @@ int main(int argc, char** argv) {
 #endif
 '''
 STORE = 'if (wide) *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{lo[0], lo[1], hi[0], hi[1]};'
-MFMA = 'acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[r + ky], wf[ky][i], acc[r][i], 0, 0, 0);'
+MFMA = 'acc[r][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xq[r], wq[i], acc[r][i], 0, 0, 0);'
 STAMP_SUBS = [
     ('__global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(', '__device__ long long g_stamps[512 * 16];\n__global__ void __launch_bounds__(HC_NT, 2) hconv_kernel('),
     ('    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;', '    long long TS[12]; TS[0] = clock64();\n    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;'),
     ('    issue(0);\n    commit(0);\n    if (nchunk > 1) issue(1);\n    __syncthreads();', '    TS[1] = clock64(); issue(0);\n    commit(0);\n    if (nchunk > 1) issue(1);\n    __syncthreads(); TS[2] = clock64();'),
-    ('        step(buf, 2);\n        __syncthreads();', '        step(buf, 2);\n        __syncthreads(); if (c < 8) TS[3 + c] = clock64();'),
+    ('        }\n        __syncthreads();', '        }\n        __syncthreads(); if (c < 8) TS[3 + c] = clock64();'),
     ('// ---- host side (called from conv.hip', '// host'),
 ]
 STAMP_TAIL = ('}\n#undef HC_FENCE', '    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TS[11] = clock64();\n    if (tid == 0) { for (int i = 0; i < 12; ++i) g_stamps[blockIdx.x * 16 + i] = TS[i]; g_stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg(6164); }\n}\n#undef HC_FENCE')
@@ -89,7 +89,7 @@ VARIANTS = {
     'stamps': [(a, b.replace('long long TS[12]', 'long long TS[16]')) for a, b in STAMP_SUBS[:4]] + EPI_SUBS + [(STAMP_TAIL[0], STAMP_TAIL[1].replace('i < 12; ++i) g_stamps[blockIdx.x * 16 + i]', 'i < 15; ++i) g_stamps[blockIdx.x * 16 + i]').replace('g_stamps[blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg(6164);', ''))],
     'base': [],
     'nostore': [(STORE, STORE.replace('if (wide)', 'if (wide && lo[0] == 0x12345678u)'))],
-    'nomfma': [(MFMA, 'acc[r][i][0] += (float)wf[ky][i][0] * (float)xf[r + ky][0];')],
+    'nomfma': [(MFMA, 'acc[r][i][0] += (float)wq[i][0] * (float)xq[r][0];')],
     'noloopload': [('if (c + 2 < nchunk) issue(c + 2);', 'if (c + 2 < nchunk && P.N == 12345) issue(c + 2);')],
     'nocommit': [('if (c + 1 < nchunk) commit(buf ^ 1);', 'if (c + 1 < nchunk && P.N == 12345) commit(buf ^ 1);')],
     'noload_nocommit': [('if (c + 2 < nchunk) issue(c + 2);', 'if (c + 2 < nchunk && P.N == 12345) issue(c + 2);'),
