@@ -30,7 +30,7 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 11   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 12   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive)
                              * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive)
@@ -39,7 +39,8 @@ typedef void* spi_stream_t;           /* hipStream_t */
                              * 10: + spi_affine_multi_fwd / _bwd, spi_modulate_multi_fwd / _bwd (additive)
                              * 11: + spi_conv2d_plan (additive); spi_conv_desc gained act_dtype (fp16 activation tensors; appended: 0 = the behaviour of 10),
                              *     + spi_upfirdn2d_fused_t / spi_tail_bwd_t / spi_chan_dot_t / spi_seg_flags_t / spi_filtered_lrelu_t,
-                             *     SPI_DTYPE_F64 for spi_bias_act_t / spi_upfirdn2d_t (additive) */
+                             *     SPI_DTYPE_F64 for spi_bias_act_t / spi_upfirdn2d_t (additive)
+                             * 12: + spi_tail_bwd_dot_t (additive); spi_conv2d_workspace_bytes / workspace of fp16 activation tensors select the direct fp16 kernels */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -260,6 +261,13 @@ int spi_upfirdn2d_fused_t(const void* x, const float* f, void* y, int N, int C, 
                           float clamp, int dtype, spi_stream_t stream);
 int spi_tail_bwd_t(const void* dy, const void* y, void* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
                    int64_t HW, int act, float alpha, float gain, float clamp, int dtype, spi_stream_t stream);
+/* spi_tail_bwd_t plus, from the same pass, zdot[n*C + c] += sum_hw dz[n,c,hw] * z[n,c,hw] (zdot [N*C]: CALLER zeroes), z = the conv result reconstructed
+ * from the saved output y exactly as spi_chan_dot(act != 0) reconstructs its b' (inverse activation / gain, minus z_bias[c] and z_noise[hw] *
+ * z_noise_gain[0]; NULL = none): the second of the two dot products of the frozen-weight style gradient (networks_stylegan2._ModConvFrozen;
+ * the reference's autograd computes the full weight gradient for it, networks_stylegan2.py:71-88) without re-reading dz and y (ABI 12). */
+int spi_tail_bwd_dot_t(const void* dy, const void* y, void* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
+                       int64_t HW, int act, float alpha, float gain, float clamp, const float* z_bias, const float* z_noise, const float* z_noise_gain,
+                       float* zdot, int dtype, spi_stream_t stream);
 int spi_chan_dot_t(const void* a, const void* b, float* out, int64_t rows, int C, int64_t HW, const float* bias, const float* noise,
                    const float* noise_gain, int act, float alpha, float gain, int dtype, spi_stream_t stream);
 int spi_seg_flags_t(const void* x, int32_t* flags, int N, int C, int64_t HW, int dtype, spi_stream_t stream);

@@ -50,6 +50,10 @@ conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
 # direct fp16 kernel (hconv.hip: the input patch staged once for all nine taps, weights pre-converted to their LDS image).  Off = implicit GEMM.
 conv_direct_fp16 = os.environ.get('SPI_CONV_DIRECT_FP16', '1') != '0'
 
+# frozen-weight modulated convs (stage 1): the <dz, z> dot product of the style gradient comes out of the layer-tail backward pass (spi_tail_bwd_dot_t)
+# instead of a second pass over dz and y.  Off = the separate spi_chan_dot launch.
+fuse_tail_dot = os.environ.get('SPI_FUSE_TAIL_DOT', '1') != '0'
+
 # stage 1: capture the projector step in a HIP graph after an eager warm-up step and replay it (projectors/common.py).  The step is
 # GPU-bound either way; the graph takes the ~10 ms of host enqueue work per step off the CPU.  Off: every step is enqueued eagerly.
 stage1_hip_graph = os.environ.get('SPI_STAGE1_GRAPH', '1') != '0'

@@ -280,13 +280,19 @@ __device__ __forceinline__ void store4(_Float16* p, float a, float b, float c, f
 // of channels.  Per channel the block adds 4 wave-partials to d_bias[c]; the per-pixel sums stay in
 // registers over the channel loop and are added to d_pixsum once.
 // ------------------------------------------------------------------------------------------------
-template <int PX, typename T = float>
+// optional fused per-(n, c) dot product  zdot[n*C + c] += sum_p dz[n,c,p] * z[n,c,p]  with z = the layer's conv result reconstructed from its output
+// (inverse activation, minus bias and noise -- exactly spi_chan_dot's b'): the frozen-weight style gradient needs it (networks_stylegan2._ModConvFrozen),
+// and here dz and y are in registers already -- a separate spi_chan_dot pass reads both tensors again (3 % of a stage-1 step).
+struct ZDot { float* out; const float* bias; const float* noise; const float* noise_gain; };
+
+template <int PX, typename T = float, bool ZD = false>
 __global__ void __launch_bounds__(256) tail_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                        T* __restrict__ dz, float* __restrict__ d_bias,
                                                        float* __restrict__ d_pixsum, const float* __restrict__ noise,
                                                        float* __restrict__ d_strength, int N, int C, int64_t HW, int cchunk,
-                                                       ActParams ap) {
+                                                       ActParams ap, ZDot zd) {
     __shared__ float bpart[512][4];                        // per-channel wave partials of this block (host keeps cchunk <= 512)
+    __shared__ float zpart[ZD ? 2048 : 1][4];              // ZDot: per-(n, c) wave partials (host keeps cchunk * N <= 2048)
     const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PX;
     const int c_beg = blockIdx.y * cchunk, c_end = min(c_beg + cchunk, C);
     const bool ok = p0 < HW;                               // PX == 4 requires HW % 4 == 0, so a thread is all-in or all-out
@@ -300,6 +306,10 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const T* __restrict__ dy,
     const int npair = (c_end - c_beg) * N;
     float bsum = 0.f;
     int cur_c = c_beg;
+    float znz[PX];                                         // ZDot: this thread's noise * strength (pixels are fixed over the channel loop)
+    const float z_inv_alpha = (ap.act == SPI_ACT_LRELU) ? 1.f / ap.alpha : 1.f;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) znz[j] = (ZD && zd.noise && ok) ? zd.noise[p0 + j] * (zd.noise_gain ? zd.noise_gain[0] : 1.f) : 0.f;
     for (int q0 = 0; q0 < npair; q0 += UN) {
         float g[UN][PX], yy[UN][PX];
         int64_t off[UN];
@@ -330,7 +340,9 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const T* __restrict__ dy,
                 }
                 bsum = 0.f; cur_c = c;
             }
+            float zsum = 0.f;
             if (y && ok) {
+                const float zb = (ZD && zd.bias) ? zd.bias[c] : 0.f;
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
                     const float pre = yy[u][j] / ap.gain;                      // activation output before the gain (as bias_act grad=1)
@@ -340,6 +352,7 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const T* __restrict__ dy,
                     v *= ap.gain;
                     if (ap.clamp >= 0.f) v = (yy[u][j] > -ap.clamp && yy[u][j] < ap.clamp) ? v : 0.f;
                     g[u][j] = v;
+                    if (ZD) zsum = fmaf(v, (pre > 0.f ? pre : pre * z_inv_alpha) - zb - znz[j], zsum);   // (a clamped / rectified-away element has v == 0)
                 }
                 if (dz) {
                     if constexpr (PX == 4) store4(dz + off[u], g[u][0], g[u][1], g[u][2], g[u][3]);
@@ -348,6 +361,10 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const T* __restrict__ dy,
             }
 #pragma unroll
             for (int j = 0; j < PX; ++j) { pix[j] += g[u][j]; bsum += g[u][j]; }
+            if (ZD) {                                          // wave partial of this (n, c) -> LDS; one atomic per pair and block at the end
+                const float zs = wave_sum(zsum);
+                if ((threadIdx.x & 63) == 0) zpart[q][threadIdx.x >> 6] = zs;
+            }
         }
     }
     if (d_bias && npair > 0) {
@@ -359,6 +376,13 @@ __global__ void __launch_bounds__(256) tail_bwd_kernel(const T* __restrict__ dy,
         for (int i = threadIdx.x; i < c_end - c_beg; i += 256) {
             const int cl = (i + blockIdx.x) % (c_end - c_beg);                 // staggered so that blocks do not hit the same address together
             atomicAdd(d_bias + c_beg + cl, (bpart[cl][0] + bpart[cl][1]) + (bpart[cl][2] + bpart[cl][3]));
+        }
+    }
+    if (ZD) {                                              // (every block walks the pairs from another start: same-address atomics issued together serialise --
+        __syncthreads();                                   //  one atomic per wave straight from the loop ran 3 x slower than a separate spi_chan_dot pass)
+        for (int i = threadIdx.x; i < npair; i += 256) {
+            const int q = (i + (int)blockIdx.x * 37) % npair;
+            atomicAdd(zd.out + (int64_t)(q - (q / N) * N) * C + c_beg + q / N, (zpart[q][0] + zpart[q][1]) + (zpart[q][2] + zpart[q][3]));
         }
     }
     if (d_pixsum && ok) {
@@ -1428,7 +1452,8 @@ static int launch_upfirdn(const float* x, const float* f, float* y, const Upfird
 extern "C++" {
 template <typename T>
 static int tail_bwd_launch(const T* dy, const T* y, T* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
-                           int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream) {
+                           int64_t HW, int act, float alpha, float gain, float clamp, spi_stream_t stream, ZDot zd = ZDot{nullptr, nullptr, nullptr, nullptr}) {
+    SPI_REQUIRE(!zd.out || y, "spi_tail_bwd_dot: the dot product with the reconstructed conv result needs the saved output y");
     SPI_REQUIRE(dy && N > 0 && C > 0 && HW > 0, "spi_tail_bwd: bad argument");
     SPI_REQUIRE(!d_strength || (noise && d_pixsum), "spi_tail_bwd: d_strength needs noise and d_pixsum");
     SPI_REQUIRE(!y || (act >= SPI_ACT_LINEAR && act <= SPI_ACT_LRELU && gain != 0.f), "spi_tail_bwd: activation must be linear / relu / lrelu");
@@ -1444,10 +1469,15 @@ static int tail_bwd_launch(const T* dy, const T* y, T* dz, float* d_bias, float*
     // took 24 us for 2 MB (224 launches of the profiled run).
     const int64_t pix_cap = std::min<int64_t>(64, std::max<int64_t>(16, 262144 / HW));
     int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? pix_cap : 1024)));
+    if (zd.out) splits = std::max(splits, (int)(((int64_t)C * N + 2047) / 2048));   // ZDot: cchunk * N <= 2048 (LDS partials per (n, c))
+    SPI_REQUIRE(!zd.out || N <= 2048, "spi_tail_bwd_dot: batch too large");
     const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
     splits = (C + cchunk - 1) / cchunk;
-    if (vec) hipLaunchKernelGGL((tail_bwd_kernel<4, T>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
-    else hipLaunchKernelGGL((tail_bwd_kernel<1, T>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap);
+    if (zd.out) {
+        if (vec) hipLaunchKernelGGL((tail_bwd_kernel<4, T, true>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap, zd);
+        else hipLaunchKernelGGL((tail_bwd_kernel<1, T, true>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap, zd);
+    } else if (vec) hipLaunchKernelGGL((tail_bwd_kernel<4, T>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap, zd);
+    else hipLaunchKernelGGL((tail_bwd_kernel<1, T>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap, zd);
     SPI_LAUNCH_CHECK("spi_tail_bwd");
     return SPI_OK;
 }
@@ -1467,6 +1497,17 @@ int spi_tail_bwd_t(const void* dy, const void* y, void* dz, float* d_bias, float
     if (dtype == SPI_DTYPE_F16)
         return tail_bwd_launch<_Float16>((const _Float16*)dy, (const _Float16*)y, (_Float16*)dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, act, alpha, gain, clamp, stream);
     return tail_bwd_launch<float>((const float*)dy, (const float*)y, (float*)dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, act, alpha, gain, clamp, stream);
+}
+
+int spi_tail_bwd_dot_t(const void* dy, const void* y, void* dz, float* d_bias, float* d_pixsum, const float* noise, float* d_strength, int N, int C,
+                       int64_t HW, int act, float alpha, float gain, float clamp, const float* z_bias, const float* z_noise, const float* z_noise_gain,
+                       float* zdot, int dtype, spi_stream_t stream) {
+    SPI_DTYPE_CHECK("spi_tail_bwd_dot_t");
+    SPI_REQUIRE(zdot != nullptr, "spi_tail_bwd_dot_t: null zdot (spi_tail_bwd_t is the call without the dot product)");
+    const ZDot zd{zdot, z_bias, z_noise, z_noise_gain};
+    if (dtype == SPI_DTYPE_F16)
+        return tail_bwd_launch<_Float16>((const _Float16*)dy, (const _Float16*)y, (_Float16*)dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, act, alpha, gain, clamp, stream, zd);
+    return tail_bwd_launch<float>((const float*)dy, (const float*)y, (float*)dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, act, alpha, gain, clamp, stream, zd);
 }
 
 extern "C++" {

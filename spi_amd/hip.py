@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
-ABI_VERSION = 11          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
+ABI_VERSION = 12          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -69,6 +69,7 @@ _SIGS = {
     'spi_upfirdn2d_t': ([c_p] * 3 + [c_i] * 4 + [c_p, c_p] + [c_i] * 11 + [c_f, c_i, c_i, c_i, c_p], c_i),
     'spi_upfirdn2d_fused_t': ([c_p] * 3 + [c_i] * 15 + [c_f, c_i, c_i] + [c_p] * 3 + [c_i, c_f, c_f, c_f, c_i, c_p], c_i),
     'spi_tail_bwd_t': ([c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_i, c_p], c_i),
+    'spi_tail_bwd_dot_t': ([c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_l, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p, c_i, c_p], c_i),
     'spi_chan_dot_t': ([c_p, c_p, c_p, c_l, c_i, c_l, c_p, c_p, c_p, c_i, c_f, c_f, c_i, c_p], c_i),
     'spi_seg_flags_t': ([c_p, c_p, c_i, c_i, c_l, c_i, c_p], c_i),
     'spi_filtered_lrelu_t': ([c_p] * 6 + [c_i] * 14 + [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_p], c_i),

@@ -46,10 +46,12 @@ def tail_zero_elems(dy, noise, need_noise, need_strength, need_bias):
     return (dy.shape[1] if need_bias else 0) + (dy[0, 0].numel() if want_pix else 0) + (1 if (noise is not None and need_strength) else 0)
 
 
-def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise, need_strength, need_bias, zero_buf=None):
+def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise, need_strength, need_bias, zero_buf=None, zdot=None):
     """Backward of  y = clamp(act(z + noise*strength + bias)*gain)  for dy [N,C,H,W] in one launch (spi_tail_bwd).
     ``y`` None: no activation/gain/clamp was applied (dz = dy).  Returns (dz, d_noise, d_strength, d_bias).
-    ``zero_buf``: optional zeroed 1-D fp32 tensor whose first ``tail_zero_elems(...)`` entries become d_bias / the pixel sums."""
+    ``zero_buf``: optional zeroed 1-D fp32 tensor whose first ``tail_zero_elems(...)`` entries become d_bias / the pixel sums.
+    ``zdot``: optional ``(out [N*C] zeroed fp32, bias [C] or None, noise [H,W] or None, noise_gain [1] or None)`` -- the same launch adds
+    ``sum_hw dz * z`` per (n, c) into ``out``, z = the conv result reconstructed from ``y`` (spi_tail_bwd_dot_t; needs ``y``)."""
     # fp16 activation tensors (the reference's use_fp16 blocks): dy / y / dz are half, every sum stays fp32
     half = (y is not None and y.dtype == torch.float16) or (y is None and dy.dtype == torch.float16)
     dy = dy.contiguous().to(torch.float16 if half else torch.float32)
@@ -67,7 +69,12 @@ def tail_backward(dy, y, noise, strength, act_id, alpha, gain, clamp, need_noise
     pix = zero_buf[nb:nb + hw].view(dy.shape[2:]) if want_pix else None
     ds = zero_buf[nb + hw:nb + hw + 1] if want_s else None             # sum_hw pixsum * noise comes out of the same launch
     nzc = noise.contiguous().float() if want_s else None
-    if half:
+    if zdot is not None:
+        assert y is not None, 'tail_backward: zdot needs the saved output'
+        zo, zb, zn, zg = zdot
+        hip.call('spi_tail_bwd_dot_t', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), hip.ptr(nzc), hip.ptr(ds), n, c, hw, act_id, alpha,
+                 gain, clamp, hip.ptr(zb), hip.ptr(zn), hip.ptr(zg), hip.ptr(zo), hip.DTYPE_IDS[torch.float16 if half else torch.float32], hip.stream())
+    elif half:
         hip.call('spi_tail_bwd_t', hip.ptr(dy), hip.ptr(y), hip.ptr(dz), hip.ptr(d_bias), hip.ptr(pix), hip.ptr(nzc), hip.ptr(ds), n, c, hw, act_id, alpha,
                  gain, clamp, hip.DTYPE_IDS[torch.float16], hip.stream())
     else:

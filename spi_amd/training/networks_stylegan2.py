@@ -220,9 +220,12 @@ class _ModConvFrozen(torch.autograd.Function):
         # one zeroed buffer for every accumulator of this backward: layer-tail sums | <x_i, dx_i> | <dz_o, z_o>
         n_tail = bias_act.tail_zero_elems(dy, nz, ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3])
         zb = zero_arena.zeros(n_tail + n * i + (n * o if demodulate else 0), x.device)
+        # <dz_o, z_o> comes out of the layer-tail pass itself when that pass runs (dz and y are in its registers; spi_tail_bwd_dot_t)
+        from ..configs import global_config as _gc
+        fuse_cv = bool(demodulate and has_epi and _gc.fuse_tail_dot)
         dz, d_noise, d_strength, d_bias = bias_act.tail_backward(dy, y if has_epi else None, nz, ng, act_id, alpha, gain, clamp,
                                                                  ctx.needs_input_grad[4], ctx.needs_input_grad[5], ctx.needs_input_grad[3],
-                                                                 zero_buf=zb)
+                                                                 zero_buf=zb, zdot=((zb[n_tail + n * i:], bb, nz, ng) if fuse_cv else None))
         half = x.dtype == torch.float16
         d = _desc(n, i, o, h, wd, kh, pad, transposed, flip, wbs, tap_major=1, f16=f16, half=half)
         dd, dzd, w2d = d, dz, w2
@@ -241,7 +244,9 @@ class _ModConvFrozen(torch.autograd.Function):
         if demodulate:
             cv = zb[n_tail + n * i:]
             hw_out = y.shape[2] * y.shape[3]
-            if has_epi:
+            if fuse_cv:
+                pass
+            elif has_epi:
                 hip.call(cd, hip.ptr(dz), hip.ptr(y), hip.ptr(cv), n * o, o, hw_out, hip.ptr(bb), hip.ptr(nz), hip.ptr(ng), act_id, alpha,
                          gain, *dt, hip.stream())
             else:
