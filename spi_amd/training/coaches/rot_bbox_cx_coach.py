@@ -454,17 +454,32 @@ class RotBboxCoach(BaseCoach):
             import time
             t_begin = time.perf_counter()
             cap0 = RotBboxCoach.captures_total
+            # SPI_TIME_IMAGE=1: synchronised timestamps around the per-image phases (a debugging aid: the syncs cost a little throughput)
+            _tm = os.environ.get('SPI_TIME_IMAGE') == '1' and torch.cuda.is_available()
+            def _mark(marks=[]):
+                if _tm:
+                    torch.cuda.synchronize(); marks.append(time.perf_counter())
+                return marks
+            _mark()[:] = []
+            _mark()
             ctx = self.prepare_image(data)
+            _mark()
             paths_config.experiments_output_dir = os.path.join(output_dir, image_name)
             os.makedirs(paths_config.experiments_output_dir, exist_ok=True)
             if self.use_wandb:                                   # (:45-47)
                 self.log_target(ctx['image'], 'target_image')
                 self.log_target(ctx['image_m'], 'mirror_image')
             self.restart_training()
+            _mark()
             embedding_loaded = hyperparameters.load_embedding_coach_name is not None and os.path.isfile(
                 f"{paths_config.embedding_base_dir}/{hyperparameters.load_embedding_coach_name}/{image_name}.pt")
             w_pivot = self.get_inversion(image_name, ctx['image'], ctx['camera'], fg_mask=ctx['fg_mask'])
+            _mark()
             iters, losses = self.optimise_image(ctx, w_pivot, image_name)
+            if _tm:
+                m = _mark()
+                print('[time] %s: prepare_image %.3f  restart_training %.3f  stage 1 (get_inversion) %.3f  stage 2 (optimise_image) %.3f s' %
+                      (image_name, m[1] - m[0], m[2] - m[1], m[3] - m[2], m[4] - m[3]), flush=True)
             if torch.cuda.is_available():
                 torch.cuda.synchronize()
             t_loop = time.perf_counter()
