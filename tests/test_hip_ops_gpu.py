@@ -424,3 +424,51 @@ def test_plugin_boundary_fp64_and_half_filtered_lrelu(golden):
         assert y.dtype == torch.float16
         yr = osg.filtered_lrelu(x16.float(), fu=g['fl_fu'], fd=g['fl_fd'], b=b16.float(), **kw)
         assert _half_ulps(y, yr.half()) <= 1.0, (i, _half_ulps(y, yr.half()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,c,h,w,act,half', [(1, 20, 33, 35, 'lrelu', False), (3, 130, 32, 48, 'lrelu', False), (2, 64, 64, 64, 'linear', False),
+                                              (2, 48, 40, 40, 'relu', False), (2, 128, 64, 96, 'lrelu', True), (4, 600, 8, 8, 'lrelu', False)])
+def test_tail_backward_and_fused_channel_dot_vs_autograd(n, c, h, w, act, half):
+    """spi_tail_bwd(_t) / spi_tail_bwd_dot_t (ABI 12) against autograd of  y = clamp(act(z + noise * s + b) * gain):  dz, d bias, d noise, d strength --
+    and the fused per-(n, c) dot product  sum_hw dz * z  with z reconstructed from y (the frozen-weight style gradient's second dot product),
+    which also equals the separate spi_chan_dot pass it replaces.  fp32 and fp16 tensors, ragged pixel counts (scalar path), more than one channel
+    chunk, N * cchunk beyond one block's LDS partials."""
+    from spi_amd import hip
+    from spi_amd.torch_utils.ops import bias_act
+    gen = torch.Generator().manual_seed(n * 7 + c)
+    act_id, alpha, gain, clamp = {'linear': (1, 0.0, 1.3, 1.5), 'relu': (2, 0.0, 1.41, 2.0), 'lrelu': (3, 0.2, 1.41, 1.8)}[act]
+    z = torch.randn(n, c, h, w, generator=gen, dtype=torch.float64, requires_grad=True)
+    b = torch.randn(c, generator=gen, dtype=torch.float64, requires_grad=True)
+    noise = torch.randn(h, w, generator=gen, dtype=torch.float64, requires_grad=True)
+    s = torch.tensor(0.4, dtype=torch.float64, requires_grad=True)
+    pre = z + noise * s + b.view(1, -1, 1, 1)
+    a = pre if act == 'linear' else (torch.relu(pre) if act == 'relu' else torch.nn.functional.leaky_relu(pre, alpha))
+    y = (a * gain).clamp(-clamp, clamp)
+    dy = torch.randn(n, c, h, w, generator=gen, dtype=torch.float64)
+    if half:
+        dy = dy.half().double()
+    gz, gb, gn, gs = torch.autograd.grad(y, [z, b, noise, s], dy)
+    dt = torch.float16 if half else torch.float32
+    yd, dyd = y.detach().to(DEV, dt), dy.to(DEV, dt)
+    nzd, sd, bd = noise.detach().float().to(DEV), s.detach().float().to(DEV).reshape(1), b.detach().float().to(DEV)
+    zo = torch.zeros(n * c, device=DEV)
+    dz, d_noise, d_strength, d_bias = bias_act.tail_backward(dyd, yd, nzd, sd, act_id, alpha, gain, clamp, True, True, True, zdot=(zo, bd, nzd, sd))
+    tol = 2e-3 if half else 1e-5
+    # (an element that sits exactly on the clamp / at the kink after rounding y to the tensor type is a different element: compare where |y| is clear of both)
+    clear = ((y.detach().abs() - clamp).abs() > 1e-2) & (y.detach().abs() > 1e-2)
+    assert_close(dz.double().cpu() * clear, gz * clear, tol, 'dz')
+    if not half:
+        assert_close(d_bias.cpu().double(), gb, 1e-4, 'd bias')
+        assert_close(d_noise.cpu().double(), gn, 1e-4, 'd noise')
+        assert_close(d_strength.cpu().double().reshape(()), gs, 1e-4, 'd strength')
+    # the fused dot product equals the separate pass on the same tensors (same reconstruction), and the exact sum up to the rounding of y
+    if act != 'relu':                                  # (spi_chan_dot refuses relu outputs; the fused form is exact there too: dz == 0 wherever y cannot be inverted)
+        zc = torch.zeros(n * c, device=DEV)
+        name = 'spi_chan_dot_t' if half else 'spi_chan_dot'
+        extra = (hip.DTYPE_IDS[torch.float16],) if half else ()
+        hip.call(name, hip.ptr(dz), hip.ptr(yd), hip.ptr(zc), n * c, c, h * w, hip.ptr(bd), hip.ptr(nzd), hip.ptr(sd), act_id, alpha, gain, *extra, hip.stream())
+        assert_close(zo, zc, 1e-3 if half else 1e-5, 'fused <dz, z> vs spi_chan_dot')       # (half: the separate pass reads dz AFTER its rounding to fp16)
+    if not half:
+        exact = (gz * z.detach()).sum(dim=(2, 3)).reshape(-1)
+        assert_close(zo.cpu().double(), exact, 1e-4, 'fused <dz, z> vs the exact sum')
