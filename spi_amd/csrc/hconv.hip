@@ -31,7 +31,8 @@ constexpr int HC_WT_CELLS = 9 * 2 * HC_BM;                            // 2304
 constexpr int HC_IN_PASSES = (HC_IN_CELLS + HC_NT - 1) / HC_NT;       // 3
 constexpr int HC_WT_PASSES = (HC_WT_CELLS + HC_NT - 1) / HC_NT;       // 5
 constexpr int HC_OST = HC_TY * HC_TX + 4;                             // halves per output channel of the epilogue's LDS tile (+4: conflict-free 8-byte writes)
-constexpr int HC_LDS_BYTES = (2 * (HC_IN_CELLS + HC_WT_CELLS) * 16 > HC_BM * HC_OST * 2) ? 2 * (HC_IN_CELLS + HC_WT_CELLS) * 16 : HC_BM * HC_OST * 2;
+constexpr int HC_OT_BYTES = HC_BM * HC_OST * 2;                       // the epilogue's output tile; the tile's noise values (fp32) sit behind it
+constexpr int HC_LDS_BYTES = (2 * (HC_IN_CELLS + HC_WT_CELLS) * 16 > HC_OT_BYTES + HC_TY * HC_TX * 4) ? 2 * (HC_IN_CELLS + HC_WT_CELLS) * 16 : HC_OT_BYTES + HC_TY * HC_TX * 4;
 
 struct HConvParams {
     int N, nw, Mo, Ci, H, W;
@@ -270,18 +271,27 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _F
         const int mode = !any_epi ? 0 : ((ep.act == 0 || ((ep.act == SPI_ACT_LINEAR || ep.act == SPI_ACT_LRELU) && slope >= 0.f && slope <= 1.f && ep.gain > 0.f)) ? 1 : 2);
         const float g1 = ep.act ? ep.gain : 1.f, g2 = g1 * slope;
         const float cpos = (ep.act && ep.clamp >= 0.f) ? ep.clamp : __builtin_inff();
-        const float ng = ep.noise ? (ep.noise_gain ? ep.noise_gain[0] : 1.f) : 0.f;
-        const __amdgpu_buffer_rsrc_t rsN = make_rsrc(ep.noise, ep.noise ? (int64_t)HW * 4 : 0);
+        // the tile's noise * strength goes through LDS once (one load per thread) instead of 64 broadcast loads per lane
+        float* Nt = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(smem) + HC_OT_BYTES);
+        if (ep.noise) {
+            const float ng = ep.noise_gain ? ep.noise_gain[0] : 1.f;
+            const __amdgpu_buffer_rsrc_t rsN = make_rsrc(ep.noise, (int64_t)HW * 4);
+            const int nrow = tid >> 5, nx = tid & 31;          // (pixels beyond the row's end read the next row's noise: they are never stored)
+            Nt[tid] = buf_load_f32(rsN, (unsigned)((y0 + nrow) * P.W + x0 + nx) * 4u) * ng;
+            __syncthreads();
+        }
         auto tile_out = [&](auto MODE) __attribute__((always_inline)) {
             constexpr int M = decltype(MODE)::value;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = rg * 4 + r;
-                const int pix0 = (y0 + row) * P.W + x0 + 4 * fk;          // (pixels beyond the row's end read the next row's noise: they are never stored)
                 float nz[16];
                 if (M != 0) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) nz[q] = ep.noise ? buf_load_f32(rsN, (unsigned)(pix0 + (q & 3) + 8 * (q >> 2)) * 4u) * ng : 0.f;
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4_t t = ep.noise ? *reinterpret_cast<const f32x4_t*>(Nt + row * HC_TX + 8 * j + 4 * fk) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        nz[4 * j] = t[0]; nz[4 * j + 1] = t[1]; nz[4 * j + 2] = t[2]; nz[4 * j + 3] = t[3];
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -297,8 +307,7 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _F
                             if (M == 1) {
                                 v += nz[qq * 4 + e] + b;
                                 const float a = v * g1, c = v * g2;
-                                float w = fmaxf(a, c);
-                                w = (a != a) ? a : w;                      // (fmaxf drops a NaN operand only when the other is a number: both are NaN here; kept explicit)
+                                const float w = fmaxf(a, c);               // (a NaN v makes both operands NaN: the maximum is NaN, as the select form gives)
                                 v = w > cpos ? cpos : (w < -cpos ? -cpos : w);
                             } else if (M == 2) {
                                 v += nz[qq * 4 + e] + b;
