@@ -56,6 +56,10 @@ int64_t spi_hconv_workspace_bytes(const WinoParams& P) __attribute__((visibility
 int spi_hconv_launch(const WinoParams& P, const void* in, const float* w, void* out, const Epilogue& ep, void* workspace, hipStream_t st, bool img_ready = false)
     __attribute__((visibility("hidden")));
 
+// ... and of a STRIDE-2 3x3 conv (the data gradient of a stride-2 transposed conv; P = that dgrad problem, IH x IW = its gradient operand)
+bool spi_hconv_s2_eligible(const WinoParams& P) __attribute__((visibility("hidden")));
+int spi_hconv_s2_launch(const WinoParams& P, int IH, int IW, const void* in, const float* w, void* out, void* workspace, hipStream_t st, bool img_ready = false)
+    __attribute__((visibility("hidden")));
 // Direct fp16 weight gradient of the same layers (hconv.hip): x [N,Ci,H,W] / dy [N,Mo,H,W] fp16 tensors, dw fp32 and zeroed
 bool spi_hwgrad_eligible(const WinoParams& P) __attribute__((visibility("hidden")));
 int64_t spi_hwgrad_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));     // partial-sum buffer that replaces the atomics (optional)

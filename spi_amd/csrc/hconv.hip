@@ -351,6 +351,188 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_kernel(HConvParams P, const _F
 #undef HC_FENCE
 
 // =====================================================================================================================================
+// The same direct scheme for a STRIDE-2 3x3 convolution of fp16 tensors -- the data gradient of the use_fp16 blocks' stride-2 transposed conv0
+// (dx[i,y,x] = sum_{o,ky,kx} W[o,i,ky,kx] dz[o, 2y+ky, 2x+kx]; conv2d_resample.py:114-131's conv_transpose2d run backwards).  A block owns 8 x 32
+// output pixels x 128 channels; the chunk's 17 x 65 patch of dz is staged once as cells, a fragment reads every second cell of a row (pixel 2x + kx;
+// 2-way LDS bank conflicts: the matrix pipe is 16 x faster than these reads need).  A wave: 4 rows x 32 pixels x 32 channels, 9 patch-row fragments and
+// 3 weight fragments for 12 MFMAs per kx.  Output leaves through LDS in 16-byte pieces (whole rows of one block: no line is shared between blocks).
+constexpr int H2_TY = 8, H2_TX = 32;
+constexpr int H2_IY = 2 * H2_TY + 1, H2_IX = 2 * H2_TX + 1;
+constexpr int H2_IN_CELLS = 2 * H2_IY * H2_IX;                        // 2210
+constexpr int H2_IN_PASSES = (H2_IN_CELLS + HC_NT - 1) / HC_NT;       // 5
+constexpr int H2_OST = H2_TY * H2_TX + 4;
+constexpr int H2_LDS_BYTES = 2 * (H2_IN_CELLS + HC_WT_CELLS) * 16;    // 144 448 (> the 66 560 bytes of the epilogue tile)
+
+struct HConvS2Params {
+    int N, nw, Mo, Ci, H, W, IH, IW;    // output H x W, input (gradient operand) IH x IW
+    int tx, ty;
+    int64_t in_bs, out_bs;
+    const int32_t* seg_flags; int nseg;
+};
+
+__global__ void __launch_bounds__(HC_NT, 2) hconv_s2_kernel(HConvS2Params P, const _Float16* __restrict__ in, const u32x4_t* __restrict__ wimg,
+                                                            _Float16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) u32x4_t smem[H2_LDS_BYTES / 16];
+    u32x4_t (*In_s)[H2_IN_CELLS] = reinterpret_cast<u32x4_t (*)[H2_IN_CELLS]>(smem);
+    u32x4_t (*Wt_s)[HC_WT_CELLS] = reinterpret_cast<u32x4_t (*)[HC_WT_CELLS]>(smem + 2 * H2_IN_CELLS);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int rg = wave & 1, cg = wave >> 1;                  // row group (4 rows), output-channel quarter (32)
+    int bx = blockIdx.x;
+    const int ntile = P.tx * P.ty;
+    if ((ntile & 7) == 0) bx = (bx & 7) * (ntile >> 3) + (bx >> 3);          // an XCD owns a band of tiles (see hconv_kernel)
+    const int tyi = bx / P.tx, txi = bx - tyi * P.tx;
+    const int y0 = tyi * H2_TY, x0 = txi * H2_TX;
+    const int mb = blockIdx.y, n = blockIdx.z;
+    const int HW = P.H * P.W, IHW = P.IH * P.IW;
+    _Float16* ob = out + (int64_t)n * P.out_bs + (int64_t)mb * HC_BM * HW;
+
+    if (P.seg_flags) {                                                        // no flagged gradient segment in the receptive field: zeros
+        const int32_t* fl = P.seg_flags + (int64_t)n * P.nseg;
+        const int ya = 2 * y0, yb = min(2 * (y0 + H2_TY - 1) + 2, P.IH - 1);
+        const int xa = 2 * x0, xb = min(2 * (x0 + H2_TX - 1) + 2, P.IW - 1);
+        int any = 0;
+        for (int idx = tid; idx < H2_IY * 8; idx += HC_NT) {
+            const int y = ya + (idx >> 3);
+            if (y <= yb) {
+                const int sg = ((y * P.IW + xa) >> 4) + (idx & 7);
+                if (sg <= ((y * P.IW + xb) >> 4)) any |= fl[sg];
+            }
+        }
+        if (!__syncthreads_or(any)) {
+            const int xe = min(H2_TX, P.W - x0), ye = min(H2_TY, P.H - y0);
+            for (int e = tid; e < HC_BM * H2_TY * H2_TX; e += HC_NT) {
+                const int x = e % H2_TX, r = (e / H2_TX) % H2_TY, m = e / (H2_TY * H2_TX);
+                if (r < ye && x < xe) ob[(int64_t)m * HW + (int64_t)(y0 + r) * P.W + x0 + x] = (_Float16)0.f;
+            }
+            return;
+        }
+    }
+
+    const _Float16* inb = in + (int64_t)n * P.in_bs;
+    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(inb, P.in_bs * 2);
+    unsigned ivoff[H2_IN_PASSES];
+#pragma unroll
+    for (int p = 0; p < H2_IN_PASSES; ++p) {
+        const int cell = tid + p * HC_NT;
+        const int g = cell / (H2_IY * H2_IX), rem = cell - g * (H2_IY * H2_IX);
+        const int py = rem / H2_IX, px = rem - py * H2_IX;
+        const int iy = 2 * y0 + py, ix = 2 * x0 + px;
+        const bool ok = cell < H2_IN_CELLS && iy < P.IH && ix < P.IW;
+        ivoff[p] = ok ? (unsigned)((g * 8 * IHW + iy * P.IW + ix) * 2) : BUF_OOB;
+    }
+    const int nchunk = P.Ci / HC_KC;
+    const int nwi = P.nw > 1 ? n : 0;
+    const u32x4_t* wbase = wimg + ((int64_t)nwi * (P.Mo / HC_BM) + mb) * nchunk * HC_WT_CELLS;
+    const int chs2 = __builtin_amdgcn_readfirstlane(IHW * 2);
+
+    unsigned xr[H2_IN_PASSES][8];
+    u32x4_t wr[HC_WT_PASSES];
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        c = min(c, nchunk - 1);
+        const int soff0 = __builtin_amdgcn_readfirstlane(c * HC_KC * chs2);
+#pragma unroll
+        for (int p = 0; p < H2_IN_PASSES; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xr[p][j] = __builtin_bit_cast(unsigned short, __builtin_amdgcn_raw_buffer_load_b16(rsI, (int)ivoff[p], soff0 + j * chs2, 0));
+        const u32x4_t* wp = wbase + (int64_t)c * HC_WT_CELLS;
+#pragma unroll
+        for (int p = 0; p < HC_WT_PASSES; ++p) wr[p] = wp[min(tid + p * HC_NT, HC_WT_CELLS - 1)];
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < H2_IN_PASSES; ++p) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(xr[p][j]));
+            const u32x4_t v = {xr[p][0] | (xr[p][1] << 16), xr[p][2] | (xr[p][3] << 16), xr[p][4] | (xr[p][5] << 16), xr[p][6] | (xr[p][7] << 16)};
+            if ((p + 1) * HC_NT <= H2_IN_CELLS || tid + p * HC_NT < H2_IN_CELLS) In_s[buf][tid + p * HC_NT] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < HC_WT_PASSES; ++p)
+            if ((p + 1) * HC_NT <= HC_WT_CELLS || tid + p * HC_NT < HC_WT_CELLS) Wt_s[buf][tid + p * HC_NT] = wr[p];
+    };
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[r][q] = 0.f;
+
+    auto step = [&](int buf, int kx) __attribute__((always_inline)) {
+        const half8_t* I = reinterpret_cast<const half8_t*>(In_s[buf]) + (fk * H2_IY + 8 * rg) * H2_IX + 2 * fr + kx;
+        const half8_t* Wt = reinterpret_cast<const half8_t*>(Wt_s[buf]) + fk * HC_BM + cg * 32 + fr;
+        half8_t xf[9], wf[3];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) xf[q] = I[q * H2_IX];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) wf[ky] = Wt[(ky * 3 + kx) * 2 * HC_BM];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[2 * r + ky], wf[ky], acc[r], 0, 0, 0);
+    };
+#define HC_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    issue(0);
+    commit(0);
+    if (nchunk > 1) issue(1);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        step(buf, 0);
+        HC_FENCE();
+        if (c + 1 < nchunk) commit(buf ^ 1);
+        HC_FENCE();
+        step(buf, 1);
+        HC_FENCE();
+        if (c + 2 < nchunk) issue(c + 2);
+        HC_FENCE();
+        step(buf, 2);
+        __syncthreads();
+    }
+#undef HC_FENCE
+
+    // ---- epilogue (a data gradient: nothing to apply): round once, tile through LDS as [channel][row][x], out in 16-byte pieces
+    _Float16* Ot = reinterpret_cast<_Float16*>(smem);
+    {
+        typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+        const int co = cg * 32 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            _Float16* dst = Ot + co * H2_OST + (rg * 4 + r) * H2_TX + 4 * fk;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const half4_t h = {(_Float16)acc[r][qq * 4], (_Float16)acc[r][qq * 4 + 1], (_Float16)acc[r][qq * 4 + 2], (_Float16)acc[r][qq * 4 + 3]};
+                *reinterpret_cast<half4_t*>(dst + 8 * qq) = h;
+            }
+        }
+    }
+    __syncthreads();
+    {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const bool wide = (P.W & 7) == 0 && (HW & 7) == 0 && (reinterpret_cast<uintptr_t>(ob) & 15) == 0;
+#pragma unroll 4
+        for (int k = 0; k < HC_BM * H2_TY * (H2_TX / 8) / HC_NT; ++k) {
+            const int id = tid + k * HC_NT;
+            const int xq = id & 3, row = (id >> 2) & (H2_TY - 1), co = id >> 5;
+            const int y = y0 + row, x = x0 + xq * 8;
+            const u32x2_t* src = reinterpret_cast<const u32x2_t*>(Ot + co * H2_OST + row * H2_TX + xq * 8);
+            const u32x2_t lo = src[0], hi = src[1];
+            if (y < P.H && x < P.W) {
+                _Float16* dst = ob + (int64_t)co * HW + (int64_t)y * P.W + x;
+                if (wide) *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{lo[0], lo[1], hi[0], hi[1]};
+                else {
+                    const unsigned w4[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (x + e < P.W) dst[e] = __builtin_bit_cast(_Float16, (unsigned short)(w4[e >> 1] >> ((e & 1) * 16)));
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================================================================
 // Direct fp16 weight gradient of the same layers: dW[co][tap][ci] += sum_pixels dy[co][y][x] * x[ci][y + ky - 1][x + kx - 1].
 // GEMM per tap: m = output channel, n = input channel, K = pixels -- and in NCHW eight consecutive pixels of one channel ARE the 16 bytes an MFMA
 // operand lane holds: both tiles go to LDS as straight 16-byte copies (no transpose, no conversion).  The implicit-GEMM wgrad_kernel stages
@@ -621,5 +803,27 @@ int spi_hwgrad_launch(const WinoParams& Wp, const void* x, const void* dy, float
     if (parts)
         hipLaunchKernelGGL(hwgrad_reduce_kernel, dim3((unsigned)((E + 255) / 256), (unsigned)(Wp.nw > 1 ? Wp.N : 1)), dim3(256), 0, st,
                            static_cast<const float*>(workspace), dw, E, P.slots_per_set, Wp.nw > 1 ? Wp.wbs : 0);
+    return SPI_OK;
+}
+
+// ---- stride-2 variant: Wp describes the data-gradient problem of a stride-2 transposed 3x3 conv (Wp.H x Wp.W = dx, widx[ky * 3 + kx]); IH x IW = dz
+bool spi_hconv_s2_eligible(const WinoParams& P) {
+    const int64_t blocks = (int64_t)((P.W + H2_TX - 1) / H2_TX) * ((P.H + H2_TY - 1) / H2_TY) * (P.Mo / HC_BM) * P.N;
+    return P.Mo % HC_BM == 0 && P.Ci % HC_KC == 0 && P.in_bs * 2 < (1ll << 31) && P.out_bs * 2 < (1ll << 31) && blocks >= 128 && !P.out_flags;
+}
+
+int spi_hconv_s2_launch(const WinoParams& Wp, int IH, int IW, const void* in, const float* w, void* out, void* workspace, hipStream_t st, bool img_ready) {
+    HConvS2Params P;
+    P.N = Wp.N; P.nw = Wp.nw; P.Mo = Wp.Mo; P.Ci = Wp.Ci; P.H = Wp.H; P.W = Wp.W; P.IH = IH; P.IW = IW;
+    P.tx = (Wp.W + H2_TX - 1) / H2_TX; P.ty = (Wp.H + H2_TY - 1) / H2_TY;
+    P.in_bs = Wp.in_bs; P.out_bs = Wp.out_bs;
+    P.seg_flags = Wp.seg_flags; P.nseg = Wp.nseg;
+    u32x4_t* img = static_cast<u32x4_t*>(workspace);
+    if (!img_ready) {
+        const int64_t cells = (int64_t)Wp.nw * Wp.Mo * Wp.Ci * 9 / 8;
+        hipLaunchKernelGGL(hconv_weight_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, Wp, w, img, cells);
+    }
+    dim3 grid((unsigned)(P.tx * P.ty), (unsigned)(Wp.Mo / HC_BM), (unsigned)Wp.N);
+    hipLaunchKernelGGL(hconv_s2_kernel, grid, dim3(HC_NT), 0, st, P, static_cast<const _Float16*>(in), img, static_cast<_Float16*>(out));
     return SPI_OK;
 }

@@ -174,7 +174,8 @@ def test_conv2d_fp16_operands_vs_rounded_reference(n, i, o, h, k, transposed):
 
 
 @pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 24, 3, False), (1, 64, 128, 40, 3, False), (2, 16, 3, 33, 1, False), (1, 32, 64, 12, 3, True),
-                                                  (1, 128, 128, 128, 3, False), (2, 32, 256, 125, 3, False), (2, 128, 256, 128, 3, False)])      # last two: hconv.hip forward (+ dgrad)
+                                                  (1, 128, 128, 128, 3, False), (2, 32, 256, 125, 3, False), (2, 128, 256, 128, 3, False), (2, 128, 32, 128, 3, True)])
+# (the last three: hconv.hip forward (+ dgrad); the transposed one: its stride-2 data-gradient kernel)
 def test_conv2d_fp16_tensors_vs_rounded_reference(n, i, o, h, k, transposed):
     """fp16 ACTIVATION TENSORS (round 5, spi_conv_desc.act_dtype; the reference's use_fp16 blocks, networks_stylegan2.py:421-436): x, y, dy, dx are
     half tensors in HBM, weights / weight gradients fp32, fp32 accumulation.  Every pass equals the fp64 convolution of the fp16-rounded
@@ -291,6 +292,54 @@ def test_direct_fp16_conv_vs_implicit_gemm_epilogue_and_skipping(n, i, o, h, wd,
             assert float(yn.float().abs().max()) == 0
         if kind == 'box':
             assert float((yn == 0).float().mean()) > 0.3
+
+
+@pytest.mark.parametrize('n,i,o,h,wd,shared', [(2, 128, 48, 128, 128, False), (1, 256, 32, 120, 160, True)])
+def test_direct_fp16_stride2_dgrad_of_transposed_conv(n, i, o, h, wd, shared):
+    """hconv_s2_kernel: the data gradient of a stride-2 transposed 3x3 conv on fp16 tensors (a stride-2 conv of the gradient).  The plan names it;
+    its result equals the implicit GEMM's up to one fp16 ulp on a few elements (same products, another summation order), also on ragged tiles;
+    a sparse gradient (dy_seg_flags) skips tiles without changing anything."""
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.configs import global_config
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(n * 100 + i)
+    x = torch.randn(n, i, h, wd, generator=gen).half().to(DEV).requires_grad_(True)
+    w = (torch.randn(*(() if shared else (n,)), o, i, 3, 3, generator=gen) / (i * 9) ** 0.5).to(DEV)
+    d = conv2d_mfma._desc(n, i, o, h, wd, 3, 0, True, False, 0 if shared else o * i * 9, tap_major=1, f16=True, half=True)
+    ws = conv2d_mfma._workspace(d, 1, x.device)
+    plan = (ctypes.c_int32 * 8)()
+    hip.call('spi_conv2d_plan', ctypes.byref(d), 1, plan)
+    assert ws is not None and plan[0] == 2 and plan[2] == 256, list(plan)
+    assert conv2d_mfma._workspace(d, 0, x.device) is None                           # (the forward keeps the implicit GEMM)
+
+    def run(direct, dy, sparse=False):
+        old = global_config.conv_direct_fp16
+        global_config.conv_direct_fp16 = direct
+        try:
+            y = conv2d_mfma.conv2d(x, w, transposed=True, fp16=True, sparse_grad=True)
+            with conv2d_mfma.sparse_gradients(sparse):
+                (gx,) = torch.autograd.grad(y, [x], dy)
+        finally:
+            global_config.conv_direct_fp16 = old
+        return gx
+    oh, ow = 2 * h + 1, 2 * wd + 1
+    dy = torch.randn(n, o, oh, ow, generator=gen).half().to(DEV)
+    a, b = run(True, dy).float(), run(False, dy).float()
+    ulp = torch.ldexp(torch.ones_like(b), torch.floor(torch.log2(b.abs().clamp_min(6.1e-5))).to(torch.int32) - 10)
+    e = ((a - b).abs() - 2e-5 * b.abs().max()).clamp_min(0) / ulp
+    assert float(e.max()) <= 1.0 and float((e > 0).float().mean()) < 2e-2, (float(e.max()), float((e > 0).float().mean()))
+    old_min = conv2d_mfma.SPARSE_MIN_PIXELS
+    conv2d_mfma.SPARSE_MIN_PIXELS = 1
+    try:
+        for kind in ('box', 'blobs', 'pixel', 'empty'):
+            dym = _masked_gradient((n, o, oh, ow), gen, kind).half().to(DEV)
+            gd, gs = run(True, dym), run(True, dym, sparse=True)
+            assert torch.equal(gs, gd), kind
+            if kind == 'empty':
+                assert float(gs.float().abs().max()) == 0
+    finally:
+        conv2d_mfma.SPARSE_MIN_PIXELS = old_min
 
 
 def test_direct_fp16_wgrad_partial_sums_and_atomics_agree_through_the_c_abi():
