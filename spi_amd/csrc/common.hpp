@@ -60,6 +60,10 @@ int spi_hconv_launch(const WinoParams& P, const void* in, const float* w, void* 
 bool spi_hconv_s2_eligible(const WinoParams& P) __attribute__((visibility("hidden")));
 int spi_hconv_s2_launch(const WinoParams& P, int IH, int IW, const void* in, const float* w, void* out, void* workspace, hipStream_t st, bool img_ready = false)
     __attribute__((visibility("hidden")));
+// ... and the FORWARD of a stride-2 transposed 3x3 conv (P.H x P.W = input, output 2H+1 x 2W+1; both row parities, two launches)
+bool spi_hconv_t2_eligible(const WinoParams& P) __attribute__((visibility("hidden")));
+int spi_hconv_t2_launch(const WinoParams& P, const void* in, const float* w, void* out, void* workspace, hipStream_t st, bool img_ready = false)
+    __attribute__((visibility("hidden")));
 // Direct fp16 weight gradient of the same layers (hconv.hip): x [N,Ci,H,W] / dy [N,Mo,H,W] fp16 tensors, dw fp32 and zeroed
 bool spi_hwgrad_eligible(const WinoParams& P) __attribute__((visibility("hidden")));
 int64_t spi_hwgrad_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));     // partial-sum buffer that replaces the atomics (optional)

@@ -1233,6 +1233,16 @@ static bool make_hconv_s2(const spi_conv_desc* d, const IGemmParams& P, WinoPara
     Wp.seg_flags = P.seg_flags; Wp.out_flags = nullptr; Wp.nseg = P.nseg; Wp.ksplit = 1;
     return spi_hconv_s2_eligible(Wp);
 }
+// Direct fp16 forward of a stride-2 transposed 3x3 conv (hconv.hip; P = make_forward(d), whose four parity classes the kernel re-derives itself)
+static bool make_hconv_t2(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
+    if (d->act_dtype != SPI_DTYPE_F16 || d->compute_f16 != 1 || !d->transposed || d->kh != 3 || d->kw != 3) return false;
+    Wp.N = P.N; Wp.nw = d->w_batch_stride ? P.N : 1; Wp.Mo = P.Mo; Wp.Ci = P.Ci; Wp.H = d->H; Wp.W = d->W;
+    Wp.bx = Wp.by = 0; Wp.ocp = 0;
+    Wp.in_bs = P.in_bs; Wp.out_bs = P.out_bs; Wp.wbs = P.wbs; Wp.u_bs = 0; Wp.wsm = P.wsm; Wp.wsc = P.wsc;
+    for (int ky = 0; ky < 3; ++ky) for (int kx = 0; kx < 3; ++kx) Wp.widx[ky * 3 + kx] = tap_w(d, ky, kx);
+    Wp.seg_flags = nullptr; Wp.out_flags = P.out_flags; Wp.nseg = P.out_nseg; Wp.ksplit = 1;
+    return spi_hconv_t2_eligible(Wp);
+}
 // Direct fp16 weight gradient (hconv.hip) eligibility (P = make_forward(d)): as make_hconv, plus whole 4 x 32-pixel tiles and a dense gradient
 static bool make_hwgrad(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
     if (d->act_dtype != SPI_DTYPE_F16 || d->compute_f16 != 1 || d->transposed || d->kh != 3 || d->pad != 1 || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
@@ -1263,6 +1273,7 @@ int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass) {
     if (pass == 0) make_forward(d, P); else make_dgrad(d, P);
     if (make_hconv(d, P, Wp)) return spi_hconv_workspace_bytes(Wp);
     if (pass == 1 && make_hconv_s2(d, P, Wp)) return spi_hconv_workspace_bytes(Wp);
+    if (pass == 0 && make_hconv_t2(d, P, Wp)) return spi_hconv_workspace_bytes(Wp);
     return make_wino(d, P, Wp) ? spi_wino_workspace_bytes(Wp) : 0;
 }
 
@@ -1278,6 +1289,7 @@ int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass) {
     }
     if (d->workspace && make_hconv(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) return 0;
     if (d->workspace && pass == 1 && make_hconv_s2(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) return 0;
+    if (d->workspace && pass == 0 && make_hconv_t2(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) return 0;
     if (d->workspace && make_wino(d, P, Wp) && d->workspace_bytes >= spi_wino_workspace_bytes(Wp)) return Wp.ksplit > 1 ? 1 : 0;
     return plan_igemm(P, d->compute_f16).nsplit > 1 ? 1 : 0;
 }
@@ -1314,6 +1326,10 @@ int spi_conv2d_plan(const spi_conv_desc* d, int pass, int32_t* out8) {
         make_forward(d, P);
         if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
     } else make_dgrad(d, P);
+    if (d->workspace && pass == 0 && make_hconv_t2(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) {
+        out8[0] = 2; out8[1] = 128; out8[2] = 512; out8[3] = 1; out8[4] = (int32_t)((int64_t)(((P.OW + 1) / 2 + 31) / 32) * (((P.OH + 1) / 2 + 7) / 8) * (P.Mo / 128) * P.N * 2); out8[5] = 512;
+        return SPI_OK;
+    }
     if (d->workspace && pass == 1 && make_hconv_s2(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) {
         out8[0] = 2; out8[1] = 128; out8[2] = 256; out8[3] = 1; out8[4] = (int32_t)((int64_t)((P.OW + 31) / 32) * ((P.OH + 7) / 8) * (P.Mo / 128) * P.N); out8[5] = 512;
         return SPI_OK;
@@ -1347,6 +1363,12 @@ int spi_conv2d_fwd(const spi_conv_desc* d, const float* x, const float* w, float
     if (d->out_seg_flags) { P.out_flags = d->out_seg_flags; P.out_nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS); }
     Epilogue ep{d->bias, d->noise, d->noise_gain, d->act, d->alpha, d->act ? d->gain : 1.f, d->act ? d->clamp : -1.f};
     WinoParams Wp;
+    if (d->workspace && make_hconv_t2(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) {
+        SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
+        rc = spi_hconv_t2_launch(Wp, x, w, y, d->workspace, as_stream(stream), d->workspace_ready != 0); if (rc) return rc;
+        SPI_LAUNCH_CHECK("spi_conv2d_fwd (direct fp16, transposed)");
+        return SPI_OK;
+    }
     if (d->workspace && make_hconv(d, P, Wp) && d->workspace_bytes >= spi_hconv_workspace_bytes(Wp)) {
         SPI_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0, "spi_conv2d_fwd: workspace must be 16-byte aligned");
         rc = spi_hconv_launch(Wp, x, w, y, ep, d->workspace, as_stream(stream), d->workspace_ready != 0); if (rc) return rc;

@@ -533,6 +533,252 @@ __global__ void __launch_bounds__(HC_NT, 2) hconv_s2_kernel(HConvS2Params P, con
 }
 
 // =====================================================================================================================================
+// ... and for the FORWARD of that stride-2 transposed 3x3 conv (out[o, 2y+ky, 2x+kx] += x[i,y,x] W[o,i,ky,kx]; conv2d_resample.py:114-131).  Output
+// parity class (py, px) at class position (Y, X):  out[o, 2Y+py, 2X+px] = sum_{a in A(py), b in B(px)} x[i, Y-a, X-b] W[o,i,py+2a,px+2b],
+// A(0) = B(0) = {0, 1}, A(1) = B(1) = {0}: 4 + 2 + 2 + 1 = 9 taps per position, no multiplication by an inserted zero.  The implicit GEMM runs
+// the four classes as separate sets of blocks: the two x-parity classes write the ALTERNATE pixels of the same 128-byte lines from different
+// blocks -- a third of its time is those stores.  Here a launch handles one row parity PY; a block owns 8 class rows x 32 class
+// columns x 128 output channels and BOTH x-parity classes (a wave: 4 rows x 32 columns x 32 channels x 2 classes = 128 accumulators), i.e. whole
+// 64-pixel runs of 8 output rows: the two classes are interleaved on their way through LDS and leave as 16-byte pieces.  32-channel chunks
+// (36 / 18 MFMAs per wave and barrier); the 9 x 33 input patch of a chunk is staged once for all taps.
+constexpr int T2_TY = 8, T2_TX = 32, T2_KC = 32, T2_G = T2_KC / 8;
+constexpr int T2_IY = T2_TY + 1, T2_IX = T2_TX + 1;
+constexpr int T2_IN_CELLS = T2_G * T2_IY * T2_IX;                       // 1188
+constexpr int T2_IN_PASSES = (T2_IN_CELLS + HC_NT - 1) / HC_NT;         // 3
+constexpr int T2_OST = T2_TY * 2 * T2_TX + 8;                           // halves per output channel of the epilogue tile (8 rows x 64 pixels, + 16 bytes)
+template <int PY> struct T2Cfg {
+    static constexpr int NA = PY == 0 ? 2 : 1;                          // row taps (a)
+    static constexpr int WT_CELLS = NA * 3 * T2_G * HC_BM;              // weight cells per chunk: [a][kx][g][co]
+    static constexpr int WT_PASSES = (WT_CELLS + HC_NT - 1) / HC_NT;    // 6 / 3
+    static constexpr int BUF_CELLS = T2_IN_CELLS + WT_CELLS;
+    static constexpr int LDS_BYTES = (2 * BUF_CELLS * 16 > HC_BM * T2_OST * 2) ? 2 * BUF_CELLS * 16 : HC_BM * T2_OST * 2;
+};
+
+struct HConvT2Params {
+    int N, nw, Mo, Ci, H, W, OH, OW;    // input H x W, output OH x OW (= 2H+1, 2W+1)
+    int tx, ty;
+    int64_t in_bs, out_bs;
+    const int32_t* out_flags; int nseg; // needed-output map over flat OUTPUT pixels / 16 (or NULL)
+};
+
+// weights -> the fp16 LDS images of both row parities: [nw][mb][py: 6 | 3 taps][chunk][a][kx][g][co][8]  (all of py = 0 first within (nw, mb))
+__global__ void __launch_bounds__(256) hconv_t2_weight_kernel(WinoParams P, const float* __restrict__ w, u32x4_t* __restrict__ img, int64_t cells) {
+    const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= cells) return;
+    const int nchunk = P.Ci / T2_KC;
+    const int64_t per_mb = (int64_t)9 * T2_G * HC_BM * nchunk;          // cells of one (nw, mb): py = 0 (6 taps) then py = 1 (3 taps)
+    const int64_t r = id % per_mb;
+    const int64_t mbn = id / per_mb;
+    const int mb = (int)(mbn % (P.Mo / HC_BM)), nwi = (int)(mbn / (P.Mo / HC_BM));
+    const int64_t n0 = (int64_t)6 * T2_G * HC_BM * nchunk;
+    const int py = r < n0 ? 0 : 1;
+    const int64_t q = py ? r - n0 : r;
+    const int na3 = py ? 3 : 6;
+    const int co = (int)(q % HC_BM), g = (int)((q / HC_BM) % T2_G), tap = (int)((q / (T2_G * HC_BM)) % na3), c = (int)(q / ((int64_t)na3 * T2_G * HC_BM));
+    const int a = tap / 3, kx = tap % 3, ky = py + 2 * a;
+    const float* src = w + (int64_t)nwi * P.wbs + (int64_t)(mb * HC_BM + co) * P.wsm + (int64_t)(c * T2_KC + g * 8) * P.wsc + P.widx[ky * 3 + kx];
+    half8_t h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (_Float16)src[(int64_t)j * P.wsc];
+    img[id] = __builtin_bit_cast(u32x4_t, h);
+}
+
+struct __attribute__((packed, aligned(2))) T2Piece { unsigned short h[8]; };       // a 16-byte store at 2-byte alignment (output rows are 2 OW bytes long, OW odd)
+
+template <int PY>
+__device__ __forceinline__ void hconv_t2_body(const HConvT2Params& P, const _Float16* __restrict__ in, const u32x4_t* __restrict__ wimg,
+                                              _Float16* __restrict__ out, u32x4_t* smem, int bx) {
+    using Cfg = T2Cfg<PY>;
+    constexpr int NA = Cfg::NA;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fk = lane >> 5;
+    const int rg = wave & 1, cg = wave >> 1;
+    const int ntile = P.tx * P.ty;
+    if ((ntile & 7) == 0) bx = (bx & 7) * (ntile >> 3) + (bx >> 3);
+    const int tyi = bx / P.tx, txi = bx - tyi * P.tx;
+    const int y0 = tyi * T2_TY, x0 = txi * T2_TX;                        // class coordinates
+    const int mb = blockIdx.y, n = blockIdx.z;
+    const int HW = P.H * P.W;
+    const int64_t OHW = (int64_t)P.OH * P.OW;
+    _Float16* ob = out + (int64_t)n * P.out_bs + (int64_t)mb * HC_BM * OHW;
+    const int nrow = (P.OH - PY + 1) / 2;                               // class rows of this parity
+    if (y0 >= nrow) return;
+
+    if (P.out_flags) {                                                  // needed-output map: a tile nobody needs is written as zeros
+        const int32_t* fl = P.out_flags + (int64_t)n * P.nseg;
+        const int xa = 2 * x0, xb = min(2 * x0 + 2 * T2_TX - 1, P.OW - 1);
+        int any = 0;
+        for (int idx = tid; idx < T2_TY * 8; idx += HC_NT) {
+            const int yo = 2 * (y0 + (idx >> 3)) + PY;
+            if (yo < P.OH) {
+                const int sg = ((yo * P.OW + xa) >> 4) + (idx & 7);
+                if (sg <= ((yo * P.OW + xb) >> 4)) any |= fl[sg];
+            }
+        }
+        if (!__syncthreads_or(any)) {
+            for (int e = tid; e < HC_BM * T2_TY * 2 * T2_TX; e += HC_NT) {
+                const int x = e % (2 * T2_TX), r = (e / (2 * T2_TX)) % T2_TY, m = e / (T2_TY * 2 * T2_TX);
+                const int yo = 2 * (y0 + r) + PY, xo = 2 * x0 + x;
+                if (yo < P.OH && xo < P.OW) ob[(int64_t)m * OHW + (int64_t)yo * P.OW + xo] = (_Float16)0.f;
+            }
+            return;
+        }
+    }
+
+    auto in_buf = [&](int b) __attribute__((always_inline)) { return smem + b * Cfg::BUF_CELLS; };
+    auto wt_buf = [&](int b) __attribute__((always_inline)) { return smem + b * Cfg::BUF_CELLS + T2_IN_CELLS; };
+    const _Float16* inb = in + (int64_t)n * P.in_bs;
+    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(inb, P.in_bs * 2);
+    unsigned ivoff[T2_IN_PASSES];
+#pragma unroll
+    for (int p = 0; p < T2_IN_PASSES; ++p) {
+        const int cell = tid + p * HC_NT;
+        const int g = cell / (T2_IY * T2_IX), rem = cell - g * (T2_IY * T2_IX);
+        const int pr = rem / T2_IX, pc = rem - pr * T2_IX;
+        const int iy = y0 - 1 + pr, ix = x0 - 1 + pc;
+        const bool ok = cell < T2_IN_CELLS && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W;
+        ivoff[p] = ok ? (unsigned)((g * 8 * HW + iy * P.W + ix) * 2) : BUF_OOB;
+    }
+    const int nchunk = P.Ci / T2_KC;
+    const int nwi = P.nw > 1 ? n : 0;
+    const int64_t per_mb = (int64_t)9 * T2_G * HC_BM * nchunk;
+    const u32x4_t* wbase = wimg + ((int64_t)nwi * (P.Mo / HC_BM) + mb) * per_mb + (PY ? (int64_t)6 * T2_G * HC_BM * nchunk : 0);
+    const int chs2 = __builtin_amdgcn_readfirstlane(HW * 2);
+
+    unsigned xr[T2_IN_PASSES][8];
+    u32x4_t wr[Cfg::WT_PASSES];
+    auto issue = [&](int c) __attribute__((always_inline)) {
+        c = min(c, nchunk - 1);
+        const int soff0 = __builtin_amdgcn_readfirstlane(c * T2_KC * chs2);
+#pragma unroll
+        for (int p = 0; p < T2_IN_PASSES; ++p)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                xr[p][j] = __builtin_bit_cast(unsigned short, __builtin_amdgcn_raw_buffer_load_b16(rsI, (int)ivoff[p], soff0 + j * chs2, 0));
+        const u32x4_t* wp = wbase + (int64_t)c * Cfg::WT_CELLS;
+#pragma unroll
+        for (int p = 0; p < Cfg::WT_PASSES; ++p) wr[p] = wp[min(tid + p * HC_NT, Cfg::WT_CELLS - 1)];
+    };
+    auto commit = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < T2_IN_PASSES; ++p) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(xr[p][j]));
+            const u32x4_t v = {xr[p][0] | (xr[p][1] << 16), xr[p][2] | (xr[p][3] << 16), xr[p][4] | (xr[p][5] << 16), xr[p][6] | (xr[p][7] << 16)};
+            if ((p + 1) * HC_NT <= T2_IN_CELLS || tid + p * HC_NT < T2_IN_CELLS) in_buf(buf)[tid + p * HC_NT] = v;
+        }
+#pragma unroll
+        for (int p = 0; p < Cfg::WT_PASSES; ++p)
+            if ((p + 1) * HC_NT <= Cfg::WT_CELLS || tid + p * HC_NT < Cfg::WT_CELLS) wt_buf(buf)[tid + p * HC_NT] = wr[p];
+    };
+
+    f32x16 acc[2][4];                                                    // [x parity][row]
+#pragma unroll
+    for (int pxc = 0; pxc < 2; ++pxc)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[pxc][r][q] = 0.f;
+
+    // one K = 16 half of a chunk (channel groups 2 kk + fk) and one column shift b: patch rows rg*4 + r + 1 - a at column fr + 1 - b;
+    // b = 0 feeds kx = 0 (x parity 0) and kx = 1 (x parity 1), b = 1 feeds kx = 2 (x parity 0)
+    auto step = [&](int buf, int kk, int b) __attribute__((always_inline)) {
+        const half8_t* I = reinterpret_cast<const half8_t*>(in_buf(buf)) + ((2 * kk + fk) * T2_IY + rg * 4) * T2_IX + fr + 1 - b;
+        const half8_t* Wt = reinterpret_cast<const half8_t*>(wt_buf(buf)) + (2 * kk + fk) * HC_BM + cg * 32 + fr;
+        half8_t xf[3 + NA];
+#pragma unroll
+        for (int q = 0; q < 3 + NA; ++q) xf[q] = I[(q + 2 - NA) * T2_IX];          // patch rows rg*4 + (2 - NA) .. rg*4 + 4
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            if (b == 0) {
+                const half8_t w0 = Wt[((a * 3 + 0) * T2_G) * HC_BM], w1 = Wt[((a * 3 + 1) * T2_G) * HC_BM];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const half8_t x = xf[r + 1 - a - (2 - NA)];
+                    acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w0, acc[0][r], 0, 0, 0);
+                    acc[1][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, w1, acc[1][r], 0, 0, 0);
+                }
+            } else {
+                const half8_t w2 = Wt[((a * 3 + 2) * T2_G) * HC_BM];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[0][r] = __builtin_amdgcn_mfma_f32_32x32x16_f16(xf[r + 1 - a - (2 - NA)], w2, acc[0][r], 0, 0, 0);
+            }
+        }
+    };
+#define HC_FENCE() do { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+    issue(0);
+    commit(0);
+    if (nchunk > 1) issue(1);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        step(buf, 0, 0);
+        HC_FENCE();
+        if (c + 1 < nchunk) commit(buf ^ 1);
+        HC_FENCE();
+        step(buf, 0, 1);
+        step(buf, 1, 0);
+        HC_FENCE();
+        if (c + 2 < nchunk) issue(c + 2);
+        HC_FENCE();
+        step(buf, 1, 1);
+        __syncthreads();
+    }
+#undef HC_FENCE
+
+    // ---- epilogue (no fused tail in transposed mode: the FIR pass owns it): round once; the two x-parity classes are interleaved into whole output
+    //      rows in LDS ([channel][8 rows][64 pixels]) and leave in 16-byte pieces
+    _Float16* Ot = reinterpret_cast<_Float16*>(smem);
+    {
+        const int co = cg * 32 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            _Float16* dst = Ot + co * T2_OST + (rg * 4 + r) * 2 * T2_TX + 8 * fk;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                half8_t h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { h[2 * e] = (_Float16)acc[0][r][qq * 4 + e]; h[2 * e + 1] = (_Float16)acc[1][r][qq * 4 + e]; }
+                *reinterpret_cast<half8_t*>(dst + 16 * qq) = h;
+            }
+        }
+    }
+    __syncthreads();
+    {
+#pragma unroll 4
+        for (int k = 0; k < HC_BM * T2_TY * (2 * T2_TX / 8) / HC_NT; ++k) {
+            const int id = tid + k * HC_NT;
+            const int xq = id & 7, row = (id >> 3) & (T2_TY - 1), co = id >> 6;
+            const int yo = 2 * (y0 + row) + PY, xo = 2 * x0 + xq * 8;
+            const T2Piece v = __builtin_bit_cast(T2Piece, *reinterpret_cast<const u32x4_t*>(Ot + co * T2_OST + row * 2 * T2_TX + xq * 8));
+            if (yo < P.OH && xo < P.OW) {
+                _Float16* dst = ob + (int64_t)co * OHW + (int64_t)yo * P.OW + xo;
+                if (xo + 8 <= P.OW) {
+                    // one 16-byte store at 2-byte alignment (rows are 2 OW bytes, OW odd): the compiler splits a store it knows to be unaligned into
+                    // eight 2-byte ones; the hardware (unaligned access mode, the Linux default) takes it whole
+                    const u32x4_t vv = __builtin_bit_cast(u32x4_t, v);
+                    asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(vv) : "memory");
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (xo + e < P.OW) dst[e] = __builtin_bit_cast(_Float16, v.h[e]);
+                }
+            }
+        }
+    }
+}
+
+// one launch for both row parities: the first gridDim.x / 2 blocks take the even output rows (6 taps: twice the work), the rest the odd ones
+__global__ void __launch_bounds__(HC_NT, 2) hconv_t2_kernel(HConvT2Params P, const _Float16* __restrict__ in, const u32x4_t* __restrict__ wimg,
+                                                            _Float16* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) u32x4_t smem[T2Cfg<0>::LDS_BYTES / 16];
+    static_assert(T2Cfg<0>::LDS_BYTES >= T2Cfg<1>::LDS_BYTES, "one LDS block serves both parities");
+    const int ntile = P.tx * P.ty;
+    if ((int)blockIdx.x < ntile) hconv_t2_body<0>(P, in, wimg, out, smem, (int)blockIdx.x);
+    else hconv_t2_body<1>(P, in, wimg, out, smem, (int)blockIdx.x - ntile);
+}
+
+// =====================================================================================================================================
 // Direct fp16 weight gradient of the same layers: dW[co][tap][ci] += sum_pixels dy[co][y][x] * x[ci][y + ky - 1][x + kx - 1].
 // GEMM per tap: m = output channel, n = input channel, K = pixels -- and in NCHW eight consecutive pixels of one channel ARE the 16 bytes an MFMA
 // operand lane holds: both tiles go to LDS as straight 16-byte copies (no transpose, no conversion).  The implicit-GEMM wgrad_kernel stages
@@ -825,5 +1071,28 @@ int spi_hconv_s2_launch(const WinoParams& Wp, int IH, int IW, const void* in, co
     }
     dim3 grid((unsigned)(P.tx * P.ty), (unsigned)(Wp.Mo / HC_BM), (unsigned)Wp.N);
     hipLaunchKernelGGL(hconv_s2_kernel, grid, dim3(HC_NT), 0, st, P, static_cast<const _Float16*>(in), img, static_cast<_Float16*>(out));
+    return SPI_OK;
+}
+
+// ---- forward of a stride-2 transposed 3x3 conv: Wp.H x Wp.W = INPUT, Wp.Mo / Ci = output / input channels, widx[ky * 3 + kx]
+bool spi_hconv_t2_eligible(const WinoParams& P) {
+    const int oh = 2 * P.H + 1, ow = 2 * P.W + 1;
+    const int64_t blocks = (int64_t)(((ow + 1) / 2 + T2_TX - 1) / T2_TX) * (((oh + 1) / 2 + T2_TY - 1) / T2_TY) * (P.Mo / HC_BM) * P.N;
+    return P.Mo % HC_BM == 0 && P.Ci % T2_KC == 0 && P.in_bs * 2 < (1ll << 31) && P.out_bs * 2 < (1ll << 31) && blocks >= 128 && !P.seg_flags;
+}
+
+int spi_hconv_t2_launch(const WinoParams& Wp, const void* in, const float* w, void* out, void* workspace, hipStream_t st, bool img_ready) {
+    HConvT2Params P;
+    P.N = Wp.N; P.nw = Wp.nw; P.Mo = Wp.Mo; P.Ci = Wp.Ci; P.H = Wp.H; P.W = Wp.W; P.OH = 2 * Wp.H + 1; P.OW = 2 * Wp.W + 1;
+    P.tx = ((P.OW + 1) / 2 + T2_TX - 1) / T2_TX; P.ty = ((P.OH + 1) / 2 + T2_TY - 1) / T2_TY;
+    P.in_bs = Wp.in_bs; P.out_bs = Wp.out_bs;
+    P.out_flags = Wp.out_flags; P.nseg = Wp.nseg;
+    u32x4_t* img = static_cast<u32x4_t*>(workspace);
+    if (!img_ready) {
+        const int64_t cells = (int64_t)Wp.nw * Wp.Mo * Wp.Ci * 9 / 8;
+        hipLaunchKernelGGL(hconv_t2_weight_kernel, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, Wp, w, img, cells);
+    }
+    dim3 grid((unsigned)(2 * P.tx * P.ty), (unsigned)(Wp.Mo / HC_BM), (unsigned)Wp.N);
+    hipLaunchKernelGGL(hconv_t2_kernel, grid, dim3(HC_NT), 0, st, P, static_cast<const _Float16*>(in), img, static_cast<_Float16*>(out));
     return SPI_OK;
 }

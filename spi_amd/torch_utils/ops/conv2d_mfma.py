@@ -101,8 +101,8 @@ def _workspace(d, pass_id, device, w=None, frozen=False):
     `w` + `frozen` (shared weights that take no gradient): the transformed weights are cached across calls, see `_frozen_ws`."""
     from ...configs import global_config
     direct_f16 = d.compute_f16 == 1 and d.act_dtype == 1 and global_config.conv_direct_fp16     # hconv.hip: fp16 tensors, 3x3, stride 1
-    # (a transposed conv has a direct kernel for its data gradient only: a stride-2 conv of the fp16 gradient)
-    if d.kh != 3 or (d.transposed and not (direct_f16 and pass_id == 1)) or not (direct_f16 or (global_config.conv_winograd and d.compute_f16 in (0, 3))):
+    # (a transposed conv has direct kernels for its forward and its data gradient -- a stride-2 conv of the fp16 gradient --, not for its weight gradient)
+    if d.kh != 3 or (d.transposed and not (direct_f16 and pass_id < 2)) or not (direct_f16 or (global_config.conv_winograd and d.compute_f16 in (0, 3))):
         return None
     nbytes = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), pass_id)
     if nbytes <= 0:

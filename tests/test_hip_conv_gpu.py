@@ -174,8 +174,9 @@ def test_conv2d_fp16_operands_vs_rounded_reference(n, i, o, h, k, transposed):
 
 
 @pytest.mark.parametrize('n,i,o,h,k,transposed', [(2, 32, 48, 24, 3, False), (1, 64, 128, 40, 3, False), (2, 16, 3, 33, 1, False), (1, 32, 64, 12, 3, True),
-                                                  (1, 128, 128, 128, 3, False), (2, 32, 256, 125, 3, False), (2, 128, 256, 128, 3, False), (2, 128, 32, 128, 3, True)])
-# (the last three: hconv.hip forward (+ dgrad); the transposed one: its stride-2 data-gradient kernel)
+                                                  (1, 128, 128, 128, 3, False), (2, 32, 256, 125, 3, False), (2, 128, 256, 128, 3, False), (2, 128, 32, 128, 3, True),
+                                                  (2, 32, 128, 120, 3, True)])
+# (the last four: hconv.hip forward (+ dgrad); the transposed ones: the stride-2 data-gradient kernel / the transposed forward kernel)
 def test_conv2d_fp16_tensors_vs_rounded_reference(n, i, o, h, k, transposed):
     """fp16 ACTIVATION TENSORS (round 5, spi_conv_desc.act_dtype; the reference's use_fp16 blocks, networks_stylegan2.py:421-436): x, y, dy, dx are
     half tensors in HBM, weights / weight gradients fp32, fp32 accumulation.  Every pass equals the fp64 convolution of the fp16-rounded
@@ -340,6 +341,49 @@ def test_direct_fp16_stride2_dgrad_of_transposed_conv(n, i, o, h, wd, shared):
                 assert float(gs.float().abs().max()) == 0
     finally:
         conv2d_mfma.SPARSE_MIN_PIXELS = old_min
+
+
+@pytest.mark.parametrize('n,i,o,h,wd,shared', [(2, 32, 128, 120, 136, False), (1, 64, 256, 128, 128, True)])
+def test_direct_fp16_transposed_forward(n, i, o, h, wd, shared):
+    """hconv_t2_kernel: the forward of a stride-2 transposed 3x3 conv on fp16 tensors (both x-parity classes in one block, whole output rows, 16-byte
+    stores at 2-byte alignment).  The plan names it; equal to the implicit GEMM up to one fp16 ulp on a few elements, ragged class grids included
+    (2H+1 is odd); needed-output maps skip tiles and leave the flagged pixels bit-identical."""
+    import ctypes
+    from spi_amd import hip
+    from spi_amd.configs import global_config
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    gen = torch.Generator().manual_seed(n * 10 + i)
+    x = torch.randn(n, i, h, wd, generator=gen).half().to(DEV)
+    w = (torch.randn(*(() if shared else (n,)), o, i, 3, 3, generator=gen) / (i * 9) ** 0.5).to(DEV)
+    d = conv2d_mfma._desc(n, i, o, h, wd, 3, 0, True, False, 0 if shared else o * i * 9, tap_major=1, f16=True, half=True)
+    ws = conv2d_mfma._workspace(d, 0, x.device)
+    plan = (ctypes.c_int32 * 8)()
+    hip.call('spi_conv2d_plan', ctypes.byref(d), 0, plan)
+    assert ws is not None and plan[0] == 2, list(plan)
+
+    def run(direct, needed=None):
+        old = global_config.conv_direct_fp16
+        global_config.conv_direct_fp16 = direct
+        try:
+            with conv2d_mfma.needed_output(needed):
+                return conv2d_mfma.conv2d(x, w, transposed=True, fp16=True, sparse_grad=True)
+        finally:
+            global_config.conv_direct_fp16 = old
+    ya, yb = run(True), run(False)
+    assert ya.dtype == torch.float16 and tuple(ya.shape) == (n, o, 2 * h + 1, 2 * wd + 1)
+    a, b = ya.float(), yb.float()
+    ulp = torch.ldexp(torch.ones_like(b), torch.floor(torch.log2(b.abs().clamp_min(6.1e-5))).to(torch.int32) - 10)
+    e = ((a - b).abs() - 2e-5 * b.abs().max()).clamp_min(0) / ulp
+    assert float(e.max()) <= 1.0 and float((e > 0).float().mean()) < 2e-2, (float(e.max()), float((e > 0).float().mean()))
+    oh, ow = 2 * h + 1, 2 * wd + 1
+    for kind in ('box', 'blobs', 'pixel', 'empty'):
+        m = (_masked_gradient((n, 1, oh, ow), gen, kind) != 0).to(DEV)
+        yn = run(True, needed={(oh, ow): conv2d_mfma.seg_flags(m.float())})
+        assert torch.equal(yn * m, ya * m), kind
+        if kind == 'empty':
+            assert float(yn.float().abs().max()) == 0
+        if kind == 'box':
+            assert float((yn == 0).float().mean()) > 0.3
 
 
 def test_direct_fp16_wgrad_partial_sums_and_atomics_agree_through_the_c_abi():
