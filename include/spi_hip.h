@@ -356,8 +356,9 @@ typedef struct spi_conv_desc {
      * compute_f16 = 0 and 3 (the 6-product split asks for fp32-equivalent products, which fp32 Winograd delivers faster on these layers).
      * fp16 activation tensors (act_dtype = SPI_DTYPE_F16, compute_f16 = 1): the same opt-in selects the DIRECT fp16 kernels for 3x3 / stride-1 / pad-1
      * layers -- forward / dgrad (output channels a multiple of 128, reduction channels a multiple of 16, at least 128 tiles of 16 x 32 pixels): the
-     * workspace receives the weights converted to fp16 in their LDS layout (`workspace_ready` applies); the data gradient of a stride-2 TRANSPOSED 3x3
-     * conv (a stride-2 conv of the gradient; input channels a multiple of 128) likewise; weight gradient (128 | O, 64 | I, 32 | W,
+     * workspace receives the weights converted to fp16 in their LDS layout (`workspace_ready` applies); the forward of a stride-2 TRANSPOSED 3x3
+     * conv (output channels a multiple of 128, input channels of 32) and its data gradient (a stride-2 conv of the gradient; input channels a multiple
+     * of 128) likewise; weight gradient (128 | O, 64 | I, 32 | W,
      * 4 | H, no dy_seg_flags): the workspace receives one partial sum per workgroup and dw is OVERWRITTEN with their sum (deterministic); a smaller
      * non-null workspace still selects the kernel, which then adds into the zeroed dw with fp32 atomics.  Same products and fp32 accumulation as the
      * implicit GEMM, another summation order. */

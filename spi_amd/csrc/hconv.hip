@@ -1,3 +1,5 @@
+// (this file: hconv_kernel -- stride-1 forward / dgrad; hconv_s2_kernel -- stride-2 conv = dgrad of the transposed conv0; hconv_t2_kernel -- forward of the
+//  transposed conv0; hwgrad_kernel -- stride-1 weight gradient; all for fp16 activation tensors, the use_fp16 super-resolution blocks of configs[4])
 // Direct 3x3 (stride 1, pad 1) convolution of fp16 activation tensors on v_mfma_f32_32x32x16_f16 -- the forward and data-gradient passes of the
 // use_fp16 super-resolution blocks' conv1 layers (eg3d/training/networks_stylegan2.py:421-436, superresolution.py:271-277; BASELINE configs[4]).
 //
