@@ -1119,7 +1119,8 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
     const int cfg = plan.cfg, nsplit = plan.nsplit;
     if (ioh) {
         // fp16 activation tensors exist on the buffer-descriptor path of the fp16 operand mode only (whole 16-channel slabs, < 2 GiB per sample)
-        SPI_REQUIRE(f16 == 1 && nsplit == 1 && (P.Ci % BK == 0) && (P.in_bs * 2 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31)),
+        // (the same size predicate as plan_igemm's `f16_ok` and launch_igemm's `buf`: a sample that passes here takes the buffer-descriptor kernel)
+        SPI_REQUIRE(f16 == 1 && nsplit == 1 && (P.Ci % BK == 0) && (P.in_bs * 4 < (1ll << 31)) && (P.w_elems * 4 < (1ll << 31)),
                     "spi_conv2d: act_dtype = fp16 needs compute_f16 = 1 and a reduction channel count that is a multiple of 16 (got %d)", P.Ci);
     }
     if (nsplit > 1 && !out_zeroed) {

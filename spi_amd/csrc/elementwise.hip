@@ -1471,7 +1471,11 @@ static int tail_bwd_launch(const T* dy, const T* y, T* dz, float* d_bias, float*
     int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? pix_cap : 1024)));
     if (zd.out) splits = std::max(splits, (int)(((int64_t)C * N + 2047) / 2048));   // ZDot: cchunk * N <= 2048 (LDS partials per (n, c))
     SPI_REQUIRE(!zd.out || N <= 2048, "spi_tail_bwd_dot: batch too large");
-    const int cchunk = (C + splits - 1) / splits;                     // <= 512 (LDS partials)
+    // (the dot product divides by the activation's slope to reconstruct the conv result: same condition as spi_chan_dot)
+    SPI_REQUIRE(!zd.out || ((act == SPI_ACT_LINEAR || act == SPI_ACT_LRELU) && (act != SPI_ACT_LRELU || alpha != 0.f)),
+                "spi_tail_bwd_dot: only linear / lrelu (alpha != 0) outputs can be inverted");
+    int cchunk = (C + splits - 1) / splits;                           // <= 512 (LDS partials)
+    if (zd.out) cchunk = std::min(cchunk, std::max(1, 2048 / N));    // ceil(C / ceil(C N / 2048)) can exceed 2048 / N (C = 5, N = 1500): clamp, then recount
     splits = (C + cchunk - 1) / cchunk;
     if (zd.out) {
         if (vec) hipLaunchKernelGGL((tail_bwd_kernel<4, T, true>), dim3(gx, (unsigned)splits), dim3(256), 0, as_stream(stream), dy, y, dz, d_bias, d_pixsum, noise, d_strength, N, C, HW, cchunk, ap, zd);

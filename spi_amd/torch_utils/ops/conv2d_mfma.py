@@ -89,6 +89,16 @@ def _desc(n, i, o, h, w, k, pad, transposed, flip, wbs, bias=None, noise=None, n
 # The workspace of such a conv is kept per (weight tensor, pass) and handed back with `workspace_ready = 1` (round 5); an in-place update of the
 # weights (`_version`) or another tensor at the same address drops it.
 _frozen_ws = {}
+_FROZEN_SWEEP_AT = 512
+_pinned_retired = []
+
+
+def _sweep_frozen():
+    """Drop the entries whose weight tensor is gone and whose workspace no captured launch has been handed (`pinned`).  Nothing else is ever
+    freed: a live graph replays `workspace_ready = 1` launches that read the workspace by address (clearing the whole table, or
+    replacing an entry after an in-place weight update, left such graphs reading freed memory)."""
+    for key in [k for k, e in _frozen_ws.items() if e[2]() is None and not e[3]]:
+        del _frozen_ws[key]
 
 
 def _frozen_key(w, pass_id, d):
@@ -110,16 +120,28 @@ def _workspace(d, pass_id, device, w=None, frozen=False):
     if frozen and w is not None and pass_id < 2 and d.w_batch_stride == 0:
         key = _frozen_key(w, pass_id, d)
         hit = _frozen_ws.get(key)
+        capturing = torch.cuda.is_current_stream_capturing()
         # (the entry holds a weak reference to the tensor OBJECT: a temporary -- e.g. a freshly modulated weight under no_grad -- dies, and the
         #  next temporary of that shape that the caching allocator puts at the same address must not inherit its transform)
-        if hit is not None and hit[2]() is w and hit[0] == w._version and hit[1].numel() == nbytes:
-            d.workspace, d.workspace_bytes, d.workspace_ready = hit[1].data_ptr(), nbytes, 1
+        if hit is not None and hit[2]() is w and hit[1].numel() == nbytes:
+            # A workspace that was handed to a CAPTURED launch with `workspace_ready = 1` is baked into that graph by address: it is pinned
+            # (never freed, never replaced) from then on.  An in-place update of the weights re-transforms INTO the same workspace -- graphs
+            # that skip the transform then read the current weights' transform, which is what an eager call would compute.
+            if capturing:
+                hit[3] = True
+            d.workspace, d.workspace_bytes = hit[1].data_ptr(), nbytes
+            if hit[0] == w._version:
+                d.workspace_ready = 1
+            else:
+                hit[0] = w._version
             return hit[1]
-        if not torch.cuda.is_current_stream_capturing():       # (a workspace born inside a capture lives in the graph's pool: not cacheable)
-            if len(_frozen_ws) > 512:
-                _frozen_ws.clear()
+        if not capturing:       # (a workspace born inside a capture lives in the graph's pool: not cacheable)
+            if len(_frozen_ws) > _FROZEN_SWEEP_AT:
+                _sweep_frozen()
+            if hit is not None and hit[3]:
+                _pinned_retired.append(hit[1])      # (a dead tensor's entry whose workspace a graph still reads: the key is reused, the memory is not)
             ws = torch.empty(nbytes, device=device, dtype=torch.uint8)
-            _frozen_ws[key] = (w._version, ws, weakref.ref(w))
+            _frozen_ws[key] = [w._version, ws, weakref.ref(w), False]
             d.workspace, d.workspace_bytes = ws.data_ptr(), nbytes
             return ws
     ws = torch.empty(nbytes, device=device, dtype=torch.uint8)

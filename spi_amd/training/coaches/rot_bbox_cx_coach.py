@@ -113,15 +113,20 @@ class RotBboxCoach(BaseCoach):
         else:
             with torch.no_grad():
                 buf.copy_(w_pivot.detach())
+        self._refresh_frozen_planes(ctx, buf)
+        return buf
+
+    def _refresh_frozen_planes(self, ctx, w_pivot):
+        """The frozen generator's tri-planes for `w_pivot`, written into the tensor a captured depth branch reads (only when the ctx says they are
+        stale: `_adopt_ctx` clears `stable_planes_cached` for every new image)."""
         planes = getattr(self, '_frozen_planes_buf', None)
         if planes is not None and not ctx.get('stable_planes_cached', False) and hyperparameters.pt_depth_lambda > 0:
             with torch.no_grad():
-                fresh = self.original_G._planes(buf, noise_mode='const')
+                fresh = self.original_G._planes(w_pivot, noise_mode='const')
                 if fresh.shape == planes.shape:
                     planes.copy_(fresh)
                     self.original_G._last_planes = planes
                     ctx['stable_planes_cached'] = True
-        return buf
 
     def _next_generation(self):
         self._generation = getattr(self, '_generation', 0) + 1
@@ -243,6 +248,11 @@ class RotBboxCoach(BaseCoach):
             self._late_stop = late
             return True, late[1]
         steps_before = self.optimizer.step_count
+        # A caller that drives train_step itself after a second prepare_image (bench.py, tools) never went through optimise_image's
+        # _bind_pivot: the persistent ctx then says the frozen tri-planes are stale while the captured depth branch would still read the
+        # previous image's.  Refresh them here, before the first replay that needs them.
+        if ctx is getattr(self, '_ctx_persist', None) and not ctx.get('stable_planes_cached', False) and i % self.rot_bs == 0:
+            self._refresh_frozen_planes(ctx, w_pivot.detach())
         st['graph'].replay()
         losses = {k: v.clone() for k, v in st['losses'].items()}  # the graph's outputs are overwritten by the next replay
         self.optimizer.step(skip=self._g2['stop'])               # predicated on the device: a stop of THIS iteration (or an earlier one) freezes it

@@ -926,8 +926,11 @@ def test_frozen_weight_winograd_transform_is_cached_and_follows_the_weights():
     y2, gx2 = run(w)                                                                 # served from the cache
     assert len(cm._frozen_ws) == 2
     assert torch.equal(y1, y_ref) and torch.equal(gx1, gx_ref) and torch.equal(y2, y_ref) and torch.equal(gx2, gx_ref)
+    addrs = sorted(e[1].data_ptr() for e in cm._frozen_ws.values())
     w.mul_(2.0)                                                                      # in-place update: the cached transform is stale
     y3, gx3 = run(w)
+    # ... and is redone INTO the same workspace: a graph that baked the address with workspace_ready = 1 keeps reading live memory
+    assert sorted(e[1].data_ptr() for e in cm._frozen_ws.values()) == addrs
     assert_close(y3, 2 * y_ref, 1e-6, 'cached transform after an in-place weight update') 
     assert_close(gx3, 2 * gx_ref, 1e-6, 'cached dgrad transform after an in-place weight update')
     y4, _ = run(w)
@@ -943,4 +946,43 @@ def test_frozen_weight_winograd_transform_is_cached_and_follows_the_weights():
     assert t.data_ptr() == addr or os.environ.get('SPI_EFENCE') == '1', 'the caching allocator was expected to reuse the block (test premise)'
     yb, _ = run(t)
     assert_close(yb, 6 * ya, 1e-6, 'a new tensor at a dead tensor\'s address')
+    # the sweep past the size limit drops dead tensors' entries only -- never a live tensor's, never one a captured launch was handed (pinned)
     cm._frozen_ws.clear()
+    run(w)
+    t = w * 0.25
+    run(t)
+    assert len(cm._frozen_ws) == 4
+    live = {k: e[1].data_ptr() for k, e in cm._frozen_ws.items() if e[2]() is w}
+    next(e for e in cm._frozen_ws.values() if e[2]() is t)[3] = True                 # as if a capture had been handed this workspace
+    del t
+    cm._sweep_frozen()
+    assert len(cm._frozen_ws) == 3 and all(cm._frozen_ws[k][1].data_ptr() == a for k, a in live.items())
+    assert sum(1 for e in cm._frozen_ws.values() if e[3]) == 1
+    cm._frozen_ws.clear()
+
+
+@pytest.mark.parametrize('half', [False, True])
+def test_conv2d_takes_channels_last_tensors_by_relayout(half):
+    """The reference's use_fp16 blocks hand conv2d_resample channels_last tensors (networks_stylegan2.py:424, conv2d_resample.py:31-43).  `spi_conv2d_*`
+    take dense NCHW (include/spi_hip.h at spi_conv_desc; INTEGRATION.md sections 1c / 4): the binding relayouts -- a channels_last input or output
+    gradient gives bit-identical results to the NCHW call, forward, data gradient and weight gradient, fp32 and fp16 activation tensors."""
+    from spi_amd.torch_utils.ops import conv2d_mfma as cm
+    gen = torch.Generator().manual_seed(5)
+    dt = torch.float16 if half else torch.float32
+    x = torch.randn(2, 32, 40, 44, generator=gen).to(DEV).to(dt)
+    w = (torch.randn(2, 48, 32, 3, 3, generator=gen) * 0.06).to(DEV)
+    dy = torch.randn(2, 48, 40, 44, generator=gen).to(DEV).to(dt)
+
+    def run(xin, dyin):
+        xin = xin.detach().requires_grad_(True)
+        wg = w.detach().requires_grad_(True)
+        y = cm.conv2d(xin, wg, padding=1, fp16=half)
+        gx, gw = torch.autograd.grad(y, [xin, wg], dyin)
+        return y, gx, gw
+    ref = run(x, dy)
+    xcl, dycl = x.contiguous(memory_format=torch.channels_last), dy.contiguous(memory_format=torch.channels_last)
+    assert not xcl.is_contiguous()
+    got = run(xcl, dycl)
+    assert ref[0].dtype == dt and got[0].dtype == dt
+    for a, b, name in zip(got, ref, ('y', 'dx', 'dw')):
+        assert torch.equal(a, b), name

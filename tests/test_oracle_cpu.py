@@ -219,6 +219,16 @@ def test_integration_doc_struct_matches_the_header():
     fields_h = re.search(r'typedef struct spi_conv_desc \{(.*?)\} spi_conv_desc;', open(os.path.join(ROOT, 'include', 'spi_hip.h')).read(), re.S).group(1)
     for name in (f[0] for f in hip.ConvDesc._fields_):
         assert re.search(r'\b%s\b' % name, fields_h), name
+    # the version literal the doc's binding asserts is the header's (round-5 review: the doc still said 10 at ABI 12)
+    header = open(os.path.join(ROOT, 'include', 'spi_hip.h')).read()
+    abi = int(re.search(r'#define SPI_ABI_VERSION (\d+)', header).group(1))
+    assert [int(v) for v in re.findall(r'spi_abi_version\(\) == (\d+)', doc)] == [abi] * len(re.findall(r'spi_abi_version\(\) == ', doc)) and 'spi_abi_version() == ' in doc
+    assert hip.ABI_VERSION == abi == hip.lib().spi_abi_version()
+    # ... and the construction example builds (keyword fields that exist)
+    ex = re.search(r'\nd = spi_conv_desc\((.*?)\)\n#', doc, re.S)
+    assert ex, 'construction example not found'
+    kw = re.findall(r'\b([A-Za-z_0-9]+)=', ex.group(1))
+    assert kw and set(kw) <= set(f[0] for f in hip.ConvDesc._fields_), kw
 
 
 def test_product_has_no_cpu_fallback():
