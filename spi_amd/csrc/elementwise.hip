@@ -1471,9 +1471,9 @@ static int tail_bwd_launch(const T* dy, const T* y, T* dz, float* d_bias, float*
     int splits = (int)std::min<int64_t>(C, std::max<int64_t>((C + 511) / 512, std::min<int64_t>(1024 / gx, d_pixsum ? pix_cap : 1024)));
     if (zd.out) splits = std::max(splits, (int)(((int64_t)C * N + 2047) / 2048));   // ZDot: cchunk * N <= 2048 (LDS partials per (n, c))
     SPI_REQUIRE(!zd.out || N <= 2048, "spi_tail_bwd_dot: batch too large");
-    // (the dot product divides by the activation's slope to reconstruct the conv result: same condition as spi_chan_dot)
-    SPI_REQUIRE(!zd.out || ((act == SPI_ACT_LINEAR || act == SPI_ACT_LRELU) && (act != SPI_ACT_LRELU || alpha != 0.f)),
-                "spi_tail_bwd_dot: only linear / lrelu (alpha != 0) outputs can be inverted");
+    // (the dot product reconstructs the conv result from y by dividing negative values by the slope: a leaky ReLU with slope 0 would form 0 * inf.
+    //  ReLU is fine -- dz is exactly 0 wherever y cannot be inverted)
+    SPI_REQUIRE(!zd.out || act != SPI_ACT_LRELU || alpha != 0.f, "spi_tail_bwd_dot: a leaky ReLU output with slope 0 cannot be inverted");
     int cchunk = (C + splits - 1) / splits;                           // <= 512 (LDS partials)
     if (zd.out) cchunk = std::min(cchunk, std::max(1, 2048 / N));    // ceil(C / ceil(C N / 2048)) can exceed 2048 / N (C = 5, N = 1500): clamp, then recount
     splits = (C + cchunk - 1) / cchunk;
