@@ -965,7 +965,7 @@ def test_frozen_weight_winograd_transform_is_cached_and_follows_the_weights():
 def test_conv2d_takes_channels_last_tensors_by_relayout(half):
     """The reference's use_fp16 blocks hand conv2d_resample channels_last tensors (networks_stylegan2.py:424, conv2d_resample.py:31-43).  `spi_conv2d_*`
     take dense NCHW (include/spi_hip.h at spi_conv_desc; INTEGRATION.md sections 1c / 4): the binding relayouts -- a channels_last input or output
-    gradient gives the NCHW call's results (forward and data gradient bit for bit, the weight gradient up to the order of its atomics), fp32 and fp16 activation tensors."""
+    gradient gives the NCHW call's results (up to the summation order of split-K atomics), fp32 and fp16 activation tensors."""
     from spi_amd.torch_utils.ops import conv2d_mfma as cm
     gen = torch.Generator().manual_seed(5)
     dt = torch.float16 if half else torch.float32
@@ -984,5 +984,9 @@ def test_conv2d_takes_channels_last_tensors_by_relayout(half):
     assert not xcl.is_contiguous()
     got = run(xcl, dycl)
     assert ref[0].dtype == dt and got[0].dtype == dt
-    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
-    assert_close(got[2], ref[2], 1e-6, 'dw')            # (split-K weight gradient: atomics, summation order differs run to run)
+    # (small grids take split-K with atomics: the summation order differs run to run, so the NCHW call is reproduced to a few fp32 roundings -- resp.
+    #  one fp16 rounding of them -- not bit for bit)
+    tol = 1e-3 if half else 1e-6
+    assert_close(got[0].float(), ref[0].float(), tol, 'y')
+    assert_close(got[1].float(), ref[1].float(), tol, 'dx')
+    assert_close(got[2], ref[2], 1e-6, 'dw')
