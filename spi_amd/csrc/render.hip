@@ -90,7 +90,9 @@ __global__ void relayout_kernel(const float* __restrict__ src, float* __restrict
 //   Phase B: one point per lane, decoder weights are wave-uniform -> scalar loads + v_fmac with an
 //   SGPR operand.  Outputs return through LDS so global stores are full lines again.
 // ------------------------------------------------------------------------------------------------
+static int g_spi_debug = 0;   // spi_debug_set: profiling experiments only
 constexpr int DT = 256;        // points per tile == threads per block
+constexpr int FWD_MFMA_GRID = 512;      // persistent blocks of decode_fwd_mfma_kernel: two per CU
 constexpr int FS = 36;         // LDS row stride (floats)
 constexpr int DEC_IN = 32, DEC_HID = 64, DEC_OUT = 33;
 
@@ -179,6 +181,7 @@ __device__ __forceinline__ int64_t out_row(const DecodeArgs& a, int64_t g) {
     return ray * a.out_S + a.out_off + (g - ray * a.S);
 }
 
+__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // C/D row of accumulator register r in half h
 constexpr float THIRD = 1.f / 3.f;        // the mean over the three planes (renderer.py:62-64)
 struct Corner { int x0, y0; float wx0, wx1, wy0, wy1; };
 
@@ -454,6 +457,186 @@ __global__ void __launch_bounds__(DT) decode_fwd_kernel(DecodeArgs a, const floa
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoder forward on the matrix cores (round 6): fp32 operands cut into three bf16 pieces, six piece products on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+//   decode_fwd_kernel above is vector-issue bound: ~1040 packed FMAs + ~460 other vector instructions per 32 points and wave,
+//   0.39 of the vector peak and 0.33 of the L2 gather rate at the same time (profiles/r05*, roofline_gather).  An fp32 MFMA does
+//   not help on gfx950 (v_mfma_f32_32x32x2_f32 shares the FP32 lanes with the VALU, 64 cycles for 4096 FLOP: the 96 MFMAs of a
+//   32-point tile are as long as the packed FMAs).  The bf16 pipe is 16x faster per instruction: a truncating three-way split
+//   x = x0 + x1 + x2 is EXACT for an fp32 number (3 x 8 mantissa bits), and the six products x0 y0, x0 y1, x1 y0, x0 y2, x1 y1,
+//   x2 y0 carry everything above 2^-24 |x y| -- the arithmetic is fp32's, not bf16's (conv.hip's split_bf16, NS = 3; same
+//   scheme as its `bf16x6` mode).  Per 32 points and wave: 48 MFMAs (32 cycles each) + ~270 vector instructions for the
+//   splits instead of ~1040 FMAs.
+//   Orientation: D[feature][point] -- the lane owns a point, the accumulator registers its features.  The accumulator layout
+//   of layer 1 (register r of half h = hidden row rowmap(r, h)) IS a valid B-operand layout of layer 2 once the reduction axis
+//   of W2 is enumerated in the same order (virtual k = 8 registers of a half): no transposition between the layers.
+//   The weights are split once per block into REGISTERS (24 fragments x 4 dwords; the kernel is persistent, two blocks per
+//   CU): the main loop reads nothing but its own points' 128-byte feature rows from LDS.
+//   The density row of W2 (one output) is a 32-term dot product per lane + one cross-half add on the vector ALUs.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+// eight fp32 -> three packed bf16x8 pieces (bit patterns; truncation: v == p0 + p1 + p2 exactly)
+__device__ __forceinline__ void split3_bf16x8(const float (&v)[8], u32x4_t (&p)[3]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = v[2 * i], x1 = v[2 * i + 1];
+        p[0][i] = __builtin_amdgcn_perm(__float_as_uint(x1), __float_as_uint(x0), 0x07060302u);
+        const float r0 = x0 - __uint_as_float(__float_as_uint(x0) & 0xffff0000u), r1 = x1 - __uint_as_float(__float_as_uint(x1) & 0xffff0000u);
+        p[1][i] = __builtin_amdgcn_perm(__float_as_uint(r1), __float_as_uint(r0), 0x07060302u);
+        const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u), s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+        p[2][i] = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+    }
+}
+#define SPI_MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, (a)), __builtin_bit_cast(bf16x8_t, (b)), (c), 0, 0, 0)
+// the six significant piece products of one K = 16 step, small terms first (conv.hip's mfma_split<3>)
+__device__ __forceinline__ f32x16_t mfma_split6(const u32x4_t (&a)[3], const u32x4_t (&b)[3], f32x16_t acc) {
+    acc = SPI_MFMA_BF16(a[2], b[0], acc);
+    acc = SPI_MFMA_BF16(a[0], b[2], acc);
+    acc = SPI_MFMA_BF16(a[1], b[1], acc);
+    acc = SPI_MFMA_BF16(a[1], b[0], acc);
+    acc = SPI_MFMA_BF16(a[0], b[1], acc);
+    acc = SPI_MFMA_BF16(a[0], b[0], acc);
+    return acc;
+}
+
+__global__ void __launch_bounds__(DT, 2) decode_fwd_mfma_kernel(DecodeArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                                const float* __restrict__ w2, const float* __restrict__ b2,
+                                                                float* __restrict__ rgb, float* __restrict__ sigma, int64_t tiles) {
+    __shared__ __attribute__((aligned(16))) float feat[DT * FS];          // rows [point][36]: features 0..31 | out row 32
+    __shared__ __attribute__((aligned(16))) float tab[2][80];             // per half h: b1[32 mt + rowmap(r, h)] (32) | W2[0][same] (32) | b2[1 + rowmap(r, h)] (16)
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, q = lane & 31, hh = lane >> 5;
+    const int64_t total = (int64_t)a.N * a.P;
+    if (t < 160) {
+        const int h = t / 80, e = t - h * 80;
+        float v;
+        if (e < 32) v = b1[(e >> 4) * 32 + rowmap(e & 15, h)];
+        else if (e < 64) v = w2[((e - 32) >> 4) * 32 + rowmap(e & 15, h)];
+        else v = b2[1 + rowmap(e - 64, h)];
+        tab[h][e] = v;
+    }
+    // ---- the block's weight fragments, split once, in registers for the whole kernel
+    //  A1[mt][s]: W1[32 mt + q][16 s + 8 hh + e]                          (reduction axis = input channel)
+    //  A2[s]    : W2[1 + q][16 s + 8 (e >> 2) + 4 hh + (e & 3)]           (reduction axis = hidden unit, in layer 1's accumulator order)
+    u32x4_t A1[2][2][3], A2[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w1t[(16 * s + 8 * hh + e) * DEC_HID + 32 * mt + q];
+            split3_bf16x8(v, A1[mt][s]);
+        }
+    if (rgb) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w2[(1 + q) * DEC_HID + 16 * s + 8 * (e >> 2) + 4 * hh + (e & 3)];
+            split3_bf16x8(v, A2[s]);
+        }
+    }
+    const float b2s = b2[0];
+    const unsigned plane_bytes = (unsigned)(a.H * a.W * DEC_IN * 4);
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(a.planes, (int64_t)a.N * 3 * plane_bytes);          // host: < 2 GiB
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int64_t base = tile * DT;
+        __syncthreads();                                               // the previous tile's rows are no longer in use (first pass: tab is written)
+        // ---- phase A: this thread's point -> gather record + output row; then the eight gather passes (gather_tile's two steps)
+        const int last = (int)min((int64_t)DT - 1, total - 1 - base);
+        {
+            const TileIndex ti = tile_index(a, base);
+            int n; int64_t ray; int k; float x, y, z;
+            const int sc = min(t, last);
+            tile_point(a, ti, base, sc, n, ray, k);
+            point_xyz_at(a, base + sc, n, ray, x, y, z);
+            write_gather_record(feat + t * FS, n, x, y, z, a.W, a.H, plane_bytes, true);
+            feat[t * FS + 32] = __int_as_float(t <= last ? (int)out_row_at(a, base + t, ray, k) : -1);       // (host: rows < 2^31)
+        }
+        __syncthreads();
+        gather_from_records(feat, rs, last + 1);
+        __syncthreads();
+        // ---- phase B: 32 points per pass and wave, everything below touches only this wave's 64 rows
+#pragma unroll 1
+        for (int nt = 0; nt < 2; ++nt) {
+            float* frow = feat + (wave * 64 + nt * 32 + q) * FS;
+            const float* tb = tab[hh];
+            f32x16_t H1[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(tb + mt * 16 + 4 * g);
+                    H1[mt][4 * g] = bv.x; H1[mt][4 * g + 1] = bv.y; H1[mt][4 * g + 2] = bv.z; H1[mt][4 * g + 3] = bv.w;
+                }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float4 f0 = *reinterpret_cast<const float4*>(frow + 16 * s + 8 * hh), f1 = *reinterpret_cast<const float4*>(frow + 16 * s + 8 * hh + 4);
+                const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+                u32x4_t B[3];
+                split3_bf16x8(v, B);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) H1[mt] = mfma_split6(A1[mt][s], B, H1[mt]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) H1[mt][r] = softplus_fast(H1[mt][r]);
+            // density: the lane's 32 hidden units against the density row of W2, the other 32 from the lane's partner in the other half
+            float sg = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 wv = *reinterpret_cast<const float4*>(tb + 32 + mt * 16 + 4 * g);
+                    sg = fmaf(wv.x, H1[mt][4 * g], sg); sg = fmaf(wv.y, H1[mt][4 * g + 1], sg);
+                    sg = fmaf(wv.z, H1[mt][4 * g + 2], sg); sg = fmaf(wv.w, H1[mt][4 * g + 3], sg);
+                }
+            sg += __shfl_xor(sg, 32, WAVE);
+            const int orow = __float_as_int(frow[32]);
+            if (hh == 0 && orow >= 0) sigma[orow] = sg + b2s;
+            if (rgb) {
+                f32x16_t Y;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bv = *reinterpret_cast<const float4*>(tb + 64 + 4 * g);
+                    Y[4 * g] = bv.x; Y[4 * g + 1] = bv.y; Y[4 * g + 2] = bv.z; Y[4 * g + 3] = bv.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = H1[s >> 1][8 * (s & 1) + e];
+                    u32x4_t B[3];
+                    split3_bf16x8(v, B);
+                    Y = mfma_split6(A2[s], B, Y);
+                }
+                // colour channel rowmap(r, hh) = (r & 3) + 8 (r >> 2) + 4 hh: four 16-byte pieces of the point's own row (its features are dead)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<float4*>(frow + 8 * g + 4 * hh) =
+                        make_float4(sigmoid_fast(Y[4 * g]) * 1.002f - 0.001f, sigmoid_fast(Y[4 * g + 1]) * 1.002f - 0.001f,
+                                    sigmoid_fast(Y[4 * g + 2]) * 1.002f - 0.001f, sigmoid_fast(Y[4 * g + 3]) * 1.002f - 0.001f);
+            }
+        }
+        if (rgb) {
+            // the wave's 64 colour rows leave as whole 128-byte rows (8 lanes per row); a wave's LDS operations complete in order: no barrier
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int sp = wave * 64 + it * 8 + (lane >> 3), q4 = lane & 7;
+                const int orow = __float_as_int(feat[sp * FS + 32]);
+                const f32x4_t v = *reinterpret_cast<const f32x4_t*>(feat + sp * FS + q4 * 4);
+                if (orow >= 0) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(rgb + (int64_t)orow * DEC_IN + q4 * 4));
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const float* __restrict__ w1t, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         const float* __restrict__ d_rgb, const float* __restrict__ d_sigma,
@@ -577,36 +760,40 @@ __global__ void __launch_bounds__(DT) decode_bwd_kernel(DecodeArgs a, const floa
 //   across tiles and are written once to a scratch row that decoder_partial_reduce_kernel sums.
 // ------------------------------------------------------------------------------------------------
 constexpr int WIN = 16;                       // window edge in texels; WIN*WIN*32 int32 accumulators <= DT*FS floats of LDS
-typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-// weight fragments, one 64-lane row per MFMA k-step (built by decoder_frag_kernel for every call)
-constexpr int FRAG_A1 = 0;                          // [2][16][64]  W1[mt*32+q][2s+h]                      (A of H1)
-constexpr int FRAG_A3 = FRAG_A1 + 2 * 16 * 64;      // [2][17][64]  W2[1+rowmap(r',h)][mt*32+q]; step 16: sigma row in half 0   (A of dH1)
-constexpr int FRAG_A4 = FRAG_A3 + 2 * 17 * 64;      // [32][64]     W1[mt'*32+rowmap(r',h)][q]              (A of dF)
-constexpr int FRAG_TOTAL = FRAG_A4 + 32 * 64;       // 6272 floats
-constexpr int TSTRIDE = 34;                         // row stride (floats) of a wave's 32 x 32 transposition tile: 8-byte aligned rows, conflict-free
-constexpr int TTILE = 32 * TSTRIDE;                 //   ds_write_b32 columns / ds_read_b64 rows
+// weight fragments (built by decoder_frag_kernel for every call), round 6: bf16 PIECES.  A fragment = one A operand of
+// v_mfma_f32_32x32x16_bf16 = 16 bytes per lane (8 consecutive virtual-k values of row q, k-group h), three pieces per operand
+// (split3_bf16x8: the truncating three-way split is exact for fp32), 64 lanes x uint4 = 256 dwords each:
+//   A1 [mt 2][s 2][piece 3]   W1[32 mt + q][16 s + 8 h + e]                                   (H1 = W1 F:          M = hidden, K = channel)
+//   A3 [mt 2][s 2][piece 3]   W2[1 + rowmap(8 s + e, h)][32 mt + q]                            (dH1 = W2^T dY:      M = hidden, K = colour, in dY's register order)
+//   A4 [s 4][piece 3]         W1[32 (s >> 1) + rowmap(8 (s & 1) + e, h)][q]                     (dF = W1^T dpre1:    M = channel, K = hidden, in dpre1's register order)
+// followed by the density row of W2 in the accumulator order of a half: wsig[h][16 mt + r] = W2[0][32 mt + rowmap(r, h)].
+constexpr int FRAG_A1 = 0, FRAG_A3 = 12, FRAG_A4 = 24, FRAG_N = 36;       // fragment indices
+constexpr int FRAG_WSIG = FRAG_N * 256;                                    // dword offset of wsig [2][32]
+constexpr int FRAG_TOTAL = FRAG_WSIG + 64;                                 // 9280 dwords
 constexpr int PART_ROW = 4352;                      // scratch row per wave: dW1 2048 | dW2 2112 | db1 64 | db2 33 | pad
 constexpr int PART_DW2 = 2048, PART_DB1 = 4160, PART_DB2 = 4224;
 constexpr int BWD_MAX_GRID = 512;
 
-__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }   // C/D row of accumulator register r in half h
-
 __global__ void decoder_frag_kernel(const float* __restrict__ w1t, const float* __restrict__ w2, float* __restrict__ frag) {
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < FRAG_TOTAL; idx += gridDim.x * blockDim.x) {
-        const int lane = idx & 63, q = lane & 31, h = lane >> 5;
-        float v;
-        if (idx < FRAG_A3) {
-            const int st = idx >> 6, mt = st >> 4, s2 = st & 15;
-            v = w1t[(2 * s2 + h) * DEC_HID + mt * 32 + q];                               // W1[j][i] = w1t[i][j]
-        } else if (idx < FRAG_A4) {
-            const int st = (idx - FRAG_A3) >> 6, mt = st / 17, r = st - mt * 17;
-            v = r < 16 ? w2[(1 + rowmap(r, h)) * DEC_HID + mt * 32 + q] : (h == 0 ? w2[mt * 32 + q] : 0.f);
-        } else {
-            const int st = (idx - FRAG_A4) >> 6, mt = st >> 4, r = st & 15;
-            v = w1t[q * DEC_HID + mt * 32 + rowmap(r, h)];
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < 12 * 64) {
+        const int grp = idx >> 6, lane = idx & 63, q = lane & 31, h = lane >> 5;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (grp < 4) { const int mt = grp >> 1, s2 = grp & 1; v[e] = w1t[(16 * s2 + 8 * h + e) * DEC_HID + 32 * mt + q]; }             // W1[j][i] = w1t[i][j]
+            else if (grp < 8) { const int mt = (grp - 4) >> 1, s2 = grp & 1; v[e] = w2[(1 + rowmap(8 * s2 + e, h)) * DEC_HID + 32 * mt + q]; }
+            else { const int s4 = grp - 8; v[e] = w1t[q * DEC_HID + 32 * (s4 >> 1) + rowmap(8 * (s4 & 1) + e, h)]; }
         }
-        frag[idx] = v;
+        u32x4_t pc[3];
+        split3_bf16x8(v, pc);
+        u32x4_t* out = reinterpret_cast<u32x4_t*>(frag) + (grp * 3) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[c * 64] = pc[c];
+    } else if (idx < 12 * 64 + 64) {
+        const int e = idx - 12 * 64, h = e >> 5, mr = e & 31;
+        frag[FRAG_WSIG + e] = w2[(mr >> 4) * 32 + rowmap(mr & 15, h)];
     }
 }
 
@@ -774,22 +961,18 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
     // ray r is d_rgb[r][:] * d_rgb_scale[i] (what the ray marcher's backward produces: a per-ray vector times a per-sample
     // scalar); the 2 MB per-ray array stays in L2 and the 128 B per point of gradient traffic disappears.
     //
-    // LDS map (floats; one array so that the regions phase B borrows are contiguous):
+    // LDS map (dwords):
     //   feat  [DT][FS]   rows [point][36]: features 0..31 | d_sigma 32 | ray 33 | colour-gradient scale 34; phase B overwrites 0..31 with d_feat
-    //   gbuf  [DT][FS]   phase B: weight fragments (FRAG_TOTAL = 6272) then, WGRAD, the waves' transposition tiles; phase C: the scatter window
-    //   small 6 x [DT]   s_x s_y s_z (phase A: coordinates; phase C: s_x = fast-path base) | s_cxy s_wx s_wy (phase C) -- free in phase B: the
-    //                    transposition tiles run on from gbuf's tail into them (4 x 1088 floats from offset FRAG_TOTAL of gbuf)
+    //   gbuf  [FRAG_TOTAL]  the bf16 weight fragments (36 x 256 dwords) + the density row of W2 in accumulator order (64)
     //   s_row [DT], s_acc [8]
-    constexpr int LDS_GBUF = DT * FS, LDS_SMALL = 2 * DT * FS, LDS_ROW = LDS_SMALL + 6 * DT, LDS_ACC = LDS_ROW + DT;
+    // (Until round 5 the weight gradients' operands were transposed through four 4.25 KB LDS tiles behind 25 KB of fp32 fragments; the
+    //  transpositions now run on the matrix cores -- see `transpose` below -- and the room went to the bf16 pieces of the fragments.)
+    constexpr int LDS_GBUF = DT * FS, LDS_ROW = LDS_GBUF + FRAG_TOTAL, LDS_ACC = LDS_ROW + DT;
     __shared__ __attribute__((aligned(16))) float lds[LDS_ACC + 8];
+    static_assert((LDS_ACC + 8) * 4 <= 80 * 1024, "two blocks per CU");
     float* const feat = lds;
     float* const gbuf = lds + LDS_GBUF;
-    float* const s_x = lds + LDS_SMALL; float* const s_y = s_x + DT; float* const s_z = s_y + DT;
-    int* const s_cxy = reinterpret_cast<int*>(s_z + DT);      // per plane: window-relative corner (x0 - wx0) | (y0 - wy0) << 16, biased by +0x4000
-    float* const s_wx = s_z + 2 * DT; float* const s_wy = s_wx + DT;      // per plane: bilinear fractions
     int* const s_row = reinterpret_cast<int*>(lds + LDS_ROW);  // row index into the [R*S] sample arrays (-1 = padding point)
-    int* const s_acc = reinterpret_cast<int*>(lds + LDS_ACC);
-    static_assert(FRAG_TOTAL + 4 * TTILE <= DT * FS + 6 * DT, "fragments + transposition tiles must fit gbuf and the small arrays");
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6, q = lane & 31, hh = lane >> 5;
     // Weight-gradient accumulators: the four 32x32 tiles of a wave (dW1 rows 0-31 / 32-63, dW2 colour rows x hidden 0-31 / 32-63) stay
@@ -807,7 +990,7 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         for (int r = 0; r < 16; ++r) { accW1[i][r] = 0.f; accW2[i][r] = 0.f; }
     // The weight fragments go to LDS ONCE (round 2 re-copied the 25 KB for every tile: the scatter phase used to overwrite them).
     if (!(a.dbg & 4))
-        for (int i = t; i < FRAG_TOTAL; i += DT) gbuf[i] = frag_g[i];
+        for (int i = t; i < FRAG_TOTAL / 4; i += DT) reinterpret_cast<float4*>(gbuf)[i] = reinterpret_cast<const float4*>(frag_g)[i];
     // A tile's point data comes out of a chain of dependent loads: count -> order -> permutation / depth / ray -> gradient rows.  A wave issues
     // in order, so a chain resolved at the top of a tile stalls it for three memory latencies (and a load inside a divergent `if` makes hipcc
     // wait for everything outstanding).  The chain is spread over the tile loop instead -- the id two tiles ahead, permutation / depth / ray
@@ -891,13 +1074,15 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         int q_ = q, hh_ = hh;                                   // opaque per iteration: keeps ~70 lane_-derived address terms from being
         asm volatile("" : "+v"(q_), "+v"(hh_));                 // hoisted out of the tile loop and parked in (spilled) registers
         const int lane_ = q_ + 32 * hh_;
-        const float* frag = gbuf;                              // LDS copy: one conflict-free 64-lane_ row per k-step
+        const u32x4_t* frag = reinterpret_cast<const u32x4_t*>(gbuf) + lane_;      // fragment f: frag[f * 64], one ds_read_b128 per lane
+        const float* wsig = gbuf + FRAG_WSIG + 32 * hh_;           // W2[0][32 mt + rowmap(r, hh)] at [16 mt + r]
         const float* b1 = b1_g + opq;
         const float* b2 = b2_g + opq;
         float* frow = feat + (pbase + q_) * FS;                 // the lane_'s own point (orientation 1: lane_ <-> point)
-        const float dsq = hh_ == 0 ? frow[32] : 0.f;            // d_sigma of the lane_'s point, counted once (half 0)
+        const float dsg = frow[32];                             // d_sigma of the lane_'s point
+        const float dsq = hh_ == 0 ? dsg : 0.f;                 //   ... counted once (half 0) in the bias sum
         // d_rgb of the lane_'s point straight from HBM (its row is 128 contiguous bytes; each half takes 4 x 16 B), requested
-        // now and consumed after the two forward layers
+        // now and consumed after the forward layer
         const int myrow = s_row[pbase + q_];
         // (unconditional loads on a clamped row, zeroed afterwards: a guarded load `ok ? *p : 0` becomes an exec-masked region
         // that ends in s_waitcnt vmcnt(0) -- 4 + 16 serialised HBM round trips per 32 points before this was changed)
@@ -913,6 +1098,10 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 dr[g] = make_float4(keep ? v.x * gsc : 0.f, keep ? v.y * gsc : 0.f, keep ? v.z * gsc : 0.f, keep ? v.w * gsc : 0.f);
             }
         }
+        // Round 6: the three products of the data path (H1 = W1 F, dH1 = W2^T dY, dF = W1^T dpre1) run on v_mfma_f32_32x32x16_bf16 with every
+        // fp32 operand cut into three bf16 pieces and the six significant piece products accumulated in fp32 (decode_fwd_mfma_kernel's scheme:
+        // the arithmetic stays fp32's, 72 MFMAs of 32 cycles instead of 98 of 64); the activations are split in registers, in the
+        // accumulator's own (register, half) order = the virtual K order the fragments were built in.
         // H1[j][p] = softplus(W1 F + b1)
         f32x16_t H1[2];
 #pragma unroll
@@ -920,10 +1109,16 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) H1[mt][r] = b1[mt * 32 + rowmap(r, hh_)];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float fb = frow[2 * s + hh_];
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const float4 f0 = *reinterpret_cast<const float4*>(frow + 16 * s2 + 8 * hh_), f1 = *reinterpret_cast<const float4*>(frow + 16 * s2 + 8 * hh_ + 4);
+            const float v[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+            u32x4_t B[3];
+            split3_bf16x8(v, B);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) H1[mt] = SPI_MFMA(frag[FRAG_A1 + (mt * 16 + s) * 64 + lane_], fb, H1[mt]);
+            for (int mt = 0; mt < 2; ++mt) {
+                const u32x4_t A[3] = {frag[(FRAG_A1 + (mt * 2 + s2) * 3) * 64], frag[(FRAG_A1 + (mt * 2 + s2) * 3 + 1) * 64], frag[(FRAG_A1 + (mt * 2 + s2) * 3 + 2) * 64]};
+                H1[mt] = mfma_split6(A, B, H1[mt]);
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -932,6 +1127,7 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
         // dY1[o][p] (orientation 1: lane <-> point) = d_rgb * d(sigmoid * 1.002 - 0.001), the sigmoid read back from the saved colour rows:
         // (c + 0.001) / 1.002.  RGB == false: only the density gradient is non-zero (SPI's depth branch) -> the whole colour layer drops out.
         f32x16_t Y1;
+        u32x4_t BY[2][3];                                      // dY1 as B operand of dH1 / A operand of its transposition: pieces of registers 8 s .. 8 s + 7
         if (RGB) {
             const float4* crp = reinterpret_cast<const float4*>(colors + (int64_t)max(myrow, 0) * DEC_IN + 4 * hh_);
 #pragma unroll
@@ -946,43 +1142,60 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 const float dv1 = (r & 3) == 0 ? d4.x : ((r & 3) == 1 ? d4.y : ((r & 3) == 2 ? d4.z : d4.w));      // channel rowmap(r,hh_) = (r&3) + 8(r>>2) + 4hh
                 Y1[r] = dv1 * 1.002f * sg * (1.f - sg);
             }
-        }
-        // ---- weight gradients, part 1: dW2[o][j] += sum_p dY[o][p] H1[j][p] (contraction over the tile's 32 points).
-        // The MFMA wants the contracted index on the K axis, i.e. both operands with the FEATURE in the lane position ("orientation 2"),
-        // while H1 sits in accumulator layout (lane <-> point).  Round 2 recomputed the activations in orientation 2 (H2 = F W1^T,
-        // dH2 = dY W2: 66 extra MFMAs per 32 points = 4 224 matrix-pipe cycles); now each 32 x 32 tile is transposed through a 4.25 KB
-        // LDS tile of the wave's own (16 ds_write_b32 + 8 ds_read_b64, ~10^2 cycles).  dY in orientation 2 comes straight from the
-        // global gradient / colour rows (32 lanes read one 128-byte row).
-        float* const tsc = gbuf + FRAG_TOTAL + wave * TTILE;       // this wave's transposition tile [32][TSTRIDE]
-        auto transpose = [&](const f32x16_t& v, f32x16_t& out) {
-            // in : lane (p = q_, hh_) holds v[r]   = X[rowmap(r, hh_)][p]
-            // out: lane (j = q_, hh_) holds out[r] = X[j][rowmap(r, hh_)]     (rowmap(r,h) = (r&3) + 8(r>>2) + 4h: r, r+1 are adjacent columns)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) tsc[rowmap(r, hh_) * TSTRIDE + q_] = v[r];
-            asm volatile("" ::: "memory");                     // one wave's LDS operations execute in order: no wait needed, only no reordering
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float2 t2 = *reinterpret_cast<const float2*>(tsc + q_ * TSTRIDE + 8 * (g >> 1) + 4 * hh_ + 2 * (g & 1));
-                out[2 * g] = t2.x; out[2 * g + 1] = t2.y;
+                for (int e = 0; e < 8; ++e) v[e] = Y1[8 * s2 + e];
+                split3_bf16x8(v, BY[s2]);
             }
-            asm volatile("" ::: "memory");
+        }
+        // ---- weight gradients: they contract over the tile's 32 POINTS, i.e. both MFMA operands need the FEATURE in the lane position
+        // ("orientation 2"), while the activations sit in accumulator layout (lane <-> point).  Round 2 recomputed them in orientation 2 (66 extra
+        // MFMAs per 32 points), rounds 3-5 sent every 32 x 32 tile through a 4.25 KB LDS tile.  Round 6: the transposition is a matrix product with
+        // the identity.  An accumulator-layout tile X[feature][point] of a lane IS a valid A operand with M = point and K = feature (A and B operands
+        // have the same register form), and D = A I has the lane on N = feature and the registers on M = point: out[r] = X[q][point rowmap(r, hh)].
+        // With X as bf16 pieces (exact split, products with 1.0 exact, three fp32 additions that reproduce x) the transposition is exact, costs
+        // 6 MFMAs of 32 cycles per 32 x 32 tile and no LDS at all -- and the pieces are the ones the data path needs anyway.
+        u32x4_t IDN[2];                                        // identity in virtual-K order: B[k = (hh, e) of step s][n = q] = (rowmap(8 s + e, hh) == q)
+        if (WGRAD) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    IDN[s2][i] = (rowmap(8 * s2 + 2 * i, hh_) == q_ ? 0x3f80u : 0u) | (rowmap(8 * s2 + 2 * i + 1, hh_) == q_ ? 0x3f800000u : 0u);
+        }
+        auto transpose = [&](const u32x4_t (&x0)[3], const u32x4_t (&x1)[3], f32x16_t& out) {
+            // in : pieces of the registers 0..7 (x0) and 8..15 (x1) of a tile the lane (p = q_, hh_) holds as v[r] = X[rowmap(r, hh_)][p]
+            // out: lane (j = q_, hh_) holds out[r] = X[j][point rowmap(r, hh_)]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[r] = 0.f;
+#pragma unroll
+            for (int c = 2; c >= 0; --c) {                     // small pieces first
+                out = SPI_MFMA_BF16(x0[c], IDN[0], out);
+                out = SPI_MFMA_BF16(x1[c], IDN[1], out);
+            }
         };
         if (WGRAD) {
             f32x16_t Y2;                                           // orientation 2: dY[1 + q_][point rowmap(r, hh_)]
             if (RGB) {
-                // Round 4: the same 32 x 32 block of dY as Y1, transposed through the wave's LDS tile like H1 / dpre1 below.  Until round 3 it was
-                // rebuilt from global memory in this orientation: 32 more loads of the gradient / colour rows per lane with 64-bit address
-                // arithmetic, selects and the sigmoid derivative again -- ~400 of the phase's ~1500 vector instructions (ISA count), all of them
-                // stealing matrix-pipe cycles from the fp32 MFMAs around them.  Same values bit for bit.
-                transpose(Y1, Y2);
+                transpose(BY[0], BY[1], Y2);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s_b2 += Y2[r];
             }
             s_d += dsq;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                u32x4_t BH[2][3];                              // H1 tile i in pieces: registers 0..7 | 8..15
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = H1[i][8 * s2 + e];
+                    split3_bf16x8(v, BH[s2]);
+                }
                 f32x16_t HT;
-                transpose(H1[i], HT);                              // HT[r] = H1[i*32 + q_][point rowmap(r, hh_)]
+                transpose(BH[0], BH[1], HT);                       // HT[r] = H1[i*32 + q_][point rowmap(r, hh_)]
                 float ls = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -992,28 +1205,48 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 s_sig[i] += ls;
             }
         }
-        // dH1[j][p] = W2^T dY1 (+ sigma row) -> dpre1 = dH1 * softplus'(pre1)
+        // dH1[j][p] = W2^T dY1 (colour rows on the matrix cores, the density row as a rank-1 term on the vector ALUs) -> dpre1 = dH1 * softplus'(pre1)
         f32x16_t dH1[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dH1[mt][r] = 0.f;
+            for (int g = 0; g < 4; ++g) {
+                const float4 wv = *reinterpret_cast<const float4*>(wsig + mt * 16 + 4 * g);
+                dH1[mt][4 * g] = wv.x * dsg; dH1[mt][4 * g + 1] = wv.y * dsg; dH1[mt][4 * g + 2] = wv.z * dsg; dH1[mt][4 * g + 3] = wv.w * dsg;
+            }
+        if (RGB) {
 #pragma unroll
-        for (int r = RGB ? 0 : 16; r < 17; ++r) {
-            const float bv = r < 16 ? Y1[r & 15] : dsq;
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) dH1[mt] = SPI_MFMA(frag[FRAG_A3 + (mt * 17 + r) * 64 + lane_], bv, dH1[mt]);
+                for (int mt = 0; mt < 2; ++mt) {
+                    const u32x4_t A[3] = {frag[(FRAG_A3 + (mt * 2 + s2) * 3) * 64], frag[(FRAG_A3 + (mt * 2 + s2) * 3 + 1) * 64], frag[(FRAG_A3 + (mt * 2 + s2) * 3 + 2) * 64]};
+                    dH1[mt] = mfma_split6(A, BY[s2], dH1[mt]);
+                }
         }
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dH1[mt][r] *= (H1[mt][r] > 20.f) ? 1.f : (1.f - exp_fast(-H1[mt][r]));
-        // ---- weight gradients, part 2: dW1[j][c] += sum_p dpre1[j][p] F[c][p]; the B operand is read from the feature rows (still F)
-        if (WGRAD) {
+        // dF[i][p] = W1^T dpre1, and (WGRAD) dW1[j][c] += sum_p dpre1[j][p] F[c][p]; the B operand of the latter is read from the feature rows (still F)
+        f32x16_t dF;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+        for (int r = 0; r < 16; ++r) dF[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            u32x4_t BD[2][3];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = dH1[i][8 * s2 + e];
+                split3_bf16x8(v, BD[s2]);
+                const int s4 = 2 * i + s2;
+                const u32x4_t A[3] = {frag[(FRAG_A4 + s4 * 3) * 64], frag[(FRAG_A4 + s4 * 3 + 1) * 64], frag[(FRAG_A4 + s4 * 3 + 2) * 64]};
+                dF = mfma_split6(A, BD[s2], dF);
+            }
+            if (WGRAD) {
                 f32x16_t DT_;
-                transpose(dH1[i], DT_);                            // DT_[r] = dpre1[i*32 + q_][point rowmap(r, hh_)]
+                transpose(BD[0], BD[1], DT_);                      // DT_[r] = dpre1[i*32 + q_][point rowmap(r, hh_)]
                 float lb = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1023,16 +1256,6 @@ __global__ void __launch_bounds__(DT, 2) decode_bwd_tiled_kernel(TiledArgs a, co
                 s_b1[i] += lb;
             }
         }
-        // dF[i][p] = W1^T dpre1
-        f32x16_t dF;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dF[r] = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                dF = SPI_MFMA(frag[FRAG_A4 + (mt * 16 + r) * 64 + lane_], dH1[mt][r], dF);
-            }
         // this tile's feature rows are dead now (the weight gradients are done with them): d_feat takes their place
 #pragma unroll
         for (int r = 0; r < 16; ++r) frow[rowmap(r, hh_)] = dF[r] * THIRD;           // the plane mean contributes the 1/3
@@ -1994,7 +2217,6 @@ static void zero_decoder_grads(float* dw1, float* db1, float* dw2, float* db2, h
     spi_zero_async(dw2, DEC_OUT * DEC_HID, st); spi_zero_async(db2, DEC_OUT, st);
 }
 
-static int g_spi_debug = 0;
 extern "C" {
 
 void spi_debug_set(int flags) { g_spi_debug = flags; }      /* profiling experiments only; 0 in normal operation */
@@ -2078,7 +2300,13 @@ int spi_triplane_decode_fwd(const float* planes_nhwc, const float* coords, const
     if (rc) return rc;
     SPI_REQUIRE(sigma, "spi_triplane_decode_fwd: null output");          // rgb may be NULL: densities only
     const int64_t total = (int64_t)N * P;
-    hipLaunchKernelGGL(decode_fwd_kernel, dim3((unsigned)ceil_div64(total, DT)), dim3(DT), 0, as_stream(stream), a, w1, b1, w2, b2, rgb, sigma);
+    const int64_t tiles = ceil_div64(total, DT);
+    // the split-bf16 matrix-core kernel keeps a point's output row in 32 bits; spi_debug_set(256) selects the vector-ALU kernel (A/B measurements)
+    if (!(g_spi_debug & 256) && (out_S == 0 ? total : (total / a.S) * (int64_t)out_S) < ((int64_t)1 << 31))
+        hipLaunchKernelGGL(decode_fwd_mfma_kernel, dim3((unsigned)std::min<int64_t>(tiles, FWD_MFMA_GRID)), dim3(DT), 0, as_stream(stream), a, w1, b1, w2, b2, rgb,
+                           sigma, tiles);
+    else
+        hipLaunchKernelGGL(decode_fwd_kernel, dim3((unsigned)tiles), dim3(DT), 0, as_stream(stream), a, w1, b1, w2, b2, rgb, sigma);
     SPI_LAUNCH_CHECK("spi_triplane_decode_fwd");
     return SPI_OK;
 }
@@ -2134,7 +2362,7 @@ int spi_triplane_decode_bwd_sorted(const float* planes_nhwc, const float* ray_o,
     a.order = order; a.count = count;
     hipLaunchKernelGGL(bin_points_kernel, dim3((unsigned)(N * a.patches)), dim3(256), 0, st, depths_sorted, ray_active, M, S, ray_w, a.patch2d,
                        a.patches, order, count);
-    hipLaunchKernelGGL(decoder_frag_kernel, dim3(9), dim3(1024), 0, st, w1t, w2, frag);
+    hipLaunchKernelGGL(decoder_frag_kernel, dim3(13), dim3(64), 0, st, w1t, w2, frag);
 #define SPI_BWD_LAUNCH(WG, RGBF) hipLaunchKernelGGL((decode_bwd_tiled_kernel<WG, RGBF>), dim3(grid), dim3(DT), 0, st, a, frag, b1, b2, d_rgb, d_rgb_scale, colors, d_sigma, part)
     if (wgrad) {
         if (d_rgb) SPI_BWD_LAUNCH(true, true); else SPI_BWD_LAUNCH(true, false);
