@@ -48,9 +48,11 @@ def parse():
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--depth', type=int, default=96, help='coarse = fine samples per ray')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline', choices=('sample', 'full'), default='sample',
-                    help="sample (default, ~30 s): 1 warm-up + 1 timed stage-1 'mir' step + 1 timed plain stage-2 iteration of the oracle; "
-                         'full (~4 min): + one whole 4-iteration stage-2 super-cycle with the rot / mirror-rot / depth branches and a thread-scaling line')
+    ap.add_argument('--cpu-baseline', choices=('sample', 'protocol', 'full'), default='protocol',
+                    help="sample (~45 s): 1 warm-up + 1 timed stage-1 'mir' step + 1 timed plain stage-2 iteration of the oracle; "
+                         'protocol (default, ~2.5 min): + the every-4th-iteration branch iteration (rot / mirror-rot / depth), i.e. one whole 4-iteration stage-2 '
+                         'super-cycle MEASURED in this process -- the value is the same stage mix as the GPU line, not an upper bound; '
+                         'full (~4 min): + a thread-scaling line')
     ap.add_argument('--no-winograd', action='store_true', help='3x3 convolutions on the implicit-GEMM kernels only (global_config.conv_winograd = False)')
     ap.add_argument('--dense', action='store_true', help='NOT the benchmark configuration: switch off the data-driven skipping of exactly-zero gradients / '
                                                          'unneeded SR tiles in the masked pseudo-view branches (dense bound of the same step)')
@@ -128,20 +130,26 @@ def cpu_baseline(depth, narrow, mode='sample', k1=8, k2=16):
     res = dict(unit='iters/s', cores=cores, kind='port', host_threads_available=ncpu,
                stage1_mir_iters_per_s=1.0 / t_s1, stage2_plain_iters_per_s=1.0 / t_plain,
                seconds=dict(warmup=t_warm, stage1_step=t_s1, stage2_plain_iteration=t_plain))
-    if mode == 'full':
+    if mode in ('protocol', 'full'):
         t_branch = timed(lambda: olp.stage2_iteration(st, 0, data, w, opts, lp, bx, hp=hp))                   # i % 4 == 0: all three branches
         t_cycle = t_branch + 3 * t_plain
         res['seconds'].update(stage2_branch_iteration=t_branch, stage2_super_cycle=t_cycle)
         res['stage2_rotbbox_iters_per_s'] = 4.0 / t_cycle
         res['value'] = (k1 + k2) / (k1 * t_s1 + k2 * t_cycle / 4.0)
-        scal = {}
-        for th in (8, 16, 32, 64, 128, ncpu):
-            if th <= ncpu and th not in scal:
-                torch.set_num_threads(th)
-                scal[th] = timed(lambda: olp.stage2_iteration(st, 1, data, w, opts, lp, bx, hp=hp))
-        torch.set_num_threads(cores)
-        res['thread_scaling_s_per_plain_iteration'] = scal
-        res['sample'] = (f"full protocol: 1 warm-up, 1 'mir' step ({t_s1:.1f} s), one 4-iteration RotBbox super-cycle ({t_cycle:.1f} s: branch iteration "
+        if mode == 'full':
+            scal = {}
+            for th in (8, 16, 32, 64, 128, ncpu):
+                if th <= ncpu and th not in scal:
+                    torch.set_num_threads(th)
+                    scal[th] = timed(lambda: olp.stage2_iteration(st, 1, data, w, opts, lp, bx, hp=hp))
+            torch.set_num_threads(cores)
+            res['thread_scaling_s_per_plain_iteration'] = scal
+        else:
+            full = os.path.join(ROOT, 'profiles', 'cpu_baseline_full.json')
+            if os.path.exists(full):
+                res['thread_scaling_recorded'] = {'s_per_plain_iteration': json.load(open(full)).get('thread_scaling_s_per_plain_iteration'),
+                                                  'note': 'profiles/cpu_baseline_full.json (`bench.py --cpu-baseline full`): why 32 of the host threads -- NOT measured in this process; everything else in this object is'}
+        res['sample'] = (f"full protocol, measured in this process: 1 warm-up, 1 'mir' step ({t_s1:.1f} s), one 4-iteration RotBbox super-cycle ({t_cycle:.1f} s: branch iteration "
                          f'{t_branch:.1f} s + 3 x plain {t_plain:.1f} s); value = the same {k1}:{k2} stage mix as the `value` of the GPU line')
     else:
         # without the branch iteration the stage-2 rate is an UPPER bound for the CPU (the branches only add work): say so
@@ -156,6 +164,46 @@ def cpu_baseline(depth, narrow, mode='sample', k1=8, k2=16):
             res['full_protocol_is_a_replayed_record'] = 'profiles/cpu_baseline_full.json: NOT measured in this process (this run timed the 2-iteration sample above)'
     res['sample'] += f'; 512^2, {depth}+{depth} samples, torch {torch.__version__} CPU fp32, {cores} threads of {ncpu}'
     return res
+
+
+def elementwise_roofline(dev):
+    """Roofline line of the HBM-bound elementwise kernels the round-5 profile had no line for (layer tails 4.5 %, 4x4 FIR 4.0 %, ATen elementwise 3.6 %
+    of the GPU time): achieved GB/s of ALGORITHMIC bytes at the largest layer they run on (SR b512: 128 channels at 512^2, one image), HIP events on
+    the launch stream, outside the timed region.  `aten_elementwise` is a torch add of the same footprint -- what an ATen launch reaches at this size; the
+    loop's ATen launches are mostly small (5-6 us on average), so their share is launch-bound, not bandwidth-bound."""
+    from spi_amd.torch_utils.ops import bias_act as ba, upfirdn2d as U
+
+    def timed(fn, n=10):
+        for _ in range(3):
+            fn()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in ev:
+            a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / n * 1e-3
+    C, H = 128, 512
+    peak = 8000.0
+    res = {}
+    with torch.no_grad():
+        dy, y = torch.randn(1, C, H, H, device=dev), torch.randn(1, C, H, H, device=dev)
+        noise, st = torch.randn(H, H, device=dev), torch.ones(1, device=dev)
+        t = timed(lambda: ba.tail_backward(dy, y, noise, st, 3, 0.2, 1.414, 256.0, False, True, True))
+        by = dy.numel() * 12                                   # dy and y read, dz written (the bias / noise sums are O(C + H^2))
+        res['tail_bwd_kernel'] = {'shape': f'[1,{C},{H},{H}] lrelu, clamp, bias + noise sums', 'bytes': by, 'avg_launch_us': t * 1e6, 'achieved': by / t / 1e9, 'frac': by / t / 1e9 / peak}
+        f = U.setup_filter([1, 3, 3, 1]).to(dev)
+        x = torch.randn(1, C, H + 1, H + 1, device=dev)
+        b = torch.randn(C, device=dev)
+        t = timed(lambda: U.upfirdn2d_bias_act(x, f, noise=noise, noise_strength=torch.ones((), device=dev), bias=b, padding=[1, 1, 1, 1], gain=4, act='lrelu', act_gain=1.414, clamp=256))
+        by = (x.numel() + C * H * H) * 4
+        res['upfirdn2d_4x4_tiled_kernel'] = {'shape': f'[1,{C},{H + 1},{H + 1}] -> {H}^2, fused noise / bias / lrelu / clamp (the tail of an up-sampling layer)', 'bytes': by,
+                                             'avg_launch_us': t * 1e6, 'achieved': by / t / 1e9, 'frac': by / t / 1e9 / peak}
+        a2, o2 = torch.randn(1, C, H, H, device=dev), torch.empty(1, C, H, H, device=dev)
+        t = timed(lambda: torch.add(dy, a2, out=o2))
+        by = dy.numel() * 12
+        res['aten_elementwise'] = {'shape': f'torch.add on [1,{C},{H},{H}]', 'bytes': by, 'avg_launch_us': t * 1e6, 'achieved': by / t / 1e9, 'frac': by / t / 1e9 / peak}
+    worst = min(v['achieved'] for v in res.values())
+    return {'kernel': 'tail_bwd_kernel / upfirdn2d_4x4_tiled_kernel / ATen elementwise at SR b512 (128 channels, 512^2)', 'bound': 'hbm', 'achieved': worst, 'peak': peak, 'unit': 'GB/s',
+            'frac': worst / peak, 'kernels': res, 'note': 'achieved = slowest of the three; algorithmic bytes (every tensor element read or written once)'}
 
 
 def conv_roofline(dev, f16, prec=0):
@@ -837,6 +885,10 @@ def main():
                                           'note': 'algorithmic FLOPs of the decoder backward per live point / call time (gather, MLP on the matrix cores, plane-gradient scatter '
                                                   'all inside the call); the scatter is LDS-atomic / flush bound, see DESIGN.md 3'}
         out['roofline_mfma'] = conv_roofline(dev, bool(args.sr_fp16), global_config.conv_precision)
+        try:
+            out['roofline_elementwise'] = elementwise_roofline(dev)
+        except Exception as e:                                    # noqa: BLE001
+            out['roofline_elementwise'] = {'error': repr(e)}
         if sustained is not None:
             out['sustained'] = sustained
         if alt is not None:

@@ -5,6 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 from spi_amd import hip
+if os.environ.get('SPI_HIP_LIB'):                       # A/B against another build of the library
+    hip.LIB_PATH = os.environ['SPI_HIP_LIB']
 from spi_amd.training.volumetric_rendering import renderer as R
 from spi_amd.training.triplane import OSGDecoder
 from spi_amd.utils import camera_utils as cu
