@@ -30,7 +30,7 @@ typedef void* spi_stream_t;           /* hipStream_t */
 #define SPI_ERR_UNSUPPORTED -2        /* valid request this build has no kernel for */
 #define SPI_ERR_LAUNCH      -3        /* hipGetLastError() != hipSuccess after the launch */
 
-#define SPI_ABI_VERSION 12   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
+#define SPI_ABI_VERSION 13   /* 2: spi_raymarch_bwd gained d_color_scale, spi_triplane_decode_bwd_sorted gained d_rgb_scale
                              * 3: spi_conv_desc gained workspace / workspace_bytes (Winograd path), spi_conv2d_workspace_bytes
                              * 4: + spi_sample_from_planes_fwd / _bwd (additive)
                              * 5: + contextual / roi_align / adam_pred / filtered_lrelu_fused   6: + spi_affine_fwd / _bwd   7: + spi_decoder_gains (additive)
@@ -40,7 +40,8 @@ typedef void* spi_stream_t;           /* hipStream_t */
                              * 11: + spi_conv2d_plan (additive); spi_conv_desc gained act_dtype (fp16 activation tensors; appended: 0 = the behaviour of 10),
                              *     + spi_upfirdn2d_fused_t / spi_tail_bwd_t / spi_chan_dot_t / spi_seg_flags_t / spi_filtered_lrelu_t,
                              *     SPI_DTYPE_F64 for spi_bias_act_t / spi_upfirdn2d_t (additive)
-                             * 12: + spi_tail_bwd_dot_t (additive); spi_conv2d_workspace_bytes / workspace of fp16 activation tensors select the direct fp16 kernels */
+                             * 12: + spi_tail_bwd_dot_t (additive); spi_conv2d_workspace_bytes / workspace of fp16 activation tensors select the direct fp16 kernels
+                             * 13: + spi_conv_wino_f4_set (additive); the Winograd workspace of a >= 256^2 layer is 2.25x larger (36 instead of 16 frequencies) */
 int         spi_abi_version(void);
 int         spi_sizeof_conv_desc(void);   /* sizeof(spi_conv_desc) of THIS build: bindings assert it against their own struct */
 const char* spi_last_error(void);     /* thread-local, valid until the next failing call */
@@ -380,6 +381,12 @@ typedef struct spi_conv_desc {
 /* bytes of workspace with which pass (0 forward, 1 dgrad, 2 wgrad) takes its Winograd path (fp16 activation tensors: its direct fp16 kernel); 0 = the
  * pass has none for this shape */
 int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass);
+/* Minimal-filtering tile of the fp32 Winograd forward / dgrad path (process-wide, host logic only; call it BEFORE sizing workspaces: the size differs).
+ * 1 (default, or SPI_CONV_WINO_F4 unset): F(4x4, 3x3) -- 36 multiplications per 4x4 output tile and channel pair, 4x fewer than the direct sum --
+ * where its 16 x 32-pixel blocks fill the chip (H % 16 == 0, W % 32 == 0, >= 256 blocks: the 256^2 / 512^2 layers), F(2x2, 3x3) elsewhere.
+ * 0 (or SPI_CONV_WINO_F4=0): F(2x2, 3x3) everywhere.  Both are fp32 throughout; F(4x4) differs from the direct sum by ~1e-6 of the tensor's range
+ * instead of ~2e-7 (what cuDNN's fp32 Winograd, the algorithm the reference runs through torch.nn.functional.conv2d at conv2d_gradfix.py:50-56, does too). */
+void spi_conv_wino_f4_set(int on);
 /* 1 if pass (0 forward, 1 dgrad) of `d` -- with the workspace `d` carries -- accumulates into its output through atomics (and therefore clears
  * it first unless d->out_zeroed), 0 if it overwrites, < 0 on a bad descriptor.  Host logic only: no launch, no device access. */
 int spi_conv2d_out_accumulates(const spi_conv_desc* d, int pass);

@@ -40,7 +40,8 @@ struct WinoParams {
     int nseg;
     int ksplit;                   // > 1: the channel reduction is cut into ksplit ranges of slabs (blockIdx.z = n * ksplit + range); partial outputs are
                                   //      atomically added into a ZEROED out and the epilogue runs afterwards (small layers: too few blocks to fill 256 CUs)
-    int64_t u_bs_of() const { return (int64_t)16 * Ci * ocp; }      // floats of one transformed weight set
+    int f4;                       // 1: F(4x4, 3x3) (wino4_conv_kernel: 36 frequencies, 16 x 32-pixel blocks) instead of F(2x2, 3x3); set by the dispatcher
+    int64_t u_bs_of() const { return (int64_t)(f4 ? 36 : 16) * Ci * ocp; }      // floats of one transformed weight set
 };
 int64_t spi_wino_workspace_bytes(const WinoParams& P) __attribute__((visibility("hidden")));
 int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const Epilogue& ep, void* workspace, hipStream_t st, bool u_ready = false)

@@ -1144,7 +1144,16 @@ static int dispatch_igemm(const IGemmParams& P, const float* in, const float* w,
 
 // Winograd eligibility of a forward / dgrad problem: 3x3, stride 1, pad 1, exact fp32, whole 8-channel slabs, and enough 16 x 16 x 64
 // blocks to fill the 256 CUs once (smaller layers keep the implicit GEMM, whose split-K fills the chip).
+// F(4x4, 3x3) switch: on unless SPI_CONV_WINO_F4=0 (A/B measurements, the precision table of DESIGN.md) or spi_conv_wino_f4_set(0)
+static int g_wino_f4 = -1;
+static bool wino_f4_enabled() {
+    if (g_wino_f4 < 0) { const char* e = getenv("SPI_CONV_WINO_F4"); g_wino_f4 = (e && e[0] == '0') ? 0 : 1; }
+    return g_wino_f4 != 0;
+}
+extern "C" void spi_conv_wino_f4_set(int on) { g_wino_f4 = on ? 1 : 0; }
+
 static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
+    Wp.f4 = 0;
     // (compute_f16 = 3, the 6-product bf16 split, asks for fp32-equivalent products: the fp32 Winograd path is at least that precise and faster
     //  than the split implicit GEMM on these layers, so it serves that mode too; modes 1 and 2 trade precision for speed and keep their kernels)
     if (d->transposed || d->kh != 3 || d->pad != 1 || (d->compute_f16 != 0 && d->compute_f16 != 3) || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
@@ -1166,6 +1175,8 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
     // (not with a needed-output map: the split's separate epilogue pass would write act(bias + noise) into the tiles the kernel skipped, where
     //  the unsplit path leaves exact zeros -- the contract of out_seg_flags must not depend on the block count)
     Wp.ksplit = (blocks >= 128 && blocks < 256 && P.Ci / 8 >= 32 && !P.out_flags) ? 2 : 1;
+    // Round 6: F(4x4, 3x3) where its 16 x 32-pixel x 64-channel blocks still fill the 256 CUs (the >= 256^2 layers): 1.78x fewer MFMAs than F(2x2, 3x3)
+    Wp.f4 = (wino_f4_enabled() && P.OH % 16 == 0 && P.OW % 32 == 0 && (int64_t)(P.OH / 16) * (P.OW / 32) * (Wp.ocp / 64) * P.N >= 256 && Wp.ksplit == 1) ? 1 : 0;
     return blocks >= 128 && P.Mo >= 48;
 }
 
@@ -1188,6 +1199,7 @@ static int wino_conv(WinoParams& Wp, const IGemmParams& P, const float* in, cons
 // 32-pixel strip, and enough tile rows per block for the 64 x 64 x 16 accumulators' prologue / 144-atomic epilogue to amortise.  A masked
 // gradient (dy_seg_flags) is handled inside the kernel: tile rows without a flagged segment are skipped.
 static bool make_wino_wgrad(const spi_conv_desc* d, const IGemmParams& P, WinoParams& Wp) {
+    Wp.f4 = 0;
     if (d->transposed || d->kh != 3 || d->pad != 1 || (d->compute_f16 != 0 && d->compute_f16 != 3) || P.ncls != 1 || P.cls[0].taps.T != 9) return false;
     if (P.IH != P.OH || P.IW != P.OW || P.OW < 32 || P.OH < 16) return false;
     if ((int64_t)P.OH * P.OW * 64 * 4 >= (1ll << 31) || P.Mo < 32 || P.Ci < 32) return false;

@@ -634,12 +634,422 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
     }
 }
 
+// =================================================================================================
+// Round 6: Winograd F(4x4, 3x3) for the >= 256^2 layers -- forward / dgrad of the super-resolution convolutions, 40 % of the Winograd time.
+//
+//     Y = A^T [ (G g G^T) (.) (B^T d B) ] A          g: 3x3 taps, d: 6x6 patch, Y: 4x4 outputs; interpolation points 0, +-1, +-2, inf (Lavin & Gray)
+//
+// 36 multiplications per 4x4 output tile and channel pair instead of 64 with F(2x2, 3x3) and 144 direct: 1.78x fewer MFMAs than wino_conv_kernel,
+// still v_mfma_f32_32x32x2_f32 with fp32 operands.  The price is arithmetic in the transforms (coefficients up to 8 instead of +-1: the result differs
+// from the direct sum by ~1e-6 of the tensor's range instead of ~2e-7 -- measured per layer in tests/test_hip_conv_gpu.py and stated in DESIGN.md; cuDNN's
+// fp32 Winograd for the reference is this algorithm) and 2.25x as much transformed data per input pixel.
+//
+// One block = 4 x 8 tiles (16 x 32 output pixels) x 64 output channels x 36 frequencies = 73 728 accumulators = 288 per lane (one wave per SIMD).
+// A wave owns 32 output channels x the 32 tiles x 18 frequencies (rows a = 3 fh .. 3 fh + 2 of the 6 x 6 frequency grid).  Per slab of 4 input channels:
+//   * U (transformed weights [f 36][h 2][oc 64][j 2], channel k = 2 j + h, written in exactly this image by wino4_weight_kernel) and the slab's raw
+//     4 x 18 x 34 input window (LDS rows of 36 floats) go global -> LDS directly (LDS-DMA, one resp. two slabs ahead), as in wino_conv_kernel;
+//   * a thread transforms HALF of one 6 x 6 patch (three rows of B^T d, then (.) B: 72 fused multiply-adds) and writes 18 values of V [f][h][tile 32][j 2];
+//   * every wave runs 36 MFMAs (18 frequencies x 2 k-steps), operands read as one 8-byte LDS fragment per (frequency, operand).
+// The output transform A^T M A needs all six rows a of a tile: each wave applies its three rows, the two waves of an output-channel half exchange
+// half of their partial 4 x 4 tiles through LDS, and each finishes (noise / bias / activation epilogue, 16-byte stores) two of the four output rows.
+// =================================================================================================
+#ifndef W4_INTERLEAVE
+#define W4_INTERLEAVE 1
+#endif
+constexpr int W4KC = 4;                      // input channels per slab
+constexpr int W4U = 36 * 2 * 64 * 2;         // floats of one U slab image in LDS (36 KB)
+constexpr int W4V = 36 * 2 * 32 * 2;         // floats of one V slab (18 KB)
+constexpr int W4RC = 36;                     // floats per LDS row of the raw window (34 used)
+constexpr int W4RAW = 41 * 64;               // floats of one raw window [4][18][36] = 2592, rounded up to whole wave transfers
+constexpr int W4LDS = 2 * W4U + 2 * W4V + 2 * W4RAW;     // 32 896 floats = 128.5 KB
+
+// U[n][slab][f][h][ocp][j] = (G g G^T)[f] of channel c = slab*4 + 2j + h, output channel oc (zero rows up to ocp); the transform in double, rounded once
+__global__ void __launch_bounds__(256) wino4_weight_kernel(WinoParams P, const float* __restrict__ w, float* __restrict__ U) {
+    const int64_t total = (int64_t)P.nw * (P.Ci / W4KC) * 2 * P.ocp;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        const int oc = (int)(g % P.ocp);
+        int64_t r = g / P.ocp;
+        const int h = (int)(r & 1); r >>= 1;
+        const int slab = (int)(r % (P.Ci / W4KC));
+        const int n = (int)(r / (P.Ci / W4KC));
+        float u[2][36];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double gk[3][3];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) gk[t / 3][t % 3] = 0.0;
+            if (oc < P.Mo) {
+                const float* wp = w + (int64_t)n * P.wbs + (int64_t)oc * P.wsm + (int64_t)(slab * W4KC + 2 * j + h) * P.wsc;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) gk[t / 3][t % 3] = (double)wp[P.widx[t]];       // widx[(dy+1)*3 + (dx+1)]
+            }
+            double t6[6][3];                                                             // G g
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const double g0 = gk[0][s], g1 = gk[1][s], g2 = gk[2][s];
+                t6[0][s] = g0 * 0.25;
+                t6[1][s] = -(g0 + g1 + g2) * (1.0 / 6.0);
+                t6[2][s] = -(g0 - g1 + g2) * (1.0 / 6.0);
+                t6[3][s] = g0 * (1.0 / 24.0) + g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0);
+                t6[4][s] = g0 * (1.0 / 24.0) - g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0);
+                t6[5][s] = g2;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {                                                // (G g) G^T
+                const double g0 = t6[a][0], g1 = t6[a][1], g2 = t6[a][2];
+                u[j][a * 6 + 0] = (float)(g0 * 0.25);
+                u[j][a * 6 + 1] = (float)(-(g0 + g1 + g2) * (1.0 / 6.0));
+                u[j][a * 6 + 2] = (float)(-(g0 - g1 + g2) * (1.0 / 6.0));
+                u[j][a * 6 + 3] = (float)(g0 * (1.0 / 24.0) + g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0));
+                u[j][a * 6 + 4] = (float)(g0 * (1.0 / 24.0) - g1 * (1.0 / 12.0) + g2 * (1.0 / 6.0));
+                u[j][a * 6 + 5] = (float)g2;
+            }
+        }
+        float2* dst = reinterpret_cast<float2*>(U + (int64_t)n * P.u_bs) + ((int64_t)(slab * 36) * 2 + h) * P.ocp + oc;
+#pragma unroll
+        for (int f = 0; f < 36; ++f) dst[(int64_t)f * 2 * P.ocp] = make_float2(u[0][f], u[1][f]);
+    }
+}
+
+// 1-D input transform B^T (6 -> 6), rows selected at compile time: t = B^T d
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+template <int HALF>
+__device__ __forceinline__ void w4_bt_rows(const float (&d)[6], float (&t)[3]) {
+    if (HALF == 0) {
+        t[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+        const float a = fmaf(-4.f, d[2], d[4]), b = fmaf(-4.f, d[1], d[3]);
+        t[1] = a + b; t[2] = a - b;
+    } else {
+        const float c = d[4] - d[2], e = d[3] - d[1];
+        t[0] = fmaf(2.f, e, c); t[1] = fmaf(-2.f, e, c);
+        t[2] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+    }
+}
+__device__ __forceinline__ void w4_bt_full(const float (&d)[6], float (&t)[6]) {
+    t[0] = fmaf(4.f, d[0], fmaf(-5.f, d[2], d[4]));
+    const float a = fmaf(-4.f, d[2], d[4]), b = fmaf(-4.f, d[1], d[3]);
+    t[1] = a + b; t[2] = a - b;
+    const float c = d[4] - d[2], e = d[3] - d[1];
+    t[3] = fmaf(2.f, e, c); t[4] = fmaf(-2.f, e, c);
+    t[5] = fmaf(4.f, d[1], fmaf(-5.f, d[3], d[5]));
+}
+
+__global__ void __launch_bounds__(256, 1) wino4_conv_kernel(WinoParams P, const float* __restrict__ in, const float* __restrict__ U,
+                                                            float* __restrict__ out, WinoEpilogue ep) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // Us[2][W4U] | Vs[2][W4V] | Rs[2][W4RAW]
+    float* Us = lds;
+    float* Vs = lds + 2 * W4U;
+    float* Rs = lds + 2 * W4U + 2 * W4V;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l32 = lane & 31;
+    const int ocw = wave & 1, fh = wave >> 1;                         // MFMA role: 32 output channels, frequency rows a = 3 fh .. 3 fh + 2
+    const int n = blockIdx.z, oc0 = blockIdx.y * WOC;
+    const int bxi = blockIdx.x % P.bx, byi = blockIdx.x / P.bx;       // (P.bx: 32-pixel block columns)
+    const int oy0 = byi * 16, ox0 = bxi * 32;
+    const int64_t HW = (int64_t)P.H * P.W;
+    float* ob = out + (int64_t)n * P.out_bs;
+
+    // ---- needed-output map (forward) / zero-segment map of the gradient operand (dgrad): nothing flagged in the block's output rows resp.
+    //      receptive field -> the result is exactly zero: write it and leave (wino_conv_kernel's rule on a 16 x 32 block)
+    if (P.out_flags || P.seg_flags) {
+        const int32_t* fl = (P.out_flags ? P.out_flags : P.seg_flags) + (int64_t)n * P.nseg;
+        const int halo = P.out_flags ? 0 : 1;
+        const int ylo = max(oy0 - halo, 0), yhi = min(oy0 + 15 + halo, P.H - 1);
+        const int xlo = max(ox0 - halo, 0), xhi = min(ox0 + 31 + halo, P.W - 1);
+        int any = 0;
+        const int rows = yhi - ylo + 1;
+        for (int e = tid; e < rows * 4; e += 256) {                  // <= 4 segments per row (34 pixels span at most 4 when rows start on a segment boundary or not)
+            const int iy = ylo + (e >> 2);
+            const int sg = ((iy * P.W + xlo) >> 4) + (e & 3);
+            if (sg <= ((iy * P.W + xhi) >> 4)) any |= fl[sg];
+        }
+        if (!__syncthreads_or(any)) {
+            for (int e = tid; e < WOC * 512; e += 256) {
+                const int m = oc0 + (e >> 9), yy = oy0 + ((e >> 5) & 15), xx = ox0 + (e & 31);
+                if (m < P.Mo) ob[(int64_t)m * HW + (int64_t)yy * P.W + xx] = 0.f;
+            }
+            return;
+        }
+    }
+
+    const __amdgpu_buffer_rsrc_t rsI = make_rsrc(in + (int64_t)n * P.in_bs, P.in_bs * 4);
+    const int chs4 = __builtin_amdgcn_readfirstlane((int)HW * 4);
+    const int nslab = P.Ci / W4KC;
+    // raw window image [4 channels][18 rows][36 columns] (columns 34, 35 unused): lane l of wave transfer T writes slot T * 64 + l
+    unsigned voffR[11];
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const int slot = (i * 4 + wave) * 64 + lane;
+        const int ch = slot / (18 * W4RC), rem = slot - ch * (18 * W4RC), r = rem / W4RC, c = rem - r * W4RC;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + c;
+        voffR[i] = (slot < W4KC * 18 * W4RC && c < 34 && iy >= 0 && iy < P.H && ix >= 0 && ix < P.W) ? (unsigned)(ch * chs4 + (iy * P.W + ix) * 4) : BUF_OOB;
+    }
+    // U slab image: 72 rows (f, h) of 64 oc x 2 floats = 512 B; wave transfer T (16 B per lane) carries rows 2 T, 2 T + 1
+    unsigned uvoff[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int T = i * 4 + wave, row = 2 * T + (lane >> 5);
+        uvoff[i] = (unsigned)((((int64_t)row * P.ocp + oc0) * 2) * 4 + (lane & 31) * 16);
+    }
+    const char* Ubase = reinterpret_cast<const char*>(U + (int64_t)n * P.u_bs);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+    auto copy_u = [&](int buf, int s, int i) {
+        s = min(s, nslab - 1);
+        const char* src = Ubase + (int64_t)s * 72 * P.ocp * 8;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((buf * W4U + (i * 4 + wave) * 256) * 4));
+        SPI_LDS_DMA_GLOBAL_X4(dst, uvoff[i], src);
+    };
+    auto copy_raw = [&](int rbuf, int s, int i) {
+        s = min(s, nslab - 1);
+        const int soff = __builtin_amdgcn_readfirstlane(s * W4KC * chs4);
+        if (i < 10 || wave == 0) {                                   // 41 wave transfers: the last round is wave 0's alone
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((2 * W4U + 2 * W4V + rbuf * W4RAW + (i * 4 + wave) * 64) * 4));
+            SPI_LDS_DMA_BUFFER_X1(dst, voffR[i], rsI, soff);
+        }
+    };
+
+    // ---- transform role: tile = lane & 31 (ty = tile >> 3, tx = tile & 7), channel k = (wave & 1) + 2 (lane >> 5)  [h_ = wave & 1, j_ = lane >> 5],
+    //      rows a = 3 half .. 3 half + 2 of the frequency grid, half = wave >> 1
+    const int t_h = wave & 1, t_j = lane >> 5, t_half = wave >> 1;
+    const int t_k = t_h + 2 * t_j;
+    const int ty = l32 >> 3, tx = l32 & 7;
+    const int roff = (t_k * 18 + 4 * ty) * W4RC + 4 * tx;            // the patch's first float in the raw window
+    auto transform = [&](const float* Rb, float* Vb) {
+        float T[3][6];
+        // rows of the patch: half 0 needs d rows 0..4, half 1 rows 1..5; column c of (B^T d) from the column c of d
+        float d[6][6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {
+            if ((t_half == 0 && r == 5) || (t_half == 1 && r == 0)) {          // (wave-uniform)
+#pragma unroll
+                for (int c = 0; c < 6; ++c) d[r][c] = 0.f;
+                continue;
+            }
+            const float4 lo = *reinterpret_cast<const float4*>(Rb + roff + r * W4RC);
+            const float2 hi = *reinterpret_cast<const float2*>(Rb + roff + r * W4RC + 4);
+            d[r][0] = lo.x; d[r][1] = lo.y; d[r][2] = lo.z; d[r][3] = lo.w; d[r][4] = hi.x; d[r][5] = hi.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const float col[6] = {d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], d[5][c]};
+            float t3[3];
+            if (t_half == 0) w4_bt_rows<0>(col, t3); else w4_bt_rows<1>(col, t3);
+            T[0][c] = t3[0]; T[1][c] = t3[1]; T[2][c] = t3[2];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            float v[6];
+            w4_bt_full(T[a], v);
+#pragma unroll
+            for (int b = 0; b < 6; ++b) Vb[((((3 * t_half + a) * 6 + b) * 2 + t_h) * 32 + l32) * 2 + t_j] = v[b];
+        }
+    };
+
+    f32x16 acc[18];
+#pragma unroll
+    for (int f = 0; f < 18; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    // prologue: U[0], raw[0], raw[1] -> LDS; V[0] from raw[0]
+#pragma unroll
+    for (int i = 0; i < 11; ++i) { if (i < 9) copy_u(0, 0, i); copy_raw(0, 0, i); copy_raw(1, 1, i); }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    transform(Rs, Vs);
+    __syncthreads();
+
+    const int aoff = ((fh * 18 * 2 + h) * 64 + ocw * 32 + l32) * 2, boff = ((fh * 18 * 2 + h) * 32 + l32) * 2;
+#if !W4_INTERLEAVE
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        const float* Ub = Us + buf * W4U + aoff;
+        const float* Vb = Vs + buf * W4V + boff;
+        // this iteration's transfers: raw[s+2] -> the raw buffer slab s lived in, U[s+1] -> the other U buffer
+#pragma unroll
+        for (int i = 0; i < 11; ++i) { if (i < 9) copy_u(buf ^ 1, s + 1, i); copy_raw(buf, s + 2, i); }
+        // raw[s+1] -> V[s+1] (its transfers were awaited at the end of the previous iteration)
+        transform(Rs + (buf ^ 1) * W4RAW, Vs + (buf ^ 1) * W4V);
+#pragma unroll
+        for (int f = 0; f < 18; ++f) {
+            const float2 a2 = *reinterpret_cast<const float2*>(Ub + f * 256);
+            const float2 b2 = *reinterpret_cast<const float2*>(Vb + f * 128);
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2.x, acc[f], 0, 0, 0);
+            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2.y, acc[f], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this iteration's transfers have landed
+        __syncthreads();
+    }
+#else
+    // Hand-interleaved main loop (wino_conv_kernel's scheme): behind EVERY MFMA one micro-slot of side work -- an fp32 MFMA occupies the pipe for 64
+    // cycles after a 4-cycle issue, a handful of instructions per slot run in its shadow.  36 slots per slab:
+    //   * the operand fragments two frequencies ahead (slots with an even index),
+    //   * this iteration's transfers: U[s+1] (9) on slots 1, 5, 9, ... and raw[s+2] (11) on slots 3, 7, 11, ... (+ the last two on 35 / 33's neighbours),
+    //   * raw[s+1] -> V[s+1]: five patch rows on slots 0..4, the six column transforms on slots 6..16, then per frequency row a the row transform
+    //     and its six stores on slots 18 + 6 a .. 23 + 6 a.
+    float d[6][6], T[3][6], v[6];
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        const float* Ub = Us + buf * W4U + aoff;
+        const float* Vb = Vs + buf * W4V + boff;
+        const float* Rn = Rs + (buf ^ 1) * W4RAW;
+        float* Vw = Vs + (buf ^ 1) * W4V;
+        // MFMA order: frequencies in groups of three, k-step inside the group outermost -- slot m = 6 g + 3 j + i is frequency 3 g + i, k-step j: the two
+        // MFMAs of an accumulator are three slots (192 cycles) apart instead of back to back (a dependent MFMA waits for its predecessor's last pass)
+        float2 af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { af[0][i] = *reinterpret_cast<const float2*>(Ub + i * 256); bf[0][i] = *reinterpret_cast<const float2*>(Vb + i * 128); }
+#pragma unroll
+        for (int m = 0; m < 36; ++m) {
+            const int g = m / 6, j = (m % 6) / 3, i3 = m % 3, f = 3 * g + i3;
+            const float av = j ? af[g & 1][i3].y : af[g & 1][i3].x, bv = j ? bf[g & 1][i3].y : bf[g & 1][i3].x;
+            // 288 accumulators do not fit the 256 AGPRs: left to itself the compiler parks two of the 18 tiles in VGPRs and swaps them through an AGPR
+            // tile around their MFMAs (96 v_accvgpr moves per slab).  Frequencies 16 and 17 are pinned to VGPRs instead: the MFMA takes VGPR C / D.
+            if (f < 16) acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[f], 0, 0, 0);
+            else asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[f]) : "v"(av), "v"(bv));
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < 6 && (m % 6) < 3) {                                          // the next group's fragments, one frequency per slot
+                af[(g + 1) & 1][i3] = *reinterpret_cast<const float2*>(Ub + (3 * (g + 1) + i3) * 256);
+                bf[(g + 1) & 1][i3] = *reinterpret_cast<const float2*>(Vb + (3 * (g + 1) + i3) * 128);
+            }
+#ifndef W4_NO_DMA
+            // all 20 transfers in the first 20 slots: the barrier at the end of the slab waits for them, 16 MFMAs (~1000 cycles) later
+            if (m < 20) { if (m & 1) { if ((m >> 1) < 9) copy_u(buf ^ 1, s + 1, m >> 1); } else copy_raw(buf, s + 2, m >> 1); }
+            if (m == 19) copy_raw(buf, s + 2, 10);
+#endif
+#ifndef W4_NO_XFORM
+            if (m < 5) {                                                            // patch rows (half 0: rows 0..4, half 1: rows 1..5)
+                const int r = m + t_half;
+                const float4 lo = *reinterpret_cast<const float4*>(Rn + roff + r * W4RC);
+                const float2 hi = *reinterpret_cast<const float2*>(Rn + roff + r * W4RC + 4);
+                d[m][0] = lo.x; d[m][1] = lo.y; d[m][2] = lo.z; d[m][3] = lo.w; d[m][4] = hi.x; d[m][5] = hi.y;
+            }
+            if (m >= 6 && m < 18 && (m & 1) == 0) {                                 // column c of B^T d (three rows of it)
+                const int c = (m - 6) >> 1;
+                // half 0: d[0..4] are patch rows 0..4; half 1: d[0..4] are patch rows 1..5
+                if (t_half == 0) {
+                    const float col[6] = {d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], 0.f};
+                    float t3[3]; w4_bt_rows<0>(col, t3); T[0][c] = t3[0]; T[1][c] = t3[1]; T[2][c] = t3[2];
+                } else {
+                    const float col[6] = {0.f, d[0][c], d[1][c], d[2][c], d[3][c], d[4][c]};
+                    float t3[3]; w4_bt_rows<1>(col, t3); T[0][c] = t3[0]; T[1][c] = t3[1]; T[2][c] = t3[2];
+                }
+            }
+            if (m >= 18) {
+                const int a = (m - 18) / 6, ph = (m - 18) % 6;
+                if (ph == 0) w4_bt_full(T[a], v);
+                if (ph >= 2 && ph < 5) {
+                    const int b0 = 2 * (ph - 2);
+                    Vw[((((3 * t_half + a) * 6 + b0) * 2 + t_h) * 32 + l32) * 2 + t_j] = v[b0];
+                    Vw[((((3 * t_half + a) * 6 + b0 + 1) * 2 + t_h) * 32 + l32) * 2 + t_j] = v[b0 + 1];
+                }
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this iteration's transfers have landed
+        __syncthreads();
+    }
+#endif
+
+    // ---- output transform A^T M A + epilogue.  C/D layout: col = lane & 31 (tile), row = (r & 3) + 8 (r >> 2) + 4 h.
+    //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  Per accumulator row r the wave has M[a][b], a = 3 fh + (0, 1, 2), b = 0..5:
+    //   R[a][j] = sum_b M[a][b] A[b][j], then its share of Y[i][j] = sum_a A^T[i][a] R[a][j].  The wave keeps output rows i = 2 fh, 2 fh + 1 and
+    //   hands rows 2 (1 - fh), 2 (1 - fh) + 1 to its partner (same ocw, other fh) through LDS: [8 values][4 rows r][64 lanes] per wave and chunk.
+    //   (The main loop's buffers are free: its last iteration ended with a barrier.)
+    float* xch = lds + wave * 2048 + lane;                            // this wave's outgoing chunk
+    const float* xin = lds + (wave ^ 2) * 2048 + lane;                // the partner's
+    const int oy = oy0 + 4 * ty + 2 * fh, ox = ox0 + 4 * tx;
+    const int64_t pix = (int64_t)oy * P.W + ox;
+    float nz[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nz[i][j] = 0.f;
+    if (ep.noise) {
+        const float ng = ep.noise_gain ? ep.noise_gain[0] : 1.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 nv = *reinterpret_cast<const float4*>(ep.noise + pix + (int64_t)i * P.W);
+            nz[i][0] = nv.x * ng; nz[i][1] = nv.y * ng; nz[i][2] = nv.z * ng; nz[i][3] = nv.w * ng;
+        }
+    }
+    const bool has_epi = ep.act != 0 || ep.bias || ep.noise;
+#pragma unroll
+    for (int rc = 0; rc < 4; ++rc) {
+        float keep[4][2][4];                                          // [r in chunk][output row of mine][column]
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rc * 4 + rr;
+            float R[3][4];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float m0 = acc[a * 6 + 0][r], m1 = acc[a * 6 + 1][r], m2 = acc[a * 6 + 2][r], m3 = acc[a * 6 + 3][r], m4 = acc[a * 6 + 4][r], m5 = acc[a * 6 + 5][r];
+                const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+                R[a][0] = m0 + s1 + s2; R[a][1] = fmaf(2.f, d2, d1); R[a][2] = fmaf(4.f, s2, s1); R[a][3] = fmaf(8.f, d2, d1) + m5;
+            }
+            float Y[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (fh == 0) {                                        // a = 0, 1, 2: columns [1 0 0 0], [1 1 1 1], [1 -1 1 -1] of A^T
+                    const float s = R[1][j] + R[2][j], dd = R[1][j] - R[2][j];
+                    Y[0][j] = R[0][j] + s; Y[1][j] = dd; Y[2][j] = s; Y[3][j] = dd;
+                } else {                                              // a = 3, 4, 5: columns [1 2 4 8], [1 -2 4 -8], [0 0 0 1]
+                    const float s = R[0][j] + R[1][j], dd = R[0][j] - R[1][j];
+                    Y[0][j] = s; Y[1][j] = 2.f * dd; Y[2][j] = 4.f * s; Y[3][j] = fmaf(8.f, dd, R[2][j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    keep[rr][i][j] = fh == 0 ? Y[i][j] : Y[2 + i][j];
+                    xch[((i * 4 + j) * 4 + rr) * 64] = fh == 0 ? Y[2 + i][j] : Y[i][j];
+                }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = rc * 4 + rr;
+            const int m = oc0 + ocw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float bv = (ep.bias && m < P.Mo) ? ep.bias[m] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float y[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = keep[rr][i][j] + xin[((i * 4 + j) * 4 + rr) * 64];
+                    if (has_epi) v = conv_act_gain_clamp(ep.act, ep.alpha, ep.gain, ep.clamp, v + nz[i][j] + bv);
+                    y[j] = v;
+                }
+                if (m < P.Mo) *reinterpret_cast<float4*>(ob + (int64_t)m * HW + pix + (int64_t)i * P.W) = make_float4(y[0], y[1], y[2], y[3]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 int64_t spi_wino_workspace_bytes(const WinoParams& P) { return (int64_t)P.nw * P.u_bs_of() * 4; }
 
 int spi_wino_launch(WinoParams P, const float* in, const float* w, float* out, const WinoEpilogue& ep, void* workspace, hipStream_t st, bool u_ready) {
     float* U = static_cast<float*>(workspace);
     P.u_bs = P.nw > 1 ? P.u_bs_of() : 0;
+    if (P.f4) {
+        if (!u_ready) {
+            const int64_t total = (int64_t)P.nw * (P.Ci / W4KC) * 2 * P.ocp;
+            const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);
+            WinoParams Pw = P; Pw.u_bs = P.u_bs_of();
+            hipLaunchKernelGGL(wino4_weight_kernel, dim3(grid), dim3(256), 0, st, Pw, w, U);
+        }
+        constexpr size_t lds4 = (size_t)W4LDS * sizeof(float);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(wino4_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        if (e != hipSuccess) { spi_set_error("winograd F(4x4,3x3) conv: cannot reserve %zu bytes of LDS: %s", lds4, hipGetErrorString(e)); return SPI_ERR_LAUNCH; }
+        P.bx = P.W / 32; P.by = P.H / 16;
+        dim3 grid4((unsigned)(P.bx * P.by), (unsigned)(P.ocp / WOC), (unsigned)P.N);
+        hipLaunchKernelGGL(wino4_conv_kernel, grid4, dim3(256), lds4, st, P, in, U, out, ep);
+        return SPI_OK;
+    }
     if (!u_ready) {           // (u_ready: the workspace still holds the transform of these weights from an earlier call -- frozen weights, spi_conv_desc.workspace_ready)
         const int64_t total = (int64_t)P.nw * (P.Ci / WKC) * 2 * P.ocp;
         const unsigned grid = (unsigned)std::min<int64_t>((total + 255) / 256, 8192);

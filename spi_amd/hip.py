@@ -11,7 +11,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'csrc', 'libspi_hip.so')
 _lib = None
-ABI_VERSION = 12          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
+ABI_VERSION = 13          # SPI_ABI_VERSION of include/spi_hip.h this binding was written against
 
 c_f = ctypes.c_float
 c_i = ctypes.c_int
@@ -79,6 +79,7 @@ _SIGS = {
     'spi_conv2d_workspace_bytes': ([ctypes.POINTER(ConvDesc), c_i], c_l),
     'spi_conv2d_out_accumulates': ([ctypes.POINTER(ConvDesc), c_i], c_i),
     'spi_conv2d_plan': ([ctypes.POINTER(ConvDesc), c_i, c_p], c_i),
+    'spi_conv_wino_f4_set': ([c_i], None),
     'spi_conv2d_fwd': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
     'spi_conv2d_dgrad': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),
     'spi_conv2d_wgrad': ([ctypes.POINTER(ConvDesc), c_p, c_p, c_p, c_p], c_i),

@@ -4,6 +4,8 @@ import ctypes, os, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from spi_amd import hip
+if os.environ.get('SPI_HIP_LIB'):                       # A/B against another build of the library
+    hip.LIB_PATH = os.environ['SPI_HIP_LIB']
 from spi_amd.torch_utils.ops import conv2d_mfma as cm
 
 SHAPES = [  # name, N, I, O, H, k, transposed, per_sample
