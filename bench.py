@@ -53,6 +53,7 @@ def parse():
                          'protocol (default, ~2.5 min): + the every-4th-iteration branch iteration (rot / mirror-rot / depth), i.e. one whole 4-iteration stage-2 '
                          'super-cycle MEASURED in this process -- the value is the same stage mix as the GPU line, not an upper bound; '
                          'full (~4 min): + a thread-scaling line')
+    ap.add_argument('--no-wino-f2-leg', action='store_true', help='skip the extra leg that times the same steps with F(2x2,3x3) Winograd on every layer (`wino_f2`)')
     ap.add_argument('--no-winograd', action='store_true', help='3x3 convolutions on the implicit-GEMM kernels only (global_config.conv_winograd = False)')
     ap.add_argument('--dense', action='store_true', help='NOT the benchmark configuration: switch off the data-driven skipping of exactly-zero gradients / '
                                                          'unneeded SR tiles in the masked pseudo-view branches (dense bound of the same step)')
@@ -288,11 +289,17 @@ def conv_roofline(dev, f16, prec=0):
                 a.record(); fn(dd); b.record()
             torch.cuda.synchronize()
             avg = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
-            wres[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12, 'executed': flop / 2.25 / (avg * 1e-3) / 1e12,
-                          'frac_executed': flop / 2.25 / (avg * 1e-3) / 1e12 / peak}
-        out['winograd'] = {'kernel': 'wino_weight_kernel + wino_conv_kernel (F(2x2,3x3): fwd, dgrad), wino_wgrad_kernel (F(3x3,2x2): wgrad, incl. its memset of dw), same layer',
+            # multiplications saved by the minimal-filtering tile the pass runs: F(4x4,3x3) 144 / 36 = 4 (forward / dgrad of this layer with
+            # global_config.conv_winograd_f4), F(2x2,3x3) and the F(3x3,2x2) weight gradient 36 / 16 = 2.25
+            red = 4.0 if (global_config.conv_winograd_f4 and pid < 2) else 2.25
+            wres[name] = {'avg_launch_us': avg * 1e3, 'achieved': flop / (avg * 1e-3) / 1e12, 'executed': flop / red / (avg * 1e-3) / 1e12,
+                          'frac_executed': flop / red / (avg * 1e-3) / 1e12 / peak, 'multiplications_saved': red}
+        f4 = bool(global_config.conv_winograd_f4)
+        out['winograd'] = {'kernel': ('wino4_weight_kernel + wino4_conv_kernel (F(4x4,3x3): fwd, dgrad)' if f4 else 'wino_weight_kernel + wino_conv_kernel (F(2x2,3x3): fwd, dgrad)')
+                                     + ', wino_wgrad_kernel (F(3x3,2x2): wgrad, incl. its memset of dw), same layer',
                            'passes': wres,
-                           'note': 'fp32 operands and accumulation; 16 MFMA multiplications per 2x2 tile and channel pair instead of 36; these are the kernels the loop runs for this layer'}
+                           'note': 'fp32 operands and accumulation; ' + ('36 MFMA multiplications per 4x4 tile and channel pair instead of 144' if f4 else '16 MFMA multiplications per 2x2 tile and channel pair instead of 36')
+                                   + ' (forward / dgrad); these are the kernels the loop runs for this layer'}
     return out
 
 
@@ -753,6 +760,32 @@ def main():
                        'NOT the benchmark value'}
         marks.clear(); marks.update(main_marks)
         global_config.conv_precision = {'f32': 0, 'bf16x6': 3, 'bf16x3': 2}[args.conv_precision]
+    wino_f2 = None
+    if global_config.conv_winograd and global_config.conv_winograd_f4 and not args.no_wino_f2_leg and ok and not pti and not os.environ.get('SPI_TORCH_PROFILE'):
+        # the same K steps once more with F(2x2, 3x3) Winograd everywhere (round 5's arithmetic: ~2e-6 of the range per layer instead of F(4x4)'s ~4e-5):
+        # reported beside the benchmark value so that the precision trade of the >= 256^2 layers is visible; never `value`.
+        global_config.conv_winograd_f4 = False
+        main_marks = dict(marks)
+        f2_err = None
+        try:
+            leg_warm = 8 if global_config.stage2_hip_graph else 4
+            run(2 if k1 else 0, leg_warm if k2 else 0, step1_next, step2_next)      # graphs are re-captured for another arithmetic
+            sdist.barrier(); torch.cuda.synchronize()
+            run(k1, k2, step1_next + 2, step2_next + leg_warm)
+        except Exception as e:                                    # noqa: BLE001
+            f2_err = repr(e)
+        torch.cuda.synchronize(); sdist.barrier()
+        bad = sdist.reduce_stats([0.0 if f2_err is None else 1.0], device=dev)[0]
+        f2_s = sdist.reduce_stats([marks.get('stage1_s', 0.0), marks.get('stage2_s', 0.0)], device=dev, op='max')
+        wino_f2 = {'error': f2_err or 'failed on another rank'} if bad else {
+            'value': mix_value(f2_s[0], f2_s[1]), 'unit': 'iters/s',
+            'stage1_mir_iters_per_s_per_gpu': 1e3 / marks['stage1_ms_per_step'] if k1 else None,
+            'stage2_rotbbox_iters_per_s_per_gpu': 1e3 / marks['stage2_ms_per_step'] if k2 else None,
+            'note': 'same K steps with global_config.conv_winograd_f4 = False: F(2x2, 3x3) minimal filtering on every Winograd layer (the >= 256^2 layers of `value` run '
+                    'F(4x4, 3x3): 1.78x fewer multiplications, result within ~4e-5 of the range of the direct sum instead of ~2e-6; both fp32 operands and accumulation); '
+                    'NOT the benchmark value'}
+        marks.clear(); marks.update(main_marks)
+        global_config.conv_winograd_f4 = True
     dense_leg = None
     if not args.dense and not args.no_dense_leg and ok and k2 and not pti and not os.environ.get('SPI_TORCH_PROFILE'):
         # the dense bound of the same step: the stage-2 iterations once more with the data-driven skipping of exactly-zero gradients /
@@ -896,6 +929,8 @@ def main():
             out['sustained'] = sustained
         if alt is not None:
             out['alt'] = alt
+        if wino_f2 is not None:
+            out['wino_f2'] = wino_f2
         if dense_leg is not None:
             out['dense'] = dense_leg
         mb = (out.get('roofline_march_bwd') or {}).get('masked_launches_only') or {}

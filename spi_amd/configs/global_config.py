@@ -45,6 +45,10 @@ exploit_sparsity = True
 # Winograd F(2x2, 3x3) for the 3x3 / stride-1 forward and data-gradient passes of the large layers and F(3x3, 2x2) for their weight
 # gradients (winograd.hip): fp32 operands and accumulation, 2.25x fewer MFMAs; results differ from the direct sums by a few fp32 roundings.  Off = implicit GEMM everywhere.
 conv_winograd = os.environ.get('SPI_CONV_WINOGRAD', '1') != '0'
+# conv_winograd_f4 (round 6; SPI_CONV_WINO_F4=0 switches it off): the >= 256^2 layers' Winograd forward / dgrad use F(4x4, 3x3) -- 36 multiplications per
+#      4x4 output tile and channel pair, 1.78x fewer than F(2x2, 3x3) -- where its 16 x 32-pixel blocks fill the chip; fp32 operands and accumulation, the
+#      result within 4e-5 of the tensor's range of the direct sum (F(2x2): 2e-6).  False: F(2x2, 3x3) everywhere (`bench.py` reports that rate beside `value`).
+conv_winograd_f4 = os.environ.get('SPI_CONV_WINO_F4', '1') != '0'
 
 # fp16 activation tensors (configs[4]): the 3x3 / stride-1 forward and data-gradient passes whose output channels come in blocks of 128 run the
 # direct fp16 kernel (hconv.hip: the input patch staged once for all nine taps, weights pre-converted to their LDS image).  Off = implicit GEMM.

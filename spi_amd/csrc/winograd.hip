@@ -887,7 +887,10 @@ __global__ void __launch_bounds__(256, 1) wino4_conv_kernel(WinoParams P, const 
     //   * this iteration's transfers: U[s+1] (9) on slots 1, 5, 9, ... and raw[s+2] (11) on slots 3, 7, 11, ... (+ the last two on 35 / 33's neighbours),
     //   * raw[s+1] -> V[s+1]: five patch rows on slots 0..4, the six column transforms on slots 6..16, then per frequency row a the row transform
     //     and its six stores on slots 18 + 6 a .. 23 + 6 a.
-    float d[6][6], T[3][6], v[6];
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 d2[5][3], T2[3][3];                                        // five patch rows / three transformed rows as column PAIRS (v_pk_fma_f32 / v_pk_add_f32)
+    float v[6];
+    const f32x2 k4 = {4.f, 4.f}, km4 = {-4.f, -4.f}, km5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, km2 = {-2.f, -2.f};
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
         const float* Ub = Us + buf * W4U + aoff;
@@ -922,22 +925,23 @@ __global__ void __launch_bounds__(256, 1) wino4_conv_kernel(WinoParams P, const 
                 const int r = m + t_half;
                 const float4 lo = *reinterpret_cast<const float4*>(Rn + roff + r * W4RC);
                 const float2 hi = *reinterpret_cast<const float2*>(Rn + roff + r * W4RC + 4);
-                d[m][0] = lo.x; d[m][1] = lo.y; d[m][2] = lo.z; d[m][3] = lo.w; d[m][4] = hi.x; d[m][5] = hi.y;
+                d2[m][0] = f32x2{lo.x, lo.y}; d2[m][1] = f32x2{lo.z, lo.w}; d2[m][2] = f32x2{hi.x, hi.y};
             }
-            if (m >= 6 && m < 18 && (m & 1) == 0) {                                 // column c of B^T d (three rows of it)
-                const int c = (m - 6) >> 1;
-                // half 0: d[0..4] are patch rows 0..4; half 1: d[0..4] are patch rows 1..5
-                if (t_half == 0) {
-                    const float col[6] = {d[0][c], d[1][c], d[2][c], d[3][c], d[4][c], 0.f};
-                    float t3[3]; w4_bt_rows<0>(col, t3); T[0][c] = t3[0]; T[1][c] = t3[1]; T[2][c] = t3[2];
-                } else {
-                    const float col[6] = {0.f, d[0][c], d[1][c], d[2][c], d[3][c], d[4][c]};
-                    float t3[3]; w4_bt_rows<1>(col, t3); T[0][c] = t3[0]; T[1][c] = t3[1]; T[2][c] = t3[2];
+            if (m == 6 || m == 8 || m == 10) {                                       // columns 2 p, 2 p + 1 of B^T d (three rows of it), packed
+                const int p = (m - 6) >> 1;
+                if (t_half == 0) {                                                  // d2[0..4] = patch rows 0..4: rows 0, 1, 2 of B^T
+                    T2[0][p] = __builtin_elementwise_fma(k4, d2[0][p], __builtin_elementwise_fma(km5, d2[2][p], d2[4][p]));
+                    const f32x2 a = __builtin_elementwise_fma(km4, d2[2][p], d2[4][p]), b = __builtin_elementwise_fma(km4, d2[1][p], d2[3][p]);
+                    T2[1][p] = a + b; T2[2][p] = a - b;
+                } else {                                                            // d2[0..4] = patch rows 1..5: rows 3, 4, 5 of B^T
+                    const f32x2 c = d2[3][p] - d2[1][p], e = d2[2][p] - d2[0][p];
+                    T2[0][p] = __builtin_elementwise_fma(k2, e, c); T2[1][p] = __builtin_elementwise_fma(km2, e, c);
+                    T2[2][p] = __builtin_elementwise_fma(k4, d2[0][p], __builtin_elementwise_fma(km5, d2[2][p], d2[4][p]));
                 }
             }
             if (m >= 18) {
                 const int a = (m - 18) / 6, ph = (m - 18) % 6;
-                if (ph == 0) w4_bt_full(T[a], v);
+                if (ph == 0) { const float Ta[6] = {T2[a][0].x, T2[a][0].y, T2[a][1].x, T2[a][1].y, T2[a][2].x, T2[a][2].y}; w4_bt_full(Ta, v); }
                 if (ph >= 2 && ph < 5) {
                     const int b0 = 2 * (ph - 2);
                     Vw[((((3 * t_half + a) * 6 + b0) * 2 + t_h) * 32 + l32) * 2 + t_j] = v[b0];

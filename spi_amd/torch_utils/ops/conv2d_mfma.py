@@ -105,6 +105,19 @@ def _frozen_key(w, pass_id, d):
     return (id(w), w.data_ptr(), tuple(w.shape), pass_id, int(d.flip), int(d.w_tap_major), int(d.compute_f16), int(d.act_dtype), str(w.device))
 
 
+_wino_f4_state = None
+
+
+def _sync_wino_f4():
+    """`global_config.conv_winograd_f4` -> the library's process-wide switch (spi_conv_wino_f4_set), before a workspace is sized with it."""
+    global _wino_f4_state
+    from ...configs import global_config
+    want = bool(global_config.conv_winograd_f4)
+    if want != _wino_f4_state:
+        hip.lib().spi_conv_wino_f4_set(1 if want else 0)
+        _wino_f4_state = want
+
+
 def _workspace(d, pass_id, device, w=None, frozen=False):
     """Scratch memory with which `pass_id` (0 forward, 1 dgrad, 2 wgrad) of the conv `d` takes its Winograd path (None: it has none, or
     ``global_config.conv_winograd`` is off).  Comes from torch's caching allocator: no device allocation after warm-up.
@@ -114,6 +127,7 @@ def _workspace(d, pass_id, device, w=None, frozen=False):
     # (a transposed conv has direct kernels for its forward and its data gradient -- a stride-2 conv of the fp16 gradient --, not for its weight gradient)
     if d.kh != 3 or (d.transposed and not (direct_f16 and pass_id < 2)) or not (direct_f16 or (global_config.conv_winograd and d.compute_f16 in (0, 3))):
         return None
+    _sync_wino_f4()
     nbytes = hip.lib().spi_conv2d_workspace_bytes(ctypes.byref(d), pass_id)
     if nbytes <= 0:
         return None

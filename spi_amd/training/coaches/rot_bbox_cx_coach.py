@@ -210,7 +210,7 @@ class RotBboxCoach(BaseCoach):
         if ctx.get('pivot_ptr') != w_pivot.data_ptr():          # a new pivot for the same image constants is a new set of baked-in addresses
             ctx['pivot_ptr'], ctx['pivot_generation'] = w_pivot.data_ptr(), self._next_generation()
         key = (ctx['generation'], ctx['pivot_generation'], id(self.G), id(self.optimizer), float(hyperparameters.LPIPS_value_threshold),    # (the threshold is baked in,
-               global_config.conv_precision, global_config.conv_winograd, global_config.enable_fp16_blocks, global_config.exploit_sparsity)   # and so is the arithmetic)
+               global_config.conv_precision, global_config.conv_winograd, global_config.conv_winograd_f4, global_config.enable_fp16_blocks, global_config.exploit_sparsity)   # and so is the arithmetic)
         if getattr(self, '_g2_key', None) != key:
             self._g2_key = key
             self._g2 = dict(stop=torch.zeros(1, device=self.device, dtype=torch.uint8), pending=collections.deque(),

@@ -220,7 +220,7 @@ class Projection:
     def _graph_step(self, step):
         from ...configs import global_config
         # the captured launches bake in the arithmetic of the run: another setting drops the graph (one eager step, then a new capture)
-        key = (global_config.conv_precision, global_config.conv_winograd, global_config.enable_fp16_blocks, global_config.exploit_sparsity)
+        key = (global_config.conv_precision, global_config.conv_winograd, global_config.conv_winograd_f4, global_config.enable_fp16_blocks, global_config.exploit_sparsity)
         if getattr(self, '_graph_key', key) != key:
             self._graph, self._n_eager = None, 0
         self._graph_key = key

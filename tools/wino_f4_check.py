@@ -16,7 +16,7 @@ def rel(a, b):
     return ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
 
 
-for (N, I, O, H, W, per, epi) in ((1, 8, 64, 256, 512, False, False), (1, 64, 128, 256, 256, True, True), (2, 16, 64, 256, 512, False, False), (1, 128, 128, 512, 512, True, True)):
+for (N, I, O, H, W, per, epi) in ((1, 128, 64, 256, 512, False, False), (1, 128, 128, 256, 256, True, True), (2, 256, 64, 256, 512, False, False), (1, 128, 128, 512, 512, True, True), (1, 256, 256, 256, 256, True, False)):
     gen = torch.Generator().manual_seed(I + O)
     x = torch.randn(N, I, H, W, generator=gen).to(DEV)
     w = (torch.randn(*((N,) if per else ()), O, I, 3, 3, generator=gen) / (I * 9) ** 0.5).to(DEV)
@@ -29,7 +29,8 @@ for (N, I, O, H, W, per, epi) in ((1, 8, 64, 256, 512, False, False), (1, 64, 12
         ref = (torch.nn.functional.leaky_relu(z, 0.2) * 1.3).clamp(-2.0, 2.0)
     outs = {}
     for mode in ('f4', 'f2', 'igemm'):
-        L.spi_conv_wino_f4_set(1 if mode == 'f4' else 0)
+        global_config.conv_winograd_f4 = mode == 'f4'
+        cm._sync_wino_f4()
         global_config.conv_winograd = mode != 'igemm'
         cm._frozen_ws.clear()
         d = cm._desc(N, I, O, H, W, 3, 1, False, True, O * I * 9 if per else 0, tap_major=1)
@@ -39,5 +40,6 @@ for (N, I, O, H, W, per, epi) in ((1, 8, 64, 256, 512, False, False), (1, 64, 12
         torch.cuda.synchronize()
         print(f'  {mode}: workspace {nb} bytes ({nb // (4 * I * ((O + 63) // 64 * 64) * (N if per else 1))} frequencies), vs fp64 torch conv (sample 0): {rel(outs[mode][0:1], ref):.2e}', flush=True)
     print(f'{(N, I, O, H, W, per, epi)}: f4 vs f2 {rel(outs["f4"], outs["f2"]):.2e}, f4 vs igemm {rel(outs["f4"], outs["igemm"]):.2e}', flush=True)
-L.spi_conv_wino_f4_set(1)
+global_config.conv_winograd_f4 = True
+cm._sync_wino_f4()
 global_config.conv_winograd = True
