@@ -383,8 +383,8 @@ typedef struct spi_conv_desc {
 int64_t spi_conv2d_workspace_bytes(const spi_conv_desc* d, int pass);
 /* Minimal-filtering tile of the fp32 Winograd forward / dgrad path (process-wide, host logic only; call it BEFORE sizing workspaces: the size differs).
  * 1 (default, or SPI_CONV_WINO_F4 unset): F(4x4, 3x3) -- 36 multiplications per 4x4 output tile and channel pair, 4x fewer than the direct sum --
- * where its 16 x 32-pixel blocks fill the chip (H % 16 == 0, W % 32 == 0, H W >= 256^2, >= 128 reduction channels, >= 256 blocks: the generator's
- * 256^2 / 512^2 layers), F(2x2, 3x3) elsewhere.
+ * where its 16 x 32-pixel blocks fill the chip (H % 16 == 0, W % 32 == 0, H W >= 256^2 with >= 128 reduction channels or H W >= 128^2 with >= 256, >= 256 blocks: the
+ * generator's 128^2 (batched) / 256^2 / 512^2 layers), F(2x2, 3x3) elsewhere.
  * 0 (or SPI_CONV_WINO_F4=0): F(2x2, 3x3) everywhere.  Both are fp32 throughout; F(4x4) differs from the direct sum by ~1e-6 of the tensor's range
  * instead of ~2e-7 (what cuDNN's fp32 Winograd, the algorithm the reference runs through torch.nn.functional.conv2d at conv2d_gradfix.py:50-56, does too). */
 void spi_conv_wino_f4_set(int on);

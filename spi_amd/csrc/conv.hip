@@ -1176,9 +1176,9 @@ static bool make_wino(const spi_conv_desc* d, const IGemmParams& P, WinoParams& 
     //  the unsplit path leaves exact zeros -- the contract of out_seg_flags must not depend on the block count)
     Wp.ksplit = (blocks >= 128 && blocks < 256 && P.Ci / 8 >= 32 && !P.out_flags) ? 2 : 1;
     // Round 6: F(4x4, 3x3) where its 16 x 32-pixel x 64-channel blocks still fill the 256 CUs (the >= 256^2 layers): 1.78x fewer MFMAs than F(2x2, 3x3)
-    // (>= 128 reduction channels at >= 256^2: the generator's b256 / super-resolution layers.  The VGG layers of the LPIPS / BoxCX losses -- 64 channels at
+    // (>= 128 reduction channels at >= 256^2, >= 256 at 128^2: the generator's b128 (batched) / b256 / super-resolution layers.  The VGG layers of the LPIPS / BoxCX losses -- 64 channels at
     //  256^2, 128 at 128^2 -- keep F(2x2): their ReLU / max-pool decisions amplify rounding noise into isolated gradient elements, tests/test_hip_losses_gpu.py)
-    Wp.f4 = (wino_f4_enabled() && P.OH % 16 == 0 && P.OW % 32 == 0 && P.Ci >= 128 && (int64_t)P.OH * P.OW >= 65536 &&
+    Wp.f4 = (wino_f4_enabled() && P.OH % 16 == 0 && P.OW % 32 == 0 && ((P.Ci >= 128 && (int64_t)P.OH * P.OW >= 65536) || (P.Ci >= 256 && (int64_t)P.OH * P.OW >= 16384)) &&
              (int64_t)(P.OH / 16) * (P.OW / 32) * (Wp.ocp / 64) * P.N >= 256 && Wp.ksplit == 1) ? 1 : 0;
     return blocks >= 128 && P.Mo >= 48;
 }
