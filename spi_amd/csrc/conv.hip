@@ -1082,6 +1082,218 @@ static void launch_igemm(const IGemmParams& P, const float* in, const float* w, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 6: weight gradient of the stride-2 TRANSPOSED 3x3 convolutions (conv0 of every up-sampling block; conv2d_resample.py:114-131), fp32.
+//     dW[o][i][ky][kx] = sum_{y, x} in[i][y][x] * dY[o][2 y + ky][2 x + kx]                    (in: H x W, dY: (2 H + 1) x (2 W + 1))
+// wgrad_kernel runs this as four parity-class GEMMs whose dY operand is read with stride 2 (half of every sector wasted, `in` read four times):
+// 0.50 - 0.57 of the fp32 peak, the single most expensive conv launch of the loop.  Here one block owns 64 output x 64 input channels x ALL NINE
+// taps (144 accumulators per lane, VGPR-form MFMAs, two blocks per CU) and walks input rows of a 16-pixel column strip:
+//   * per step the three dY rows 2 y .. 2 y + 2 (33 columns, contiguous 132-byte runs) and the input row piece arrive through plain buffer loads --
+//     per-thread constant vector offsets, the row in the scalar offset: no address arithmetic -- one step ahead of the MFMAs;
+//   * on their way into LDS the dY rows are DE-INTERLEAVED into the operand streams of the three kx taps: even columns E[j] = dY[2 j], odd columns
+//     O[j] = dY[2 j + 1]; tap kx = 0 contracts in[x] with E[x], kx = 1 with O[x], kx = 2 with E[x + 1].  An MFMA's two K slots are the lane halves, so
+//     each stream is stored per half: Eh0 / Eh1 / Oh0 / Oh1 (x = 2 s + h) and the shifted Eh0s[s] = E[2 s + 2] -- five arrays per row, every A fragment
+//     one 16-byte LDS read of four K steps, no shuffles (the fp16 kernel hwgrad_kernel needs v_alignbit for the same shift);
+//   * 72 MFMAs per step and wave (9 taps x 8 K steps), three accumulators interleaved.
+// The pixel reduction is split over blocks (column strips x row chunks x samples); partial sums meet in the zeroed dW through fp32 atomics like the
+// other weight-gradient kernels.  A masked gradient (dy_seg_flags) skips the steps whose dY rows are flagged zero.
+// ------------------------------------------------------------------------------------------------
+struct TWgradParams {
+    int N, Mo, Ci, H, W, OW;
+    int64_t in_bs, out_bs, wbs;
+    int wsm, wsc, widx9[9];
+    int xsegs, rows_per_chunk, ncib;
+    const int32_t* seg_flags; int nseg;
+};
+constexpr int TW_PX = 16;                       // input pixels (K) per step
+constexpr int TW_ARR = 64 * 8 + 8 * 4;          // floats of one operand array [64 channels][8 K steps], 16 bytes of padding per 8 channels (conflict-free 16-byte reads)
+constexpr int TW_DY = 15 * TW_ARR;              // one dY stage: [row 3][stream 5]
+constexpr int TW_X = 2 * TW_ARR;                // one input stage: [half 2]
+constexpr int TW_STAGE = TW_DY + TW_X;          // 9248 floats
+constexpr int TW_MAXROWS = 256;
+
+__global__ void __launch_bounds__(256, 2) twgrad_kernel(TWgradParams P, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dw) {
+    __shared__ __attribute__((aligned(16))) float lds[2 * TW_STAGE];
+    __shared__ unsigned char live[TW_MAXROWS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l32 = lane & 31;
+    const int cw = wave >> 1, iw = wave & 1;                          // MFMA quadrant: 32 output x 32 input channels
+    const int n = blockIdx.z;
+    const int cob = (blockIdx.y / P.ncib) * 64, cib = (blockIdx.y % P.ncib) * 64;
+    const int xseg = blockIdx.x % P.xsegs, rchunk = blockIdx.x / P.xsegs;
+    const int ix0 = xseg * TW_PX;
+    const int r0 = rchunk * P.rows_per_chunk, r1 = min(r0 + P.rows_per_chunk, P.H);
+    const int nrows = r1 - r0;
+    if (nrows <= 0) return;
+    const int OHW = (2 * P.H + 1) * P.OW;
+    // ---- which steps carry a gradient (masked launches): the three dY rows of a step over the strip's 33 columns
+    if (P.seg_flags) {
+        const int32_t* fl = P.seg_flags + (int64_t)n * P.nseg;
+        for (int j = tid; j < nrows; j += 256) {
+            int any = 0;
+            for (int r = 0; r < 3; ++r) {
+                const int base = (2 * (r0 + j) + r) * P.OW + 2 * ix0;
+                for (int sg = base >> 4; sg <= (base + 32) >> 4; ++sg) any |= fl[sg];
+            }
+            live[j] = any != 0;
+        }
+    } else {
+        for (int j = tid; j < nrows; j += 256) live[j] = 1;
+    }
+    __syncthreads();
+    auto next_live = [&](int j) { while (j < nrows && !live[j]) ++j; return j; };     // (block-uniform)
+    int cur = next_live(0);
+    if (cur >= nrows) return;
+
+    // ---- loaders: per-thread constant vector offsets, the step / row in the scalar offset
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(dy + (int64_t)n * P.out_bs + (int64_t)cob * OHW, (int64_t)64 * OHW * 4);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(x + (int64_t)n * P.in_bs + (int64_t)cib * P.H * P.W, (int64_t)64 * P.H * P.W * 4);
+    const int w8 = tid >> 5, e = tid & 31;                           // dY loads: column e of 8 channel rows per pass, 24 passes = [row 3][8 channel groups]
+    const int voffY = (w8 * OHW + e) * 4;
+    // destinations of column e: even e = E[j], j = e / 2 -> stream j & 1 (Eh0 / Eh1) at s = j >> 1, and for even j >= 2 also Eh0s at s = j / 2 - 1;
+    //                           odd e = O[j], j = e / 2 -> stream 2 + (j & 1) at s = j >> 1
+    const int jj = e >> 1;
+    const int arr0 = (e & 1) ? 2 + (jj & 1) : (jj & 1), s0 = jj >> 1;
+    const bool two = !(e & 1) && !(jj & 1) && jj >= 2;
+    const int ldsY0 = arr0 * TW_ARR + w8 * 8 + s0;                    // + (row * 5) * TW_ARR + (8 g) * 8 + g * 4 for channel group g = i & 7 (co = 8 g + w8)
+    const int ldsY1 = 4 * TW_ARR + w8 * 8 + (jj >> 1) - 1;
+    // the 33rd column E[16] of every (row, channel): threads 0..191, stream Eh0s at s = 7
+    const int xr = tid >> 6, xc = tid & 63;                          // (tid < 192)
+    const int voffE = (xc * OHW + 32) * 4;
+    const int ldsE = (xr * 5 + 4) * TW_ARR + xc * 8 + (xc >> 3) * 4 + 7;
+    // input row piece: 64 channels x 16 pixels = 256 float4
+    const int xci = tid >> 2, xp4 = (tid & 3) * 4;
+    const int voffX = (xci * P.H * P.W + xp4) * 4;
+    const int ldsX = TW_DY + xci * 8 + (xci >> 3) * 4 + (xp4 >> 1);
+
+    float ry[24], re = 0.f;
+    f32x4_t rx;
+    auto load_step = [&](int j) {
+        const int iy = r0 + j;
+        const int sbase = ((2 * iy) * P.OW + 2 * ix0) * 4;
+#pragma unroll
+        for (int i = 0; i < 24; ++i)
+            ry[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, voffY, sbase + ((8 * (i & 7)) * OHW + (i >> 3) * P.OW) * 4, 0));
+        if (tid < 192) re = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, voffE, sbase + xr * P.OW * 4, 0));
+        rx = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const char*>(x + (int64_t)n * P.in_bs + (int64_t)cib * P.H * P.W) + voffX + (iy * P.W + ix0) * 4);
+    };
+    // one dY pass (8 channel rows) of the staged registers -> LDS; the passes are issued one per MFMA behind the last tap row of a step
+    auto store_pass = [&](float* st, int i) __attribute__((always_inline)) {
+        const int off = ((i >> 3) * 5) * TW_ARR + (8 * (i & 7)) * 8 + (i & 7) * 4;
+        st[ldsY0 + off] = ry[i];
+        if (two) st[ldsY1 + off] = ry[i];
+    };
+    auto store_tail = [&](float* st) __attribute__((always_inline)) {
+        if (tid < 192) st[ldsE] = re;
+        *reinterpret_cast<float2*>(st + ldsX) = make_float2(rx.x, rx.z);                 // half 0: pixels xp4, xp4 + 2
+        *reinterpret_cast<float2*>(st + ldsX + TW_ARR) = make_float2(rx.y, rx.w);        // half 1: pixels xp4 + 1, xp4 + 3
+    };
+    auto store_step = [&](float* st) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) store_pass(st, i);
+        store_tail(st);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // operand fragment bases (floats): A = dY stream of tap kx for this lane's half, B = the input row
+    const int co_l = cw * 32 + l32, ci_l = iw * 32 + l32;
+    const int aoff = co_l * 8 + (co_l >> 3) * 4;
+    const int a_kx[3] = {(h ? 1 : 0) * TW_ARR + aoff, (h ? 3 : 2) * TW_ARR + aoff, (h ? 4 : 1) * TW_ARR + aoff};
+    const int boff = TW_DY + h * TW_ARR + ci_l * 8 + (ci_l >> 3) * 4;
+
+    load_step(cur);
+    store_step(lds);
+    __syncthreads();
+    int buf = 0;
+    while (true) {
+        const int nxt = next_live(cur + 1);
+        const bool has_next = nxt < nrows;
+        if (has_next) load_step(nxt);
+        const float* st = lds + buf * TW_STAGE;
+        const float4 b0 = *reinterpret_cast<const float4*>(st + boff), b1 = *reinterpret_cast<const float4*>(st + boff + 4);
+        const float bk[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            float ak[3][8];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 a0 = *reinterpret_cast<const float4*>(st + ky * 5 * TW_ARR + a_kx[kx]), a1 = *reinterpret_cast<const float4*>(st + ky * 5 * TW_ARR + a_kx[kx] + 4);
+                ak[kx][0] = a0.x; ak[kx][1] = a0.y; ak[kx][2] = a0.z; ak[kx][3] = a0.w; ak[kx][4] = a1.x; ak[kx][5] = a1.y; ak[kx][6] = a1.z; ak[kx][7] = a1.w;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(ak[kx][k], bk[k], acc[ky * 3 + kx], 0, 0, 0);
+                    // the next step's rows (requested at the top of this step, ~48 MFMAs ago) go to the other stage behind the last tap row's MFMAs, one
+                    // pass per MFMA: the LDS writes run in the matrix pipe's shadow instead of after it
+                    if (ky == 2 && has_next) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_pass(lds + (buf ^ 1) * TW_STAGE, k * 3 + kx);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        }
+        if (!has_next) break;
+        store_tail(lds + (buf ^ 1) * TW_STAGE);
+        __syncthreads();
+        buf ^= 1; cur = nxt;
+    }
+    // ---- partial sums -> dW (zeroed by the caller side): C/D layout col = lane & 31 (input channel), row = (r & 3) + 8 (r >> 2) + 4 h (output channel)
+    float* dwn = dw + (P.wbs ? (int64_t)n * P.wbs : 0) + (int64_t)(cib + ci_l) * P.wsc;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = cob + cw * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            atomicAdd(dwn + (int64_t)m * P.wsm + P.widx9[t], acc[t][r]);
+        }
+}
+
+// eligibility + launch of twgrad_kernel (P = make_forward(d) of a transposed conv); returns false when the problem keeps the generic kernel
+static bool twgrad_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SPI_CONV_TWGRAD"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on != 0;
+}
+static bool launch_twgrad(const spi_conv_desc* d, const IGemmParams& P, const float* x, const float* dy, float* dw, hipStream_t st) {
+    if (!twgrad_enabled() || !d->transposed || d->kh != 3 || d->kw != 3 || d->compute_f16 != 0 || d->act_dtype != 0) return false;
+    if (P.Mo % 64 || P.Ci % 64 || P.IW % TW_PX || P.OH != 2 * P.IH + 1 || P.OW != 2 * P.IW + 1 || P.ncls != 4) return false;
+    if ((int64_t)64 * P.OH * P.OW * 4 >= (1ll << 31) || (int64_t)64 * P.IH * P.IW * 4 >= (1ll << 31)) return false;
+    if ((int64_t)P.IH * P.IW < 16384) return false;          // small planes: the blocks' 36 864 atomics each outweigh the MFMAs, the generic split keeps them
+    TWgradParams T;
+    T.N = P.N; T.Mo = P.Mo; T.Ci = P.Ci; T.H = P.IH; T.W = P.IW; T.OW = P.OW;
+    T.in_bs = P.in_bs; T.out_bs = P.out_bs; T.wbs = P.wbs; T.wsm = P.wsm; T.wsc = P.wsc;
+    for (int t = 0; t < 9; ++t) T.widx9[t] = -1;
+    for (int c = 0; c < P.ncls; ++c) {
+        const ClassParams& C = P.cls[c];
+        for (int t = 0; t < C.taps.T; ++t) {
+            const int ky = C.ooy - 2 * C.taps.dy[t], kx = C.oox - 2 * C.taps.dx[t];      // make_forward: dy = -(ky - py) / 2
+            if (ky < 0 || ky > 2 || kx < 0 || kx > 2) return false;
+            T.widx9[ky * 3 + kx] = C.taps.widx[t];
+        }
+    }
+    for (int t = 0; t < 9; ++t) if (T.widx9[t] < 0) return false;
+    T.xsegs = P.IW / TW_PX; T.ncib = P.Ci / 64;
+    const int64_t base = (int64_t)T.xsegs * (P.Mo / 64) * T.ncib * P.N;
+    // ~512 blocks (two per CU, one round: measured best of 256 .. 2048 on 256 -> 128 at 256^2), at least 8 rows per block (below that the 36 864
+    // atomics of a block cost more than its MFMAs)
+    static int target = 0;
+    if (!target) { const char* e = getenv("SPI_TWGRAD_BLOCKS"); target = e ? atoi(e) : 512; if (target < 64) target = 512; }
+    int chunks = (int)std::max<int64_t>(1, std::min<int64_t>((target + base - 1) / base, P.IH / 8));
+    T.rows_per_chunk = std::min((P.IH + chunks - 1) / chunks, TW_MAXROWS);
+    chunks = (P.IH + T.rows_per_chunk - 1) / T.rows_per_chunk;
+    T.seg_flags = d->dy_seg_flags; T.nseg = (int)(((int64_t)P.OH * P.OW + SPI_SEG_PIXELS - 1) / SPI_SEG_PIXELS);
+    dim3 grid((unsigned)(T.xsegs * chunks), (unsigned)((P.Mo / 64) * T.ncib), (unsigned)P.N);
+    hipLaunchKernelGGL(twgrad_kernel, grid, dim3(256), 0, st, T, x, dy, dw);
+    return true;
+}
+
 // tile configuration and number of K ranges of a forward / dgrad implicit GEMM (host logic shared by the launch and spi_conv2d_out_accumulates)
 struct IGemmPlan { int cfg, nsplit; };
 static IGemmPlan plan_igemm(const IGemmParams& P, int f16) {
@@ -1452,6 +1664,10 @@ int spi_conv2d_wgrad(const spi_conv_desc* d, const float* x, const float* dy, fl
     }
     if (!d->dw_zeroed) {
         spi_zero_async(dw, nw * wsz, as_stream(stream));
+    }
+    if (launch_twgrad(d, P, x, dy, dw, as_stream(stream))) {            // stride-2 transposed 3x3, fp32: the nine-tap kernel
+        SPI_LAUNCH_CHECK("spi_conv2d_wgrad (transposed, direct)");
+        return SPI_OK;
     }
     {
         WinoParams Wp;

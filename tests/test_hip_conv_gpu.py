@@ -65,6 +65,42 @@ def test_conv_fwd_dgrad_wgrad_vs_oracle(case):
     assert_close(hw, gw, 1e-4 if big else 2e-5, 'conv wgrad')
 
 
+TWGRAD_CASES = [  # N, I, O, H, W, per_sample, masked      (stride-2 transposed 3x3, channels in whole 64-blocks, W % 16 == 0: twgrad_kernel)
+    (1, 256, 128, 256, 256, True, False),      # SR block1.conv0 / b256.conv0: the most expensive conv launch of the loop
+    (2, 64, 128, 40, 48, True, False),         # per-sample weights, rows that do not fill a chunk evenly
+    (3, 128, 64, 32, 32, False, False),        # batch summed into ONE weight set
+    (2, 64, 64, 64, 64, False, True),          # masked gradient (dy_seg_flags): steps without a flagged segment are skipped
+]
+
+
+@pytest.mark.parametrize('case', TWGRAD_CASES)
+def test_conv_transposed_wgrad_direct_kernel_vs_oracle(case):
+    """Round 6: the weight gradient of the stride-2 transposed 3x3 convolutions on its own kernel (twgrad_kernel: 64 x 64 channels x all nine taps per
+    block, dY rows de-interleaved into the three kx operand streams on their way into LDS) against autograd of F.conv_transpose2d on the CPU.  The sums run
+    over up to 65 536 pixels with fp32 atomics between blocks: 1e-4 of the tensor's range on the real layer size like the other weight-gradient tests."""
+    from spi_amd.torch_utils.ops import conv2d_mfma
+    N, I, O, H, W, per, masked = case
+    torch.set_num_threads(min(__import__('os').cpu_count() or 1, 32))
+    gen = torch.Generator().manual_seed(N * 10 + O)
+    x = torch.randn(N, I, H, W, generator=gen)
+    w = (torch.randn(*((N,) if per else ()), O, I, 3, 3, generator=gen) / (I * 9) ** 0.5).requires_grad_(True)
+    ref = _ref_conv(x, w, 0, True, False)
+    dy = torch.randn(ref.shape, generator=gen)
+    if masked:
+        m = torch.zeros(ref.shape[-2:])
+        m[20:60, 70:110] = 1                       # a box: most 16-pixel segments of dY are exactly zero
+        dy = dy * m
+    gw, = torch.autograd.grad(ref, [w], dy)
+    xg, wg = x.to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True)
+    y = conv2d_mfma.conv2d(xg, wg, padding=0, transposed=True, flip=False, sparse_grad=masked)
+    if masked:
+        with conv2d_mfma.sparse_gradients():
+            hw, = torch.autograd.grad(y, [wg], dy.to(DEV))
+    else:
+        hw, = torch.autograd.grad(y, [wg], dy.to(DEV))
+    assert_close(hw, gw, 1e-4 if H * W >= 65536 else 2e-5, 'transposed conv wgrad (direct kernel)')
+
+
 def test_conv_fused_epilogue_vs_oracle():
     from spi_amd.torch_utils.ops import conv2d_mfma
     gen = torch.Generator().manual_seed(8)

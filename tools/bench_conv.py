@@ -13,6 +13,8 @@ SHAPES = [  # name, N, I, O, H, k, transposed, per_sample
     ('sr0.conv1 256->256 @256', 1, 256, 256, 256, 3, False, True),
     ('sr1.conv0 256->128 up 256->513', 1, 256, 128, 256, 3, True, True),
     ('sr0.conv0 32->256 up 128->257', 1, 32, 256, 128, 3, True, True),
+    ('b256.conv0 256->128 up 128->257', 1, 256, 128, 128, 3, True, True),
+    ('sr1.conv0 N=4 256->128 up 256->513', 4, 256, 128, 256, 3, True, True),
     ('b256.conv1 128->128 @256', 1, 128, 128, 256, 3, False, True),
     ('b128.conv1 256->256 @128', 1, 256, 256, 128, 3, False, True),
     ('b64.conv1 512->512 @64', 1, 512, 512, 64, 3, False, True),
