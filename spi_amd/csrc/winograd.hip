@@ -653,9 +653,6 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WinoWgradParams P, c
 // The output transform A^T M A needs all six rows a of a tile: each wave applies its three rows, the two waves of an output-channel half exchange
 // half of their partial 4 x 4 tiles through LDS, and each finishes (noise / bias / activation epilogue, 16-byte stores) two of the four output rows.
 // =================================================================================================
-#ifndef W4_INTERLEAVE
-#define W4_INTERLEAVE 1
-#endif
 constexpr int W4KC = 4;                      // input channels per slab
 constexpr int W4U = 36 * 2 * 64 * 2;         // floats of one U slab image in LDS (36 KB)
 constexpr int W4V = 36 * 2 * 32 * 2;         // floats of one V slab (18 KB)
@@ -860,33 +857,15 @@ __global__ void __launch_bounds__(256, 1) wino4_conv_kernel(WinoParams P, const 
     __syncthreads();
 
     const int aoff = ((fh * 18 * 2 + h) * 64 + ocw * 32 + l32) * 2, boff = ((fh * 18 * 2 + h) * 32 + l32) * 2;
-#if !W4_INTERLEAVE
-    for (int s = 0; s < nslab; ++s) {
-        const int buf = s & 1;
-        const float* Ub = Us + buf * W4U + aoff;
-        const float* Vb = Vs + buf * W4V + boff;
-        // this iteration's transfers: raw[s+2] -> the raw buffer slab s lived in, U[s+1] -> the other U buffer
-#pragma unroll
-        for (int i = 0; i < 11; ++i) { if (i < 9) copy_u(buf ^ 1, s + 1, i); copy_raw(buf, s + 2, i); }
-        // raw[s+1] -> V[s+1] (its transfers were awaited at the end of the previous iteration)
-        transform(Rs + (buf ^ 1) * W4RAW, Vs + (buf ^ 1) * W4V);
-#pragma unroll
-        for (int f = 0; f < 18; ++f) {
-            const float2 a2 = *reinterpret_cast<const float2*>(Ub + f * 256);
-            const float2 b2 = *reinterpret_cast<const float2*>(Vb + f * 128);
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2.x, acc[f], 0, 0, 0);
-            acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2.y, acc[f], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this iteration's transfers have landed
-        __syncthreads();
-    }
-#else
     // Hand-interleaved main loop (wino_conv_kernel's scheme): behind EVERY MFMA one micro-slot of side work -- an fp32 MFMA occupies the pipe for 64
     // cycles after a 4-cycle issue, a handful of instructions per slot run in its shadow.  36 slots per slab:
-    //   * the operand fragments two frequencies ahead (slots with an even index),
-    //   * this iteration's transfers: U[s+1] (9) on slots 1, 5, 9, ... and raw[s+2] (11) on slots 3, 7, 11, ... (+ the last two on 35 / 33's neighbours),
-    //   * raw[s+1] -> V[s+1]: five patch rows on slots 0..4, the six column transforms on slots 6..16, then per frequency row a the row transform
-    //     and its six stores on slots 18 + 6 a .. 23 + 6 a.
+    //   * the operand fragments of the next group of three frequencies (first three slots of a group),
+    //   * this iteration's 20 transfers (U[s+1]: 9, raw[s+2]: 11) on slots 0..19, so that the barrier at the end of the slab finds them landed,
+    //   * raw[s+1] -> V[s+1]: five patch rows on slots 0..4, the three packed column-pair transforms on slots 6, 8, 10, then per frequency row a the
+    //     row transform and its six stores on slots 18 + 6 a .. 23 + 6 a.
+    // (A first version without the slots -- transfers, transform, then 36 MFMAs -- ran at F(2x2)'s speed; the steps to 1.3x: transfers early,
+    //  two accumulator tiles pinned to VGPRs, packed column transform.  Ablation, same box: MFMAs + fragments alone 237 us, + transform 307, + transfers 315
+    //  on 128 -> 128 at 512^2: build with -DW4_NO_DMA / -DW4_NO_XFORM to repeat it.)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 d2[5][3], T2[3][3];                                        // five patch rows / three transformed rows as column PAIRS (v_pk_fma_f32 / v_pk_add_f32)
     float v[6];
@@ -954,7 +933,6 @@ __global__ void __launch_bounds__(256, 1) wino4_conv_kernel(WinoParams P, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this iteration's transfers have landed
         __syncthreads();
     }
-#endif
 
     // ---- output transform A^T M A + epilogue.  C/D layout: col = lane & 31 (tile), row = (r & 3) + 8 (r >> 2) + 4 h.
     //   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  Per accumulator row r the wave has M[a][b], a = 3 fh + (0, 1, 2), b = 0..5:
