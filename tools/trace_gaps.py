@@ -20,6 +20,8 @@ span = max(r[1] for r in rows) - rows[0][0]
 busy = 0
 hist = defaultdict(lambda: [0, 0])
 after = defaultdict(lambda: [0, 0])
+pairs = defaultdict(lambda: [0, 0])
+prev_name = None
 cur_end = rows[0][0]
 for s, e, name in rows:
     if s > cur_end:
@@ -30,11 +32,14 @@ for s, e, name in rows:
         if g >= 20000:
             after[name][0] += 1
             after[name][1] += g
+            pairs[(prev_name, name)][0] += 1
+            pairs[(prev_name, name)][1] += g
         busy += e - s
         cur_end = e
     else:
         busy += max(0, e - cur_end)
         cur_end = max(cur_end, e)
+    prev_name = name
 print(f'kernels {len(rows)}  span {span / 1e6:.2f} ms  busy {busy / 1e6:.2f} ms ({100 * busy / span:.1f} %)  idle {(span - busy) / 1e6:.2f} ms')
 for b in ('<2us', '2-5us', '5-20us', '20-100us', '0.1-1ms', '>1ms'):
     n, t = hist[b]
@@ -42,3 +47,16 @@ for b in ('<2us', '2-5us', '5-20us', '20-100us', '0.1-1ms', '>1ms'):
 print('kernels launched late (after a gap >= 20 us):')
 for name, (n, t) in sorted(after.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f'  {t / 1e6:8.2f} ms n={n:5d}  {name}')
+print('gaps >= 20 us by (kernel before -> kernel after):')
+for (a, b), (n, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f'  {t / 1e6:8.2f} ms n={n:5d} avg {t / n / 1e3:7.1f} us  {str(a)[-38:]:38s} -> {b[-38:]}')
+# timeline around the iteration boundaries: the kernels after the 3rd-last adam_multi_kernel (start of an iteration) and before the 2nd-last one (its end)
+adam = [i for i, r in enumerate(rows) if 'adam_multi' in r[2]]
+if len(adam) >= 3:
+    def show(i0, i1, title):
+        print(title)
+        for i in range(max(i0, 1), min(i1, len(rows))):
+            s, e, name = rows[i]
+            print(f'  +{(s - rows[i0][0]) / 1e3:9.1f} us  gap {(s - max(r[1] for r in rows[max(0, i - 4):i])) / 1e3:7.1f}  dur {(e - s) / 1e3:8.1f}  {name[-60:]}')
+    show(adam[-3], adam[-3] + 28, 'timeline: adam_multi_kernel of one iteration and the first kernels of the next')
+    show(adam[-2] - 24, adam[-2] + 1, 'timeline: the last kernels of that iteration')
