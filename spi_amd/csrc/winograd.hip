@@ -952,8 +952,8 @@ __global__ void __launch_bounds__(256, 1) wino4_conv_kernel(WinoParams P, const 
         const float ng = ep.noise_gain ? ep.noise_gain[0] : 1.f;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float4 nv = *reinterpret_cast<const float4*>(ep.noise + pix + (int64_t)i * P.W);
-            nz[i][0] = nv.x * ng; nz[i][1] = nv.y * ng; nz[i][2] = nv.z * ng; nz[i][3] = nv.w * ng;
+            const float* np = ep.noise + pix + (int64_t)i * P.W;          // (scalar loads: a noise map that is a view need not be 16-byte aligned)
+            nz[i][0] = np[0] * ng; nz[i][1] = np[1] * ng; nz[i][2] = np[2] * ng; nz[i][3] = np[3] * ng;
         }
     }
     const bool has_epi = ep.act != 0 || ep.bias || ep.noise;
