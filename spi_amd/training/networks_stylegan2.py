@@ -144,17 +144,56 @@ def multi_modulate(layers, styles):
     non-fp32 / non-GPU tensors, more than 32 layers."""
     if styles is None or not (1 <= len(layers) <= hip.MODULATE_MAX_JOBS):
         return None
-    cfg, ws_ = [], []
+    cfg, ws_, frozen = [], [], []
     for m, s in zip(layers, styles):
         w = m.weight
         if not (w.is_cuda and w.dtype == torch.float32 and s.dtype == torch.float32 and w.shape[1] * w.shape[2] * w.shape[3] * 12 <= 64 * 1024):
             return None
-        if torch.is_grad_enabled() and not w.requires_grad and s.requires_grad:
-            return None                                            # stage 1: _ModConvFrozen
+        frozen.append(torch.is_grad_enabled() and not w.requires_grad and s.requires_grad)      # stage 1: _ModConvFrozen
         torgb = isinstance(m, ToRGBLayer)
         cfg.append((not torgb, float(m.weight_gain) if torgb else 1.0))
         ws_.append(w)
+    if all(frozen):
+        return _multi_modulate_frozen(tuple(cfg), styles, ws_)
+    if any(frozen):
+        return None
     return _MultiModulate.apply(tuple(cfg), *styles, *ws_)
+
+
+class FrozenMod(tuple):
+    """(w2 [N,O,k,k,I], dcoef [N,O] or None) of one frozen-weight layer, modulated ahead of its forward by `_multi_modulate_frozen`."""
+
+
+def _multi_modulate_frozen(cfg, styles, weights):
+    """Round 6: stage 1's frozen-weight layers (`_ModConvFrozen`) modulated in ONE launch ahead of the forward, like `_MultiModulate` does for the
+    trainable path: 26 `spi_modulate_fwd` launches per synthesis (each a few us of work behind a ~3 us launch boundary) become one
+    `spi_modulate_multi_fwd`.  No autograd here -- `_ModConvFrozen.backward` forms the style gradient from the saved w2 / dcoef as before.
+    Same kernel bodies as the per-layer launches: bit-equal weights."""
+    with torch.no_grad():
+        nl = len(cfg)
+        st = [s.detach().contiguous().float() for s in styles]
+        wt = [w.detach().contiguous().float() for w in weights]
+        n = st[0].shape[0]
+        dev = wt[0].device
+        wflat = torch.empty(sum(n * w.numel() for w in wt), device=dev, dtype=torch.float32)
+        dflat = torch.empty(max(1, sum(n * w.shape[0] for w, c in zip(wt, cfg) if c[0])), device=dev, dtype=torch.float32)
+        jobs = (hip.ModulateJob * nl)()
+        outs, wo, do = [], 0, 0
+        for l, (w, s, (demod, sgain)) in enumerate(zip(wt, st, cfg)):
+            o, i, kh, kw = w.shape
+            assert s.shape == (n, i)
+            w2 = wflat[wo:wo + n * w.numel()].view(n, o, kh, kw, i)
+            wo += n * w.numel()
+            dc = None
+            if demod:
+                dc = dflat[do:do + n * o].view(n, o)
+                do += n * o
+            j = jobs[l]
+            j.weight, j.styles, j.w_out, j.dcoef = w.data_ptr(), s.data_ptr(), w2.data_ptr(), (dc.data_ptr() if dc is not None else None)
+            j.style_gain, j.O, j.I, j.T, j.demodulate = float(sgain), o, i, kh * kw, int(demod)
+            outs.append(FrozenMod((w2, dc)))
+        hip.call('spi_modulate_multi_fwd', jobs, nl, n, hip.stream())
+    return outs
 
 
 def _tap_energy(weight):
@@ -177,7 +216,7 @@ class _ModConvFrozen(torch.autograd.Function):
     the weight-gradient GEMM (20 % of a stage-1 step) disappears.  Same value up to fp32 rounding."""
 
     @staticmethod
-    def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16, ww=None):
+    def forward(ctx, x, weight, styles, bias, noise, strength, pad, transposed, flip, act_id, alpha, gain, clamp, demodulate, style_gain, f16, ww=None, pre=None):
         import ctypes
         from ..torch_utils.ops.conv2d_mfma import _desc, _workspace, _out_tensor, out_size, half_io
         half = half_io(x, f16)                             # fp16 activation tensors (use_fp16 blocks): x, y, dy, dx are half
@@ -186,10 +225,14 @@ class _ModConvFrozen(torch.autograd.Function):
         st = styles.detach().contiguous().float()
         o, i, kh, kw = weight.shape
         n, ns = x.shape[0], st.shape[0]
-        w2 = torch.empty(ns, o, kh, kw, i, device=x.device, dtype=torch.float32)
-        dcoef = torch.empty(ns, o, device=x.device, dtype=torch.float32) if demodulate else None
-        hip.call('spi_modulate_fwd', hip.ptr(weight), hip.ptr(st), hip.ptr(w2), hip.ptr(dcoef), ns, o, i, kh * kw, int(demodulate),
-                 float(style_gain), hip.stream())
+        if pre is not None:                                # modulated ahead of the forward with every other layer (_multi_modulate_frozen)
+            w2, dcoef = pre
+            assert w2.shape == (ns, o, kh, kw, i) and (dcoef is not None) == bool(demodulate)
+        else:
+            w2 = torch.empty(ns, o, kh, kw, i, device=x.device, dtype=torch.float32)
+            dcoef = torch.empty(ns, o, device=x.device, dtype=torch.float32) if demodulate else None
+            hip.call('spi_modulate_fwd', hip.ptr(weight), hip.ptr(st), hip.ptr(w2), hip.ptr(dcoef), ns, o, i, kh * kw, int(demodulate),
+                     float(style_gain), hip.stream())
         h, wd = x.shape[2], x.shape[3]
         wbs = o * i * kh * kw if ns == n and n > 1 else (0 if ns == 1 else o * i * kh * kw)
         if ns == 1:
@@ -256,7 +299,7 @@ class _ModConvFrozen(torch.autograd.Function):
         ds = torch.empty(ns, i, device=x.device, dtype=torch.float32)
         hip.call('spi_style_grad', hip.ptr(a), hip.ptr(cv), hip.ptr(st), hip.ptr(dcoef), hip.ptr(ww), hip.ptr(ds), n, ns, i, o, sgain, hip.stream())
         return (dx if ctx.needs_input_grad[0] else None, None, ds, d_bias, d_noise, d_strength,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
 @misc.profiled_function
@@ -289,12 +332,15 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
                 assert act_id in (1, 3), 'fused epilogue of the frozen-weight path supports linear / lrelu'
                 a_, g_, c_ = float(d_alpha), float(d_gain if gain is None else gain), float(-1 if clamp is None else clamp)
             return _ModConvFrozen.apply(x, weight, styles, bias, noise, noise_strength, int(padding), False, not flip_weight, act_id, a_, g_, c_,
-                                        bool(demodulate), float(style_gain), conv2d_mfma.precision(fp16), _tap_energy(weight) if demodulate else None)
+                                        bool(demodulate), float(style_gain), conv2d_mfma.precision(fp16), _tap_energy(weight) if demodulate else None,
+                                        w_mod if isinstance(w_mod, FrozenMod) else None)
         assert kh == 3 and padding == 1 and resample_filter is not None and resample_filter.ndim == 2
         z = _ModConvFrozen.apply(x, weight, styles, None, None, None, 0, True, flip_weight, 0, 0.0, 1.0, -1.0, bool(demodulate),
-                                 float(style_gain), conv2d_mfma.precision(fp16), _tap_energy(weight) if demodulate else None)
+                                 float(style_gain), conv2d_mfma.precision(fp16), _tap_energy(weight) if demodulate else None,
+                                 w_mod if isinstance(w_mod, FrozenMod) else None)
         return upfirdn2d.upfirdn2d_bias_act(z, resample_filter, noise=noise, noise_strength=noise_strength, bias=bias,
                                             padding=[1, 1, 1, 1], gain=up ** 2, act=(act or 'linear'), act_gain=gain, clamp=clamp)
+    assert not isinstance(w_mod, FrozenMod)
     w = w_mod if w_mod is not None else modulate_weights(weight, styles, demodulate, style_gain)   # w_mod: this layer's share of `multi_modulate`
     if styles.shape[0] == 1 and n > 1:
         w = w[0]

@@ -983,7 +983,7 @@ def test_conv_out_zeroed_flag_and_zero_arena():
 def test_multi_modulate_equals_the_per_layer_modulation(n):
     """`multi_modulate` (spi_modulate_multi_fwd / _bwd): the weight modulation of all layers of a network in one launch each way -- the same kernel
     bodies over a job table: modulated weights bit-equal to `modulate_weights` per layer (3x3 demodulated convs and 1x1 ToRGB layers with their
-    weight gain), style and weight gradients equal, a layer without an incoming gradient skipped, None on stage 1's frozen-weight path."""
+    weight gain), style and weight gradients equal, a layer without an incoming gradient skipped; on stage 1's frozen-weight path (round 6) the same launch hands `_ModConvFrozen` its (w2, dcoef) pairs."""
     from spi_amd.training.networks_stylegan2 import SynthesisLayer, ToRGBLayer, modulate_weights, multi_modulate
     gen = torch.Generator().manual_seed(60 + n)
     layers = [SynthesisLayer(64, 128, 512, 16), SynthesisLayer(128, 128, 512, 16), ToRGBLayer(128, 96, 512), SynthesisLayer(128, 32, 512, 32, up=2),
@@ -1009,7 +1009,26 @@ def test_multi_modulate_equals_the_per_layer_modulation(n):
             assert_close(a, b, 1e-6, f'multi-modulate gradient {k}')
     for m in layers:
         m.requires_grad_(False)
-    assert multi_modulate(layers, styles) is None                # frozen weights + styles that need a gradient: stage 1's own path
+    # frozen weights + styles that need a gradient (stage 1): the layers' weights still come out of ONE launch, as (w2, dcoef) pairs for _ModConvFrozen
+    from spi_amd.training.networks_stylegan2 import FrozenMod
+    fz = multi_modulate(layers, styles)
+    assert fz is not None and all(isinstance(p, FrozenMod) for p in fz)
+    for (w2, dc), b, m in zip(fz, ref, layers):
+        assert torch.equal(w2, b.detach()) and (dc is None) == isinstance(m, ToRGBLayer) and not w2.requires_grad
+    # ... and a layer run with its pair gives the per-layer launch's output and style gradient
+    xin = torch.randn(n, 64, 16, 16, generator=gen).to(DEV)
+    outs = []
+    for wm in (None, fz[0]):
+        s0 = styles[0].detach().clone().requires_grad_(True)
+        y0 = layers[0](xin, None, noise_mode='none', styles=s0, w_mod=wm)
+        gs, = torch.autograd.grad(y0.square().sum(), [s0])
+        outs.append((y0.detach(), gs))
+    # (the 16^2 layer runs split-K with atomics: two launches of the SAME weights differ in the last bits)
+    assert_close(outs[0][0], outs[1][0], 1e-6, 'frozen layer output, weights modulated ahead') and None
+    assert_close(outs[0][1], outs[1][1], 1e-5, 'frozen layer style gradient, weights modulated ahead')
+    layers[2].requires_grad_(True)
+    assert multi_modulate(layers, styles) is None                # a mix of frozen and trainable layers keeps the per-layer paths
+    layers[2].requires_grad_(False)
     with torch.no_grad():
         got = multi_modulate(layers, styles)                     # inference: fine
     assert got is not None and torch.equal(got[2], ref[2])
