@@ -862,7 +862,9 @@ def main():
                          'bytes_per_ray': per_ray, 'rays_per_launch': (sum(march_rays) / max(len(march_rays), 1)),
                          'note': 'HIP events on the launch stream around every final-march launch of an eagerly enqueued repeat of the timed steps, run in this '
                                  'process right after the timed region (the timed steps themselves are HIP-graph replays, which cannot carry events); '
-                                 'stage 1 (N = 2) and stage 2 (N = 1 main view, N = 4 pseudo-view branches) launches'},
+                                 'stage 1 (N = 2) and stage 2 (N = 1 main view, N = 4 pseudo-view branches) launches',
+                         'traffic_source': 'profiles/raymarch_pmc.json: FETCH_SIZE (doubled, MI355X_MICROARCH.md) + WRITE_SIZE of separate --pmc passes over this kernel '
+                                           '(round 4; the kernel has not changed since), scaled from 16 384 rays to this run\'s average launch -- a committed counter record, not re-collected in this process'},
         }
         # second HBM line: the march BACKWARD.  Algorithmic bytes per ACTIVE ray: read S*(C+2)*4 (colours, density, depth)
         # + (C+1)*4 incoming gradients, write S*2*4 (density gradient + colour-gradient scale; the [R,S,C] colour gradient is never
